@@ -1,0 +1,545 @@
+// fx_api.cpp — context management and the batch driver behind include/fx.h.
+//
+// A context owns every device buffer (sized once from fx_limits: no allocation in the
+// steady state), a stream, and lazily created pinned host mirrors.  fx_process_batch
+// enqueues the stage kernels of fx_kernels.hip on the context's stream; with FX_OUT_HOST
+// it also copies the results back and synchronises.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fx.h"
+#include "fx_device.h"
+
+extern "C" {
+size_t fxk_ring_lds_bytes(uint32_t cap);
+size_t fxk_merge_lds_bytes(uint32_t cap, uint32_t n_rings);
+size_t fxk_desc_lds_bytes(uint32_t cap);
+hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t desc_big);
+void fxk_prep(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
+void fxk_rings(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap_small,
+               uint32_t cap_big, uint32_t big_grid);
+void fxk_merge(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap_small,
+               uint32_t cap_big, uint32_t big_grid);
+void fxk_offsets(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
+void fxk_desc(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap_small,
+              uint32_t cap_big, uint32_t grid_small, uint32_t big_grid, uint32_t mode);
+void fxk_rng_ord(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
+void fxk_pack_features(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, void *dst,
+                       uint32_t capacity, uint32_t grid);
+}
+
+namespace {
+thread_local std::string g_last_error;
+
+fx_status fail(fx_status s, const std::string &msg) {
+  g_last_error = msg;
+  return s;
+}
+#define FX_HIP(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess)                                                                         \
+      return fail(e_ == hipErrorOutOfMemory ? FX_ERR_OOM : FX_ERR_HIP,                            \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                             \
+  } while (0)
+
+constexpr int kMetaSlots = 8;
+constexpr uint32_t kRingCapSmall = 512, kMergeCapSmall = 512, kDescCapSmall = 1024;
+}  // namespace
+
+struct fx_ctx {
+  fx_params params;
+  fx_limits lim;
+  int device = 0;
+  int n_cu = 256;
+  FxDevParams dp;
+  FxBuffers buf;
+  std::vector<void *> dev_allocs;
+  std::vector<void *> host_allocs;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  // per-batch scan table: ring of pinned slots so back-to-back batches never overwrite one in flight
+  FxScanMeta *h_meta[kMetaSlots] = {};
+  hipEvent_t meta_ev[kMetaSlots] = {};
+  bool meta_used[kMetaSlots] = {};
+  int meta_next = 0;
+  FxScanMeta *d_meta = nullptr;
+  // host-input staging
+  float *d_stage = nullptr;
+  std::vector<float> repack;
+  // pinned host mirrors (lazy)
+  uint32_t *h_n_kp = nullptr, *h_kp_offset = nullptr, *h_flags = nullptr, *h_n_filt = nullptr, *h_n_kpc = nullptr,
+           *h_n_cand = nullptr, *h_cand_size = nullptr, *h_kpc_cand = nullptr, *h_kp_size = nullptr,
+           *h_kp_nbrs = nullptr;
+  int32_t *h_cand_kp = nullptr;
+  float *h_keypoints = nullptr, *h_desc = nullptr, *h_filtered = nullptr, *h_kpc = nullptr, *h_cand = nullptr;
+  // profiling
+  bool profiling = false;
+  hipEvent_t ev[FX_N_STAGES + 1] = {};
+  bool ev_valid = false;
+  uint32_t last_batch = 0;
+};
+
+namespace {
+
+template <typename T>
+fx_status dev_alloc(fx_ctx *c, T **p, size_t count) {
+  void *q = nullptr;
+  const size_t bytes = (count ? count : 1) * sizeof(T);
+  hipError_t e = hipMalloc(&q, bytes);
+  if (e != hipSuccess) return fail(FX_ERR_OOM, std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e));
+  c->dev_allocs.push_back(q);
+  *p = (T *)q;
+  return FX_OK;
+}
+template <typename T>
+fx_status host_alloc(fx_ctx *c, T **p, size_t count) {
+  if (*p) return FX_OK;
+  void *q = nullptr;
+  const size_t bytes = (count ? count : 1) * sizeof(T);
+  hipError_t e = hipHostMalloc(&q, bytes, hipHostMallocDefault);
+  if (e != hipSuccess) return fail(FX_ERR_OOM, std::string("hipHostMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e));
+  c->host_allocs.push_back(q);
+  *p = (T *)q;
+  return FX_OK;
+}
+#define FX_TRY(expr)              \
+  do {                            \
+    fx_status s_ = (expr);        \
+    if (s_ != FX_OK) return s_;   \
+  } while (0)
+
+}  // namespace
+
+extern "C" {
+
+const char *fx_last_error(void) { return g_last_error.c_str(); }
+
+fx_status fx_create(const fx_params *params, const fx_limits *limits, int device_id, fx_ctx **out) {
+  if (!params || !limits || !out) return fail(FX_ERR_INVALID_ARG, "null argument");
+  *out = nullptr;
+  int n_dev = 0;
+  hipError_t e = hipGetDeviceCount(&n_dev);
+  if (e != hipSuccess || n_dev <= 0)
+    return fail(FX_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + (e != hipSuccess ? hipGetErrorString(e) : "0 devices"));
+  if (device_id < 0 || device_id >= n_dev) return fail(FX_ERR_INVALID_ARG, "device_id out of range");
+
+  fx_limits L = *limits;
+  fx_limits D;
+  fx_limits_default(&D, L.max_batch, L.max_points);
+  if (!L.max_ring_points) L.max_ring_points = D.max_ring_points;
+  if (!L.max_ring_candidates) L.max_ring_candidates = D.max_ring_candidates;
+  if (!L.max_candidates) L.max_candidates = D.max_candidates;
+  if (!L.max_keypoints) L.max_keypoints = D.max_keypoints;
+  if (!L.max_neighbors) L.max_neighbors = D.max_neighbors;
+  if (!L.max_total_keypoints) L.max_total_keypoints = D.max_total_keypoints;
+  if (!L.max_kpc_points) L.max_kpc_points = D.max_kpc_points;
+  if (L.max_batch == 0 || L.max_points == 0) return fail(FX_ERR_INVALID_ARG, "max_batch and max_points must be > 0");
+  if (L.max_points > (1u << 20)) return fail(FX_ERR_INVALID_ARG, "max_points > 2^20 (descriptor sort key packs the point index in 20 bits)");
+  if (params->n_rings < 1 || params->n_rings > 1024) return fail(FX_ERR_INVALID_ARG, "n_rings must be in [1, 1024]");
+  if (!(params->descriptor_radius > 0.0) || !(params->el_step_deg > 0.0))
+    return fail(FX_ERR_INVALID_ARG, "descriptor_radius and el_step_deg must be > 0");
+  if (L.max_ring_candidates > L.max_ring_points) L.max_ring_candidates = L.max_ring_points;
+  // LDS budget of the large tiers (160 KiB per workgroup on gfx950)
+  const size_t kLds = 160 * 1024;
+  if (fxk_ring_lds_bytes(L.max_ring_points) > kLds) return fail(FX_ERR_INVALID_ARG, "max_ring_points exceeds the LDS budget (<= 2550)");
+  if (fxk_merge_lds_bytes(L.max_candidates, params->n_rings) > kLds)
+    return fail(FX_ERR_INVALID_ARG, "max_candidates exceeds the LDS budget (<= ~4000)");
+  if (fxk_desc_lds_bytes(L.max_neighbors) > kLds) return fail(FX_ERR_INVALID_ARG, "max_neighbors exceeds the LDS budget (<= ~4800)");
+  if (L.max_keypoints > 65535 || L.max_candidates > 32768 || L.max_ring_points > 32768)
+    return fail(FX_ERR_INVALID_ARG, "limit exceeds the 16-bit packing of the order replay");
+
+  FX_HIP(hipSetDevice(device_id));
+  fx_ctx *c = new fx_ctx();
+  c->params = *params;
+  c->lim = L;
+  c->device = device_id;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+
+  // ---- constants, narrowed where PCL narrows them
+  FxDevParams &P = c->dp;
+  std::memset(&P, 0, sizeof(P));
+  P.x_min = (float)params->x_min;  // PassThrough::setFilterLimits(const float&, const float&)
+  P.x_max = (float)params->x_max;
+  P.y_min = (float)params->y_min;
+  P.y_max = (float)params->y_max;
+  P.z_min = (float)params->z_min;
+  P.z_max = (float)params->z_max;
+  P.n_rings = params->n_rings;
+  {
+    // EuclideanClusterExtraction narrows the tolerance to float; KdTreeFLANN squares it in double
+    const double tol = (double)(float)params->cluster_tolerance;
+    P.r2_cluster = (float)(tol * tol);
+    const double crt = (double)(float)params->cluster_radius_threshold;
+    P.r2_merge = (float)(crt * crt);
+  }
+  P.min_count = (uint32_t)params->cluster_min_count;
+  P.max_count = (uint32_t)params->cluster_max_count;
+  P.gate_diameter = 2 * params->cluster_radius_threshold;
+  P.crt = params->cluster_radius_threshold;
+  P.ndc = (uint32_t)params->number_detection_channels;
+  P.secondary_max = (uint32_t)params->secondary_max;
+  {
+    const double R = params->descriptor_radius, rd = params->descriptor_radius / 5.0;
+    P.r2_search = (float)(R * R);  // 3DSC hands its radii to the tree as doubles
+    P.r2_density = (float)(rd * rd);
+    const double rs = (R + rd) * 1.0001 + 1e-4;  // conservative superset radius of the support set
+    P.r2_support = (float)(rs * rs);
+  }
+  P.estimate_descriptors = params->estimate_descriptors;
+  P.max_points = L.max_points;
+  P.max_ring_cands = L.max_ring_candidates;
+  P.max_candidates = L.max_candidates;
+  P.max_keypoints = L.max_keypoints;
+  P.max_total_kp = L.max_total_keypoints;
+  P.max_kpc = L.max_kpc_points;
+  P.max_neighbors = L.max_neighbors;
+  P.max_ring_points = L.max_ring_points;
+
+  fx_status st = FX_OK;
+  auto bail = [&](fx_status s) {
+    fx_destroy(c);
+    return s;
+  };
+#define FX_A(expr)                     \
+  st = (expr);                         \
+  if (st != FX_OK) return bail(st)
+
+  const size_t B = L.max_batch, R = (size_t)params->n_rings;
+  FxBuffers &b = c->buf;
+  std::memset(&b, 0, sizeof(b));
+  FX_A(dev_alloc(c, &c->d_meta, B));
+  b.meta = c->d_meta;
+  float2 *d_win = nullptr;
+  FX_A(dev_alloc(c, &d_win, R));
+  b.ring_win = d_win;
+  FxScTables *d_tab = nullptr;
+  FX_A(dev_alloc(c, &d_tab, 1));
+  b.tables = d_tab;
+  float2 *d_xa = nullptr;
+  FX_A(dev_alloc(c, &d_xa, L.max_keypoints));
+  b.xaxis = d_xa;
+  FX_A(dev_alloc(c, &b.filt, B * L.max_points));
+  FX_A(dev_alloc(c, &b.n_filt, B));
+  FX_A(dev_alloc(c, &b.ring_cand, B * R * L.max_ring_candidates));
+  FX_A(dev_alloc(c, &b.ring_cand_size, B * R * L.max_ring_candidates));
+  FX_A(dev_alloc(c, &b.ring_cand_cnt, B * R));
+  FX_A(dev_alloc(c, &b.kpc_pool, B * L.max_kpc_points));
+  FX_A(dev_alloc(c, &b.kpc_pool_cand, B * L.max_kpc_points));
+  FX_A(dev_alloc(c, &b.kpc_used, B));
+  FX_A(dev_alloc(c, &b.kpc_ring_off, B * R));
+  FX_A(dev_alloc(c, &b.kpc_ring_cnt, B * R));
+  FX_A(dev_alloc(c, &b.cand, B * L.max_candidates));
+  FX_A(dev_alloc(c, &b.cand_size, B * L.max_candidates));
+  FX_A(dev_alloc(c, &b.cand_kp, B * L.max_candidates));
+  FX_A(dev_alloc(c, &b.n_cand, B));
+  FX_A(dev_alloc(c, &b.keypoints, B * L.max_keypoints));
+  FX_A(dev_alloc(c, &b.kp_size, B * L.max_keypoints));
+  FX_A(dev_alloc(c, &b.kp_nbrs, B * L.max_keypoints));
+  FX_A(dev_alloc(c, &b.rng_ord, B * L.max_keypoints));
+  FX_A(dev_alloc(c, &b.n_kp, B));
+  FX_A(dev_alloc(c, &b.kp_offset, B + 1));
+  FX_A(dev_alloc(c, &b.kpc, B * L.max_kpc_points));
+  FX_A(dev_alloc(c, &b.kpc_cand, B * L.max_kpc_points));
+  FX_A(dev_alloc(c, &b.n_kpc, B));
+  FX_A(dev_alloc(c, &b.desc, (size_t)L.max_total_keypoints * FX_DESC_FLOATS));
+  FX_A(dev_alloc(c, &b.flags, B));
+  FX_A(dev_alloc(c, &b.big_rings, B * R));
+  FX_A(dev_alloc(c, &b.big_merge, B));
+  FX_A(dev_alloc(c, &b.big_desc, L.max_total_keypoints));
+  FX_A(dev_alloc(c, &b.counters, 8));
+
+  // ---- tables
+  {
+    std::vector<float2> win(R);
+    const double half = params->el_step_deg / 2.0;
+    for (size_t i = 0; i < R; ++i) {
+      // ref: node.cpp:200-201: centre (i-7)*2-1, limits centre -+ 1.0, narrowed to float by PassThrough
+      const double centre = params->el0_deg + (double)i * params->el_step_deg;
+      win[i].x = (float)(centre - half);
+      win[i].y = (float)(centre + half);
+    }
+    if (hipMemcpy(d_win, win.data(), R * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess)
+      return bail(fail(FX_ERR_HIP, "upload ring windows"));
+    FxScTables T;
+    std::vector<float> lut(FX_DESC_BINS);
+    fx_sc3d_tables(params->descriptor_radius, T.radii, T.theta, T.phi, lut.data());
+    for (int k = 0; k < 11; ++k)
+      for (int j = 0; j < 15; ++j) T.lut[k * 15 + j] = lut[k * 15 + j];  // azimuth bin 0; all azimuth bins are equal
+    if (hipMemcpy(d_tab, &T, sizeof(T), hipMemcpyHostToDevice) != hipSuccess)
+      return bail(fail(FX_ERR_HIP, "upload 3DSC tables"));
+    std::vector<float2> xa(L.max_keypoints);
+    for (uint32_t k = 0; k < L.max_keypoints; ++k) {
+      float xy[2];
+      fx_sc3d_xaxis(k, xy);
+      xa[k].x = xy[0];
+      xa[k].y = xy[1];
+    }
+    if (hipMemcpy(d_xa, xa.data(), xa.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess)
+      return bail(fail(FX_ERR_HIP, "upload 3DSC x-axes"));
+  }
+  for (int i = 0; i < kMetaSlots; ++i) {
+    FX_A(host_alloc(c, &c->h_meta[i], B));
+    if (hipEventCreateWithFlags(&c->meta_ev[i], hipEventDisableTiming) != hipSuccess)
+      return bail(fail(FX_ERR_HIP, "hipEventCreate"));
+  }
+  for (int i = 0; i <= FX_N_STAGES; ++i)
+    if (hipEventCreate(&c->ev[i]) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipEventCreate"));
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess)
+    return bail(fail(FX_ERR_HIP, "hipStreamCreate"));
+  c->stream = c->own_stream;
+  {
+    hipError_t ce = fxk_configure(fxk_ring_lds_bytes(L.max_ring_points), fxk_merge_lds_bytes(L.max_candidates, params->n_rings),
+                                  fxk_desc_lds_bytes(L.max_neighbors));
+    if (ce != hipSuccess) return bail(fail(FX_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(ce)));
+  }
+  if (hipMemset(b.counters, 0, 8 * sizeof(uint32_t)) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
+  if (hipMemset(b.kp_offset, 0, (B + 1) * sizeof(uint32_t)) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
+  if (hipMemset(b.n_kp, 0, B * sizeof(uint32_t)) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
+#undef FX_A
+  *out = c;
+  return FX_OK;
+}
+
+void fx_destroy(fx_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+  (void)hipDeviceSynchronize();
+  for (void *p : c->dev_allocs) (void)hipFree(p);
+  for (void *p : c->host_allocs) (void)hipHostFree(p);
+  if (c->d_stage) (void)hipFree(c->d_stage);
+  for (int i = 0; i < kMetaSlots; ++i)
+    if (c->meta_ev[i]) (void)hipEventDestroy(c->meta_ev[i]);
+  for (int i = 0; i <= FX_N_STAGES; ++i)
+    if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+fx_status fx_set_stream(fx_ctx *c, void *hip_stream) {
+  if (!c) return fail(FX_ERR_INVALID_ARG, "null ctx");
+  c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+  return FX_OK;
+}
+fx_status fx_set_profiling(fx_ctx *c, int enabled) {
+  if (!c) return fail(FX_ERR_INVALID_ARG, "null ctx");
+  c->profiling = enabled != 0;
+  c->ev_valid = false;
+  return FX_OK;
+}
+fx_status fx_get_limits(const fx_ctx *c, fx_limits *l) {
+  if (!c || !l) return fail(FX_ERR_INVALID_ARG, "null argument");
+  *l = c->lim;
+  return FX_OK;
+}
+fx_status fx_get_timings(fx_ctx *c, fx_timings *t) {
+  if (!c || !t) return fail(FX_ERR_INVALID_ARG, "null argument");
+  std::memset(t, 0, sizeof(*t));
+  if (!c->ev_valid) return fail(FX_ERR_INVALID_ARG, "no profiled batch (fx_set_profiling first)");
+  FX_HIP(hipEventSynchronize(c->ev[FX_N_STAGES]));
+  for (int i = 0; i < FX_N_STAGES; ++i) FX_HIP(hipEventElapsedTime(&t->ms[i], c->ev[i], c->ev[i + 1]));
+  FX_HIP(hipEventElapsedTime(&t->total_ms, c->ev[0], c->ev[FX_N_STAGES]));
+  return FX_OK;
+}
+fx_status fx_synchronize(fx_ctx *c) {
+  if (!c) return fail(FX_ERR_INVALID_ARG, "null ctx");
+  FX_HIP(hipStreamSynchronize(c->stream));
+  return FX_OK;
+}
+
+fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch, uint32_t flags, fx_batch_view *out) {
+  if (!c || (!scans && batch) || !out) return fail(FX_ERR_INVALID_ARG, "null argument");
+  if (batch > c->lim.max_batch) return fail(FX_ERR_TOO_LARGE, "batch > max_batch");
+  FX_HIP(hipSetDevice(c->device));
+  const fx_limits &L = c->lim;
+  hipStream_t s = c->stream;
+
+  // ---- scan table
+  const int slot = c->meta_next;
+  c->meta_next = (c->meta_next + 1) % kMetaSlots;
+  if (c->meta_used[slot]) FX_HIP(hipEventSynchronize(c->meta_ev[slot]));
+  FxScanMeta *hm = c->h_meta[slot];
+  const bool in_dev = (flags & FX_IN_DEVICE) != 0;
+  for (uint32_t i = 0; i < batch; ++i) {
+    const fx_scan_desc &d = scans[i];
+    if (d.n_points > L.max_points) return fail(FX_ERR_TOO_LARGE, "scan has more points than max_points");
+    if (d.n_points && !d.points) return fail(FX_ERR_INVALID_ARG, "scan with null points");
+    if (d.stride_bytes < 16 || (d.stride_bytes % 16) != 0) return fail(FX_ERR_INVALID_ARG, "stride_bytes must be a multiple of 16");
+    if (((uintptr_t)d.points % 16) != 0) return fail(FX_ERR_INVALID_ARG, "points must be 16-byte aligned");
+    hm[i].n = d.n_points;
+    hm[i].pad_ = 0;
+    fx_rotation_from_roll_pitch(d.roll, d.pitch, hm[i].R);
+    if (in_dev) {
+      hm[i].pts = (const float *)d.points;
+      hm[i].stride_f = d.stride_bytes / 4;
+    }
+  }
+  if (!in_dev && batch) {
+    if (!c->d_stage) {
+      void *q = nullptr;
+      hipError_t e = hipMalloc(&q, (size_t)L.max_batch * L.max_points * 16);
+      if (e != hipSuccess) return fail(FX_ERR_OOM, std::string("staging hipMalloc: ") + hipGetErrorString(e));
+      c->d_stage = (float *)q;
+    }
+    for (uint32_t i = 0; i < batch; ++i) {
+      const fx_scan_desc &d = scans[i];
+      float *dst = c->d_stage + (size_t)i * L.max_points * 4;
+      hm[i].pts = dst;
+      hm[i].stride_f = 4;
+      if (!d.n_points) continue;
+      if (d.stride_bytes == 16) {
+        FX_HIP(hipMemcpyAsync(dst, d.points, (size_t)d.n_points * 16, hipMemcpyHostToDevice, s));
+      } else {
+        c->repack.resize((size_t)d.n_points * 4);
+        const uint8_t *src = (const uint8_t *)d.points;
+        for (uint32_t p = 0; p < d.n_points; ++p) std::memcpy(&c->repack[(size_t)p * 4], src + (size_t)p * d.stride_bytes, 16);
+        FX_HIP(hipMemcpy(dst, c->repack.data(), (size_t)d.n_points * 16, hipMemcpyHostToDevice));
+      }
+    }
+  }
+  if (batch) FX_HIP(hipMemcpyAsync(c->d_meta, hm, (size_t)batch * sizeof(FxScanMeta), hipMemcpyHostToDevice, s));
+  FX_HIP(hipEventRecord(c->meta_ev[slot], s));
+  c->meta_used[slot] = true;
+
+  // ---- kernels
+  const FxDevParams &P = c->dp;
+  const FxBuffers &B = c->buf;
+  const bool prof = c->profiling;
+  const uint32_t big_grid = (uint32_t)c->n_cu;
+  if (prof) FX_HIP(hipEventRecord(c->ev[0], s));
+  FX_HIP(hipMemsetAsync(B.counters, 0, 8 * sizeof(uint32_t), s));
+  if (batch) {
+    fxk_prep(s, P, B, batch);
+    if (prof) FX_HIP(hipEventRecord(c->ev[1], s));
+    const uint32_t ring_small = L.max_ring_points < kRingCapSmall ? L.max_ring_points : kRingCapSmall;
+    fxk_rings(s, P, B, batch, ring_small, L.max_ring_points, big_grid);
+    if (prof) FX_HIP(hipEventRecord(c->ev[2], s));
+    const uint32_t merge_small = L.max_candidates < kMergeCapSmall ? L.max_candidates : kMergeCapSmall;
+    fxk_merge(s, P, B, batch, merge_small, L.max_candidates, big_grid);
+    if (prof) FX_HIP(hipEventRecord(c->ev[3], s));
+    fxk_offsets(s, P, B, batch);
+    if (prof) FX_HIP(hipEventRecord(c->ev[4], s));
+    if (P.estimate_descriptors) {
+      const uint32_t desc_small = L.max_neighbors < kDescCapSmall ? L.max_neighbors : kDescCapSmall;
+      const uint32_t grid = (uint32_t)c->n_cu * 16u;
+      fxk_desc(s, P, B, batch, desc_small, L.max_neighbors, grid, big_grid, 0);
+      fxk_rng_ord(s, P, B, batch);
+      fxk_desc(s, P, B, batch, desc_small, L.max_neighbors, grid, big_grid, 1);
+    }
+    if (prof) FX_HIP(hipEventRecord(c->ev[5], s));
+    if (prof) FX_HIP(hipEventRecord(c->ev[6], s));
+    FX_HIP(hipGetLastError());
+  } else if (prof) {
+    for (int i = 1; i <= FX_N_STAGES; ++i) FX_HIP(hipEventRecord(c->ev[i], s));
+  }
+  c->ev_valid = prof;
+  c->last_batch = batch;
+
+  // ---- view
+  std::memset(out, 0, sizeof(*out));
+  out->batch = batch;
+  out->max_points = L.max_points;
+  out->max_keypoints = L.max_keypoints;
+  out->max_candidates = L.max_candidates;
+  out->max_kpc_points = L.max_kpc_points;
+  out->d_n_keypoints = B.n_kp;
+  out->d_kp_offset = B.kp_offset;
+  out->d_keypoints = (const float *)B.keypoints;
+  out->d_descriptors = B.desc;
+  out->d_flags = B.flags;
+  out->d_n_filtered = B.n_filt;
+  out->d_filtered = (const float *)B.filt;
+  out->d_n_kpc = B.n_kpc;
+  out->d_kpc = (const float *)B.kpc;
+
+  if (!(flags & FX_OUT_HOST)) return FX_OK;
+  const size_t Bm = L.max_batch;
+  FX_TRY(host_alloc(c, &c->h_n_kp, Bm));
+  FX_TRY(host_alloc(c, &c->h_kp_offset, Bm + 1));
+  FX_TRY(host_alloc(c, &c->h_flags, Bm));
+  FX_TRY(host_alloc(c, &c->h_n_filt, Bm));
+  FX_TRY(host_alloc(c, &c->h_n_kpc, Bm));
+  FX_TRY(host_alloc(c, &c->h_keypoints, Bm * L.max_keypoints * 4));
+  FX_TRY(host_alloc(c, &c->h_desc, (size_t)L.max_total_keypoints * FX_DESC_FLOATS));
+  if (batch) {
+    FX_HIP(hipMemcpyAsync(c->h_n_kp, B.n_kp, batch * 4, hipMemcpyDeviceToHost, s));
+    FX_HIP(hipMemcpyAsync(c->h_kp_offset, B.kp_offset, (batch + 1) * 4, hipMemcpyDeviceToHost, s));
+    FX_HIP(hipMemcpyAsync(c->h_flags, B.flags, batch * 4, hipMemcpyDeviceToHost, s));
+    FX_HIP(hipMemcpyAsync(c->h_n_filt, B.n_filt, batch * 4, hipMemcpyDeviceToHost, s));
+    FX_HIP(hipMemcpyAsync(c->h_n_kpc, B.n_kpc, batch * 4, hipMemcpyDeviceToHost, s));
+    FX_HIP(hipMemcpyAsync(c->h_keypoints, B.keypoints, (size_t)batch * L.max_keypoints * 16, hipMemcpyDeviceToHost, s));
+  } else {
+    c->h_kp_offset[0] = 0;
+  }
+  FX_HIP(hipStreamSynchronize(s));
+  uint32_t total = batch ? c->h_kp_offset[batch] : 0;
+  if (total > L.max_total_keypoints) total = L.max_total_keypoints;
+  out->total_keypoints = total;
+  if (total && P.estimate_descriptors)
+    FX_HIP(hipMemcpyAsync(c->h_desc, B.desc, (size_t)total * FX_DESC_FLOATS * 4, hipMemcpyDeviceToHost, s));
+  if (flags & FX_OUT_CLOUDS) {
+    FX_TRY(host_alloc(c, &c->h_filtered, Bm * L.max_points * 4));
+    FX_TRY(host_alloc(c, &c->h_kpc, Bm * L.max_kpc_points * 4));
+    for (uint32_t i = 0; i < batch; ++i) {
+      if (c->h_n_filt[i])
+        FX_HIP(hipMemcpyAsync(c->h_filtered + (size_t)i * L.max_points * 4, B.filt + (size_t)i * L.max_points,
+                              (size_t)c->h_n_filt[i] * 16, hipMemcpyDeviceToHost, s));
+      if (c->h_n_kpc[i])
+        FX_HIP(hipMemcpyAsync(c->h_kpc + (size_t)i * L.max_kpc_points * 4, B.kpc + (size_t)i * L.max_kpc_points,
+                              (size_t)c->h_n_kpc[i] * 16, hipMemcpyDeviceToHost, s));
+    }
+    out->h_filtered = c->h_filtered;
+    out->h_kpc = c->h_kpc;
+  }
+  if (flags & FX_OUT_DEBUG) {
+    FX_TRY(host_alloc(c, &c->h_n_cand, Bm));
+    FX_TRY(host_alloc(c, &c->h_cand, Bm * L.max_candidates * 4));
+    FX_TRY(host_alloc(c, &c->h_cand_size, Bm * L.max_candidates));
+    FX_TRY(host_alloc(c, &c->h_cand_kp, Bm * L.max_candidates));
+    FX_TRY(host_alloc(c, &c->h_kpc_cand, Bm * L.max_kpc_points));
+    FX_TRY(host_alloc(c, &c->h_kp_size, Bm * L.max_keypoints));
+    FX_TRY(host_alloc(c, &c->h_kp_nbrs, Bm * L.max_keypoints));
+    if (batch) {
+      FX_HIP(hipMemcpyAsync(c->h_n_cand, B.n_cand, batch * 4, hipMemcpyDeviceToHost, s));
+      FX_HIP(hipMemcpyAsync(c->h_cand, B.cand, (size_t)batch * L.max_candidates * 16, hipMemcpyDeviceToHost, s));
+      FX_HIP(hipMemcpyAsync(c->h_cand_size, B.cand_size, (size_t)batch * L.max_candidates * 4, hipMemcpyDeviceToHost, s));
+      FX_HIP(hipMemcpyAsync(c->h_cand_kp, B.cand_kp, (size_t)batch * L.max_candidates * 4, hipMemcpyDeviceToHost, s));
+      FX_HIP(hipMemcpyAsync(c->h_kpc_cand, B.kpc_cand, (size_t)batch * L.max_kpc_points * 4, hipMemcpyDeviceToHost, s));
+      FX_HIP(hipMemcpyAsync(c->h_kp_size, B.kp_size, (size_t)batch * L.max_keypoints * 4, hipMemcpyDeviceToHost, s));
+      FX_HIP(hipMemcpyAsync(c->h_kp_nbrs, B.kp_nbrs, (size_t)batch * L.max_keypoints * 4, hipMemcpyDeviceToHost, s));
+    }
+    out->h_n_candidates = c->h_n_cand;
+    out->h_candidates = c->h_cand;
+    out->h_cand_size = c->h_cand_size;
+    out->h_cand_keypoint = c->h_cand_kp;
+    out->h_kpc_cand = c->h_kpc_cand;
+    out->h_kp_size = c->h_kp_size;
+    out->h_kp_neighbors = c->h_kp_nbrs;
+  }
+  FX_HIP(hipStreamSynchronize(s));
+  out->h_n_keypoints = c->h_n_kp;
+  out->h_kp_offset = c->h_kp_offset;
+  out->h_keypoints = c->h_keypoints;
+  out->h_descriptors = c->h_desc;
+  out->h_flags = c->h_flags;
+  out->h_n_filtered = c->h_n_filt;
+  out->h_n_kpc = c->h_n_kpc;
+  return FX_OK;
+}
+
+fx_status fx_pack_features(fx_ctx *c, void *dst_device, uint32_t capacity_records) {
+  if (!c || !dst_device) return fail(FX_ERR_INVALID_ARG, "null argument");
+  FX_HIP(hipSetDevice(c->device));
+  fxk_pack_features(c->stream, c->dp, c->buf, c->last_batch, dst_device, capacity_records, (uint32_t)c->n_cu * 8u);
+  FX_HIP(hipGetLastError());
+  return FX_OK;
+}
+
+}  // extern "C"

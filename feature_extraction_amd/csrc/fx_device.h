@@ -1,0 +1,86 @@
+// fx_device.h — structures shared by the host driver and the gfx950 kernels.
+#ifndef FX_DEVICE_H_
+#define FX_DEVICE_H_
+#include <stdint.h>
+
+// One scan of the batch as the kernels see it.
+struct FxScanMeta {
+  const float *pts;   // device pointer, records of stride_f floats, x y z at 0 1 2
+  uint32_t n;         // points in the scan
+  uint32_t stride_f;  // record stride in floats (4 or 8)
+  float R[9];         // rotateCloud matrix, row major (ref: node.cpp:161-165)
+  uint32_t pad_;
+};
+
+// Per-context constants (narrowed exactly where PCL narrows them, see fx_api.cpp).
+struct FxDevParams {
+  // filterCloud limits as PassThrough stores them (float) (ref: node.cpp:169-183)
+  float x_min, x_max, y_min, y_max, z_min, z_max;
+  int32_t n_rings;
+  // getCylinderSegments (ref: node.cpp:269-276, 314-316)
+  float r2_cluster;
+  uint32_t min_count, max_count;
+  double gate_diameter;  // 2 * cluster_radius_threshold
+  // secondary merge (ref: node.cpp:217, 222-229)
+  double crt;
+  float r2_merge;
+  uint32_t ndc, secondary_max;
+  // 3DSC (ref: node.cpp:350-352)
+  float r2_search, r2_density, r2_support;
+  int32_t estimate_descriptors;
+  // capacities
+  uint32_t max_points, max_ring_cands, max_candidates, max_keypoints, max_total_kp, max_kpc, max_neighbors,
+      max_ring_points;
+};
+
+// 3DSC tables in device memory (built on the host by fx_sc3d_tables / fx_sc3d_xaxis).
+struct FxScTables {
+  float radii[16];
+  float theta[12];
+  float phi[13];
+  float lut[165];  // [k*15 + j]; identical for every azimuth bin
+};
+
+// Every device buffer of a context.
+struct FxBuffers {
+  const FxScanMeta *meta;
+  const float2 *ring_win;  // [n_rings] (lo, hi) as float, inclusive
+  const FxScTables *tables;
+  const float2 *xaxis;  // [max_keypoints]
+  // stage 1
+  float4 *filt;          // [B][max_points]
+  uint32_t *n_filt;      // [B]
+  // stage 2
+  float4 *ring_cand;        // [B][n_rings][max_ring_cands]
+  uint32_t *ring_cand_size; // same shape
+  uint32_t *ring_cand_cnt;  // [B][n_rings]
+  float4 *kpc_pool;         // [B][max_kpc]
+  uint32_t *kpc_pool_cand;  // [B][max_kpc]  ring-local candidate slot
+  uint32_t *kpc_used;       // [B]
+  uint32_t *kpc_ring_off;   // [B][n_rings]
+  uint32_t *kpc_ring_cnt;   // [B][n_rings]
+  // stage 3
+  float4 *cand;           // [B][max_candidates]
+  uint32_t *cand_size;    // [B][max_candidates]
+  int32_t *cand_kp;       // [B][max_candidates]
+  uint32_t *n_cand;       // [B]
+  float4 *keypoints;      // [B][max_keypoints]
+  uint32_t *kp_size;      // [B][max_keypoints]
+  uint32_t *kp_nbrs;      // [B][max_keypoints]
+  uint32_t *rng_ord;      // [B][max_keypoints]
+  uint32_t *n_kp;         // [B]
+  uint32_t *kp_offset;    // [B+1]
+  float4 *kpc;            // [B][max_kpc]
+  uint32_t *kpc_cand;     // [B][max_kpc]
+  uint32_t *n_kpc;        // [B]
+  // stage 5
+  float *desc;            // [max_total_kp][1989]
+  uint32_t *flags;        // [B]
+  // work lists for the large-capacity tiers
+  uint32_t *big_rings;    // [B*n_rings]
+  uint32_t *big_merge;    // [B]
+  uint32_t *big_desc;     // [max_total_kp]
+  uint32_t *counters;     // [8]: 0 big_rings, 1 big_merge, 2 big_desc, 3 need_rng_fix
+};
+
+#endif

@@ -1,0 +1,1009 @@
+// fx_kernels.hip — gfx950 kernels of the per-scan detector/descriptor hot path.
+//
+// Stage map (reference: src/feature_extraction_node.cpp):
+//   k_prep     rotateCloud :159-167 + filterCloud :169-183 + getElevationAngles :147-156
+//              (elevation only for points that survive the filter: it is dead otherwise)
+//   k_rings    estimateKeypoints ring loop :195-207 + getCylinderSegments :261-327
+//   k_merge    secondary merge :209-257 (+ ring-order assembly of keypoints_full / keypoint_cloud)
+//   k_offsets  batch-wide keypoint offsets
+//   k_desc     estimateDescriptors :329-355 == pcl::ShapeContext3DEstimation
+//
+// Numerics contract: every result-bearing float expression is evaluated in the operation
+// order PCL / FLANN / Eigen use and is never contracted into an FMA (this TU is built with
+// -ffp-contract=off and carries the pragma below); fp32 divide / sqrt are the correctly
+// rounded hipcc defaults.  Integer results (membership, sizes, orders) are exact.
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <math.h>
+
+#include "fx_device.h"
+#include "fx_sort_replay.h"
+#include "../../include/fx.h"
+
+#pragma clang fp contract(off)
+
+#define FX_WG 256
+#define FX_NWAVE (FX_WG / 64)
+
+namespace {
+
+// ------------------------------------------------------------------ wave / block helpers
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// Stable rank of the threads whose pred is true (order = thread index); total = number of them.
+// s_w: FX_NWAVE words of LDS scratch.  Contains two barriers.
+__device__ __forceinline__ uint32_t block_rank(bool pred, uint32_t *s_w, uint32_t &total) {
+  const unsigned long long m = __ballot(pred);
+  const uint32_t wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) s_w[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < FX_NWAVE; ++w) {
+    const uint32_t c = s_w[w];
+    base += (w < (int)wave) ? c : 0u;
+    tot += c;
+  }
+  __syncthreads();
+  total = tot;
+  return base + lanes_below(m);
+}
+
+// Exclusive prefix sum of v over the block in thread order; total = block sum.
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_w, uint32_t &total) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t t = __shfl_up(inc, d, 64);
+    if ((int)lane >= d) inc += t;
+  }
+  if (lane == 63) s_w[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < FX_NWAVE; ++w) {
+    const uint32_t c = s_w[w];
+    base += (w < (int)wave) ? c : 0u;
+    tot += c;
+  }
+  __syncthreads();
+  total = tot;
+  return base + inc - v;
+}
+
+// FLANN L2_Simple<float> over (x,y,z): ((dx*dx) + dy*dy) + dz*dz with d = query - point.
+__device__ __forceinline__ float dist2(float qx, float qy, float qz, float px, float py, float pz) {
+  const float dx = qx - px, dy = qy - py, dz = qz - pz;
+  float r = dx * dx;
+  r = r + dy * dy;
+  r = r + dz * dz;
+  return r;
+}
+
+// ------------------------------------------------------------------ union-find in LDS
+// Links always go from the larger root to the smaller one, so a component's root is its
+// smallest member index — PCL's "indices[0]" and its discovery order.
+__device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t i) {
+  volatile uint32_t *p = parent;
+  uint32_t q = p[i];
+  while (q != i) {
+    i = q;
+    q = p[i];
+  }
+  return i;
+}
+__device__ __forceinline__ void uf_union(uint32_t *parent, uint32_t a, uint32_t b) {
+  while (true) {
+    a = uf_find(parent, a);
+    b = uf_find(parent, b);
+    if (a == b) return;
+    if (a < b) {
+      const uint32_t t = a;
+      a = b;
+      b = t;
+    }
+    const uint32_t old = atomicMin(&parent[a], b);
+    if (old == a) return;
+    a = old;  // a stopped being a root meanwhile: its former parent must join b's set too
+  }
+}
+
+// Connected components of {d2(i,j) < r2} over n points held in LDS.  On return parent[i] is
+// the smallest index of i's component and csize[root] the component size.
+__device__ void cc_label(const float *px, const float *py, const float *pz, uint32_t n, float r2, uint32_t *parent,
+                         uint32_t *csize) {
+  for (uint32_t i = threadIdx.x; i < n; i += FX_WG) {
+    parent[i] = i;
+    csize[i] = 0;
+  }
+  __syncthreads();
+  // all pairs, folded so that every thread sees about n/2 partners: rows i and n-1-i
+  const uint32_t half = (n + 1) / 2;
+  for (uint32_t t = threadIdx.x; t < half; t += FX_WG) {
+    for (int pass = 0; pass < 2; ++pass) {
+      const uint32_t i = pass == 0 ? t : n - 1 - t;
+      if (pass == 1 && i == t) break;
+      const float qx = px[i], qy = py[i], qz = pz[i];
+      for (uint32_t j = i + 1; j < n; ++j) {
+        const float d = dist2(qx, qy, qz, px[j], py[j], pz[j]);
+        if (d < r2) uf_union(parent, j, i);
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n; i += FX_WG) {
+    const uint32_t r = uf_find(parent, i);
+    parent[i] = r;  // still a valid ancestor for concurrent finds
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n; i += FX_WG) atomicAdd(&csize[parent[i]], 1u);
+  __syncthreads();
+}
+
+// Size-admissible components in discovery order (ascending smallest index), then PCL's
+// final std::sort replayed by one lane.  crec[s] = (size << 16) | discovery ordinal, in the
+// order PCL returns the clusters; croot[ordinal] = root index.  Returns the cluster count.
+__device__ uint32_t cc_order(uint32_t n, const uint32_t *parent, const uint32_t *csize, uint32_t min_sz,
+                             uint32_t max_sz, uint32_t *croot, uint32_t *crec, uint32_t *s_w) {
+  uint32_t n_c = 0;
+  for (uint32_t b0 = 0; b0 < n; b0 += FX_WG) {
+    const uint32_t i = b0 + threadIdx.x;
+    bool acc = false;
+    uint32_t sz = 0;
+    if (i < n && parent[i] == i) {
+      sz = csize[i];
+      acc = sz >= min_sz && sz <= max_sz;
+    }
+    uint32_t tot;
+    const uint32_t r = block_rank(acc, s_w, tot);
+    if (acc) {
+      const uint32_t c = n_c + r;
+      croot[c] = i;
+      crec[c] = (sz << 16) | c;
+    }
+    n_c += tot;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) fx_sort_replay_desc(crec, n_c);
+  __syncthreads();
+  return n_c;
+}
+
+}  // namespace
+
+// ====================================================================== stage 1: prep
+// One workgroup per scan streams the scan once: rotate (fp32, PCL's scalar order), apply
+// the three PassThrough predicates at once, compact the survivors in input order (wave
+// ballot + prefix), and compute the elevation angle (fp64) for survivors only.
+#define FX_PREP_T 512
+#define FX_PREP_U 4
+__global__ __launch_bounds__(FX_PREP_T) void k_prep(FxDevParams P, FxBuffers B) {
+  const uint32_t scan = blockIdx.x;
+  const FxScanMeta M = B.meta[scan];
+  __shared__ uint32_t s_cnt[FX_PREP_U * (FX_PREP_T / 64)];
+  float4 *out = B.filt + (size_t)scan * P.max_points;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = FX_PREP_T / 64;
+  uint32_t base = 0;
+  const uint32_t n = M.n;
+  for (uint32_t t0 = 0; t0 < n; t0 += FX_PREP_T * FX_PREP_U) {
+    float4 v[FX_PREP_U];
+#pragma unroll
+    for (int u = 0; u < FX_PREP_U; ++u) {
+      const uint32_t i = t0 + u * FX_PREP_T + tid;
+      if (i < n)
+        v[u] = *reinterpret_cast<const float4 *>(M.pts + (size_t)i * M.stride_f);
+      else
+        v[u] = make_float4(NAN, NAN, NAN, 0.f);
+    }
+    float rx[FX_PREP_U], ry[FX_PREP_U], rz[FX_PREP_U];
+    bool keep[FX_PREP_U];
+    unsigned long long mask[FX_PREP_U];
+#pragma unroll
+    for (int u = 0; u < FX_PREP_U; ++u) {
+      const float x = v[u].x, y = v[u].y, z = v[u].z;
+      // pcl::transformPointCloud, dense branch: ((m0 x + m1 y) + m2 z) + t, t = 0
+      rx[u] = ((M.R[0] * x + M.R[1] * y) + M.R[2] * z) + 0.0f;
+      ry[u] = ((M.R[3] * x + M.R[4] * y) + M.R[5] * z) + 0.0f;
+      rz[u] = ((M.R[6] * x + M.R[7] * y) + M.R[8] * z) + 0.0f;
+      bool k = isfinite(rx[u]) && isfinite(ry[u]) && isfinite(rz[u]);
+      k = k && !(rz[u] < P.z_min || rz[u] > P.z_max);
+      k = k && !(ry[u] < P.y_min || ry[u] > P.y_max);
+      k = k && !(rx[u] < P.x_min || rx[u] > P.x_max);
+      keep[u] = k;
+      mask[u] = __ballot(k);
+      if (lane == 0) s_cnt[u * NW + wave] = (uint32_t)__popcll(mask[u]);
+    }
+    __syncthreads();
+    // output slot = survivors before this tile + survivors of earlier slices of the tile
+    //             + survivors of earlier waves in my slice + earlier lanes of my wave
+    uint32_t tile_total = 0;
+    uint32_t my_base[FX_PREP_U];
+#pragma unroll
+    for (int u = 0; u < FX_PREP_U; ++u) {
+      uint32_t before = 0, slice = 0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const uint32_t c = s_cnt[u * NW + w];
+        before += (w < (int)wave) ? c : 0u;
+        slice += c;
+      }
+      my_base[u] = tile_total + before;
+      tile_total += slice;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < FX_PREP_U; ++u) {
+      if (keep[u]) {
+        // getElevationAngles on the un-rotated point: atan2(z, |xy|) in degrees, fp64 -> fp32.
+        // (cos(az) x + sin(az) y equals |xy| to within fp64 rounding)
+        const double x = v[u].x, y = v[u].y, z = v[u].z;
+        const double el = atan2(z, sqrt(x * x + y * y)) * 180 / M_PI;
+        const uint32_t pos = base + my_base[u] + lanes_below(mask[u]);
+        out[pos] = make_float4(rx[u], ry[u], rz[u], (float)el);
+      }
+    }
+    base += tile_total;
+  }
+  if (tid == 0) {
+    B.n_filt[scan] = base;
+    B.flags[scan] = 0u;
+    B.kpc_used[scan] = 0u;
+  }
+}
+
+// ====================================================================== stage 2: rings
+struct RingLds {
+  float *px, *py, *pz, *pe, *ccx, *ccy, *ccz, *cce;
+  uint32_t *parent, *csize, *rank, *croot, *crec, *cpos, *cslot, *ckoff, *s_w;
+};
+__device__ __forceinline__ RingLds ring_carve(uint32_t *smem, uint32_t cap) {
+  RingLds L;
+  L.s_w = smem;  // 16 words of scratch
+  uint32_t *p = smem + 16;
+  L.px = (float *)p, p += cap;
+  L.py = (float *)p, p += cap;
+  L.pz = (float *)p, p += cap;
+  L.pe = (float *)p, p += cap;
+  L.ccx = (float *)p, p += cap;
+  L.ccy = (float *)p, p += cap;
+  L.ccz = (float *)p, p += cap;
+  L.cce = (float *)p, p += cap;
+  L.parent = p, p += cap;
+  L.csize = p, p += cap;
+  L.rank = p, p += cap;
+  L.croot = p, p += cap;
+  L.crec = p, p += cap;
+  L.cpos = p, p += cap;
+  L.cslot = p, p += cap;
+  L.ckoff = p, p += cap;
+  return L;
+}
+#define FX_RING_WORDS_PER_POINT 16
+
+// One (scan, ring): PassThrough on the elevation window (stable), Euclidean clustering,
+// centroid + diameter gate, candidates in PCL's cluster order, member points for keypoint_cloud.
+// Returns false when the ring does not fit `cap` points (caller defers it to the large tier).
+__device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t scan, uint32_t ring, uint32_t cap,
+                          uint32_t *smem, bool last_tier) {
+  RingLds L = ring_carve(smem, cap);
+  const uint32_t tid = threadIdx.x;
+  const uint32_t nf = B.n_filt[scan];
+  const float4 *f = B.filt + (size_t)scan * P.max_points;
+  const float2 win = B.ring_win[ring];
+  const size_t ring_slot = (size_t)scan * P.n_rings + ring;
+
+  // ---- ring split (ref: node.cpp:200-202): keep iff lo <= elevation <= hi, input order
+  uint32_t n = 0;
+  for (uint32_t b0 = 0; b0 < nf; b0 += FX_WG) {
+    const uint32_t i = b0 + tid;
+    bool in = false;
+    float4 v = make_float4(0, 0, 0, 0);
+    if (i < nf) {
+      v = f[i];
+      in = isfinite(v.w) && !(v.w < win.x || v.w > win.y);
+    }
+    uint32_t tot;
+    const uint32_t r = block_rank(in, L.s_w, tot);
+    if (in) {
+      const uint32_t pos = n + r;
+      if (pos < cap) {
+        L.px[pos] = v.x;
+        L.py[pos] = v.y;
+        L.pz[pos] = v.z;
+        L.pe[pos] = v.w;
+      }
+    }
+    n += tot;
+  }
+  if (n > cap) {
+    if (!last_tier) return false;
+    if (tid == 0) {
+      atomicOr(&B.flags[scan], FX_FLAG_RING_OVERFLOW);
+      B.ring_cand_cnt[ring_slot] = 0;
+      B.kpc_ring_off[ring_slot] = 0;
+      B.kpc_ring_cnt[ring_slot] = 0;
+    }
+    return true;
+  }
+  __syncthreads();
+  if (n == 0) {  // ref: node.cpp:263-264
+    if (tid == 0) {
+      B.ring_cand_cnt[ring_slot] = 0;
+      B.kpc_ring_off[ring_slot] = 0;
+      B.kpc_ring_cnt[ring_slot] = 0;
+    }
+    return true;
+  }
+
+  // ---- pcl::EuclideanClusterExtraction (ref: node.cpp:269-276)
+  cc_label(L.px, L.py, L.pz, n, P.r2_cluster, L.parent, L.csize);
+  const uint32_t n_c = cc_order(n, L.parent, L.csize, P.min_count, P.max_count, L.croot, L.crec, L.s_w);
+
+  // ---- per cluster, in PCL's order: fp64 sums in ascending member order, bounding box,
+  //      diameter gate, centroid (ref: node.cpp:282-325)
+  for (uint32_t s = tid; s < n_c; s += FX_WG) {
+    const uint32_t rec = L.crec[s];
+    const uint32_t sz = rec >> 16, root = L.croot[rec & 0xffffu];
+    L.cpos[root] = s;
+    double sumx = 0.0, sumy = 0.0, sumz = 0.0;
+    double minx = 1000.0, maxx = -1000.0, miny = 1000.0, maxy = -1000.0;
+    uint32_t cnt = 0;
+    for (uint32_t i = root; i < n && cnt < sz; ++i) {
+      if (L.parent[i] != root) continue;
+      const double x = L.px[i], y = L.py[i], z = L.pz[i];
+      sumx += x;
+      sumy += y;
+      sumz += z;
+      if (x < minx) minx = x;
+      if (y < miny) miny = y;
+      if (x > maxx) maxx = x;
+      if (y > maxy) maxy = y;
+      L.rank[i] = cnt++;
+    }
+    const double ddx = maxx - minx, ddy = maxy - miny;
+    const double diameter = sqrt(ddx * ddx + ddy * ddy);
+    const bool pass = diameter < P.gate_diameter;
+    L.ccx[s] = (float)(sumx / (double)sz);
+    L.ccy[s] = (float)(sumy / (double)sz);
+    L.ccz[s] = (float)(sumz / (double)sz);
+    L.cce[s] = L.pe[root];
+    L.cslot[s] = pass ? 1u : 0u;
+  }
+  __syncthreads();
+
+  // ---- slots of the gate-passing clusters and offsets of their member runs
+  uint32_t n_pass = 0, n_mem = 0;
+  for (uint32_t b0 = 0; b0 < n_c; b0 += FX_WG) {
+    const uint32_t s = b0 + tid;
+    const bool pass = s < n_c && L.cslot[s] != 0u;
+    const uint32_t sz = pass ? (L.crec[s] >> 16) : 0u;
+    uint32_t tot_p, tot_m;
+    const uint32_t slot = block_rank(pass, L.s_w, tot_p);
+    const uint32_t koff = block_excl_scan(sz, L.s_w, tot_m);
+    if (s < n_c) {
+      L.cslot[s] = pass ? (n_pass + slot) : 0xffffffffu;
+      L.ckoff[s] = n_mem + koff;
+    }
+    n_pass += tot_p;
+    n_mem += tot_m;
+  }
+  __syncthreads();
+
+  // ---- candidates of this ring (cylinderCentroids, ref: node.cpp:322)
+  float4 *rc = B.ring_cand + ring_slot * P.max_ring_cands;
+  uint32_t *rcs = B.ring_cand_size + ring_slot * P.max_ring_cands;
+  for (uint32_t s = tid; s < n_c; s += FX_WG) {
+    const uint32_t slot = L.cslot[s];
+    if (slot < P.max_ring_cands) {
+      rc[slot] = make_float4(L.ccx[s], L.ccy[s], L.ccz[s], L.cce[s]);
+      rcs[slot] = L.crec[s] >> 16;
+    }
+  }
+  // ---- member points (cylinderCloud, ref: node.cpp:310, 323) into a chunk of the scan's pool;
+  //      k_merge puts the chunks into ring order.
+  if (tid == 0) {
+    uint32_t off = 0, cnt = n_mem;
+    if (n_pass > P.max_ring_cands) atomicOr(&B.flags[scan], FX_FLAG_CAND_OVERFLOW);
+    if (n_mem) {
+      off = atomicAdd(&B.kpc_used[scan], n_mem);
+      if (off + n_mem > P.max_kpc) {
+        atomicOr(&B.flags[scan], FX_FLAG_KPC_OVERFLOW);
+        cnt = 0;
+      }
+    }
+    B.ring_cand_cnt[ring_slot] = n_pass < P.max_ring_cands ? n_pass : P.max_ring_cands;
+    B.kpc_ring_off[ring_slot] = off;
+    B.kpc_ring_cnt[ring_slot] = cnt;
+    L.s_w[8] = off;
+    L.s_w[9] = cnt;
+  }
+  __syncthreads();
+  const uint32_t off = L.s_w[8];
+  if (L.s_w[9]) {
+    float4 *pool = B.kpc_pool + (size_t)scan * P.max_kpc;
+    uint32_t *pool_c = B.kpc_pool_cand + (size_t)scan * P.max_kpc;
+    for (uint32_t i = tid; i < n; i += FX_WG) {
+      const uint32_t root = L.parent[i];
+      const uint32_t sz = L.csize[root];
+      if (sz < P.min_count || sz > P.max_count) continue;
+      const uint32_t s = L.cpos[root];
+      const uint32_t slot = L.cslot[s];
+      if (slot == 0xffffffffu) continue;
+      const uint32_t dst = off + L.ckoff[s] + L.rank[i];
+      pool[dst] = make_float4(L.px[i], L.py[i], L.pz[i], L.pe[i]);
+      pool_c[dst] = slot;
+    }
+  }
+  __syncthreads();
+  return true;
+}
+
+extern "C" __global__ __launch_bounds__(FX_WG) void k_rings_small(FxDevParams P, FxBuffers B, uint32_t cap) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const uint32_t scan = blockIdx.x / P.n_rings, ring = blockIdx.x % P.n_rings;
+  if (!ring_body(P, B, scan, ring, cap, smem, false)) {
+    if (threadIdx.x == 0) {
+      const uint32_t pos = atomicAdd(&B.counters[0], 1u);
+      B.big_rings[pos] = blockIdx.x;
+    }
+  }
+}
+extern "C" __global__ __launch_bounds__(FX_WG) void k_rings_big(FxDevParams P, FxBuffers B, uint32_t cap) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const uint32_t n_big = B.counters[0];
+  for (uint32_t w = blockIdx.x; w < n_big; w += gridDim.x) {
+    const uint32_t item = B.big_rings[w];
+    ring_body(P, B, item / P.n_rings, item % P.n_rings, cap, smem, true);
+    __syncthreads();
+  }
+}
+
+// ====================================================================== stage 3: merge
+struct MergeLds {
+  float *cx, *cy, *cz, *ce, *pz;
+  uint32_t *parent, *csize, *croot, *crec, *cpos, *rbase, *s_w;
+};
+#define FX_MERGE_WORDS_PER_CAND 10
+__device__ __forceinline__ MergeLds merge_carve(uint32_t *smem, uint32_t cap, uint32_t n_rings) {
+  MergeLds L;
+  L.s_w = smem;
+  uint32_t *p = smem + 16;
+  L.cx = (float *)p, p += cap;
+  L.cy = (float *)p, p += cap;
+  L.cz = (float *)p, p += cap;
+  L.ce = (float *)p, p += cap;
+  L.pz = (float *)p, p += cap;
+  L.parent = p, p += cap;
+  L.csize = p, p += cap;
+  L.croot = p, p += cap;
+  L.crec = p, p += cap;
+  L.cpos = p, p += cap;
+  L.rbase = p, p += (n_rings + 1);
+  return L;
+}
+
+// One scan: keypoints_full = per-ring candidates in ring order (ref: node.cpp:205), pseudo-z,
+// second Euclidean clustering, centroids -> keypoints (ref: node.cpp:212-257); then the
+// scan's keypoint_cloud chunks are laid out in ring order (ref: node.cpp:206).
+__device__ bool merge_body(const FxDevParams &P, const FxBuffers &B, uint32_t scan, uint32_t cap, uint32_t *smem,
+                           bool last_tier) {
+  MergeLds L = merge_carve(smem, cap, (uint32_t)P.n_rings);
+  const uint32_t tid = threadIdx.x;
+  const uint32_t R = (uint32_t)P.n_rings;
+  const uint32_t *rcnt = B.ring_cand_cnt + (size_t)scan * R;
+
+  // ---- ring bases
+  uint32_t C = 0;
+  for (uint32_t b0 = 0; b0 < R; b0 += FX_WG) {
+    const uint32_t r = b0 + tid;
+    const uint32_t c = r < R ? rcnt[r] : 0u;
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan(c, L.s_w, tot);
+    if (r < R) L.rbase[r] = C + ex;
+    C += tot;
+  }
+  if (tid == 0) L.rbase[R] = C;
+  __syncthreads();
+
+  if (C > P.max_candidates) {
+    if (tid == 0) {
+      atomicOr(&B.flags[scan], FX_FLAG_CAND_OVERFLOW);
+      B.n_cand[scan] = 0;
+      B.n_kp[scan] = 0;
+      B.n_kpc[scan] = 0;
+    }
+    return true;
+  }
+  if (C > cap) {
+    if (!last_tier) return false;
+    // cap == max_candidates in the last tier, so this cannot happen
+  }
+
+  float4 *cand = B.cand + (size_t)scan * P.max_candidates;
+  uint32_t *cand_size = B.cand_size + (size_t)scan * P.max_candidates;
+  int32_t *cand_kp = B.cand_kp + (size_t)scan * P.max_candidates;
+  for (uint32_t r = 0; r < R; ++r) {
+    const uint32_t c = rcnt[r], base = L.rbase[r];
+    const float4 *rc = B.ring_cand + ((size_t)scan * R + r) * P.max_ring_cands;
+    const uint32_t *rcs = B.ring_cand_size + ((size_t)scan * R + r) * P.max_ring_cands;
+    for (uint32_t j = tid; j < c; j += FX_WG) {
+      const float4 v = rc[j];
+      const uint32_t idx = base + j;
+      L.cx[idx] = v.x;
+      L.cy[idx] = v.y;
+      L.cz[idx] = v.z;
+      L.ce[idx] = v.w;
+      // ref: node.cpp:217  z = intensity*0.75*clusterRadiusThreshold/2  (double, left to right)
+      L.pz[idx] = (float)((double)v.w * 0.75 * P.crt / 2);
+      cand[idx] = v;
+      cand_size[idx] = rcs[j];
+    }
+  }
+  __syncthreads();
+
+  uint32_t K = 0;
+  if (C > 0) {  // ref: node.cpp:209-210
+    cc_label(L.cx, L.cy, L.pz, C, P.r2_merge, L.parent, L.csize);
+    const uint32_t n_c = cc_order(C, L.parent, L.csize, P.ndc, P.secondary_max, L.croot, L.crec, L.s_w);
+    K = n_c < P.max_keypoints ? n_c : P.max_keypoints;
+    if (n_c > P.max_keypoints && tid == 0) atomicOr(&B.flags[scan], FX_FLAG_KP_OVERFLOW);
+    float4 *kp = B.keypoints + (size_t)scan * P.max_keypoints;
+    uint32_t *kps = B.kp_size + (size_t)scan * P.max_keypoints;
+    for (uint32_t s = tid; s < n_c; s += FX_WG) {
+      const uint32_t rec = L.crec[s];
+      const uint32_t sz = rec >> 16, root = L.croot[rec & 0xffffu];
+      L.cpos[root] = s;
+      if (s >= K) continue;
+      double sumx = 0.0, sumy = 0.0, sumz = 0.0;
+      uint32_t cnt = 0;
+      for (uint32_t i = root; i < C && cnt < sz; ++i) {
+        if (L.parent[i] != root) continue;
+        sumx += (double)L.cx[i];
+        sumy += (double)L.cy[i];
+        sumz += (double)L.cz[i];
+        ++cnt;
+      }
+      kp[s] = make_float4((float)(sumx / (double)sz), (float)(sumy / (double)sz), (float)(sumz / (double)sz),
+                          L.ce[root]);
+      kps[s] = sz;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < C; i += FX_WG) {
+      const uint32_t root = L.parent[i];
+      const uint32_t sz = L.csize[root];
+      int32_t k = -1;
+      if (sz >= P.ndc && sz <= P.secondary_max) {
+        const uint32_t s = L.cpos[root];
+        if (s < K) k = (int32_t)s;
+      }
+      cand_kp[i] = k;
+    }
+  }
+
+  // ---- keypoint_cloud: chunks into ring order, candidate slot -> ordinal in keypoints_full
+  const uint32_t *koff = B.kpc_ring_off + (size_t)scan * R;
+  const uint32_t *kcnt = B.kpc_ring_cnt + (size_t)scan * R;
+  const float4 *pool = B.kpc_pool + (size_t)scan * P.max_kpc;
+  const uint32_t *pool_c = B.kpc_pool_cand + (size_t)scan * P.max_kpc;
+  float4 *kpc = B.kpc + (size_t)scan * P.max_kpc;
+  uint32_t *kpc_c = B.kpc_cand + (size_t)scan * P.max_kpc;
+  uint32_t run = 0;
+  for (uint32_t r = 0; r < R; ++r) {
+    const uint32_t c = kcnt[r], o = koff[r], cb = L.rbase[r];
+    for (uint32_t j = tid; j < c; j += FX_WG) {
+      kpc[run + j] = pool[o + j];
+      kpc_c[run + j] = cb + pool_c[o + j];
+    }
+    run += c;
+  }
+  if (tid == 0) {
+    B.n_cand[scan] = C;
+    B.n_kp[scan] = K;
+    B.n_kpc[scan] = run;
+  }
+  __syncthreads();
+  return true;
+}
+
+extern "C" __global__ __launch_bounds__(FX_WG) void k_merge_small(FxDevParams P, FxBuffers B, uint32_t cap) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  if (!merge_body(P, B, blockIdx.x, cap, smem, false)) {
+    if (threadIdx.x == 0) {
+      const uint32_t pos = atomicAdd(&B.counters[1], 1u);
+      B.big_merge[pos] = blockIdx.x;
+    }
+  }
+}
+extern "C" __global__ __launch_bounds__(FX_WG) void k_merge_big(FxDevParams P, FxBuffers B, uint32_t cap) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const uint32_t n_big = B.counters[1];
+  for (uint32_t w = blockIdx.x; w < n_big; w += gridDim.x) {
+    merge_body(P, B, B.big_merge[w], cap, smem, true);
+    __syncthreads();
+  }
+}
+
+// ====================================================================== stage 4: offsets
+extern "C" __global__ __launch_bounds__(FX_WG) void k_offsets(FxDevParams P, FxBuffers B, uint32_t batch) {
+  __shared__ uint32_t s_w[FX_NWAVE];
+  uint32_t run = 0;
+  for (uint32_t b0 = 0; b0 < batch; b0 += FX_WG) {
+    const uint32_t b = b0 + threadIdx.x;
+    const uint32_t c = b < batch ? B.n_kp[b] : 0u;
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan(c, s_w, tot);
+    if (b < batch) {
+      const uint32_t off = run + ex;
+      B.kp_offset[b] = off;
+      if (off + c > P.max_total_kp) atomicOr(&B.flags[b], FX_FLAG_TOTAL_KP_OVERFLOW);
+    }
+    run += tot;
+  }
+  if (threadIdx.x == 0) B.kp_offset[batch] = run;
+}
+
+// ====================================================================== stage 5: descriptors
+struct DescLds {
+  unsigned long long *nkey;
+  float *nw, *sx, *sy, *sz, *sd2, *img;
+  uint32_t *sidx, *s_w;
+};
+#define FX_DESC_WORDS_PER_POINT 8
+__device__ __forceinline__ DescLds desc_carve(uint32_t *smem, uint32_t cap) {
+  DescLds L;
+  L.s_w = smem;  // 16 words
+  uint32_t *p = smem + 16;
+  L.nkey = (unsigned long long *)p, p += 2 * cap;  // 8-byte aligned: 16 words in front
+  L.nw = (float *)p, p += cap;
+  L.sx = (float *)p, p += cap;
+  L.sy = (float *)p, p += cap;
+  L.sz = (float *)p, p += cap;
+  L.sd2 = (float *)p, p += cap;
+  L.sidx = p, p += cap;
+  L.img = (float *)p;  // FX_DESC_BINS floats
+  return L;
+}
+
+// pcl::ShapeContext3DEstimation::computePoint for one keypoint.
+//   gather   support set = cloud points within (R + R/5) of the keypoint (superset of what the
+//            neighbour query and every density query can return), rotated on the fly
+//   bin      per neighbour (d2 < R^2): r / theta / phi bins, density = #support within R/5, weight
+//   sort     by (bin, d2, index): within a bin this is PCL's accumulation order (sorted kd-tree)
+//   sum      one lane per bin run adds the weights sequentially in fp32
+// Returns false if the support set overflowed `cap` (caller defers to the large tier).
+__device__ bool desc_body(const FxDevParams &P, const FxBuffers &B, uint32_t scan, uint32_t k, uint32_t ord,
+                          uint32_t cap, uint32_t *smem, bool last_tier) {
+  DescLds L = desc_carve(smem, cap);
+  const uint32_t tid = threadIdx.x;
+  const FxScanMeta M = B.meta[scan];
+  const float4 kp = B.keypoints[(size_t)scan * P.max_keypoints + k];
+  const size_t out_row = (size_t)B.kp_offset[scan] + k;
+  if (out_row >= P.max_total_kp) return true;  // flagged by k_offsets
+  float *out = B.desc + out_row * FX_DESC_FLOATS;
+
+  if (tid < 4) L.s_w[tid] = 0;  // 0: support count, 1: binned neighbours, 2: all neighbours
+  __syncthreads();
+
+  // ---- gather
+  const uint32_t n = M.n;
+  for (uint32_t i0 = 0; i0 < n; i0 += FX_WG * 4) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t i = i0 + u * FX_WG + tid;
+      v[u] = i < n ? *reinterpret_cast<const float4 *>(M.pts + (size_t)i * M.stride_f) : make_float4(NAN, NAN, NAN, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float x = v[u].x, y = v[u].y, z = v[u].z;
+      const float rx = ((M.R[0] * x + M.R[1] * y) + M.R[2] * z) + 0.0f;
+      const float ry = ((M.R[3] * x + M.R[4] * y) + M.R[5] * z) + 0.0f;
+      const float rz = ((M.R[6] * x + M.R[7] * y) + M.R[8] * z) + 0.0f;
+      const float d = dist2(kp.x, kp.y, kp.z, rx, ry, rz);
+      // non-finite points are not part of the search surface (NaN compares false)
+      if (d < P.r2_support && isfinite(rx) && isfinite(ry) && isfinite(rz)) {
+        const uint32_t pos = atomicAdd(&L.s_w[0], 1u);
+        if (pos < cap) {
+          L.sx[pos] = rx;
+          L.sy[pos] = ry;
+          L.sz[pos] = rz;
+          L.sd2[pos] = d;
+          L.sidx[pos] = i0 + u * FX_WG + tid;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t nS = L.s_w[0];
+  if (nS > cap) {
+    if (!last_tier) return false;
+    if (tid == 0) atomicOr(&B.flags[scan], FX_FLAG_NBR_OVERFLOW);
+    for (uint32_t t = tid; t < FX_DESC_FLOATS; t += FX_WG) out[t] = t < FX_DESC_BINS ? NAN : 0.0f;
+    if (tid == 0) B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = 0xffffffffu;
+    return true;
+  }
+  for (uint32_t t = tid; t < FX_DESC_BINS; t += FX_WG) L.img[t] = 0.0f;
+
+  // ---- per-neighbour bins, density, weight
+  const FxScTables *T = B.tables;
+  const float2 xa = B.xaxis[ord];
+  const float nx = 0.0f, ny = 0.0f, nz = 1.0f;  // every normal is +z (ref: node.cpp:337-340)
+  const float ax = xa.x, ay = xa.y, az = -0.0f;
+  for (uint32_t e = tid; e < nS; e += FX_WG) {
+    const float d2 = L.sd2[e];
+    if (!(d2 < P.r2_search)) continue;
+    atomicAdd(&L.s_w[2], 1u);
+    if (fabsf(d2 - 0.0f) < FLT_EPSILON) continue;  // pcl::utils::equal(nn_dists[ne], 0.0f)
+    const float bx = L.sx[e], by = L.sy[e], bz = L.sz[e];
+    const float r = sqrtf(d2);
+    // pcl::geometry::project(neighbour, origin, normal, proj); proj -= origin; proj.normalize()
+    const float pox = bx - kp.x, poy = by - kp.y, poz = bz - kp.z;
+    const float lambda = nx * pox + (ny * poy + nz * poz);
+    float p0 = (bx - lambda * nx) - kp.x;
+    float p1 = (by - lambda * ny) - kp.y;
+    float p2 = (bz - lambda * nz) - kp.z;
+    {
+      const float zz = p0 * p0 + (p1 * p1 + p2 * p2);
+      if (zz > 0.0f) {
+        const float s = sqrtf(zz);
+        p0 /= s;
+        p1 /= s;
+        p2 /= s;
+      }
+    }
+    // cross = x_axis x proj; phi = atan2(|cross|, x_axis . proj) in degrees, mirrored by sign
+    const float c0 = ay * p2 - az * p1;
+    const float c1 = az * p0 - ax * p2;
+    const float c2 = ax * p1 - ay * p0;
+    const float cn = sqrtf(c0 * c0 + (c1 * c1 + c2 * c2));
+    const float xd = ax * p0 + (ay * p1 + az * p2);
+    float phi = (float)atan2((double)cn, (double)xd) * 57.29578f;
+    const float cdn = c0 * nx + (c1 * ny + c2 * nz);
+    phi = cdn < 0.f ? (360.0f - phi) : phi;
+    // theta = acos(clamp(normal . normalized(neighbour - origin))) in degrees
+    float n0 = pox, n1 = poy, n2 = poz;
+    {
+      const float zz = n0 * n0 + (n1 * n1 + n2 * n2);
+      if (zz > 0.0f) {
+        const float s = sqrtf(zz);
+        n0 /= s;
+        n1 /= s;
+        n2 /= s;
+      }
+    }
+    float theta = nx * n0 + (ny * n1 + nz * n2);
+    const float mx = (-1.0f < theta) ? theta : -1.0f;  // std::max(-1.0f, theta)
+    const float tc = (mx < 1.0f) ? mx : 1.0f;          // std::min(1.0f, .)
+    theta = (float)acos((double)tc) * 57.29578f;
+
+    uint32_t j = 0, kk = 0, l = 0;
+    for (uint32_t rad = 1; rad < 16; ++rad)
+      if (r <= T->radii[rad]) {
+        j = rad - 1;
+        break;
+      }
+    for (uint32_t ang = 1; ang < 12; ++ang)
+      if (theta <= T->theta[ang]) {
+        kk = ang - 1;
+        break;
+      }
+    for (uint32_t ang = 1; ang < 13; ++ang)
+      if (phi <= T->phi[ang]) {
+        l = ang - 1;
+        break;
+      }
+    // local point density: support points within R/5 of this neighbour (itself included)
+    uint32_t dens = 0;
+    for (uint32_t q = 0; q < nS; ++q) {
+      const float dd = dist2(bx, by, bz, L.sx[q], L.sy[q], L.sz[q]);
+      dens += (dd < P.r2_density) ? 1u : 0u;
+    }
+    const float w = (1.0f / (float)dens) * T->lut[kk * 15 + j];
+    const uint32_t bin = (l * 11 + kk) * 15 + j;
+    const uint32_t pos = atomicAdd(&L.s_w[1], 1u);
+    L.nkey[pos] = ((unsigned long long)bin << 52) | ((unsigned long long)__float_as_uint(d2) << 20) |
+                  (unsigned long long)L.sidx[e];
+    L.nw[pos] = w;
+  }
+  __syncthreads();
+  const uint32_t nM = L.s_w[1], nAll = L.s_w[2];
+  if (tid == 0) B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = nAll;
+  if (nAll == 0) {  // no neighbours: NaN descriptor, no RNG draw (A.8-3)
+    for (uint32_t t = tid; t < FX_DESC_FLOATS; t += FX_WG) out[t] = t < FX_DESC_BINS ? NAN : 0.0f;
+    __syncthreads();
+    return true;
+  }
+
+  // ---- sort by (bin, d2, index): bitonic network in LDS
+  uint32_t p2 = 1;
+  while (p2 < nM) p2 <<= 1;
+  for (uint32_t t = nM + tid; t < p2; t += FX_WG) L.nkey[t] = ~0ull;
+  __syncthreads();
+  for (uint32_t kb = 2; kb <= p2; kb <<= 1) {
+    for (uint32_t jb = kb >> 1; jb > 0; jb >>= 1) {
+      for (uint32_t t = tid; t < p2; t += FX_WG) {
+        const uint32_t x = t ^ jb;
+        if (x > t) {
+          const unsigned long long a = L.nkey[t], b = L.nkey[x];
+          const bool up = (t & kb) == 0;
+          if ((a > b) == up) {
+            L.nkey[t] = b;
+            L.nkey[x] = a;
+            const float wa = L.nw[t];
+            L.nw[t] = L.nw[x];
+            L.nw[x] = wa;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // ---- sequential fp32 accumulation per bin, in sorted order
+  for (uint32_t t = tid; t < nM; t += FX_WG) {
+    const uint32_t bin = (uint32_t)(L.nkey[t] >> 52);
+    if (t > 0 && (uint32_t)(L.nkey[t - 1] >> 52) == bin) continue;
+    float acc = 0.0f;
+    uint32_t e = t;
+    do {
+      acc += L.nw[e];
+      ++e;
+    } while (e < nM && (uint32_t)(L.nkey[e] >> 52) == bin);
+    L.img[bin] = acc;
+  }
+  __syncthreads();
+  for (uint32_t t = tid; t < FX_DESC_FLOATS; t += FX_WG) out[t] = t < FX_DESC_BINS ? L.img[t] : 0.0f;  // rf = 0
+  __syncthreads();
+  return true;
+}
+
+// Which scan does global keypoint row w belong to?  kp_offset is an exclusive prefix.
+__device__ __forceinline__ uint32_t scan_of_row(const uint32_t *kp_offset, uint32_t batch, uint32_t w) {
+  uint32_t lo = 0, hi = batch;  // invariant: kp_offset[lo] <= w < kp_offset[hi]
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (kp_offset[mid] <= w)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+// mode 0: every keypoint, RNG ordinal = keypoint ordinal.  mode 1: only keypoints whose
+// ordinal had to be corrected because an earlier keypoint of the scan had no neighbours.
+extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_small(FxDevParams P, FxBuffers B, uint32_t batch,
+                                                                  uint32_t cap, uint32_t mode) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  if (mode == 1 && B.counters[3] == 0) return;
+  uint32_t total = B.kp_offset[batch];
+  if (total > P.max_total_kp) total = P.max_total_kp;
+  for (uint32_t w = blockIdx.x; w < total; w += gridDim.x) {
+    const uint32_t scan = scan_of_row(B.kp_offset, batch, w);
+    const uint32_t k = w - B.kp_offset[scan];
+    uint32_t ord = k;
+    if (mode == 1) {
+      ord = B.rng_ord[(size_t)scan * P.max_keypoints + k];
+      if (ord == k) continue;
+    }
+    if (!desc_body(P, B, scan, k, ord, cap, smem, false)) {
+      if (threadIdx.x == 0) {
+        const uint32_t pos = atomicAdd(&B.counters[2], 1u);
+        B.big_desc[pos] = w;
+      }
+    }
+    __syncthreads();
+  }
+}
+extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_big(FxDevParams P, FxBuffers B, uint32_t batch,
+                                                                uint32_t cap, uint32_t mode) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  if (mode == 1 && B.counters[3] == 0) return;
+  const uint32_t n_big = B.counters[2];
+  for (uint32_t i = blockIdx.x; i < n_big; i += gridDim.x) {
+    const uint32_t w = B.big_desc[i];
+    const uint32_t scan = scan_of_row(B.kp_offset, batch, w);
+    const uint32_t k = w - B.kp_offset[scan];
+    const uint32_t ord = mode == 1 ? B.rng_ord[(size_t)scan * P.max_keypoints + k] : k;
+    desc_body(P, B, scan, k, ord, cap, smem, true);
+    __syncthreads();
+  }
+}
+
+// RNG ordinals: 3DSC draws its three numbers only for keypoints that have neighbours.
+extern "C" __global__ __launch_bounds__(FX_WG) void k_rng_ord(FxDevParams P, FxBuffers B, uint32_t batch) {
+  const uint32_t b = blockIdx.x * FX_WG + threadIdx.x;
+  if (b >= batch) return;
+  const uint32_t K = B.n_kp[b];
+  uint32_t ord = 0;
+  bool fix = false;
+  for (uint32_t k = 0; k < K; ++k) {
+    B.rng_ord[(size_t)b * P.max_keypoints + k] = ord;
+    fix = fix || (ord != k);
+    const uint32_t nb = B.kp_nbrs[(size_t)b * P.max_keypoints + k];
+    if (nb != 0u) ++ord;
+  }
+  if (fix) atomicAdd(&B.counters[3], 1u);
+}
+
+// pcl::concatenateFields(keypoints, descriptors) -> pcl::PointDescriptor records (ref: node.cpp:119).
+extern "C" __global__ __launch_bounds__(FX_WG) void k_pack_features(FxDevParams P, FxBuffers B, uint32_t batch,
+                                                                     uint8_t *dst, uint32_t capacity) {
+  uint32_t total = B.kp_offset[batch];
+  if (total > P.max_total_kp) total = P.max_total_kp;
+  if (total > capacity) total = capacity;
+  for (uint32_t w = blockIdx.x; w < total; w += gridDim.x) {
+    const uint32_t scan = scan_of_row(B.kp_offset, batch, w);
+    const uint32_t k = w - B.kp_offset[scan];
+    const float4 kp = B.keypoints[(size_t)scan * P.max_keypoints + k];
+    float *rec = reinterpret_cast<float *>(dst + (size_t)w * FX_FEATURE_RECORD_BYTES);
+    const float *src = B.desc + (size_t)w * FX_DESC_FLOATS;
+    if (threadIdx.x == 0) {
+      rec[0] = kp.x;
+      rec[1] = kp.y;
+      rec[2] = kp.z;
+      rec[3] = 1.0f;  // PCL_ADD_POINT4D padding word
+      rec[4] = kp.w;
+    }
+    for (uint32_t t = threadIdx.x; t < FX_DESC_FLOATS; t += FX_WG) rec[5 + t] = src[t];
+    if (threadIdx.x < 2) rec[5 + FX_DESC_FLOATS + threadIdx.x] = 0.0f;  // tail padding to 7984 B
+  }
+}
+
+// ====================================================================== launchers
+extern "C" {
+
+size_t fxk_ring_lds_bytes(uint32_t cap) { return (size_t)(16 + FX_RING_WORDS_PER_POINT * cap) * 4; }
+size_t fxk_merge_lds_bytes(uint32_t cap, uint32_t n_rings) {
+  return (size_t)(16 + FX_MERGE_WORDS_PER_CAND * cap + n_rings + 1) * 4;
+}
+size_t fxk_desc_lds_bytes(uint32_t cap) { return (size_t)(16 + FX_DESC_WORDS_PER_POINT * cap + FX_DESC_BINS) * 4; }
+
+hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t desc_big) {
+  hipError_t e;
+  e = hipFuncSetAttribute((const void *)k_rings_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_big);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void *)k_merge_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)merge_big);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void *)k_desc_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)desc_big);
+  return e;
+}
+
+void fxk_prep(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch) {
+  hipLaunchKernelGGL(k_prep, dim3(batch), dim3(FX_PREP_T), 0, s, P, B);
+}
+void fxk_rings(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap_small,
+               uint32_t cap_big, uint32_t big_grid) {
+  hipLaunchKernelGGL(k_rings_small, dim3(batch * P.n_rings), dim3(FX_WG), fxk_ring_lds_bytes(cap_small), s, P, B,
+                     cap_small);
+  hipLaunchKernelGGL(k_rings_big, dim3(big_grid), dim3(FX_WG), fxk_ring_lds_bytes(cap_big), s, P, B, cap_big);
+}
+void fxk_merge(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap_small,
+               uint32_t cap_big, uint32_t big_grid) {
+  hipLaunchKernelGGL(k_merge_small, dim3(batch), dim3(FX_WG), fxk_merge_lds_bytes(cap_small, P.n_rings), s, P, B,
+                     cap_small);
+  hipLaunchKernelGGL(k_merge_big, dim3(big_grid), dim3(FX_WG), fxk_merge_lds_bytes(cap_big, P.n_rings), s, P, B,
+                     cap_big);
+}
+void fxk_offsets(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch) {
+  hipLaunchKernelGGL(k_offsets, dim3(1), dim3(FX_WG), 0, s, P, B, batch);
+}
+void fxk_desc(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap_small,
+              uint32_t cap_big, uint32_t grid_small, uint32_t big_grid, uint32_t mode) {
+  hipLaunchKernelGGL(k_desc_small, dim3(grid_small), dim3(FX_WG), fxk_desc_lds_bytes(cap_small), s, P, B, batch,
+                     cap_small, mode);
+  hipLaunchKernelGGL(k_desc_big, dim3(big_grid), dim3(FX_WG), fxk_desc_lds_bytes(cap_big), s, P, B, batch, cap_big,
+                     mode);
+}
+void fxk_rng_ord(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch) {
+  hipLaunchKernelGGL(k_rng_ord, dim3((batch + FX_WG - 1) / FX_WG), dim3(FX_WG), 0, s, P, B, batch);
+}
+void fxk_pack_features(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, void *dst,
+                       uint32_t capacity, uint32_t grid) {
+  hipLaunchKernelGGL(k_pack_features, dim3(grid), dim3(FX_WG), 0, s, P, B, batch, (uint8_t *)dst, capacity);
+}
+
+}  // extern "C"

@@ -1,0 +1,185 @@
+// fx_sort_replay.h — order replay of pcl::EuclideanClusterExtraction's final
+//   std::sort(clusters.rbegin(), clusters.rend(), comparePointClusters)
+// (called from ref: src/feature_extraction_node.cpp:229 and :276 through PCL).
+//
+// The comparator is size(a) < size(b) on reverse iterators, i.e. an ascending introsort of
+// the REVERSED sequence.  libstdc++'s introsort is not stable, so the order of equally
+// sized clusters is a property of the algorithm itself; keypoint ordinals (and through the
+// 3DSC RNG stream, descriptor values) depend on it.  This file therefore re-implements the
+// algorithm's published structure — median-of-3 quicksort down to 16-element runs with a
+// 2*floor(log2 n) depth limit and heap-sort fallback, then one guarded + one unguarded
+// insertion pass — as a single sequential routine over packed records that runs on one GPU
+// lane (and on the host for the CPU test-suite).  tests/test_sort_replay.py checks the
+// permutation against the oracle's real std::sort call.
+//
+// Records are packed (size << 16) | ordinal; only the size takes part in comparisons.
+#ifndef FX_SORT_REPLAY_H_
+#define FX_SORT_REPLAY_H_
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define FX_HD __host__ __device__
+#else
+#define FX_HD
+#endif
+
+namespace fx_sort_detail {
+
+// View of the record array through reverse iterators: logical position i is rec[n-1-i].
+struct RevView {
+  uint32_t *rec;
+  int n;
+  FX_HD uint32_t get(int i) const { return rec[n - 1 - i]; }
+  FX_HD void set(int i, uint32_t v) const { rec[n - 1 - i] = v; }
+  FX_HD void swap(int i, int j) const {
+    uint32_t a = get(i), b = get(j);
+    set(i, b);
+    set(j, a);
+  }
+};
+FX_HD inline bool less_size(uint32_t a, uint32_t b) { return (a >> 16) < (b >> 16); }
+
+FX_HD inline void push_heap(const RevView &v, int first, int hole, int top, uint32_t value) {
+  int parent = (hole - 1) / 2;
+  while (hole > top && less_size(v.get(first + parent), value)) {
+    v.set(first + hole, v.get(first + parent));
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  v.set(first + hole, value);
+}
+FX_HD inline void adjust_heap(const RevView &v, int first, int hole, int len, uint32_t value) {
+  const int top = hole;
+  int child = hole;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (less_size(v.get(first + child), v.get(first + (child - 1)))) child--;
+    v.set(first + hole, v.get(first + child));
+    hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) {
+    child = 2 * (child + 1);
+    v.set(first + hole, v.get(first + (child - 1)));
+    hole = child - 1;
+  }
+  push_heap(v, first, hole, top, value);
+}
+// partial_sort(first, last, last): make_heap + sort_heap over [first, last)
+FX_HD inline void heap_sort(const RevView &v, int first, int last) {
+  const int len = last - first;
+  if (len >= 2) {
+    int parent = (len - 2) / 2;
+    while (true) {
+      uint32_t value = v.get(first + parent);
+      adjust_heap(v, first, parent, len, value);
+      if (parent == 0) break;
+      parent--;
+    }
+  }
+  int l = last;
+  while (l - first > 1) {
+    --l;
+    uint32_t value = v.get(l);
+    v.set(l, v.get(first));
+    adjust_heap(v, first, 0, l - first, value);
+  }
+}
+FX_HD inline void median_to_first(const RevView &v, int result, int a, int b, int c) {
+  const uint32_t va = v.get(a), vb = v.get(b), vc = v.get(c);
+  if (less_size(va, vb)) {
+    if (less_size(vb, vc))
+      v.swap(result, b);
+    else if (less_size(va, vc))
+      v.swap(result, c);
+    else
+      v.swap(result, a);
+  } else if (less_size(va, vc))
+    v.swap(result, a);
+  else if (less_size(vb, vc))
+    v.swap(result, c);
+  else
+    v.swap(result, b);
+}
+FX_HD inline int partition_pivot(const RevView &v, int first, int last) {
+  const int mid = first + (last - first) / 2;
+  median_to_first(v, first, first + 1, mid, last - 1);
+  int lo = first + 1, hi = last;
+  while (true) {
+    const uint32_t pivot = v.get(first);
+    while (less_size(v.get(lo), pivot)) ++lo;
+    --hi;
+    while (less_size(pivot, v.get(hi))) --hi;
+    if (!(lo < hi)) return lo;
+    v.swap(lo, hi);
+    ++lo;
+  }
+}
+FX_HD inline void linear_insert_unguarded(const RevView &v, int last) {
+  const uint32_t val = v.get(last);
+  int next = last - 1;
+  while (less_size(val, v.get(next))) {
+    v.set(last, v.get(next));
+    last = next;
+    --next;
+  }
+  v.set(last, val);
+}
+FX_HD inline void insertion_sort(const RevView &v, int first, int last) {
+  if (first == last) return;
+  for (int i = first + 1; i != last; ++i) {
+    if (less_size(v.get(i), v.get(first))) {
+      const uint32_t val = v.get(i);
+      for (int j = i; j > first; --j) v.set(j, v.get(j - 1));
+      v.set(first, val);
+    } else {
+      linear_insert_unguarded(v, i);
+    }
+  }
+}
+
+}  // namespace fx_sort_detail
+
+// Sorts rec[0..n) into the order PCL hands clusters back: descending size, ties as
+// libstdc++'s introsort leaves them.
+FX_HD inline void fx_sort_replay_desc(uint32_t *rec, uint32_t n_u) {
+  using namespace fx_sort_detail;
+  const int n = (int)n_u;
+  if (n < 2) return;
+  RevView v{rec, n};
+  const int kThreshold = 16;
+  int lg = 0;
+  for (int t = n; t > 1; t >>= 1) ++lg;
+  // explicit stack for the recursion on the right-hand part; pending ranges are disjoint,
+  // so the order they are processed in does not change the result
+  int stk_first[40], stk_last[40], stk_depth[40];
+  int sp = 0;
+  stk_first[0] = 0;
+  stk_last[0] = n;
+  stk_depth[0] = 2 * lg;
+  sp = 1;
+  while (sp > 0) {
+    --sp;
+    int first = stk_first[sp], last = stk_last[sp], depth = stk_depth[sp];
+    while (last - first > kThreshold) {
+      if (depth == 0) {
+        heap_sort(v, first, last);
+        break;
+      }
+      --depth;
+      const int cut = partition_pivot(v, first, last);
+      stk_first[sp] = cut;
+      stk_last[sp] = last;
+      stk_depth[sp] = depth;
+      ++sp;
+      last = cut;
+    }
+  }
+  if (n > kThreshold) {
+    insertion_sort(v, 0, kThreshold);
+    for (int i = kThreshold; i != n; ++i) linear_insert_unguarded(v, i);
+  } else {
+    insertion_sort(v, 0, n);
+  }
+}
+
+#endif  // FX_SORT_REPLAY_H_

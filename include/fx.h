@@ -1,0 +1,222 @@
+/*
+ * fx.h — C-ABI of the MI355X-native per-scan detector/descriptor hot path.
+ *
+ * The reference (GAVLab/feature_extraction) has no plugin/FFI boundary; its hot
+ * path is the body of FeatureExtractionNode::cloudCallback between message
+ * conversion and the first publish (ref: src/feature_extraction_node.cpp:83-115).
+ * Every entry point below replaces a piece of that body and cites it.
+ *
+ * Plain C: pointers, sizes, POD structs.  No torch / PCL / ROS types.
+ * A context is NOT thread-safe: one context per (host thread, device).
+ * All outputs are owned by the context and stay valid until the next
+ * fx_process_batch / fx_destroy on that context.
+ */
+#ifndef FX_H_
+#define FX_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FX_VERSION_MAJOR 0
+#define FX_VERSION_MINOR 1
+
+/* pcl::ShapeContext1980: 12 azimuth x 11 elevation x 15 radius bins + rf[9]
+ * (ref: include/feature_extraction/feature_extraction_node.h:35-53,75). */
+#define FX_DESC_BINS 1980
+#define FX_DESC_RF 9
+#define FX_DESC_FLOATS 1989 /* 7956 B per keypoint == sizeof(pcl::ShapeContext1980) */
+/* pcl::PointDescriptor wire record of ~features (ref: node.h:35-42): x@0 y@4 z@8
+ * pad@12 intensity@16 descriptor@20 rf@7940, sizeof 7984 (EIGEN_ALIGN16). */
+#define FX_FEATURE_RECORD_BYTES 7984
+
+typedef enum fx_status {
+  FX_OK = 0,
+  FX_ERR_INVALID_ARG = 1,
+  FX_ERR_NO_DEVICE = 2, /* no HIP device / extension unusable: never a CPU fallback */
+  FX_ERR_HIP = 3,
+  FX_ERR_OOM = 4,
+  FX_ERR_TOO_LARGE = 5 /* batch or scan exceeds the limits given to fx_create */
+} fx_status;
+
+/* Per-scan flag bits (fx_batch_view.flags).  Capacity overflow never truncates
+ * silently: the scan's outputs are then incomplete and the bit says which stage. */
+#define FX_FLAG_RING_OVERFLOW 0x1u      /* a ring held more points than limits.max_ring_points */
+#define FX_FLAG_CAND_OVERFLOW 0x2u      /* more per-ring candidates than limits.max_candidates */
+#define FX_FLAG_KP_OVERFLOW 0x4u        /* more keypoints than limits.max_keypoints */
+#define FX_FLAG_NBR_OVERFLOW 0x8u       /* a keypoint's support set exceeded limits.max_neighbors */
+#define FX_FLAG_TOTAL_KP_OVERFLOW 0x10u /* batch-wide keypoint pool exhausted */
+#define FX_FLAG_KPC_OVERFLOW 0x20u      /* keypoint_cloud exceeded its pool */
+
+/* The 14 ROS private parameters of the reference node (ref: node.cpp:9-34,
+ * members node.h:115-127) + the constants the reference hard-codes for the
+ * VLP-16 (ref: node.cpp:195, 200, 227), exposed so 64/128-ring sensors work.
+ * Doubles/ints exactly as the reference stores them; narrowing to float happens
+ * inside, where PCL does it (see oracle/fx_oracle.cpp). */
+typedef struct fx_params {
+  int32_t cloud_leveling;            /* ref: node.cpp:9   default 1 (host shell concern) */
+  double x_min, x_max;               /* ref: node.cpp:14-15  0, 75   */
+  double y_min, y_max;               /* ref: node.cpp:16-17  -30, 30 */
+  double z_min, z_max;               /* ref: node.cpp:18-19  -1.5, 5 */
+  double cluster_tolerance;          /* ref: node.cpp:24  0.65 */
+  int32_t cluster_min_count;         /* ref: node.cpp:25  5    */
+  int32_t cluster_max_count;         /* ref: node.cpp:26  50   */
+  double cluster_radius_threshold;   /* ref: node.cpp:27  0.15 */
+  int32_t number_detection_channels; /* ref: node.cpp:28  1    */
+  int32_t estimate_descriptors;      /* ref: node.cpp:33  1    */
+  double descriptor_radius;          /* ref: node.cpp:34  2.5  */
+  /* -- hard-coded in the reference, parameters here -- */
+  int32_t n_rings;       /* ref: node.cpp:195  `i<16`                       */
+  double el0_deg;        /* ref: node.cpp:200  (i-7)*2-1 at i=0  => -15     */
+  double el_step_deg;    /* ref: node.cpp:200  2 deg; window = centre +- step/2 (ref: :201) */
+  int32_t secondary_max; /* ref: node.cpp:227  setMaxClusterSize(16)        */
+} fx_params;
+
+/* Capacities fixed at fx_create (no allocation in the steady state). 0 = default. */
+typedef struct fx_limits {
+  uint32_t max_batch;           /* scans per fx_process_batch                       */
+  uint32_t max_points;          /* points per scan                                  */
+  uint32_t max_ring_points;     /* points per (scan, ring) held in LDS   (def 2048) */
+  uint32_t max_ring_candidates; /* candidates one ring may emit          (def 256)  */
+  uint32_t max_candidates;      /* per-ring candidates per scan, all rings (def 2048) */
+  uint32_t max_keypoints;       /* keypoints per scan                    (def 256)  */
+  uint32_t max_neighbors;       /* support-set points per keypoint       (def 4096) */
+  uint32_t max_total_keypoints; /* keypoints per batch (descriptor pool) (def max_batch*64) */
+  uint32_t max_kpc_points;      /* keypoint_cloud points per scan        (def 4096) */
+} fx_limits;
+
+/* One scan = what cloudCallback receives after fromPCLPointCloud2
+ * (ref: node.cpp:77-81): N points with x,y,z as float at byte offsets 0,4,8 of
+ * each record.  stride_bytes = 16 for packed float4 (x,y,z,intensity), 32 for
+ * PCL's in-memory pcl::PointXYZI.  Incoming intensity is ignored: the
+ * reference overwrites it with the elevation angle (ref: node.cpp:154).
+ * roll/pitch are the node's members (ref: node.h:116, set at node.cpp:57-70). */
+typedef struct fx_scan_desc {
+  const void *points; /* host or device pointer (see FX_IN_DEVICE), 16-byte aligned */
+  uint32_t n_points;
+  uint32_t stride_bytes; /* multiple of 16, >= 16 */
+  double roll, pitch;    /* radians; narrowed to float like Eigen::AngleAxisf (ref: node.cpp:163-164) */
+} fx_scan_desc;
+
+#define FX_IN_DEVICE 0x1u   /* fx_scan_desc.points are device pointers */
+#define FX_OUT_HOST 0x2u    /* copy results to the context's pinned host mirrors and synchronise */
+#define FX_OUT_DEBUG 0x4u   /* with FX_OUT_HOST: also copy candidates / membership arrays */
+#define FX_OUT_CLOUDS 0x8u  /* with FX_OUT_HOST: also copy the filtered cloud and keypoint_cloud */
+
+/* View of one batch's results.  `d_` = device pointers (always set),
+ * `h_` = pinned-host mirrors (set when FX_OUT_HOST, else NULL).
+ * Keypoint k of scan b:  keypoints[b*max_keypoints + k]  (x, y, z, elevation_deg)
+ *                         = the `~keypoints` cloud (ref: node.cpp:129-131, 238-257).
+ * Its descriptor:        descriptors[(kp_offset[b] + k) * FX_DESC_FLOATS ...]
+ *                         = pcl::ShapeContext1980 {descriptor[1980], rf[9]} (ref: node.cpp:353).
+ * filtered[b*max_points + i], i < n_filtered[b] = the `~cloud` topic (ref: node.cpp:137-139).
+ * kpc[b*max_kpc_points + i], i < n_kpc[b] = the `~keypoint_cloud` topic (ref: node.cpp:133-135, 206, 323). */
+typedef struct fx_batch_view {
+  uint32_t batch;
+  uint32_t max_points, max_keypoints, max_candidates, max_kpc_points;
+  uint32_t total_keypoints; /* valid only after FX_OUT_HOST */
+  /* device */
+  const uint32_t *d_n_keypoints; /* [B] */
+  const uint32_t *d_kp_offset;   /* [B+1] exclusive prefix of n_keypoints */
+  const float *d_keypoints;      /* [B][max_keypoints][4] */
+  const float *d_descriptors;    /* [max_total_keypoints][1989] */
+  const uint32_t *d_flags;       /* [B] FX_FLAG_* */
+  const uint32_t *d_n_filtered;  /* [B] */
+  const float *d_filtered;       /* [B][max_points][4] */
+  const uint32_t *d_n_kpc;       /* [B] */
+  const float *d_kpc;            /* [B][max_kpc_points][4] */
+  /* host mirrors */
+  const uint32_t *h_n_keypoints;
+  const uint32_t *h_kp_offset;
+  const float *h_keypoints;
+  const float *h_descriptors;
+  const uint32_t *h_flags;
+  const uint32_t *h_n_filtered;
+  const float *h_filtered;
+  const uint32_t *h_n_kpc;
+  const float *h_kpc;
+  /* debug / membership (host mirrors only with FX_OUT_DEBUG) */
+  const uint32_t *h_n_candidates;  /* [B]  size of keypoints_full (ref: node.cpp:205) */
+  const float *h_candidates;       /* [B][max_candidates][4]  per-ring centroids, ring order */
+  const uint32_t *h_cand_size;     /* [B][max_candidates]  points in the per-ring cluster */
+  const int32_t *h_cand_keypoint;  /* [B][max_candidates]  keypoint ordinal the candidate merged into, -1 if none */
+  const uint32_t *h_kpc_cand;      /* [B][max_kpc_points]  candidate ordinal of each keypoint_cloud point */
+  const uint32_t *h_kp_size;       /* [B][max_keypoints]   candidates merged into the keypoint */
+  const uint32_t *h_kp_neighbors;  /* [B][max_keypoints]   3DSC neighbours within descriptor_radius */
+} fx_batch_view;
+
+/* Per-stage device time of the last batch (HIP events on the context's stream). */
+#define FX_N_STAGES 6
+typedef struct fx_timings {
+  float ms[FX_N_STAGES]; /* prep, rings, merge, offsets, descriptors, (reserved) */
+  float total_ms;
+} fx_timings;
+
+typedef struct fx_ctx fx_ctx;
+
+uint32_t fx_version(void);
+const char *fx_status_str(fx_status s);
+/* message of the last failing call on this thread (HIP error string etc.) */
+const char *fx_last_error(void);
+
+/* ref: node.cpp:9-34 (defaults) */
+void fx_params_default(fx_params *p);
+/* ref: launch/keypoint_playback.launch:17-33 (the preset the launch file sets) */
+void fx_params_launch(fx_params *p);
+void fx_limits_default(fx_limits *l, uint32_t max_batch, uint32_t max_points);
+
+/* Replaces the FeatureExtractionNode constructor's parameter block (ref: node.cpp:3-34).
+ * Allocates every device/host buffer; fails with FX_ERR_NO_DEVICE when no GPU. */
+fx_status fx_create(const fx_params *params, const fx_limits *limits, int device_id, fx_ctx **out);
+void fx_destroy(fx_ctx *ctx);
+/* hipStream_t to launch on (NULL = the context's own stream). */
+fx_status fx_set_stream(fx_ctx *ctx, void *hip_stream);
+fx_status fx_set_profiling(fx_ctx *ctx, int enabled);
+fx_status fx_get_timings(fx_ctx *ctx, fx_timings *t);
+fx_status fx_get_limits(const fx_ctx *ctx, fx_limits *l);
+
+/* Replaces cloudCallback's body for a batch of B scans (ref: node.cpp:83-115):
+ * getElevationAngles (:147-156) -> rotateCloud (:159-167) -> filterCloud (:169-183)
+ * -> estimateKeypoints (:185-259, getCylinderSegments :261-327)
+ * -> estimateDescriptors (:329-355).  Empty scans give K = 0 (ref: :209-210, :263-264). */
+fx_status fx_process_batch(fx_ctx *ctx, const fx_scan_desc *scans, uint32_t batch, uint32_t flags,
+                           fx_batch_view *out);
+/* Wait for the context's stream. */
+fx_status fx_synchronize(fx_ctx *ctx);
+
+/* pcl::concatenateFields(keypoints, descriptors) (ref: node.cpp:119): packs the last
+ * batch's keypoints + descriptors into 7984-byte pcl::PointDescriptor records on
+ * the device.  dst_device must hold total_keypoints records. */
+fx_status fx_pack_features(fx_ctx *ctx, void *dst_device, uint32_t capacity_records);
+
+/* Rotation matrix of rotateCloud (ref: node.cpp:161-164): R = Ry(pitch)*Rx(roll)
+ * through Eigen's AngleAxisf -> Quaternionf -> toRotationMatrix, all float. Host only. */
+void fx_rotation_from_roll_pitch(double roll, double pitch, float R[9]);
+/* ShapeContext3DEstimation::initCompute tables (radii[16], theta[12], phi[13], lut[1980])
+ * for descriptor_radius R: rmin = R/10 (ref: node.cpp:350-352). Host only. */
+void fx_sc3d_tables(double R, float *radii16, float *theta12, float *phi13, float *lut1980);
+/* x-axis of keypoint ordinal k from the boost::mt19937(12345) stream of 3DSC. Host only. */
+void fx_sc3d_xaxis(uint32_t k, float xy[2]);
+
+/* Synthetic scan generator (the reference ships no data).
+ * Writes n_rings*n_az float4 (x,y,z,0) in firing order (azimuth-major, ring-minor). Host only. */
+typedef struct fx_synth_cfg {
+  uint32_t n_rings, n_az;
+  double el0_deg, el_step_deg;
+  uint32_t n_poles;
+  double pole_radius, pole_height;
+  double x_lo, x_hi, y_lo, y_hi; /* pole centres uniform in this box */
+  double sensor_height;          /* ground plane z = -sensor_height */
+  double wall_radius;            /* enclosing cylinder, always hit => fixed N */
+  uint64_t seed;
+} fx_synth_cfg;
+void fx_synth_cfg_vlp16(fx_synth_cfg *c, uint64_t seed);
+uint32_t fx_synth_scan(const fx_synth_cfg *c, float *xyzi_out, uint32_t capacity_points);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FX_H_ */
