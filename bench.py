@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py — VLP-16 scans/sec of the per-scan detector/descriptor hot path on MI355X.
+
+A "step" is one pass of the whole hot path (rotate+filter -> per-ring clustering -> merge ->
+3DSC descriptors, ref: src/feature_extraction_node.cpp:83-115) over one batch of synthetic
+scans that are already resident in HBM, plus — at N > 1 — the one RCCL collective of the
+path (all-gather of fixed-stride keypoint records).  Scans are frame-sharded: every rank
+owns `--batch` scans (weak scaling); there is no other data-path exchange.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant
+kernel, HIP-event timed on the launch stream inside the timed region) and `cpu_baseline`
+(the oracle's kd-tree restatement of the PCL path on the host cores; N=1 only).
+"""
+import argparse
+import concurrent.futures as cf
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured achievable)
+N_RINGS, N_AZ = 16, 1800
+REC_KP = 127  # keypoints carried per scan in the gathered record (1 header + 127 float4 = 2 KiB)
+
+
+def make_scans(capi, seeds, threads):
+    def one(seed):
+        return capi.synth_scan(capi.synth_cfg(seed))
+    with cf.ThreadPoolExecutor(max_workers=threads) as ex:
+        return list(ex.map(one, seeds))
+
+
+def cpu_baseline(params, scans, roll, pitch, threads, budget_s=20.0):
+    """Oracle (kd-tree search: the CPU restatement of the PCL path) on the host cores."""
+    from oracle import oracle_py as O
+    O.load()
+    t0 = time.perf_counter()
+    O.run(params, scans[0], roll=roll, pitch=pitch)
+    one = time.perf_counter() - t0
+    n = int(max(threads, min(len(scans), budget_s * threads / max(one, 1e-4))))
+    n = min(n, len(scans))
+    sample = scans[:n]
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(max_workers=threads) as ex:
+        ks = list(ex.map(lambda s: O.run(params, s, roll=roll, pitch=pitch)["n_keypoints"], sample))
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "scans/s", "cores": threads, "kind": "port",
+            "sample": f"first {n} scans of the batch, oracle/fx_oracle.cpp (CPU restatement of the PCL path, own kd-tree "
+                      f"leaf 15, g++ -O2), one scan per thread, {sum(ks)} keypoints; PCL itself is not installable here"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024, help="scans per GPU per step")
+    ap.add_argument("--preset", default="launch", choices=["default", "launch"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", type=int, default=4, help="scans of rank 0 checked against the oracle after timing")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from feature_extraction_amd import build, capi
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    build.build()
+    capi.load()  # raises if the HIP library is missing
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    B, N = args.batch, N_RINGS * N_AZ
+    roll, pitch = 0.02, -0.015
+    threads = os.cpu_count() or 1
+    # ---- synthetic input (SURVEY.md Appendix C / BASELINE.md config 2), seed 1000 + global scan index
+    seeds = [1000 + rank * B + b for b in range(B)]
+    scans = make_scans(capi, seeds, max(1, threads // max(1, min(world, 8))))
+    host = np.stack(scans)  # [B, N, 4]
+    d_in = torch.from_numpy(host).to(dev)  # resident in HBM before the timed region
+    params = capi.params(args.preset)
+    ctx = capi.Context(params, capi.limits(B, N), device=local_rank)
+    stream = torch.cuda.current_stream(dev)
+    ctx.set_stream(stream.cuda_stream)
+    base = d_in.data_ptr()
+    descs = ctx.make_descs([base + b * N * 16 for b in range(B)], [N] * B, 16, roll, pitch)
+    rec = torch.zeros((B, 1 + REC_KP, 4), dtype=torch.float32, device=dev)
+    gathered = torch.zeros((world * B, 1 + REC_KP, 4), dtype=torch.float32, device=dev) if world > 1 else None
+
+    def step():
+        ctx.process_raw(descs, B, capi.FX_IN_DEVICE)
+        ctx.pack_keypoint_records(rec.data_ptr(), REC_KP)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered.view(-1), rec.view(-1))
+
+    for _ in range(args.warmup):
+        step()
+    ctx.set_profiling(max(args.steps, 1))  # HIP events around every stage kernel, on the launch stream
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel durations of the timed steps (HIP events recorded inside the timed region)
+    stage_ms = {}
+    for back in range(args.steps):
+        ms, _tot = ctx.timings(back)
+        for k, v in ms.items():
+            stage_ms[k] = stage_ms.get(k, 0.0) + v / args.steps
+    ctx.set_profiling(0)
+
+    # ---- what the batch produced (for the algorithmic byte count) + a parity spot check
+    v = ctx.process_raw(descs, B, capi.FX_IN_DEVICE | capi.FX_OUT_HOST)
+    k_total = int(v.total_keypoints)
+    flags_or = int(np.bitwise_or.reduce(np.ctypeslib.as_array(v.h_flags, shape=(B,)))) if B else 0
+    n_chk = min(args.check, B) if rank == 0 else 0
+    res = []
+    if n_chk:
+        v2 = ctx.process_raw(descs, n_chk, capi.FX_IN_DEVICE | capi.FX_OUT_HOST | capi.FX_OUT_CLOUDS | capi.FX_OUT_DEBUG)
+        res = ctx.unpack(v2)
+    if world > 1:
+        kt = torch.tensor([k_total], dtype=torch.int64, device=dev)
+        dist.all_reduce(kt)
+        k_all = int(kt.item())
+    else:
+        k_all = k_total
+
+    if rank == 0:
+        parity = None
+        if n_chk:
+            from oracle import oracle_py as O
+            from tests import util
+            worst, kchk = 0.0, 0
+            for b in range(n_chk):
+                ora = O.run(params, scans[b], roll=roll, pitch=pitch)
+                st = util.compare_scan(res[b], ora, tag=f"bench scan {b}")  # raises on any mismatch
+                worst = max(worst, st["max_abs"])
+                kchk += st["K"]
+            parity = {"scans_checked": n_chk, "keypoints_checked": kchk, "keypoint_f1_vs_oracle": 1.0,
+                      "cluster_membership": "exact", "descriptor_max_abs_diff": worst}
+        dom = max(stage_ms, key=stage_ms.get)
+        # algorithmic bytes per launch of the dominant kernel = B_alg per scan x scans per launch
+        # (16 N read + 16 K + 7956 K written per scan; K measured, this rank's batch)
+        alg_bytes = 16.0 * N * B + (16.0 + 7956.0) * k_total
+        achieved = alg_bytes / (stage_ms[dom] * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "VLP-16 scans/sec (16x1800 pts), detector+descriptor", "value": world * B * args.steps / elapsed,
+            "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"batch of {B} synthetic VLP-16 scans (16x1800 pts, 64 uniform poles) per GPU, "
+                                   f"device-resident, preset '{args.preset}', roll/pitch 0.02/-0.015",
+                       "scans_per_gpu": B, "points_per_scan": N, "preset": args.preset,
+                       "parallelism": f"frame-sharded x{world}" + (", all-gather of keypoint records (RCCL)" if world > 1 else ""),
+                       "keypoints_per_scan": k_all / (world * B), "flags_or": flags_or},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "alg_bytes_per_launch": alg_bytes, "kernel_ms": stage_ms[dom]},
+            "kernel_ms": stage_ms,
+            "parity": parity,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(params, scans, roll, pitch, threads)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

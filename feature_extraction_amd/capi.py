@@ -20,8 +20,9 @@ FX_ERR_NO_DEVICE = 2
 FX_IN_DEVICE, FX_OUT_HOST, FX_OUT_DEBUG, FX_OUT_CLOUDS = 1, 2, 4, 8
 FX_FLAG_NAMES = {0x1: "RING_OVERFLOW", 0x2: "CAND_OVERFLOW", 0x4: "KP_OVERFLOW", 0x8: "NBR_OVERFLOW",
                  0x10: "TOTAL_KP_OVERFLOW", 0x20: "KPC_OVERFLOW"}
-FX_N_STAGES = 6
-STAGE_NAMES = ("prep", "rings", "merge", "offsets", "descriptors", "reserved")
+FX_N_STAGES = 7
+STAGE_NAMES = ("k_prep", "k_rings_small", "k_rings_big", "k_merge_small", "k_merge_big+k_offsets", "k_desc_small",
+               "desc_tail")
 
 
 class FxParams(C.Structure):
@@ -81,9 +82,9 @@ class FxSynthCfg(C.Structure):
 # every symbol include/fx.h declares (tests/test_capi_symbols.py checks the list against the header)
 EXPORTS = ("fx_version", "fx_status_str", "fx_last_error", "fx_params_default", "fx_params_launch",
            "fx_limits_default", "fx_create", "fx_destroy", "fx_set_stream", "fx_set_profiling", "fx_get_timings",
-           "fx_get_limits", "fx_process_batch", "fx_synchronize", "fx_pack_features",
+           "fx_get_limits", "fx_process_batch", "fx_synchronize", "fx_pack_features", "fx_pack_keypoint_records",
            "fx_rotation_from_roll_pitch", "fx_sc3d_tables", "fx_sc3d_xaxis", "fx_synth_cfg_vlp16",
-           "fx_synth_scan")
+           "fx_synth_scan", "fx_test_sort_replay")
 
 _lib = None
 
@@ -111,13 +112,14 @@ def load():
     lib.fx_destroy.restype = None
     lib.fx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     lib.fx_set_profiling.argtypes = [C.c_void_p, C.c_int]
-    lib.fx_get_timings.argtypes = [C.c_void_p, C.POINTER(FxTimings)]
+    lib.fx_get_timings.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(FxTimings)]
     lib.fx_get_limits.argtypes = [C.c_void_p, C.POINTER(FxLimits)]
     lib.fx_process_batch.argtypes = [C.c_void_p, C.POINTER(FxScanDesc), C.c_uint32, C.c_uint32,
                                      C.POINTER(FxBatchView)]
     lib.fx_process_batch.restype = C.c_int
     lib.fx_synchronize.argtypes = [C.c_void_p]
     lib.fx_pack_features.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    lib.fx_pack_keypoint_records.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     lib.fx_rotation_from_roll_pitch.argtypes = [C.c_double, C.c_double, _F32P]
     lib.fx_rotation_from_roll_pitch.restype = None
     lib.fx_sc3d_tables.argtypes = [C.c_double, _F32P, _F32P, _F32P, _F32P]
@@ -222,13 +224,17 @@ class Context:
     def set_stream(self, stream_ptr):
         check(self.lib.fx_set_stream(self.handle, C.c_void_p(stream_ptr)))
 
-    def set_profiling(self, on):
-        check(self.lib.fx_set_profiling(self.handle, 1 if on else 0))
+    def set_profiling(self, depth):
+        check(self.lib.fx_set_profiling(self.handle, int(depth)))
 
-    def timings(self):
+    def timings(self, back=0):
+        """Per-kernel device ms (HIP events on the launch stream) of the batch `back` calls ago."""
         t = FxTimings()
-        check(self.lib.fx_get_timings(self.handle, C.byref(t)))
+        check(self.lib.fx_get_timings(self.handle, back, C.byref(t)))
         return {STAGE_NAMES[i]: t.ms[i] for i in range(FX_N_STAGES)}, t.total_ms
+
+    def pack_keypoint_records(self, dst_device_ptr, rec_keypoints):
+        check(self.lib.fx_pack_keypoint_records(self.handle, C.c_void_p(dst_device_ptr), rec_keypoints))
 
     def synchronize(self):
         check(self.lib.fx_synchronize(self.handle))

@@ -22,13 +22,17 @@ size_t fxk_merge_lds_bytes(uint32_t cap, uint32_t n_rings);
 size_t fxk_desc_lds_bytes(uint32_t cap);
 hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t desc_big);
 void fxk_prep(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
-void fxk_rings(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap_small,
-               uint32_t cap_big, uint32_t big_grid);
-void fxk_merge(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap_small,
-               uint32_t cap_big, uint32_t big_grid);
+void fxk_rings_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap);
+void fxk_rings_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t grid);
+void fxk_merge_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap);
+void fxk_merge_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t grid);
 void fxk_offsets(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
-void fxk_desc(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap_small,
-              uint32_t cap_big, uint32_t grid_small, uint32_t big_grid, uint32_t mode);
+void fxk_desc_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap,
+                    uint32_t grid, uint32_t mode);
+void fxk_desc_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap,
+                  uint32_t grid, uint32_t mode);
+void fxk_pack_kp_records(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, void *dst,
+                         uint32_t rec_kp);
 void fxk_rng_ord(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
 void fxk_pack_features(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, void *dst,
                        uint32_t capacity, uint32_t grid);
@@ -79,9 +83,11 @@ struct fx_ctx {
   int32_t *h_cand_kp = nullptr;
   float *h_keypoints = nullptr, *h_desc = nullptr, *h_filtered = nullptr, *h_kpc = nullptr, *h_cand = nullptr;
   // profiling
+  // profiling: a ring of event sets so a whole timed region can be read back afterwards
   bool profiling = false;
-  hipEvent_t ev[FX_N_STAGES + 1] = {};
-  bool ev_valid = false;
+  std::vector<hipEvent_t> ev_ring;  // depth * (FX_N_STAGES + 1)
+  uint32_t ev_depth = 0, ev_count = 0;
+  hipEvent_t *ev = nullptr;  // set of the batch being enqueued
   uint32_t last_batch = 0;
 };
 
@@ -289,8 +295,6 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
     if (hipEventCreateWithFlags(&c->meta_ev[i], hipEventDisableTiming) != hipSuccess)
       return bail(fail(FX_ERR_HIP, "hipEventCreate"));
   }
-  for (int i = 0; i <= FX_N_STAGES; ++i)
-    if (hipEventCreate(&c->ev[i]) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipEventCreate"));
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess)
     return bail(fail(FX_ERR_HIP, "hipStreamCreate"));
   c->stream = c->own_stream;
@@ -317,8 +321,7 @@ void fx_destroy(fx_ctx *c) {
   if (c->d_stage) (void)hipFree(c->d_stage);
   for (int i = 0; i < kMetaSlots; ++i)
     if (c->meta_ev[i]) (void)hipEventDestroy(c->meta_ev[i]);
-  for (int i = 0; i <= FX_N_STAGES; ++i)
-    if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  for (hipEvent_t e : c->ev_ring) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -328,10 +331,17 @@ fx_status fx_set_stream(fx_ctx *c, void *hip_stream) {
   c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
   return FX_OK;
 }
-fx_status fx_set_profiling(fx_ctx *c, int enabled) {
-  if (!c) return fail(FX_ERR_INVALID_ARG, "null ctx");
-  c->profiling = enabled != 0;
-  c->ev_valid = false;
+fx_status fx_set_profiling(fx_ctx *c, int depth) {
+  if (!c || depth < 0) return fail(FX_ERR_INVALID_ARG, "bad argument");
+  FX_HIP(hipSetDevice(c->device));
+  FX_HIP(hipStreamSynchronize(c->stream));
+  for (hipEvent_t e : c->ev_ring) (void)hipEventDestroy(e);
+  c->ev_ring.clear();
+  c->ev_depth = (uint32_t)depth;
+  c->ev_count = 0;
+  c->profiling = depth > 0;
+  c->ev_ring.resize((size_t)depth * (FX_N_STAGES + 1), nullptr);
+  for (hipEvent_t &e : c->ev_ring) FX_HIP(hipEventCreate(&e));
   return FX_OK;
 }
 fx_status fx_get_limits(const fx_ctx *c, fx_limits *l) {
@@ -339,13 +349,15 @@ fx_status fx_get_limits(const fx_ctx *c, fx_limits *l) {
   *l = c->lim;
   return FX_OK;
 }
-fx_status fx_get_timings(fx_ctx *c, fx_timings *t) {
+fx_status fx_get_timings(fx_ctx *c, uint32_t back, fx_timings *t) {
   if (!c || !t) return fail(FX_ERR_INVALID_ARG, "null argument");
   std::memset(t, 0, sizeof(*t));
-  if (!c->ev_valid) return fail(FX_ERR_INVALID_ARG, "no profiled batch (fx_set_profiling first)");
-  FX_HIP(hipEventSynchronize(c->ev[FX_N_STAGES]));
-  for (int i = 0; i < FX_N_STAGES; ++i) FX_HIP(hipEventElapsedTime(&t->ms[i], c->ev[i], c->ev[i + 1]));
-  FX_HIP(hipEventElapsedTime(&t->total_ms, c->ev[0], c->ev[FX_N_STAGES]));
+  if (!c->profiling || back >= c->ev_count || back >= c->ev_depth)
+    return fail(FX_ERR_INVALID_ARG, "no profiled batch that far back (fx_set_profiling(depth) first)");
+  hipEvent_t *ev = &c->ev_ring[(size_t)((c->ev_count - 1 - back) % c->ev_depth) * (FX_N_STAGES + 1)];
+  FX_HIP(hipEventSynchronize(ev[FX_N_STAGES]));
+  for (int i = 0; i < FX_N_STAGES; ++i) FX_HIP(hipEventElapsedTime(&t->ms[i], ev[i], ev[i + 1]));
+  FX_HIP(hipEventElapsedTime(&t->total_ms, ev[0], ev[FX_N_STAGES]));
   return FX_OK;
 }
 fx_status fx_synchronize(fx_ctx *c) {
@@ -413,33 +425,42 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
   const FxBuffers &B = c->buf;
   const bool prof = c->profiling;
   const uint32_t big_grid = (uint32_t)c->n_cu;
-  if (prof) FX_HIP(hipEventRecord(c->ev[0], s));
+  if (prof) c->ev = &c->ev_ring[(size_t)(c->ev_count % c->ev_depth) * (FX_N_STAGES + 1)];
+  auto mark = [&](int i) -> hipError_t { return prof ? hipEventRecord(c->ev[i], s) : hipSuccess; };
+  FX_HIP(mark(0));
   FX_HIP(hipMemsetAsync(B.counters, 0, 8 * sizeof(uint32_t), s));
   if (batch) {
-    fxk_prep(s, P, B, batch);
-    if (prof) FX_HIP(hipEventRecord(c->ev[1], s));
     const uint32_t ring_small = L.max_ring_points < kRingCapSmall ? L.max_ring_points : kRingCapSmall;
-    fxk_rings(s, P, B, batch, ring_small, L.max_ring_points, big_grid);
-    if (prof) FX_HIP(hipEventRecord(c->ev[2], s));
     const uint32_t merge_small = L.max_candidates < kMergeCapSmall ? L.max_candidates : kMergeCapSmall;
-    fxk_merge(s, P, B, batch, merge_small, L.max_candidates, big_grid);
-    if (prof) FX_HIP(hipEventRecord(c->ev[3], s));
+    const uint32_t desc_small = L.max_neighbors < kDescCapSmall ? L.max_neighbors : kDescCapSmall;
+    const uint32_t desc_grid = (uint32_t)c->n_cu * 16u;
+    fxk_prep(s, P, B, batch);
+    FX_HIP(mark(1));
+    fxk_rings_small(s, P, B, batch, ring_small);
+    FX_HIP(mark(2));
+    fxk_rings_big(s, P, B, L.max_ring_points, big_grid);
+    FX_HIP(mark(3));
+    fxk_merge_small(s, P, B, batch, merge_small);
+    FX_HIP(mark(4));
+    fxk_merge_big(s, P, B, L.max_candidates, big_grid);
     fxk_offsets(s, P, B, batch);
-    if (prof) FX_HIP(hipEventRecord(c->ev[4], s));
+    FX_HIP(mark(5));
     if (P.estimate_descriptors) {
-      const uint32_t desc_small = L.max_neighbors < kDescCapSmall ? L.max_neighbors : kDescCapSmall;
-      const uint32_t grid = (uint32_t)c->n_cu * 16u;
-      fxk_desc(s, P, B, batch, desc_small, L.max_neighbors, grid, big_grid, 0);
+      fxk_desc_small(s, P, B, batch, desc_small, desc_grid, 0);
+      FX_HIP(mark(6));
+      fxk_desc_big(s, P, B, batch, L.max_neighbors, big_grid, 0);
       fxk_rng_ord(s, P, B, batch);
-      fxk_desc(s, P, B, batch, desc_small, L.max_neighbors, grid, big_grid, 1);
+      fxk_desc_small(s, P, B, batch, desc_small, desc_grid, 1);
+      fxk_desc_big(s, P, B, batch, L.max_neighbors, big_grid, 1);
+    } else {
+      FX_HIP(mark(6));
     }
-    if (prof) FX_HIP(hipEventRecord(c->ev[5], s));
-    if (prof) FX_HIP(hipEventRecord(c->ev[6], s));
+    FX_HIP(mark(7));
     FX_HIP(hipGetLastError());
-  } else if (prof) {
-    for (int i = 1; i <= FX_N_STAGES; ++i) FX_HIP(hipEventRecord(c->ev[i], s));
+  } else {
+    for (int i = 1; i <= FX_N_STAGES; ++i) FX_HIP(mark(i));
   }
-  c->ev_valid = prof;
+  if (prof) ++c->ev_count;
   c->last_batch = batch;
 
   // ---- view
@@ -531,6 +552,14 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
   out->h_flags = c->h_flags;
   out->h_n_filtered = c->h_n_filt;
   out->h_n_kpc = c->h_n_kpc;
+  return FX_OK;
+}
+
+fx_status fx_pack_keypoint_records(fx_ctx *c, void *dst_device, uint32_t rec_keypoints) {
+  if (!c || !dst_device || !rec_keypoints) return fail(FX_ERR_INVALID_ARG, "null argument");
+  FX_HIP(hipSetDevice(c->device));
+  if (c->last_batch) fxk_pack_kp_records(c->stream, c->dp, c->buf, c->last_batch, dst_device, rec_keypoints);
+  FX_HIP(hipGetLastError());
   return FX_OK;
 }
 

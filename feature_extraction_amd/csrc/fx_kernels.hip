@@ -953,6 +953,21 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_pack_features(FxDevParams 
   }
 }
 
+// Fixed-stride keypoint records for the cross-GPU gather: {n_kp, flags, 0, 0, kp[rec_kp] float4}.
+extern "C" __global__ __launch_bounds__(FX_WG) void k_pack_kp_records(FxDevParams P, FxBuffers B, uint32_t batch,
+                                                                       float4 *dst, uint32_t rec_kp) {
+  const uint32_t scan = blockIdx.x;
+  if (scan >= batch) return;
+  float4 *rec = dst + (size_t)scan * (rec_kp + 1);
+  const uint32_t K = B.n_kp[scan];
+  if (threadIdx.x == 0) {
+    uint4 h = make_uint4(K < rec_kp ? K : rec_kp, B.flags[scan] | (K > rec_kp ? FX_FLAG_KP_OVERFLOW : 0u), 0u, 0u);
+    rec[0] = *reinterpret_cast<float4 *>(&h);
+  }
+  const float4 *kp = B.keypoints + (size_t)scan * P.max_keypoints;
+  for (uint32_t k = threadIdx.x; k < rec_kp; k += FX_WG) rec[1 + k] = k < K ? kp[k] : make_float4(0, 0, 0, 0);
+}
+
 // ====================================================================== launchers
 extern "C" {
 
@@ -975,31 +990,35 @@ hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t desc_big) {
 void fxk_prep(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch) {
   hipLaunchKernelGGL(k_prep, dim3(batch), dim3(FX_PREP_T), 0, s, P, B);
 }
-void fxk_rings(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap_small,
-               uint32_t cap_big, uint32_t big_grid) {
-  hipLaunchKernelGGL(k_rings_small, dim3(batch * P.n_rings), dim3(FX_WG), fxk_ring_lds_bytes(cap_small), s, P, B,
-                     cap_small);
-  hipLaunchKernelGGL(k_rings_big, dim3(big_grid), dim3(FX_WG), fxk_ring_lds_bytes(cap_big), s, P, B, cap_big);
+void fxk_rings_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap) {
+  hipLaunchKernelGGL(k_rings_small, dim3(batch * P.n_rings), dim3(FX_WG), fxk_ring_lds_bytes(cap), s, P, B, cap);
 }
-void fxk_merge(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap_small,
-               uint32_t cap_big, uint32_t big_grid) {
-  hipLaunchKernelGGL(k_merge_small, dim3(batch), dim3(FX_WG), fxk_merge_lds_bytes(cap_small, P.n_rings), s, P, B,
-                     cap_small);
-  hipLaunchKernelGGL(k_merge_big, dim3(big_grid), dim3(FX_WG), fxk_merge_lds_bytes(cap_big, P.n_rings), s, P, B,
-                     cap_big);
+void fxk_rings_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t grid) {
+  hipLaunchKernelGGL(k_rings_big, dim3(grid), dim3(FX_WG), fxk_ring_lds_bytes(cap), s, P, B, cap);
+}
+void fxk_merge_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap) {
+  hipLaunchKernelGGL(k_merge_small, dim3(batch), dim3(FX_WG), fxk_merge_lds_bytes(cap, P.n_rings), s, P, B, cap);
+}
+void fxk_merge_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t grid) {
+  hipLaunchKernelGGL(k_merge_big, dim3(grid), dim3(FX_WG), fxk_merge_lds_bytes(cap, P.n_rings), s, P, B, cap);
 }
 void fxk_offsets(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch) {
   hipLaunchKernelGGL(k_offsets, dim3(1), dim3(FX_WG), 0, s, P, B, batch);
 }
-void fxk_desc(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap_small,
-              uint32_t cap_big, uint32_t grid_small, uint32_t big_grid, uint32_t mode) {
-  hipLaunchKernelGGL(k_desc_small, dim3(grid_small), dim3(FX_WG), fxk_desc_lds_bytes(cap_small), s, P, B, batch,
-                     cap_small, mode);
-  hipLaunchKernelGGL(k_desc_big, dim3(big_grid), dim3(FX_WG), fxk_desc_lds_bytes(cap_big), s, P, B, batch, cap_big,
-                     mode);
+void fxk_desc_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap,
+                    uint32_t grid, uint32_t mode) {
+  hipLaunchKernelGGL(k_desc_small, dim3(grid), dim3(FX_WG), fxk_desc_lds_bytes(cap), s, P, B, batch, cap, mode);
+}
+void fxk_desc_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap,
+                  uint32_t grid, uint32_t mode) {
+  hipLaunchKernelGGL(k_desc_big, dim3(grid), dim3(FX_WG), fxk_desc_lds_bytes(cap), s, P, B, batch, cap, mode);
 }
 void fxk_rng_ord(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch) {
   hipLaunchKernelGGL(k_rng_ord, dim3((batch + FX_WG - 1) / FX_WG), dim3(FX_WG), 0, s, P, B, batch);
+}
+void fxk_pack_kp_records(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, void *dst,
+                         uint32_t rec_kp) {
+  hipLaunchKernelGGL(k_pack_kp_records, dim3(batch), dim3(FX_WG), 0, s, P, B, batch, (float4 *)dst, rec_kp);
 }
 void fxk_pack_features(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, void *dst,
                        uint32_t capacity, uint32_t grid) {

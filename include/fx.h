@@ -149,9 +149,11 @@ typedef struct fx_batch_view {
 } fx_batch_view;
 
 /* Per-stage device time of the last batch (HIP events on the context's stream). */
-#define FX_N_STAGES 6
+#define FX_N_STAGES 7
 typedef struct fx_timings {
-  float ms[FX_N_STAGES]; /* prep, rings, merge, offsets, descriptors, (reserved) */
+  /* k_prep, k_rings_small, k_rings_big, k_merge_small, k_merge_big+k_offsets, k_desc_small,
+   * descriptor tail (k_desc_big, k_rng_ord, second pass) */
+  float ms[FX_N_STAGES];
   float total_ms;
 } fx_timings;
 
@@ -174,8 +176,11 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
 void fx_destroy(fx_ctx *ctx);
 /* hipStream_t to launch on (NULL = the context's own stream). */
 fx_status fx_set_stream(fx_ctx *ctx, void *hip_stream);
-fx_status fx_set_profiling(fx_ctx *ctx, int enabled);
-fx_status fx_get_timings(fx_ctx *ctx, fx_timings *t);
+/* depth > 0: record HIP events around every stage kernel for the next batches, keeping the
+ * last `depth` batches; 0 disables.  fx_get_timings reads the batch `back` calls ago
+ * (0 = most recent) and waits for it to finish. */
+fx_status fx_set_profiling(fx_ctx *ctx, int depth);
+fx_status fx_get_timings(fx_ctx *ctx, uint32_t back, fx_timings *t);
 fx_status fx_get_limits(const fx_ctx *ctx, fx_limits *l);
 
 /* Replaces cloudCallback's body for a batch of B scans (ref: node.cpp:83-115):
@@ -191,6 +196,12 @@ fx_status fx_synchronize(fx_ctx *ctx);
  * batch's keypoints + descriptors into 7984-byte pcl::PointDescriptor records on
  * the device.  dst_device must hold total_keypoints records. */
 fx_status fx_pack_features(fx_ctx *ctx, void *dst_device, uint32_t capacity_records);
+
+/* Fixed-stride keypoint records of the last batch for the cross-GPU gather (one RCCL
+ * collective per batch): per scan (1 + rec_keypoints) float4 = {n_kp, flags, 0, 0 as u32}
+ * followed by rec_keypoints (x, y, z, elevation) entries, zero padded.  dst_device must hold
+ * batch * (1 + rec_keypoints) * 16 bytes. */
+fx_status fx_pack_keypoint_records(fx_ctx *ctx, void *dst_device, uint32_t rec_keypoints);
 
 /* Rotation matrix of rotateCloud (ref: node.cpp:161-164): R = Ry(pitch)*Rx(roll)
  * through Eigen's AngleAxisf -> Quaternionf -> toRotationMatrix, all float. Host only. */
@@ -215,6 +226,10 @@ typedef struct fx_synth_cfg {
 } fx_synth_cfg;
 void fx_synth_cfg_vlp16(fx_synth_cfg *c, uint64_t seed);
 uint32_t fx_synth_scan(const fx_synth_cfg *c, float *xyzi_out, uint32_t capacity_points);
+
+/* Test hook: host build of the cluster-order replay the kernels run on one GPU lane
+ * (csrc/fx_sort_replay.h).  perm_out[s] = ordinal of the cluster PCL returns at position s. */
+void fx_test_sort_replay(const uint32_t *sizes, uint32_t n, uint32_t *perm_out);
 
 #ifdef __cplusplus
 }
