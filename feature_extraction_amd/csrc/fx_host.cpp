@@ -233,7 +233,8 @@ uint32_t fx_synth_scan(const fx_synth_cfg *c, float *out, uint32_t capacity) {
 void fx_test_sort_replay(const uint32_t *sizes, uint32_t n, uint32_t *perm_out) {
   uint32_t *rec = new uint32_t[n ? n : 1];
   for (uint32_t i = 0; i < n; ++i) rec[i] = (sizes[i] << 16) | i;
-  fx_sort_replay_desc(rec, n);
+  int stk[FX_SORT_STACK_WORDS];
+  fx_sort_replay_desc(rec, n, stk);
   for (uint32_t i = 0; i < n; ++i) perm_out[i] = rec[i] & 0xffffu;
   delete[] rec;
 }

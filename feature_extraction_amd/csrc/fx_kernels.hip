@@ -90,8 +90,10 @@ __device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t i) {
   volatile uint32_t *p = parent;
   uint32_t q = p[i];
   while (q != i) {
+    const uint32_t g = p[q];
+    if (g != q) p[i] = g;  // path halving: still an ancestor, so concurrent finds stay valid
     i = q;
-    q = p[i];
+    q = g;
   }
   return i;
 }
@@ -111,23 +113,56 @@ __device__ __forceinline__ void uf_union(uint32_t *parent, uint32_t a, uint32_t 
   }
 }
 
+#define FX_SCRATCH_WORDS 160  // s_w[0..15] block helpers, s_w[16..31] broadcast slots, s_w[32..151] sort stack
+#define FX_NONE 0xffffffffu
+
 // Connected components of {d2(i,j) < r2} over n points held in LDS.  On return parent[i] is
 // the smallest index of i's component and csize[root] the component size.
+//  1. run labelling: consecutive points i-1, i closer than the tolerance form runs; a wave
+//     ballot + highest-set-bit gives every point its run head (sensor rings arrive azimuth
+//     ordered, so this one scan already finds almost every cluster);
+//  2. all pairs, skipping pairs that already share an ancestor, union-find for the rest
+//     (exact for any input order: every pair is examined).
 __device__ void cc_label(const float *px, const float *py, const float *pz, uint32_t n, float r2, uint32_t *parent,
-                         uint32_t *csize) {
-  for (uint32_t i = threadIdx.x; i < n; i += FX_WG) {
-    parent[i] = i;
-    csize[i] = 0;
+                         uint32_t *csize, uint32_t *s_w) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t carry = 0;
+  for (uint32_t b0 = 0; b0 < n; b0 += FX_WG) {
+    const uint32_t i = b0 + threadIdx.x;
+    bool start = true;
+    if (i < n) {
+      csize[i] = 0;
+      if (i > 0) start = !(dist2(px[i], py[i], pz[i], px[i - 1], py[i - 1], pz[i - 1]) < r2);
+    }
+    const unsigned long long m = __ballot(start);
+    if (lane == 0) s_w[wave] = m ? (b0 + wave * 64 + (63u - (uint32_t)__clzll((long long)m))) : FX_NONE;
+    __syncthreads();
+    const unsigned long long below = m & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+    uint32_t head = carry, last = carry;
+#pragma unroll
+    for (int w = 0; w < FX_NWAVE; ++w) {
+      const uint32_t v = s_w[w];
+      if (v != FX_NONE) {
+        if (w < (int)wave) head = v;
+        last = v;
+      }
+    }
+    if (below) head = b0 + wave * 64 + (63u - (uint32_t)__clzll((long long)below));
+    __syncthreads();
+    carry = last;
+    if (i < n) parent[i] = head;
   }
   __syncthreads();
-  // all pairs, folded so that every thread sees about n/2 partners: rows i and n-1-i
+  // all pairs, folded so that every thread sees about n/2 partners: rows t and n-1-t
   const uint32_t half = (n + 1) / 2;
   for (uint32_t t = threadIdx.x; t < half; t += FX_WG) {
     for (int pass = 0; pass < 2; ++pass) {
       const uint32_t i = pass == 0 ? t : n - 1 - t;
       if (pass == 1 && i == t) break;
       const float qx = px[i], qy = py[i], qz = pz[i];
-      for (uint32_t j = i + 1; j < n; ++j) {
+      const uint32_t li = parent[i];
+      for (uint32_t j = i + 2; j < n; ++j) {
+        if (parent[j] == li) continue;  // same ancestor: already one component
         const float d = dist2(qx, qy, qz, px[j], py[j], pz[j]);
         if (d < r2) uf_union(parent, j, i);
       }
@@ -139,7 +174,21 @@ __device__ void cc_label(const float *px, const float *py, const float *pz, uint
     parent[i] = r;  // still a valid ancestor for concurrent finds
   }
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < n; i += FX_WG) atomicAdd(&csize[parent[i]], 1u);
+  // sizes: one LDS atomic per distinct root per wave
+  for (uint32_t b0 = 0; b0 < n; b0 += FX_WG) {
+    const uint32_t i = b0 + threadIdx.x;
+    bool todo = i < n;
+    const uint32_t root = todo ? parent[i] : 0u;
+    while (true) {
+      const unsigned long long act = __ballot(todo);
+      if (!act) break;
+      const uint32_t leader = (uint32_t)__ffsll((long long)act) - 1u;
+      const uint32_t r = __shfl(root, leader, 64);
+      const unsigned long long same = __ballot(todo && root == r);
+      if (lane == leader) atomicAdd(&csize[r], (uint32_t)__popcll(same));
+      if (root == r) todo = false;
+    }
+  }
   __syncthreads();
 }
 
@@ -167,9 +216,18 @@ __device__ uint32_t cc_order(uint32_t n, const uint32_t *parent, const uint32_t 
     n_c += tot;
   }
   __syncthreads();
-  if (threadIdx.x == 0) fx_sort_replay_desc(crec, n_c);
+  if (threadIdx.x == 0) fx_sort_replay_desc(crec, n_c, (int *)(s_w + 32));
   __syncthreads();
   return n_c;
+}
+
+// order-preserving map float -> uint32 (for LDS atomicMin/Max on coordinates)
+__device__ __forceinline__ uint32_t f2ord(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o) {
+  return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
 }
 
 }  // namespace
@@ -262,8 +320,8 @@ struct RingLds {
 };
 __device__ __forceinline__ RingLds ring_carve(uint32_t *smem, uint32_t cap) {
   RingLds L;
-  L.s_w = smem;  // 16 words of scratch
-  uint32_t *p = smem + 16;
+  L.s_w = smem;
+  uint32_t *p = smem + FX_SCRATCH_WORDS;
   L.px = (float *)p, p += cap;
   L.py = (float *)p, p += cap;
   L.pz = (float *)p, p += cap;
@@ -290,34 +348,54 @@ __device__ __forceinline__ RingLds ring_carve(uint32_t *smem, uint32_t cap) {
 __device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t scan, uint32_t ring, uint32_t cap,
                           uint32_t *smem, bool last_tier) {
   RingLds L = ring_carve(smem, cap);
-  const uint32_t tid = threadIdx.x;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t nf = B.n_filt[scan];
   const float4 *f = B.filt + (size_t)scan * P.max_points;
   const float2 win = B.ring_win[ring];
   const size_t ring_slot = (size_t)scan * P.n_rings + ring;
 
-  // ---- ring split (ref: node.cpp:200-202): keep iff lo <= elevation <= hi, input order
+  // ---- ring split (ref: node.cpp:200-202): keep iff lo <= elevation <= hi, input order.
+  //      Four independent loads per thread and trip, one barrier pair per 1024 points.
   uint32_t n = 0;
-  for (uint32_t b0 = 0; b0 < nf; b0 += FX_WG) {
-    const uint32_t i = b0 + tid;
-    bool in = false;
-    float4 v = make_float4(0, 0, 0, 0);
-    if (i < nf) {
-      v = f[i];
-      in = isfinite(v.w) && !(v.w < win.x || v.w > win.y);
+  for (uint32_t b0 = 0; b0 < nf; b0 += FX_WG * 4) {
+    float4 v[4];
+    bool in[4];
+    unsigned long long m[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t i = b0 + u * FX_WG + tid;
+      v[u] = i < nf ? f[i] : make_float4(0.f, 0.f, 0.f, NAN);
     }
-    uint32_t tot;
-    const uint32_t r = block_rank(in, L.s_w, tot);
-    if (in) {
-      const uint32_t pos = n + r;
-      if (pos < cap) {
-        L.px[pos] = v.x;
-        L.py[pos] = v.y;
-        L.pz[pos] = v.z;
-        L.pe[pos] = v.w;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      in[u] = isfinite(v[u].w) && !(v[u].w < win.x || v[u].w > win.y);
+      m[u] = __ballot(in[u]);
+      if (lane == 0) L.s_w[u * FX_NWAVE + wave] = (uint32_t)__popcll(m[u]);
+    }
+    __syncthreads();
+    uint32_t run = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      uint32_t before = 0, slice = 0;
+#pragma unroll
+      for (int w = 0; w < FX_NWAVE; ++w) {
+        const uint32_t c = L.s_w[u * FX_NWAVE + w];
+        before += (w < (int)wave) ? c : 0u;
+        slice += c;
       }
+      if (in[u]) {
+        const uint32_t pos = n + run + before + lanes_below(m[u]);
+        if (pos < cap) {
+          L.px[pos] = v[u].x;
+          L.py[pos] = v[u].y;
+          L.pz[pos] = v[u].z;
+          L.pe[pos] = v[u].w;
+        }
+      }
+      run += slice;
     }
-    n += tot;
+    __syncthreads();
+    n += run;
   }
   if (n > cap) {
     if (!last_tier) return false;
@@ -340,38 +418,63 @@ __device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t sca
   }
 
   // ---- pcl::EuclideanClusterExtraction (ref: node.cpp:269-276)
-  cc_label(L.px, L.py, L.pz, n, P.r2_cluster, L.parent, L.csize);
+  cc_label(L.px, L.py, L.pz, n, P.r2_cluster, L.parent, L.csize, L.s_w);
   const uint32_t n_c = cc_order(n, L.parent, L.csize, P.min_count, P.max_count, L.croot, L.crec, L.s_w);
 
-  // ---- per cluster, in PCL's order: fp64 sums in ascending member order, bounding box,
-  //      diameter gate, centroid (ref: node.cpp:282-325)
+  // ---- xy bounding box of every admissible cluster (ref: node.cpp:289-305), all points in
+  //      parallel: min/max are exact whatever the order.  The four arrays live where the
+  //      centroids go afterwards (indexed by root here, by cluster position there).
+  uint32_t *bminx = (uint32_t *)L.ccx, *bmaxx = (uint32_t *)L.ccy, *bminy = (uint32_t *)L.ccz,
+           *bmaxy = (uint32_t *)L.cce;
+  for (uint32_t c = tid; c < n_c; c += FX_WG) {
+    const uint32_t root = L.croot[c];
+    bminx[root] = f2ord(1000.0f);  // ref: node.cpp:289-290 initial values
+    bmaxx[root] = f2ord(-1000.0f);
+    bminy[root] = f2ord(1000.0f);
+    bmaxy[root] = f2ord(-1000.0f);
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < n; i += FX_WG) {
+    const uint32_t root = L.parent[i];
+    const uint32_t sz = L.csize[root];
+    if (sz < P.min_count || sz > P.max_count) continue;
+    const uint32_t ox = f2ord(L.px[i]), oy = f2ord(L.py[i]);
+    atomicMin(&bminx[root], ox);
+    atomicMax(&bmaxx[root], ox);
+    atomicMin(&bminy[root], oy);
+    atomicMax(&bmaxy[root], oy);
+  }
+  __syncthreads();
+  // ---- diameter gate per cluster, in PCL's cluster order (ref: node.cpp:314-316)
   for (uint32_t s = tid; s < n_c; s += FX_WG) {
+    const uint32_t root = L.croot[L.crec[s] & 0xffffu];
+    const double minx = ord2f(bminx[root]), maxx = ord2f(bmaxx[root]);
+    const double miny = ord2f(bminy[root]), maxy = ord2f(bmaxy[root]);
+    const double ddx = maxx - minx, ddy = maxy - miny;
+    const double diameter = sqrt(ddx * ddx + ddy * ddy);
+    L.cpos[root] = s;
+    L.cslot[s] = (diameter < P.gate_diameter) ? 1u : 0u;
+  }
+  __syncthreads();
+  // ---- centroid of the clusters that pass: fp64 sums in ascending member order
+  //      (ref: node.cpp:293-297, 317-320); the walk also ranks the members for keypoint_cloud
+  for (uint32_t s = tid; s < n_c; s += FX_WG) {
+    if (L.cslot[s] == 0u) continue;
     const uint32_t rec = L.crec[s];
     const uint32_t sz = rec >> 16, root = L.croot[rec & 0xffffu];
-    L.cpos[root] = s;
     double sumx = 0.0, sumy = 0.0, sumz = 0.0;
-    double minx = 1000.0, maxx = -1000.0, miny = 1000.0, maxy = -1000.0;
     uint32_t cnt = 0;
     for (uint32_t i = root; i < n && cnt < sz; ++i) {
       if (L.parent[i] != root) continue;
-      const double x = L.px[i], y = L.py[i], z = L.pz[i];
-      sumx += x;
-      sumy += y;
-      sumz += z;
-      if (x < minx) minx = x;
-      if (y < miny) miny = y;
-      if (x > maxx) maxx = x;
-      if (y > maxy) maxy = y;
+      sumx += (double)L.px[i];
+      sumy += (double)L.py[i];
+      sumz += (double)L.pz[i];
       L.rank[i] = cnt++;
     }
-    const double ddx = maxx - minx, ddy = maxy - miny;
-    const double diameter = sqrt(ddx * ddx + ddy * ddy);
-    const bool pass = diameter < P.gate_diameter;
     L.ccx[s] = (float)(sumx / (double)sz);
     L.ccy[s] = (float)(sumy / (double)sz);
     L.ccz[s] = (float)(sumz / (double)sz);
     L.cce[s] = L.pe[root];
-    L.cslot[s] = pass ? 1u : 0u;
   }
   __syncthreads();
 
@@ -385,7 +488,7 @@ __device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t sca
     const uint32_t slot = block_rank(pass, L.s_w, tot_p);
     const uint32_t koff = block_excl_scan(sz, L.s_w, tot_m);
     if (s < n_c) {
-      L.cslot[s] = pass ? (n_pass + slot) : 0xffffffffu;
+      L.cslot[s] = pass ? (n_pass + slot) : FX_NONE;
       L.ckoff[s] = n_mem + koff;
     }
     n_pass += tot_p;
@@ -418,12 +521,12 @@ __device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t sca
     B.ring_cand_cnt[ring_slot] = n_pass < P.max_ring_cands ? n_pass : P.max_ring_cands;
     B.kpc_ring_off[ring_slot] = off;
     B.kpc_ring_cnt[ring_slot] = cnt;
-    L.s_w[8] = off;
-    L.s_w[9] = cnt;
+    L.s_w[16] = off;
+    L.s_w[17] = cnt;
   }
   __syncthreads();
-  const uint32_t off = L.s_w[8];
-  if (L.s_w[9]) {
+  const uint32_t off = L.s_w[16];
+  if (L.s_w[17]) {
     float4 *pool = B.kpc_pool + (size_t)scan * P.max_kpc;
     uint32_t *pool_c = B.kpc_pool_cand + (size_t)scan * P.max_kpc;
     for (uint32_t i = tid; i < n; i += FX_WG) {
@@ -432,7 +535,7 @@ __device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t sca
       if (sz < P.min_count || sz > P.max_count) continue;
       const uint32_t s = L.cpos[root];
       const uint32_t slot = L.cslot[s];
-      if (slot == 0xffffffffu) continue;
+      if (slot == FX_NONE) continue;
       const uint32_t dst = off + L.ckoff[s] + L.rank[i];
       pool[dst] = make_float4(L.px[i], L.py[i], L.pz[i], L.pe[i]);
       pool_c[dst] = slot;
@@ -471,7 +574,7 @@ struct MergeLds {
 __device__ __forceinline__ MergeLds merge_carve(uint32_t *smem, uint32_t cap, uint32_t n_rings) {
   MergeLds L;
   L.s_w = smem;
-  uint32_t *p = smem + 16;
+  uint32_t *p = smem + FX_SCRATCH_WORDS;
   L.cx = (float *)p, p += cap;
   L.cy = (float *)p, p += cap;
   L.cz = (float *)p, p += cap;
@@ -547,7 +650,7 @@ __device__ bool merge_body(const FxDevParams &P, const FxBuffers &B, uint32_t sc
 
   uint32_t K = 0;
   if (C > 0) {  // ref: node.cpp:209-210
-    cc_label(L.cx, L.cy, L.pz, C, P.r2_merge, L.parent, L.csize);
+    cc_label(L.cx, L.cy, L.pz, C, P.r2_merge, L.parent, L.csize, L.s_w);
     const uint32_t n_c = cc_order(C, L.parent, L.csize, P.ndc, P.secondary_max, L.croot, L.crec, L.s_w);
     K = n_c < P.max_keypoints ? n_c : P.max_keypoints;
     if (n_c > P.max_keypoints && tid == 0) atomicOr(&B.flags[scan], FX_FLAG_KP_OVERFLOW);
@@ -971,9 +1074,9 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_pack_kp_records(FxDevParam
 // ====================================================================== launchers
 extern "C" {
 
-size_t fxk_ring_lds_bytes(uint32_t cap) { return (size_t)(16 + FX_RING_WORDS_PER_POINT * cap) * 4; }
+size_t fxk_ring_lds_bytes(uint32_t cap) { return (size_t)(FX_SCRATCH_WORDS + FX_RING_WORDS_PER_POINT * cap) * 4; }
 size_t fxk_merge_lds_bytes(uint32_t cap, uint32_t n_rings) {
-  return (size_t)(16 + FX_MERGE_WORDS_PER_CAND * cap + n_rings + 1) * 4;
+  return (size_t)(FX_SCRATCH_WORDS + FX_MERGE_WORDS_PER_CAND * cap + n_rings + 1) * 4;
 }
 size_t fxk_desc_lds_bytes(uint32_t cap) { return (size_t)(16 + FX_DESC_WORDS_PER_POINT * cap + FX_DESC_BINS) * 4; }
 

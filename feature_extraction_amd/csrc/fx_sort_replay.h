@@ -141,7 +141,9 @@ FX_HD inline void insertion_sort(const RevView &v, int first, int last) {
 
 // Sorts rec[0..n) into the order PCL hands clusters back: descending size, ties as
 // libstdc++'s introsort leaves them.
-FX_HD inline void fx_sort_replay_desc(uint32_t *rec, uint32_t n_u) {
+#define FX_SORT_STACK_WORDS 120
+// stk: FX_SORT_STACK_WORDS ints of scratch (LDS on the device, so the kernel needs no private memory)
+FX_HD inline void fx_sort_replay_desc(uint32_t *rec, uint32_t n_u, int *stk) {
   using namespace fx_sort_detail;
   const int n = (int)n_u;
   if (n < 2) return;
@@ -151,7 +153,7 @@ FX_HD inline void fx_sort_replay_desc(uint32_t *rec, uint32_t n_u) {
   for (int t = n; t > 1; t >>= 1) ++lg;
   // explicit stack for the recursion on the right-hand part; pending ranges are disjoint,
   // so the order they are processed in does not change the result
-  int stk_first[40], stk_last[40], stk_depth[40];
+  int *stk_first = stk, *stk_last = stk + 40, *stk_depth = stk + 80;
   int sp = 0;
   stk_first[0] = 0;
   stk_last[0] = n;
