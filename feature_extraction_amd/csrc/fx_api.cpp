@@ -27,10 +27,11 @@ void fxk_rings_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint
 void fxk_merge_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap);
 void fxk_merge_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t grid);
 void fxk_offsets(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
-void fxk_desc_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap,
-                    uint32_t grid, uint32_t mode);
-void fxk_desc_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap,
-                  uint32_t grid, uint32_t mode);
+void fxk_gather(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float box_margin);
+void fxk_desc_wave(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid,
+                   uint32_t mode);
+void fxk_desc_wg(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t grid,
+                 uint32_t mode, uint32_t from_list);
 void fxk_pack_kp_records(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, void *dst,
                          uint32_t rec_kp);
 void fxk_rng_ord(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
@@ -54,7 +55,7 @@ fx_status fail(fx_status s, const std::string &msg) {
   } while (0)
 
 constexpr int kMetaSlots = 8;
-constexpr uint32_t kRingCapSmall = 512, kMergeCapSmall = 512, kDescCapSmall = 1024;
+constexpr uint32_t kRingCapSmall = 512, kMergeCapSmall = 512, kListCap = 1024;
 }  // namespace
 
 struct fx_ctx {
@@ -73,6 +74,7 @@ struct fx_ctx {
   bool meta_used[kMetaSlots] = {};
   int meta_next = 0;
   FxScanMeta *d_meta = nullptr;
+  float box_margin = 0.f;
   // host-input staging
   float *d_stage = nullptr;
   std::vector<float> repack;
@@ -197,6 +199,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
     P.r2_density = (float)(rd * rd);
     const double rs = (R + rd) * 1.0001 + 1e-4;  // conservative superset radius of the support set
     P.r2_support = (float)(rs * rs);
+    c->box_margin = (float)(rs * 1.001 + 1e-3);  // k_gather's bounding-box reject, conservative
   }
   P.estimate_descriptors = params->estimate_descriptors;
   P.max_points = L.max_points;
@@ -207,6 +210,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   P.max_kpc = L.max_kpc_points;
   P.max_neighbors = L.max_neighbors;
   P.max_ring_points = L.max_ring_points;
+  P.list_cap = L.max_neighbors < kListCap ? L.max_neighbors : kListCap;
 
   fx_status st = FX_OK;
   auto bail = [&](fx_status s) {
@@ -259,6 +263,9 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   FX_A(dev_alloc(c, &b.big_rings, B * R));
   FX_A(dev_alloc(c, &b.big_merge, B));
   FX_A(dev_alloc(c, &b.big_desc, L.max_total_keypoints));
+  FX_A(dev_alloc(c, &b.list_desc, L.max_total_keypoints));
+  FX_A(dev_alloc(c, &b.s_pts, (size_t)L.max_total_keypoints * P.list_cap));
+  FX_A(dev_alloc(c, &b.s_cnt, L.max_total_keypoints));
   FX_A(dev_alloc(c, &b.counters, 8));
 
   // ---- tables
@@ -432,8 +439,7 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
   if (batch) {
     const uint32_t ring_small = L.max_ring_points < kRingCapSmall ? L.max_ring_points : kRingCapSmall;
     const uint32_t merge_small = L.max_candidates < kMergeCapSmall ? L.max_candidates : kMergeCapSmall;
-    const uint32_t desc_small = L.max_neighbors < kDescCapSmall ? L.max_neighbors : kDescCapSmall;
-    const uint32_t desc_grid = (uint32_t)c->n_cu * 16u;
+    const uint32_t desc_grid = (uint32_t)c->n_cu * 8u;
     fxk_prep(s, P, B, batch);
     FX_HIP(mark(1));
     fxk_rings_small(s, P, B, batch, ring_small);
@@ -446,16 +452,23 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
     fxk_offsets(s, P, B, batch);
     FX_HIP(mark(5));
     if (P.estimate_descriptors) {
-      fxk_desc_small(s, P, B, batch, desc_small, desc_grid, 0);
+      FX_HIP(hipMemsetAsync(B.s_cnt, 0, (size_t)L.max_total_keypoints * sizeof(uint32_t), s));
+      fxk_gather(s, P, B, batch, c->box_margin);
       FX_HIP(mark(6));
-      fxk_desc_big(s, P, B, batch, L.max_neighbors, big_grid, 0);
+      fxk_desc_wave(s, P, B, batch, desc_grid, 0);
+      FX_HIP(mark(7));
+      fxk_desc_wg(s, P, B, batch, P.list_cap, big_grid, 0, 1);
+      fxk_desc_wg(s, P, B, batch, L.max_neighbors, big_grid, 0, 0);
       fxk_rng_ord(s, P, B, batch);
-      fxk_desc_small(s, P, B, batch, desc_small, desc_grid, 1);
-      fxk_desc_big(s, P, B, batch, L.max_neighbors, big_grid, 1);
+      // second pass: only keypoints whose RNG ordinal moved (an earlier keypoint had no neighbours)
+      fxk_desc_wave(s, P, B, batch, desc_grid, 1);
+      fxk_desc_wg(s, P, B, batch, P.list_cap, big_grid, 1, 1);
+      fxk_desc_wg(s, P, B, batch, L.max_neighbors, big_grid, 1, 0);
     } else {
       FX_HIP(mark(6));
+      FX_HIP(mark(7));
     }
-    FX_HIP(mark(7));
+    FX_HIP(mark(8));
     FX_HIP(hipGetLastError());
   } else {
     for (int i = 1; i <= FX_N_STAGES; ++i) FX_HIP(mark(i));

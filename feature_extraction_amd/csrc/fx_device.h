@@ -30,7 +30,7 @@ struct FxDevParams {
   int32_t estimate_descriptors;
   // capacities
   uint32_t max_points, max_ring_cands, max_candidates, max_keypoints, max_total_kp, max_kpc, max_neighbors,
-      max_ring_points;
+      max_ring_points, list_cap;
 };
 
 // 3DSC tables in device memory (built on the host by fx_sc3d_tables / fx_sc3d_xaxis).
@@ -79,8 +79,12 @@ struct FxBuffers {
   // work lists for the large-capacity tiers
   uint32_t *big_rings;    // [B*n_rings]
   uint32_t *big_merge;    // [B]
-  uint32_t *big_desc;     // [max_total_kp]
-  uint32_t *counters;     // [8]: 0 big_rings, 1 big_merge, 2 big_desc, 3 need_rng_fix
+  uint32_t *big_desc;     // [max_total_kp]  rows whose support list overflowed list_cap
+  uint32_t *list_desc;    // [max_total_kp]  rows whose list is too long for one wavefront
+  // per-keypoint support lists written by k_gather
+  float4 *s_pts;          // [max_total_kp][list_cap]  (x, y, z rotated, point index as bits)
+  uint32_t *s_cnt;        // [max_total_kp]
+  uint32_t *counters;     // [8]: 0 big_rings, 1 big_merge, 2 big_desc, 3 need_rng_fix, 4 list_desc
 };
 
 #endif

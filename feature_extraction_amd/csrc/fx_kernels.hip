@@ -750,6 +750,293 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_offsets(FxDevParams P, FxB
 }
 
 // ====================================================================== stage 5: descriptors
+// pcl::ShapeContext3DEstimation (ref: node.cpp:329-355), in three steps:
+//   k_gather     one pass over each scan tests every (rotated) point against ALL keypoints of the
+//                scan and appends the points within R + R/5 of a keypoint to that keypoint's
+//                support list (a superset of the neighbour query and of every density query)
+//   k_desc_wave  one wavefront per keypoint: bins + density + weight per neighbour, rank sort by
+//                (bin, d2, index) == PCL's accumulation order, sequential fp32 sum per bin
+//   k_desc_list / k_desc_full   workgroup-per-keypoint tiers for long lists / lists that
+//                overflowed the global list capacity (full re-gather into LDS)
+
+// Which scan does global keypoint row w belong to?  kp_offset is an exclusive prefix.
+__device__ __forceinline__ uint32_t scan_of_row(const uint32_t *kp_offset, uint32_t batch, uint32_t w) {
+  uint32_t lo = 0, hi = batch;  // invariant: kp_offset[lo] <= w < kp_offset[hi]
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (kp_offset[mid] <= w)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+// (j, k, l) bin and lookup-table weight of one neighbour.
+// kp = keypoint (origin), b = neighbour, xa = the keypoint's 3DSC x-axis (z component is -0).
+__device__ __forceinline__ uint32_t sc3d_bin(const float4 kp, float bx, float by, float bz, float d2, const float2 xa,
+                                             const FxScTables *T, float &lut) {
+  const float nx = 0.0f, ny = 0.0f, nz = 1.0f;  // every normal is +z (ref: node.cpp:337-340)
+  const float ax = xa.x, ay = xa.y, az = -0.0f;
+  const float r = sqrtf(d2);
+  // pcl::geometry::project(neighbour, origin, normal, proj); proj -= origin; proj.normalize()
+  const float pox = bx - kp.x, poy = by - kp.y, poz = bz - kp.z;
+  const float lambda = nx * pox + (ny * poy + nz * poz);
+  float p0 = (bx - lambda * nx) - kp.x;
+  float p1 = (by - lambda * ny) - kp.y;
+  float p2 = (bz - lambda * nz) - kp.z;
+  {
+    const float zz = p0 * p0 + (p1 * p1 + p2 * p2);
+    if (zz > 0.0f) {
+      const float s = sqrtf(zz);
+      p0 /= s;
+      p1 /= s;
+      p2 /= s;
+    }
+  }
+  // cross = x_axis x proj; phi = atan2(|cross|, x_axis . proj) in degrees, mirrored by sign
+  const float c0 = ay * p2 - az * p1;
+  const float c1 = az * p0 - ax * p2;
+  const float c2 = ax * p1 - ay * p0;
+  const float cn = sqrtf(c0 * c0 + (c1 * c1 + c2 * c2));
+  const float xd = ax * p0 + (ay * p1 + az * p2);
+  float phi = (float)atan2((double)cn, (double)xd) * 57.29578f;
+  const float cdn = c0 * nx + (c1 * ny + c2 * nz);
+  phi = cdn < 0.f ? (360.0f - phi) : phi;
+  // theta = acos(clamp(normal . normalized(neighbour - origin))) in degrees
+  float n0 = pox, n1 = poy, n2 = poz;
+  {
+    const float zz = n0 * n0 + (n1 * n1 + n2 * n2);
+    if (zz > 0.0f) {
+      const float s = sqrtf(zz);
+      n0 /= s;
+      n1 /= s;
+      n2 /= s;
+    }
+  }
+  float theta = nx * n0 + (ny * n1 + nz * n2);
+  const float mx = (-1.0f < theta) ? theta : -1.0f;  // std::max(-1.0f, theta)
+  const float tc = (mx < 1.0f) ? mx : 1.0f;          // std::min(1.0f, .)
+  theta = (float)acos((double)tc) * 57.29578f;
+
+  uint32_t j = 0, kk = 0, l = 0;
+  for (uint32_t rad = 1; rad < 16; ++rad)
+    if (r <= T->radii[rad]) {
+      j = rad - 1;
+      break;
+    }
+  for (uint32_t ang = 1; ang < 12; ++ang)
+    if (theta <= T->theta[ang]) {
+      kk = ang - 1;
+      break;
+    }
+  for (uint32_t ang = 1; ang < 13; ++ang)
+    if (phi <= T->phi[ang]) {
+      l = ang - 1;
+      break;
+    }
+  lut = T->lut[kk * 15 + j];
+  return (l * 11 + kk) * 15 + j;
+}
+__device__ __forceinline__ unsigned long long sc3d_key(uint32_t bin, float d2, uint32_t idx) {
+  return ((unsigned long long)bin << 52) | ((unsigned long long)__float_as_uint(d2) << 20) | (unsigned long long)idx;
+}
+
+// ---------------------------------------------------------------- k_gather
+#define FX_GATHER_SLICES 4
+extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBuffers B, float box_margin) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  float4 *s_kp = reinterpret_cast<float4 *>(smem + 16);
+  uint32_t *s_w = smem;
+  const uint32_t scan = blockIdx.y, slice = blockIdx.x, tid = threadIdx.x;
+  uint32_t K = B.n_kp[scan];
+  if (K == 0) return;
+  const uint32_t row0 = B.kp_offset[scan];
+  if (row0 >= P.max_total_kp) return;
+  if (row0 + K > P.max_total_kp) K = P.max_total_kp - row0;
+  const FxScanMeta M = B.meta[scan];
+  // keypoints of the scan -> LDS; their bounding box (ordered-uint atomics) for a cheap reject
+  if (tid < 6) s_w[tid] = (tid & 1) ? f2ord(-INFINITY) : f2ord(INFINITY);
+  __syncthreads();
+  for (uint32_t k = tid; k < K; k += FX_WG) {
+    const float4 kp = B.keypoints[(size_t)scan * P.max_keypoints + k];
+    s_kp[k] = kp;
+    atomicMin(&s_w[0], f2ord(kp.x));
+    atomicMax(&s_w[1], f2ord(kp.x));
+    atomicMin(&s_w[2], f2ord(kp.y));
+    atomicMax(&s_w[3], f2ord(kp.y));
+    atomicMin(&s_w[4], f2ord(kp.z));
+    atomicMax(&s_w[5], f2ord(kp.z));
+  }
+  __syncthreads();
+  const float bx0 = ord2f(s_w[0]) - box_margin, bx1 = ord2f(s_w[1]) + box_margin;
+  const float by0 = ord2f(s_w[2]) - box_margin, by1 = ord2f(s_w[3]) + box_margin;
+  const float bz0 = ord2f(s_w[4]) - box_margin, bz1 = ord2f(s_w[5]) + box_margin;
+
+  const uint32_t n = M.n;
+  uint32_t chunk = (n + FX_GATHER_SLICES - 1) / FX_GATHER_SLICES;
+  chunk = (chunk + FX_WG * 4 - 1) / (FX_WG * 4) * (FX_WG * 4);
+  const uint32_t lo = slice * chunk;
+  const uint32_t hi = lo + chunk < n ? lo + chunk : n;
+  for (uint32_t i0 = lo; i0 < hi; i0 += FX_WG * 4) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t i = i0 + u * FX_WG + tid;
+      v[u] = i < hi ? *reinterpret_cast<const float4 *>(M.pts + (size_t)i * M.stride_f) : make_float4(NAN, NAN, NAN, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float x = v[u].x, y = v[u].y, z = v[u].z;
+      const float rx = ((M.R[0] * x + M.R[1] * y) + M.R[2] * z) + 0.0f;
+      const float ry = ((M.R[3] * x + M.R[4] * y) + M.R[5] * z) + 0.0f;
+      const float rz = ((M.R[6] * x + M.R[7] * y) + M.R[8] * z) + 0.0f;
+      // non-finite points are not part of the search surface; NaN fails every comparison
+      const bool near = rx >= bx0 && rx <= bx1 && ry >= by0 && ry <= by1 && rz >= bz0 && rz <= bz1 &&
+                        isfinite(rx) && isfinite(ry) && isfinite(rz);
+      if (!near) continue;
+      const uint32_t idx = i0 + u * FX_WG + tid;
+      for (uint32_t k = 0; k < K; ++k) {
+        const float4 kp = s_kp[k];
+        const float d = dist2(kp.x, kp.y, kp.z, rx, ry, rz);
+        if (d < P.r2_support) {
+          const uint32_t pos = atomicAdd(&B.s_cnt[row0 + k], 1u);
+          if (pos < P.list_cap) B.s_pts[(size_t)(row0 + k) * P.list_cap + pos] = make_float4(rx, ry, rz, __uint_as_float(idx));
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- k_desc_wave
+#define FX_WAVE_CAP 256
+#define FX_WAVE_WORDS (FX_WAVE_CAP * 8)
+__device__ __forceinline__ void desc_fill_nan(float *out, uint32_t lane, uint32_t stride) {
+  for (uint32_t t = lane; t < FX_DESC_FLOATS; t += stride) out[t] = t < FX_DESC_BINS ? NAN : 0.0f;
+}
+
+extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_wave(FxDevParams P, FxBuffers B, uint32_t batch,
+                                                                 uint32_t mode) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  if (mode == 1 && B.counters[3] == 0) return;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t *base = smem + wave * FX_WAVE_WORDS;
+  // per-wave LDS: support set (5 arrays) + unsorted (key, weight); the sorted (key, weight)
+  // arrays reuse the support-set storage once the density counts are done
+  unsigned long long *nkey = reinterpret_cast<unsigned long long *>(base);  // 2 * CAP words
+  float *nw = reinterpret_cast<float *>(base + 2 * FX_WAVE_CAP);
+  float *sx = reinterpret_cast<float *>(base + 3 * FX_WAVE_CAP);
+  float *sy = sx + FX_WAVE_CAP, *sz = sy + FX_WAVE_CAP, *sd2 = sz + FX_WAVE_CAP;
+  uint32_t *sidx = reinterpret_cast<uint32_t *>(sd2 + FX_WAVE_CAP);
+  unsigned long long *skey = reinterpret_cast<unsigned long long *>(sx);  // aliases sx, sy
+  float *sw = sz;                                                         // aliases sz
+  const FxScTables *T = B.tables;
+
+  uint32_t total = B.kp_offset[batch];
+  if (total > P.max_total_kp) total = P.max_total_kp;
+  for (uint32_t row = blockIdx.x * FX_NWAVE + wave; row < total; row += gridDim.x * FX_NWAVE) {
+    const uint32_t scan = scan_of_row(B.kp_offset, batch, row);
+    const uint32_t k = row - B.kp_offset[scan];
+    uint32_t ord = k;
+    if (mode == 1) {
+      ord = B.rng_ord[(size_t)scan * P.max_keypoints + k];
+      if (ord == k) continue;
+    }
+    const uint32_t nS = B.s_cnt[row];
+    if (nS > FX_WAVE_CAP) {  // long list: workgroup tiers
+      if (lane == 0) {
+        const uint32_t pos = atomicAdd(&B.counters[nS > P.list_cap ? 2 : 4], 1u);
+        (nS > P.list_cap ? B.big_desc : B.list_desc)[pos] = row;
+      }
+      continue;
+    }
+    const float4 kp = B.keypoints[(size_t)scan * P.max_keypoints + k];
+    const float2 xa = B.xaxis[ord];
+    float *out = B.desc + (size_t)row * FX_DESC_FLOATS;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t e = lane; e < nS; e += 64) {
+      const float4 v = B.s_pts[(size_t)row * P.list_cap + e];
+      sx[e] = v.x;
+      sy[e] = v.y;
+      sz[e] = v.z;
+      sidx[e] = __float_as_uint(v.w);
+      sd2[e] = dist2(kp.x, kp.y, kp.z, v.x, v.y, v.z);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // zero the output row now; the bin sums are scattered into it at the end
+    for (uint32_t t = lane; t < FX_DESC_FLOATS; t += 64) out[t] = 0.0f;
+
+    uint32_t nAll = 0, nM = 0;
+    for (uint32_t e0 = 0; e0 < nS; e0 += 64) {
+      const uint32_t e = e0 + lane;
+      const float d2 = e < nS ? sd2[e] : INFINITY;
+      const bool nb = d2 < P.r2_search;
+      nAll += (uint32_t)__popcll(__ballot(nb));
+      const bool use = nb && !(fabsf(d2 - 0.0f) < FLT_EPSILON);  // pcl::utils::equal(nn_dists[ne], 0.0f)
+      unsigned long long key = 0;
+      float w = 0.f;
+      if (use) {
+        const float bx = sx[e], by = sy[e], bz = sz[e];
+        float lut;
+        const uint32_t bin = sc3d_bin(kp, bx, by, bz, d2, xa, T, lut);
+        uint32_t dens = 0;  // support points within R/5 of this neighbour (itself included)
+        for (uint32_t q = 0; q < nS; ++q) dens += (dist2(bx, by, bz, sx[q], sy[q], sz[q]) < P.r2_density) ? 1u : 0u;
+        w = (1.0f / (float)dens) * lut;
+        key = sc3d_key(bin, d2, sidx[e]);
+      }
+      const unsigned long long um = __ballot(use);
+      if (use) {
+        const uint32_t pos = nM + lanes_below(um);
+        nkey[pos] = key;
+        nw[pos] = w;
+      }
+      nM += (uint32_t)__popcll(um);
+    }
+    if (lane == 0) B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = nAll;
+    if (nAll == 0) {  // no neighbours: NaN descriptor, no RNG draw (A.8-3)
+      __builtin_amdgcn_s_waitcnt(0);  // the zero fill first
+      desc_fill_nan(out, lane, 64);
+      continue;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // rank sort (keys are unique: they end in the point index)
+    for (uint32_t e0 = 0; e0 < nM; e0 += 64) {
+      const uint32_t e = e0 + lane;
+      if (e < nM) {
+        const unsigned long long key = nkey[e];
+        uint32_t rank = 0;
+        for (uint32_t q = 0; q < nM; ++q) rank += (nkey[q] < key) ? 1u : 0u;
+        skey[rank] = key;
+        sw[rank] = nw[e];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // the zero fill must have landed before the sums go on top of it
+    __builtin_amdgcn_s_waitcnt(0);
+    for (uint32_t e0 = 0; e0 < nM; e0 += 64) {
+      const uint32_t e = e0 + lane;
+      if (e >= nM) continue;
+      const uint32_t bin = (uint32_t)(skey[e] >> 52);
+      if (e > 0 && (uint32_t)(skey[e - 1] >> 52) == bin) continue;
+      float acc = 0.0f;
+      uint32_t q = e;
+      do {
+        acc += sw[q];
+        ++q;
+      } while (q < nM && (uint32_t)(skey[q] >> 52) == bin);
+      out[bin] = acc;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---------------------------------------------------------------- workgroup tiers
 struct DescLds {
   unsigned long long *nkey;
   float *nw, *sx, *sy, *sz, *sd2, *img;
@@ -771,156 +1058,97 @@ __device__ __forceinline__ DescLds desc_carve(uint32_t *smem, uint32_t cap) {
   return L;
 }
 
-// pcl::ShapeContext3DEstimation::computePoint for one keypoint.
-//   gather   support set = cloud points within (R + R/5) of the keypoint (superset of what the
-//            neighbour query and every density query can return), rotated on the fly
-//   bin      per neighbour (d2 < R^2): r / theta / phi bins, density = #support within R/5, weight
-//   sort     by (bin, d2, index): within a bin this is PCL's accumulation order (sorted kd-tree)
-//   sum      one lane per bin run adds the weights sequentially in fp32
-// Returns false if the support set overflowed `cap` (caller defers to the large tier).
-__device__ bool desc_body(const FxDevParams &P, const FxBuffers &B, uint32_t scan, uint32_t k, uint32_t ord,
-                          uint32_t cap, uint32_t *smem, bool last_tier) {
+// One keypoint by a whole workgroup.  from_list: the support set comes from k_gather's list;
+// otherwise it is re-gathered from the scan (lists that overflowed P.list_cap).
+// Returns false if the support set does not fit `cap` (only possible when !from_list).
+__device__ bool desc_body(const FxDevParams &P, const FxBuffers &B, uint32_t row, uint32_t scan, uint32_t k,
+                          uint32_t ord, uint32_t cap, uint32_t *smem, bool from_list) {
   DescLds L = desc_carve(smem, cap);
   const uint32_t tid = threadIdx.x;
   const FxScanMeta M = B.meta[scan];
   const float4 kp = B.keypoints[(size_t)scan * P.max_keypoints + k];
-  const size_t out_row = (size_t)B.kp_offset[scan] + k;
-  if (out_row >= P.max_total_kp) return true;  // flagged by k_offsets
-  float *out = B.desc + out_row * FX_DESC_FLOATS;
+  float *out = B.desc + (size_t)row * FX_DESC_FLOATS;
 
   if (tid < 4) L.s_w[tid] = 0;  // 0: support count, 1: binned neighbours, 2: all neighbours
   __syncthreads();
-
-  // ---- gather
-  const uint32_t n = M.n;
-  for (uint32_t i0 = 0; i0 < n; i0 += FX_WG * 4) {
-    float4 v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const uint32_t i = i0 + u * FX_WG + tid;
-      v[u] = i < n ? *reinterpret_cast<const float4 *>(M.pts + (size_t)i * M.stride_f) : make_float4(NAN, NAN, NAN, 0);
+  uint32_t nS;
+  if (from_list) {
+    nS = B.s_cnt[row];
+    for (uint32_t e = tid; e < nS; e += FX_WG) {
+      const float4 v = B.s_pts[(size_t)row * P.list_cap + e];
+      L.sx[e] = v.x;
+      L.sy[e] = v.y;
+      L.sz[e] = v.z;
+      L.sidx[e] = __float_as_uint(v.w);
+      L.sd2[e] = dist2(kp.x, kp.y, kp.z, v.x, v.y, v.z);
     }
+    __syncthreads();
+  } else {
+    const uint32_t n = M.n;
+    for (uint32_t i0 = 0; i0 < n; i0 += FX_WG * 4) {
+      float4 v[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float x = v[u].x, y = v[u].y, z = v[u].z;
-      const float rx = ((M.R[0] * x + M.R[1] * y) + M.R[2] * z) + 0.0f;
-      const float ry = ((M.R[3] * x + M.R[4] * y) + M.R[5] * z) + 0.0f;
-      const float rz = ((M.R[6] * x + M.R[7] * y) + M.R[8] * z) + 0.0f;
-      const float d = dist2(kp.x, kp.y, kp.z, rx, ry, rz);
-      // non-finite points are not part of the search surface (NaN compares false)
-      if (d < P.r2_support && isfinite(rx) && isfinite(ry) && isfinite(rz)) {
-        const uint32_t pos = atomicAdd(&L.s_w[0], 1u);
-        if (pos < cap) {
-          L.sx[pos] = rx;
-          L.sy[pos] = ry;
-          L.sz[pos] = rz;
-          L.sd2[pos] = d;
-          L.sidx[pos] = i0 + u * FX_WG + tid;
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t i = i0 + u * FX_WG + tid;
+        v[u] = i < n ? *reinterpret_cast<const float4 *>(M.pts + (size_t)i * M.stride_f) : make_float4(NAN, NAN, NAN, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float x = v[u].x, y = v[u].y, z = v[u].z;
+        const float rx = ((M.R[0] * x + M.R[1] * y) + M.R[2] * z) + 0.0f;
+        const float ry = ((M.R[3] * x + M.R[4] * y) + M.R[5] * z) + 0.0f;
+        const float rz = ((M.R[6] * x + M.R[7] * y) + M.R[8] * z) + 0.0f;
+        const float d = dist2(kp.x, kp.y, kp.z, rx, ry, rz);
+        if (d < P.r2_support && isfinite(rx) && isfinite(ry) && isfinite(rz)) {
+          const uint32_t pos = atomicAdd(&L.s_w[0], 1u);
+          if (pos < cap) {
+            L.sx[pos] = rx;
+            L.sy[pos] = ry;
+            L.sz[pos] = rz;
+            L.sd2[pos] = d;
+            L.sidx[pos] = i0 + u * FX_WG + tid;
+          }
         }
       }
     }
-  }
-  __syncthreads();
-  const uint32_t nS = L.s_w[0];
-  if (nS > cap) {
-    if (!last_tier) return false;
-    if (tid == 0) atomicOr(&B.flags[scan], FX_FLAG_NBR_OVERFLOW);
-    for (uint32_t t = tid; t < FX_DESC_FLOATS; t += FX_WG) out[t] = t < FX_DESC_BINS ? NAN : 0.0f;
-    if (tid == 0) B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = 0xffffffffu;
-    return true;
+    __syncthreads();
+    nS = L.s_w[0];
+    if (nS > cap) {
+      if (tid == 0) {
+        atomicOr(&B.flags[scan], FX_FLAG_NBR_OVERFLOW);
+        B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = FX_NONE;
+      }
+      desc_fill_nan(out, tid, FX_WG);
+      return false;
+    }
   }
   for (uint32_t t = tid; t < FX_DESC_BINS; t += FX_WG) L.img[t] = 0.0f;
 
-  // ---- per-neighbour bins, density, weight
   const FxScTables *T = B.tables;
   const float2 xa = B.xaxis[ord];
-  const float nx = 0.0f, ny = 0.0f, nz = 1.0f;  // every normal is +z (ref: node.cpp:337-340)
-  const float ax = xa.x, ay = xa.y, az = -0.0f;
   for (uint32_t e = tid; e < nS; e += FX_WG) {
     const float d2 = L.sd2[e];
     if (!(d2 < P.r2_search)) continue;
     atomicAdd(&L.s_w[2], 1u);
     if (fabsf(d2 - 0.0f) < FLT_EPSILON) continue;  // pcl::utils::equal(nn_dists[ne], 0.0f)
     const float bx = L.sx[e], by = L.sy[e], bz = L.sz[e];
-    const float r = sqrtf(d2);
-    // pcl::geometry::project(neighbour, origin, normal, proj); proj -= origin; proj.normalize()
-    const float pox = bx - kp.x, poy = by - kp.y, poz = bz - kp.z;
-    const float lambda = nx * pox + (ny * poy + nz * poz);
-    float p0 = (bx - lambda * nx) - kp.x;
-    float p1 = (by - lambda * ny) - kp.y;
-    float p2 = (bz - lambda * nz) - kp.z;
-    {
-      const float zz = p0 * p0 + (p1 * p1 + p2 * p2);
-      if (zz > 0.0f) {
-        const float s = sqrtf(zz);
-        p0 /= s;
-        p1 /= s;
-        p2 /= s;
-      }
-    }
-    // cross = x_axis x proj; phi = atan2(|cross|, x_axis . proj) in degrees, mirrored by sign
-    const float c0 = ay * p2 - az * p1;
-    const float c1 = az * p0 - ax * p2;
-    const float c2 = ax * p1 - ay * p0;
-    const float cn = sqrtf(c0 * c0 + (c1 * c1 + c2 * c2));
-    const float xd = ax * p0 + (ay * p1 + az * p2);
-    float phi = (float)atan2((double)cn, (double)xd) * 57.29578f;
-    const float cdn = c0 * nx + (c1 * ny + c2 * nz);
-    phi = cdn < 0.f ? (360.0f - phi) : phi;
-    // theta = acos(clamp(normal . normalized(neighbour - origin))) in degrees
-    float n0 = pox, n1 = poy, n2 = poz;
-    {
-      const float zz = n0 * n0 + (n1 * n1 + n2 * n2);
-      if (zz > 0.0f) {
-        const float s = sqrtf(zz);
-        n0 /= s;
-        n1 /= s;
-        n2 /= s;
-      }
-    }
-    float theta = nx * n0 + (ny * n1 + nz * n2);
-    const float mx = (-1.0f < theta) ? theta : -1.0f;  // std::max(-1.0f, theta)
-    const float tc = (mx < 1.0f) ? mx : 1.0f;          // std::min(1.0f, .)
-    theta = (float)acos((double)tc) * 57.29578f;
-
-    uint32_t j = 0, kk = 0, l = 0;
-    for (uint32_t rad = 1; rad < 16; ++rad)
-      if (r <= T->radii[rad]) {
-        j = rad - 1;
-        break;
-      }
-    for (uint32_t ang = 1; ang < 12; ++ang)
-      if (theta <= T->theta[ang]) {
-        kk = ang - 1;
-        break;
-      }
-    for (uint32_t ang = 1; ang < 13; ++ang)
-      if (phi <= T->phi[ang]) {
-        l = ang - 1;
-        break;
-      }
-    // local point density: support points within R/5 of this neighbour (itself included)
+    float lut;
+    const uint32_t bin = sc3d_bin(kp, bx, by, bz, d2, xa, T, lut);
     uint32_t dens = 0;
-    for (uint32_t q = 0; q < nS; ++q) {
-      const float dd = dist2(bx, by, bz, L.sx[q], L.sy[q], L.sz[q]);
-      dens += (dd < P.r2_density) ? 1u : 0u;
-    }
-    const float w = (1.0f / (float)dens) * T->lut[kk * 15 + j];
-    const uint32_t bin = (l * 11 + kk) * 15 + j;
+    for (uint32_t q = 0; q < nS; ++q)
+      dens += (dist2(bx, by, bz, L.sx[q], L.sy[q], L.sz[q]) < P.r2_density) ? 1u : 0u;
     const uint32_t pos = atomicAdd(&L.s_w[1], 1u);
-    L.nkey[pos] = ((unsigned long long)bin << 52) | ((unsigned long long)__float_as_uint(d2) << 20) |
-                  (unsigned long long)L.sidx[e];
-    L.nw[pos] = w;
+    L.nkey[pos] = sc3d_key(bin, d2, L.sidx[e]);
+    L.nw[pos] = (1.0f / (float)dens) * lut;
   }
   __syncthreads();
   const uint32_t nM = L.s_w[1], nAll = L.s_w[2];
   if (tid == 0) B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = nAll;
   if (nAll == 0) {  // no neighbours: NaN descriptor, no RNG draw (A.8-3)
-    for (uint32_t t = tid; t < FX_DESC_FLOATS; t += FX_WG) out[t] = t < FX_DESC_BINS ? NAN : 0.0f;
+    desc_fill_nan(out, tid, FX_WG);
     __syncthreads();
     return true;
   }
-
   // ---- sort by (bin, d2, index): bitonic network in LDS
   uint32_t p2 = 1;
   while (p2 < nM) p2 <<= 1;
@@ -963,55 +1191,20 @@ __device__ bool desc_body(const FxDevParams &P, const FxBuffers &B, uint32_t sca
   return true;
 }
 
-// Which scan does global keypoint row w belong to?  kp_offset is an exclusive prefix.
-__device__ __forceinline__ uint32_t scan_of_row(const uint32_t *kp_offset, uint32_t batch, uint32_t w) {
-  uint32_t lo = 0, hi = batch;  // invariant: kp_offset[lo] <= w < kp_offset[hi]
-  while (hi - lo > 1) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (kp_offset[mid] <= w)
-      lo = mid;
-    else
-      hi = mid;
-  }
-  return lo;
-}
-
-// mode 0: every keypoint, RNG ordinal = keypoint ordinal.  mode 1: only keypoints whose
-// ordinal had to be corrected because an earlier keypoint of the scan had no neighbours.
-extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_small(FxDevParams P, FxBuffers B, uint32_t batch,
-                                                                  uint32_t cap, uint32_t mode) {
+// tier 2: rows whose list is longer than a wavefront handles (list_desc), support set from the list
+// tier 3: rows whose list overflowed (big_desc), support set re-gathered from the scan
+extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_wg(FxDevParams P, FxBuffers B, uint32_t batch, uint32_t cap,
+                                                               uint32_t mode, uint32_t from_list) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   if (mode == 1 && B.counters[3] == 0) return;
-  uint32_t total = B.kp_offset[batch];
-  if (total > P.max_total_kp) total = P.max_total_kp;
-  for (uint32_t w = blockIdx.x; w < total; w += gridDim.x) {
-    const uint32_t scan = scan_of_row(B.kp_offset, batch, w);
-    const uint32_t k = w - B.kp_offset[scan];
-    uint32_t ord = k;
-    if (mode == 1) {
-      ord = B.rng_ord[(size_t)scan * P.max_keypoints + k];
-      if (ord == k) continue;
-    }
-    if (!desc_body(P, B, scan, k, ord, cap, smem, false)) {
-      if (threadIdx.x == 0) {
-        const uint32_t pos = atomicAdd(&B.counters[2], 1u);
-        B.big_desc[pos] = w;
-      }
-    }
-    __syncthreads();
-  }
-}
-extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_big(FxDevParams P, FxBuffers B, uint32_t batch,
-                                                                uint32_t cap, uint32_t mode) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  if (mode == 1 && B.counters[3] == 0) return;
-  const uint32_t n_big = B.counters[2];
-  for (uint32_t i = blockIdx.x; i < n_big; i += gridDim.x) {
-    const uint32_t w = B.big_desc[i];
-    const uint32_t scan = scan_of_row(B.kp_offset, batch, w);
-    const uint32_t k = w - B.kp_offset[scan];
+  const uint32_t n_items = B.counters[from_list ? 4 : 2];
+  const uint32_t *items = from_list ? B.list_desc : B.big_desc;
+  for (uint32_t i = blockIdx.x; i < n_items; i += gridDim.x) {
+    const uint32_t row = items[i];
+    const uint32_t scan = scan_of_row(B.kp_offset, batch, row);
+    const uint32_t k = row - B.kp_offset[scan];
     const uint32_t ord = mode == 1 ? B.rng_ord[(size_t)scan * P.max_keypoints + k] : k;
-    desc_body(P, B, scan, k, ord, cap, smem, true);
+    desc_body(P, B, row, scan, k, ord, cap, smem, from_list != 0);
     __syncthreads();
   }
 }
@@ -1086,7 +1279,7 @@ hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t desc_big) {
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void *)k_merge_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)merge_big);
   if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void *)k_desc_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)desc_big);
+  e = hipFuncSetAttribute((const void *)k_desc_wg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)desc_big);
   return e;
 }
 
@@ -1108,13 +1301,17 @@ void fxk_merge_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint
 void fxk_offsets(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch) {
   hipLaunchKernelGGL(k_offsets, dim3(1), dim3(FX_WG), 0, s, P, B, batch);
 }
-void fxk_desc_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap,
-                    uint32_t grid, uint32_t mode) {
-  hipLaunchKernelGGL(k_desc_small, dim3(grid), dim3(FX_WG), fxk_desc_lds_bytes(cap), s, P, B, batch, cap, mode);
+void fxk_gather(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float box_margin) {
+  hipLaunchKernelGGL(k_gather, dim3(FX_GATHER_SLICES, batch), dim3(FX_WG), (16 + 4 * (size_t)P.max_keypoints) * 4, s, P, B,
+                     box_margin);
 }
-void fxk_desc_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap,
-                  uint32_t grid, uint32_t mode) {
-  hipLaunchKernelGGL(k_desc_big, dim3(grid), dim3(FX_WG), fxk_desc_lds_bytes(cap), s, P, B, batch, cap, mode);
+void fxk_desc_wave(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid,
+                   uint32_t mode) {
+  hipLaunchKernelGGL(k_desc_wave, dim3(grid), dim3(FX_WG), (size_t)FX_NWAVE * FX_WAVE_WORDS * 4, s, P, B, batch, mode);
+}
+void fxk_desc_wg(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t grid,
+                 uint32_t mode, uint32_t from_list) {
+  hipLaunchKernelGGL(k_desc_wg, dim3(grid), dim3(FX_WG), fxk_desc_lds_bytes(cap), s, P, B, batch, cap, mode, from_list);
 }
 void fxk_rng_ord(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch) {
   hipLaunchKernelGGL(k_rng_ord, dim3((batch + FX_WG - 1) / FX_WG), dim3(FX_WG), 0, s, P, B, batch);
