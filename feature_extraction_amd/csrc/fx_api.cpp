@@ -22,6 +22,7 @@ size_t fxk_merge_lds_bytes(uint32_t cap, uint32_t n_rings);
 size_t fxk_desc_lds_bytes(uint32_t cap);
 hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t desc_big);
 void fxk_prep(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
+void fxk_bucket(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float el0, float inv_step);
 void fxk_rings_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap);
 void fxk_rings_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t grid);
 void fxk_merge_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap);
@@ -211,6 +212,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   P.max_neighbors = L.max_neighbors;
   P.max_ring_points = L.max_ring_points;
   P.list_cap = L.max_neighbors < kListCap ? L.max_neighbors : kListCap;
+  P.ring_slot_cap = L.max_points + L.max_points / 8 + 64;  // a point on a window boundary sits in two rings
 
   fx_status st = FX_OK;
   auto bail = [&](fx_status s) {
@@ -240,10 +242,11 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   FX_A(dev_alloc(c, &b.ring_cand, B * R * L.max_ring_candidates));
   FX_A(dev_alloc(c, &b.ring_cand_size, B * R * L.max_ring_candidates));
   FX_A(dev_alloc(c, &b.ring_cand_cnt, B * R));
-  FX_A(dev_alloc(c, &b.kpc_pool, B * L.max_kpc_points));
-  FX_A(dev_alloc(c, &b.kpc_pool_cand, B * L.max_kpc_points));
-  FX_A(dev_alloc(c, &b.kpc_used, B));
-  FX_A(dev_alloc(c, &b.kpc_ring_off, B * R));
+  FX_A(dev_alloc(c, &b.ring_pts, B * P.ring_slot_cap));
+  FX_A(dev_alloc(c, &b.ring_off, B * R));
+  FX_A(dev_alloc(c, &b.ring_cnt, B * R));
+  FX_A(dev_alloc(c, &b.kpc_pool, B * P.ring_slot_cap));
+  FX_A(dev_alloc(c, &b.kpc_pool_cand, B * P.ring_slot_cap));
   FX_A(dev_alloc(c, &b.kpc_ring_cnt, B * R));
   FX_A(dev_alloc(c, &b.cand, B * L.max_candidates));
   FX_A(dev_alloc(c, &b.cand_size, B * L.max_candidates));
@@ -267,6 +270,8 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   FX_A(dev_alloc(c, &b.s_pts, (size_t)L.max_total_keypoints * P.list_cap));
   FX_A(dev_alloc(c, &b.s_cnt, L.max_total_keypoints));
   FX_A(dev_alloc(c, &b.counters, 8));
+  FX_A(dev_alloc(c, &b.stamps, 32));
+  if (hipMemset(b.stamps, 0, 32 * 8) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
 
   // ---- tables
   {
@@ -441,6 +446,7 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
     const uint32_t merge_small = L.max_candidates < kMergeCapSmall ? L.max_candidates : kMergeCapSmall;
     const uint32_t desc_grid = (uint32_t)c->n_cu * 8u;
     fxk_prep(s, P, B, batch);
+    fxk_bucket(s, P, B, batch, (float)c->params.el0_deg, (float)(1.0 / c->params.el_step_deg));
     FX_HIP(mark(1));
     fxk_rings_small(s, P, B, batch, ring_small);
     FX_HIP(mark(2));
@@ -565,6 +571,15 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
   out->h_flags = c->h_flags;
   out->h_n_filtered = c->h_n_filt;
   out->h_n_kpc = c->h_n_kpc;
+  return FX_OK;
+}
+
+// Diagnostic (-DFX_STAMPS builds): cumulative per-phase cycle counters of the ring kernel.
+fx_status fx_debug_stamps(fx_ctx *c, unsigned long long *out32) {
+  if (!c || !out32) return fail(FX_ERR_INVALID_ARG, "null argument");
+  FX_HIP(hipSetDevice(c->device));
+  FX_HIP(hipStreamSynchronize(c->stream));
+  FX_HIP(hipMemcpy(out32, c->buf.stamps, 32 * 8, hipMemcpyDeviceToHost));
   return FX_OK;
 }
 

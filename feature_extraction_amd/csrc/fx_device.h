@@ -30,7 +30,7 @@ struct FxDevParams {
   int32_t estimate_descriptors;
   // capacities
   uint32_t max_points, max_ring_cands, max_candidates, max_keypoints, max_total_kp, max_kpc, max_neighbors,
-      max_ring_points, list_cap;
+      max_ring_points, list_cap, ring_slot_cap;
 };
 
 // 3DSC tables in device memory (built on the host by fx_sc3d_tables / fx_sc3d_xaxis).
@@ -50,14 +50,16 @@ struct FxBuffers {
   // stage 1
   float4 *filt;          // [B][max_points]
   uint32_t *n_filt;      // [B]
-  // stage 2
+  // stage 2a: ring-major copy of the filtered cloud
+  float4 *ring_pts;         // [B][ring_slot_cap]
+  uint32_t *ring_off;       // [B][n_rings]
+  uint32_t *ring_cnt;       // [B][n_rings]
+  // stage 2b
   float4 *ring_cand;        // [B][n_rings][max_ring_cands]
   uint32_t *ring_cand_size; // same shape
   uint32_t *ring_cand_cnt;  // [B][n_rings]
-  float4 *kpc_pool;         // [B][max_kpc]
-  uint32_t *kpc_pool_cand;  // [B][max_kpc]  ring-local candidate slot
-  uint32_t *kpc_used;       // [B]
-  uint32_t *kpc_ring_off;   // [B][n_rings]
+  float4 *kpc_pool;         // [B][ring_slot_cap]  ring r's members start at ring_off[r]
+  uint32_t *kpc_pool_cand;  // [B][ring_slot_cap]  ring-local candidate slot
   uint32_t *kpc_ring_cnt;   // [B][n_rings]
   // stage 3
   float4 *cand;           // [B][max_candidates]
@@ -84,6 +86,7 @@ struct FxBuffers {
   // per-keypoint support lists written by k_gather
   float4 *s_pts;          // [max_total_kp][list_cap]  (x, y, z rotated, point index as bits)
   uint32_t *s_cnt;        // [max_total_kp]
+  unsigned long long *stamps;  // [32] diagnostic build only (-DFX_STAMPS)
   uint32_t *counters;     // [8]: 0 big_rings, 1 big_merge, 2 big_desc, 3 need_rng_fix, 4 list_desc
 };
 

@@ -113,20 +113,71 @@ __device__ __forceinline__ void uf_union(uint32_t *parent, uint32_t a, uint32_t 
   }
 }
 
-#define FX_SCRATCH_WORDS 160  // s_w[0..15] block helpers, s_w[16..31] broadcast slots, s_w[32..151] sort stack
+// Diagnostic build only (-DFX_STAMPS): per-phase cycle shares of the ring kernel, summed by
+// thread 0 of every workgroup into B.counters-adjacent debug words.  Never in the product build.
+#ifdef FX_STAMPS
+#define FX_STAMP(slot)                                                                     \
+  do {                                                                                     \
+    if (threadIdx.x == 0 && stamps_) {                                                     \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime();                        \
+      atomicAdd(&stamps_[slot], now_ - stamp_prev_);                                      \
+      stamp_prev_ = now_;                                                                  \
+    }                                                                                      \
+  } while (0)
+#define FX_STAMP_INIT(ptr)                 \
+  unsigned long long *stamps_ = (ptr);    \
+  unsigned long long stamp_prev_ = __builtin_amdgcn_s_memtime()
+#else
+#define FX_STAMP(slot)
+#define FX_STAMP_INIT(ptr)
+#endif
+
+// s_w[0..15] block helpers, [16..31] broadcast slots, [32..151] sort stack, [160..] run table
+#define FX_RUN_MAX 128
+#define FX_RUN_TABLE 160
+#define FX_SCRATCH_WORDS (FX_RUN_TABLE + (FX_RUN_MAX + 1) + 4 * FX_RUN_MAX + 7)  // 808: keeps the carve 16-byte aligned
 #define FX_NONE 0xffffffffu
 
-// Connected components of {d2(i,j) < r2} over n points held in LDS.  On return parent[i] is
-// the smallest index of i's component and csize[root] the component size.
-//  1. run labelling: consecutive points i-1, i closer than the tolerance form runs; a wave
-//     ballot + highest-set-bit gives every point its run head (sensor rings arrive azimuth
-//     ordered, so this one scan already finds almost every cluster);
-//  2. all pairs, skipping pairs that already share an ancestor, union-find for the rest
-//     (exact for any input order: every pair is examined).
-__device__ void cc_label(const float *px, const float *py, const float *pz, uint32_t n, float r2, uint32_t *parent,
-                         uint32_t *csize, uint32_t *s_w) {
+// order-preserving map float -> uint32 (for LDS atomicMin/Max on coordinates)
+__device__ __forceinline__ uint32_t f2ord(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o) {
+  return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+
+struct RunTable {  // lives in the scratch words; valid when n_runs <= FX_RUN_MAX
+  uint32_t *start;                    // [FX_RUN_MAX + 1] first point of each run, start[n_runs] = n
+  float *minx, *maxx, *miny, *maxy;   // xy bounding box of each run
+};
+__device__ __forceinline__ RunTable run_table(uint32_t *s_w) {
+  RunTable t;
+  t.start = s_w + FX_RUN_TABLE;
+  t.minx = reinterpret_cast<float *>(t.start + FX_RUN_MAX + 1);
+  t.maxx = t.minx + FX_RUN_MAX;
+  t.miny = t.maxx + FX_RUN_MAX;
+  t.maxy = t.miny + FX_RUN_MAX;
+  return t;
+}
+
+// Connected components of {d2(i,j) < r2} over n points held in LDS.  On return parent[i] is the
+// smallest index of i's component, csize[root] the component size, rid[i] the run of point i.
+//  1. run labelling: consecutive points i-1, i closer than the tolerance form runs; a wave ballot
+//     + highest-set-bit gives every point its run head.  Sensor rings arrive azimuth ordered, so
+//     this one scan already finds almost every cluster, and only run heads ever get linked.
+//  2. cross-run edges.  Few runs: every point tests the xy bounding box of each later run and
+//     scans that run's points only when the box is within the tolerance and the two are not yet
+//     one component.  Many runs (unordered input): all pairs of different runs.  Both examine
+//     every pair that could be an edge, so the result is exact for any input order.
+//  3. roots per run head, then per point; sizes per run.
+// Returns the number of runs.
+__device__ uint32_t cc_label(const float *px, const float *py, const float *pz, uint32_t n, float r2, uint32_t *parent,
+                             uint32_t *csize, uint32_t *rid, uint32_t *s_w, unsigned long long *stamps = nullptr) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t carry = 0;
+  FX_STAMP_INIT(stamps);
+  RunTable RT = run_table(s_w);
+  uint32_t carry = 0, n_runs = 0;
   for (uint32_t b0 = 0; b0 < n; b0 += FX_WG) {
     const uint32_t i = b0 + threadIdx.x;
     bool start = true;
@@ -135,68 +186,143 @@ __device__ void cc_label(const float *px, const float *py, const float *pz, uint
       if (i > 0) start = !(dist2(px[i], py[i], pz[i], px[i - 1], py[i - 1], pz[i - 1]) < r2);
     }
     const unsigned long long m = __ballot(start);
-    if (lane == 0) s_w[wave] = m ? (b0 + wave * 64 + (63u - (uint32_t)__clzll((long long)m))) : FX_NONE;
+    const unsigned long long mreal = __ballot(start && i < n);
+    if (lane == 0) {
+      s_w[wave] = m ? (b0 + wave * 64 + (63u - (uint32_t)__clzll((long long)m))) : FX_NONE;
+      s_w[4 + wave] = (uint32_t)__popcll(mreal);
+    }
     __syncthreads();
     const unsigned long long below = m & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
-    uint32_t head = carry, last = carry;
+    uint32_t head = carry, last = carry, runs_before = 0, runs_chunk = 0;
 #pragma unroll
     for (int w = 0; w < FX_NWAVE; ++w) {
-      const uint32_t v = s_w[w];
+      const uint32_t v = s_w[w], c = s_w[4 + w];
       if (v != FX_NONE) {
         if (w < (int)wave) head = v;
         last = v;
       }
+      runs_before += (w < (int)wave) ? c : 0u;
+      runs_chunk += c;
     }
     if (below) head = b0 + wave * 64 + (63u - (uint32_t)__clzll((long long)below));
+    if (i < n) {
+      parent[i] = head;
+      // run id = heads at or before me - 1
+      const uint32_t r = n_runs + runs_before + (uint32_t)__popcll(mreal & below) - 1u;
+      rid[i] = r;
+      if (start && r < FX_RUN_MAX) RT.start[r] = i;
+    }
     __syncthreads();
     carry = last;
-    if (i < n) parent[i] = head;
+    n_runs += runs_chunk;
+  }
+  const bool table = n_runs <= FX_RUN_MAX;
+  if (table) {
+    for (uint32_t r = threadIdx.x; r < n_runs; r += FX_WG) {
+      RT.minx[r] = __uint_as_float(f2ord(INFINITY));
+      RT.maxx[r] = __uint_as_float(f2ord(-INFINITY));
+      RT.miny[r] = __uint_as_float(f2ord(INFINITY));
+      RT.maxy[r] = __uint_as_float(f2ord(-INFINITY));
+    }
+    if (threadIdx.x == 0) RT.start[n_runs] = n;
   }
   __syncthreads();
-  // all pairs, folded so that every thread sees about n/2 partners: rows t and n-1-t
-  const uint32_t half = (n + 1) / 2;
-  for (uint32_t t = threadIdx.x; t < half; t += FX_WG) {
-    for (int pass = 0; pass < 2; ++pass) {
-      const uint32_t i = pass == 0 ? t : n - 1 - t;
-      if (pass == 1 && i == t) break;
+  FX_STAMP(2);
+  if (table && n_runs > 1) {
+    for (uint32_t i = threadIdx.x; i < n; i += FX_WG) {
+      const uint32_t r = rid[i];
+      const uint32_t ox = f2ord(px[i]), oy = f2ord(py[i]);
+      atomicMin(reinterpret_cast<uint32_t *>(&RT.minx[r]), ox);
+      atomicMax(reinterpret_cast<uint32_t *>(&RT.maxx[r]), ox);
+      atomicMin(reinterpret_cast<uint32_t *>(&RT.miny[r]), oy);
+      atomicMax(reinterpret_cast<uint32_t *>(&RT.maxy[r]), oy);
+    }
+    __syncthreads();
+    for (uint32_t r = threadIdx.x; r < n_runs; r += FX_WG) {
+      RT.minx[r] = ord2f(__float_as_uint(RT.minx[r]));
+      RT.maxx[r] = ord2f(__float_as_uint(RT.maxx[r]));
+      RT.miny[r] = ord2f(__float_as_uint(RT.miny[r]));
+      RT.maxy[r] = ord2f(__float_as_uint(RT.maxy[r]));
+    }
+    __syncthreads();
+    const float r2_pad = r2 * 1.001f;  // the box distance is a lower bound; pad it against fp32 rounding
+    for (uint32_t i = threadIdx.x; i < n; i += FX_WG) {
       const float qx = px[i], qy = py[i], qz = pz[i];
-      const uint32_t li = parent[i];
-      for (uint32_t j = i + 2; j < n; ++j) {
-        if (parent[j] == li) continue;  // same ancestor: already one component
-        const float d = dist2(qx, qy, qz, px[j], py[j], pz[j]);
-        if (d < r2) uf_union(parent, j, i);
+      for (uint32_t r = rid[i] + 1; r < n_runs; ++r) {
+        const float dx = fmaxf(fmaxf(RT.minx[r] - qx, qx - RT.maxx[r]), 0.0f);
+        const float dy = fmaxf(fmaxf(RT.miny[r] - qy, qy - RT.maxy[r]), 0.0f);
+        if (dx * dx + dy * dy > r2_pad) continue;
+        const uint32_t s = RT.start[r], e = RT.start[r + 1];
+        if (uf_find(parent, i) == uf_find(parent, s)) continue;  // already one component
+        for (uint32_t j = s; j < e; ++j) {
+          if (dist2(qx, qy, qz, px[j], py[j], pz[j]) < r2) {
+            uf_union(parent, j, i);
+            break;  // the two components are one now; further edges into this run add nothing
+          }
+        }
       }
     }
+  } else if (!table) {
+    // every pair (i, j > i) of different runs; pairs are dealt round-robin to the threads
+    uint32_t i = 0, k = threadIdx.x;  // k = j - (i + 1)
+    while (true) {
+      while (i + 1 < n && k >= n - 1 - i) {
+        k -= n - 1 - i;
+        ++i;
+      }
+      if (i + 1 >= n) break;
+      const uint32_t j = i + 1 + k;
+      if (rid[i] != rid[j] && dist2(px[i], py[i], pz[i], px[j], py[j], pz[j]) < r2) uf_union(parent, j, i);
+      k += FX_WG;
+    }
+  }
+  __syncthreads();
+  FX_STAMP(3);
+  // roots: run heads first (only heads are ever linked), then every point through its head
+  for (uint32_t i = threadIdx.x; i < n; i += FX_WG) {
+    const bool is_head = i == 0 || rid[i] != rid[i - 1];
+    if (is_head) parent[i] = uf_find(parent, i);
   }
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < n; i += FX_WG) {
-    const uint32_t r = uf_find(parent, i);
-    parent[i] = r;  // still a valid ancestor for concurrent finds
+    const bool is_head = i == 0 || rid[i] != rid[i - 1];
+    if (!is_head) parent[i] = parent[parent[i]];
   }
   __syncthreads();
-  // sizes: one LDS atomic per distinct root per wave
-  for (uint32_t b0 = 0; b0 < n; b0 += FX_WG) {
-    const uint32_t i = b0 + threadIdx.x;
-    bool todo = i < n;
-    const uint32_t root = todo ? parent[i] : 0u;
-    while (true) {
-      const unsigned long long act = __ballot(todo);
-      if (!act) break;
-      const uint32_t leader = (uint32_t)__ffsll((long long)act) - 1u;
-      const uint32_t r = __shfl(root, leader, 64);
-      const unsigned long long same = __ballot(todo && root == r);
-      if (lane == leader) atomicAdd(&csize[r], (uint32_t)__popcll(same));
-      if (root == r) todo = false;
-    }
+  // sizes: one atomic per run
+  if (table) {
+    for (uint32_t r = threadIdx.x; r < n_runs; r += FX_WG) atomicAdd(&csize[parent[RT.start[r]]], RT.start[r + 1] - RT.start[r]);
+  } else {
+    for (uint32_t i = threadIdx.x; i < n; i += FX_WG) atomicAdd(&csize[parent[i]], 1u);
   }
   __syncthreads();
+  FX_STAMP(4);
+  return n_runs;
 }
 
+// The sort records of up to 64 clusters held one per lane of a wavefront: the sequential
+// algorithm runs with wave-uniform control flow on v_readlane / v_writelane instead of
+// dependent LDS round trips.
+struct WaveRegView {
+  uint32_t reg;
+  int n;
+  int lane;
+  __device__ __forceinline__ uint32_t get(int i) const { return __builtin_amdgcn_readlane(reg, n - 1 - i); }
+  __device__ __forceinline__ void set(int i, uint32_t v) { reg = (lane == n - 1 - i) ? v : reg; }
+  __device__ __forceinline__ void swap(int i, int j) {
+    const uint32_t a = get(i), b = get(j);
+    set(i, b);
+    set(j, a);
+  }
+};
+
 // Size-admissible components in discovery order (ascending smallest index), then PCL's
-// final std::sort replayed by one lane.  crec[s] = (size << 16) | discovery ordinal, in the
+// final std::sort replayed sequentially.  crec[s] = (size << 16) | discovery ordinal, in the
 // order PCL returns the clusters; croot[ordinal] = root index.  Returns the cluster count.
 __device__ uint32_t cc_order(uint32_t n, const uint32_t *parent, const uint32_t *csize, uint32_t min_sz,
-                             uint32_t max_sz, uint32_t *croot, uint32_t *crec, uint32_t *s_w) {
+                             uint32_t max_sz, uint32_t *croot, uint32_t *crec, uint32_t *s_w,
+                             unsigned long long *stamps = nullptr) {
+  FX_STAMP_INIT(stamps);
   uint32_t n_c = 0;
   for (uint32_t b0 = 0; b0 < n; b0 += FX_WG) {
     const uint32_t i = b0 + threadIdx.x;
@@ -216,18 +342,19 @@ __device__ uint32_t cc_order(uint32_t n, const uint32_t *parent, const uint32_t 
     n_c += tot;
   }
   __syncthreads();
-  if (threadIdx.x == 0) fx_sort_replay_desc(crec, n_c, (int *)(s_w + 32));
+  FX_STAMP(5);
+  if (n_c > 1 && threadIdx.x < 64) {
+    if (n_c <= 64) {
+      WaveRegView v{threadIdx.x < n_c ? crec[threadIdx.x] : 0u, (int)n_c, (int)threadIdx.x};
+      fx_sort_replay_view(v, (int)n_c, (int *)(s_w + 32));
+      if (threadIdx.x < n_c) crec[threadIdx.x] = v.reg;
+    } else if (threadIdx.x == 0) {
+      fx_sort_replay_desc(crec, n_c, (int *)(s_w + 32));
+    }
+  }
   __syncthreads();
+  FX_STAMP(6);
   return n_c;
-}
-
-// order-preserving map float -> uint32 (for LDS atomicMin/Max on coordinates)
-__device__ __forceinline__ uint32_t f2ord(float f) {
-  const uint32_t u = __float_as_uint(f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float ord2f(uint32_t o) {
-  return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
 }
 
 }  // namespace
@@ -309,11 +436,136 @@ __global__ __launch_bounds__(FX_PREP_T) void k_prep(FxDevParams P, FxBuffers B) 
   if (tid == 0) {
     B.n_filt[scan] = base;
     B.flags[scan] = 0u;
-    B.kpc_used[scan] = 0u;
   }
 }
 
-// ====================================================================== stage 2: rings
+// ====================================================================== stage 2a: ring buckets
+// estimateKeypoints' ring loop (ref: node.cpp:195-202) runs 16 PassThrough filters over the
+// filtered cloud.  Here one workgroup per scan deals the filtered points to their rings in
+// one stable pass (a point on a window boundary belongs to both rings, A.3), so the ring
+// workgroups read exactly their own points, already in ring order.
+__device__ __forceinline__ uint32_t ring_membership(float el, const float2 *win, int n_rings, float el0, float inv_step,
+                                                    int &r_first) {
+  // candidate rings: the nearest centre and its two neighbours; membership by the exact windows
+  const float t = (el - el0) * inv_step + 0.5f;
+  int r0 = (t > -4.0f && t < 1.0e6f) ? (int)floorf(t) : -4;
+  r_first = r0 - 1;
+  uint32_t mask = 0;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const int r = r_first + d;
+    if (r >= 0 && r < n_rings) {
+      const float2 w = win[r];
+      if (!(el < w.x || el > w.y)) mask |= 1u << d;
+    }
+  }
+  return mask;
+}
+
+extern "C" __global__ __launch_bounds__(FX_WG) void k_bucket(FxDevParams P, FxBuffers B, float el0, float inv_step) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const uint32_t R = (uint32_t)P.n_rings;
+  uint32_t *s_w = smem;            // 16
+  uint32_t *cnt = smem + 16;       // [R] total per ring, then running fill
+  uint32_t *off = cnt + R;         // [R + 1]
+  uint32_t *cw = off + R + 1;      // [FX_NWAVE][R] per-wave counts of the current chunk
+  const uint32_t scan = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t nf = B.n_filt[scan];
+  const float4 *f = B.filt + (size_t)scan * P.max_points;
+  for (uint32_t r = tid; r < R; r += FX_WG) cnt[r] = 0;
+  __syncthreads();
+  for (uint32_t i = tid; i < nf; i += FX_WG) {
+    const float el = f[i].w;
+    int r_first;
+    uint32_t mask = isfinite(el) ? ring_membership(el, B.ring_win, P.n_rings, el0, inv_step, r_first) : 0u;
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+      if (mask & (1u << d)) atomicAdd(&cnt[r_first + d], 1u);
+  }
+  __syncthreads();
+  uint32_t total = 0;
+  for (uint32_t b0 = 0; b0 < R; b0 += FX_WG) {
+    const uint32_t r = b0 + tid;
+    const uint32_t c = r < R ? cnt[r] : 0u;
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan(c, s_w, tot);
+    if (r < R) off[r] = total + ex;
+    total += tot;
+  }
+  __syncthreads();
+  const bool overflow = total > P.ring_slot_cap;
+  uint32_t *g_off = B.ring_off + (size_t)scan * R, *g_cnt = B.ring_cnt + (size_t)scan * R;
+  for (uint32_t r = tid; r < R; r += FX_WG) {
+    g_off[r] = overflow ? 0u : off[r];
+    g_cnt[r] = overflow ? 0u : cnt[r];
+    cnt[r] = 0;  // becomes the running fill
+  }
+  if (overflow) {
+    if (tid == 0) atomicOr(&B.flags[scan], FX_FLAG_RING_OVERFLOW);
+    return;
+  }
+  __syncthreads();
+  float4 *dst = B.ring_pts + (size_t)scan * P.ring_slot_cap;
+  for (uint32_t b0 = 0; b0 < nf; b0 += FX_WG) {
+    const uint32_t i = b0 + tid;
+    float4 v = make_float4(0, 0, 0, 0);
+    int r_first = 0;
+    uint32_t mask = 0;
+    if (i < nf) {
+      v = f[i];
+      if (isfinite(v.w)) mask = ring_membership(v.w, B.ring_win, P.n_rings, el0, inv_step, r_first);
+    }
+    // rings present in this chunk: [lo, hi)
+    int lo = mask ? r_first : 0x7fffffff, hi = mask ? r_first + 3 : -1;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      lo = min(lo, __shfl_xor(lo, d, 64));
+      hi = max(hi, __shfl_xor(hi, d, 64));
+    }
+    if (lane == 0) {
+      s_w[wave] = (uint32_t)lo;
+      s_w[4 + wave] = (uint32_t)hi;
+    }
+    __syncthreads();
+    lo = 0x7fffffff, hi = -1;
+#pragma unroll
+    for (int w = 0; w < FX_NWAVE; ++w) {
+      lo = min(lo, (int)s_w[w]);
+      hi = max(hi, (int)s_w[4 + w]);
+    }
+    lo = max(lo, 0);
+    hi = min(hi, (int)R);
+    uint32_t my_rank[3] = {0, 0, 0};
+    for (int r = lo; r < hi; ++r) {
+      const int d = r - r_first;
+      const bool in = mask && d >= 0 && d < 3 && (mask & (1u << d));
+      const unsigned long long m = __ballot(in);
+      if (in) my_rank[d] = lanes_below(m);
+      if (lane == 0) cw[wave * R + r] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      if (mask & (1u << d)) {
+        const uint32_t r = (uint32_t)(r_first + d);
+        uint32_t before = 0;
+#pragma unroll
+        for (int w = 0; w < FX_NWAVE; ++w) before += (w < (int)wave) ? cw[w * R + r] : 0u;
+        dst[off[r] + cnt[r] + before + my_rank[d]] = v;
+      }
+    }
+    __syncthreads();
+    for (int r = lo + (int)tid; r < hi; r += FX_WG) {
+      uint32_t c = 0;
+#pragma unroll
+      for (int w = 0; w < FX_NWAVE; ++w) c += cw[w * R + r];
+      cnt[r] += c;
+    }
+    __syncthreads();
+  }
+}
+
+// ====================================================================== stage 2b: rings
 struct RingLds {
   float *px, *py, *pz, *pe, *ccx, *ccy, *ccz, *cce;
   uint32_t *parent, *csize, *rank, *croot, *crec, *cpos, *cslot, *ckoff, *s_w;
@@ -342,88 +594,55 @@ __device__ __forceinline__ RingLds ring_carve(uint32_t *smem, uint32_t cap) {
 }
 #define FX_RING_WORDS_PER_POINT 16
 
-// One (scan, ring): PassThrough on the elevation window (stable), Euclidean clustering,
-// centroid + diameter gate, candidates in PCL's cluster order, member points for keypoint_cloud.
-// Returns false when the ring does not fit `cap` points (caller defers it to the large tier).
+// One (scan, ring): getCylinderSegments (ref: node.cpp:261-327) on the ring's points:
+// Euclidean clustering, centroid + diameter gate, candidates in PCL's cluster order, member
+// points for keypoint_cloud.  Returns false when the ring does not fit `cap` points (the
+// caller defers it to the large tier).
 __device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t scan, uint32_t ring, uint32_t cap,
                           uint32_t *smem, bool last_tier) {
   RingLds L = ring_carve(smem, cap);
-  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t nf = B.n_filt[scan];
-  const float4 *f = B.filt + (size_t)scan * P.max_points;
-  const float2 win = B.ring_win[ring];
+  FX_STAMP_INIT(B.stamps);
+  const uint32_t tid = threadIdx.x;
   const size_t ring_slot = (size_t)scan * P.n_rings + ring;
-
-  // ---- ring split (ref: node.cpp:200-202): keep iff lo <= elevation <= hi, input order.
-  //      Four independent loads per thread and trip, one barrier pair per 1024 points.
-  uint32_t n = 0;
-  for (uint32_t b0 = 0; b0 < nf; b0 += FX_WG * 4) {
-    float4 v[4];
-    bool in[4];
-    unsigned long long m[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const uint32_t i = b0 + u * FX_WG + tid;
-      v[u] = i < nf ? f[i] : make_float4(0.f, 0.f, 0.f, NAN);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      in[u] = isfinite(v[u].w) && !(v[u].w < win.x || v[u].w > win.y);
-      m[u] = __ballot(in[u]);
-      if (lane == 0) L.s_w[u * FX_NWAVE + wave] = (uint32_t)__popcll(m[u]);
-    }
-    __syncthreads();
-    uint32_t run = 0;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      uint32_t before = 0, slice = 0;
-#pragma unroll
-      for (int w = 0; w < FX_NWAVE; ++w) {
-        const uint32_t c = L.s_w[u * FX_NWAVE + w];
-        before += (w < (int)wave) ? c : 0u;
-        slice += c;
-      }
-      if (in[u]) {
-        const uint32_t pos = n + run + before + lanes_below(m[u]);
-        if (pos < cap) {
-          L.px[pos] = v[u].x;
-          L.py[pos] = v[u].y;
-          L.pz[pos] = v[u].z;
-          L.pe[pos] = v[u].w;
-        }
-      }
-      run += slice;
-    }
-    __syncthreads();
-    n += run;
-  }
+  const uint32_t n = B.ring_cnt[ring_slot], off = B.ring_off[ring_slot];
   if (n > cap) {
     if (!last_tier) return false;
     if (tid == 0) {
       atomicOr(&B.flags[scan], FX_FLAG_RING_OVERFLOW);
       B.ring_cand_cnt[ring_slot] = 0;
-      B.kpc_ring_off[ring_slot] = 0;
       B.kpc_ring_cnt[ring_slot] = 0;
     }
     return true;
   }
-  __syncthreads();
   if (n == 0) {  // ref: node.cpp:263-264
     if (tid == 0) {
       B.ring_cand_cnt[ring_slot] = 0;
-      B.kpc_ring_off[ring_slot] = 0;
       B.kpc_ring_cnt[ring_slot] = 0;
     }
     return true;
   }
+  const float4 *src = B.ring_pts + (size_t)scan * P.ring_slot_cap + off;
+  for (uint32_t i = tid; i < n; i += FX_WG) {
+    const float4 v = src[i];
+    L.px[i] = v.x;
+    L.py[i] = v.y;
+    L.pz[i] = v.z;
+    L.pe[i] = v.w;
+  }
+  __syncthreads();
+  FX_STAMP(1);
 
   // ---- pcl::EuclideanClusterExtraction (ref: node.cpp:269-276)
-  cc_label(L.px, L.py, L.pz, n, P.r2_cluster, L.parent, L.csize, L.s_w);
-  const uint32_t n_c = cc_order(n, L.parent, L.csize, P.min_count, P.max_count, L.croot, L.crec, L.s_w);
+  const uint32_t n_runs = cc_label(L.px, L.py, L.pz, n, P.r2_cluster, L.parent, L.csize, L.rank, L.s_w, B.stamps);
+  const uint32_t n_c = cc_order(n, L.parent, L.csize, P.min_count, P.max_count, L.croot, L.crec, L.s_w, B.stamps);
+#ifdef FX_STAMPS
+  stamp_prev_ = __builtin_amdgcn_s_memtime();
+#endif
 
-  // ---- xy bounding box of every admissible cluster (ref: node.cpp:289-305), all points in
-  //      parallel: min/max are exact whatever the order.  The four arrays live where the
-  //      centroids go afterwards (indexed by root here, by cluster position there).
+  // ---- xy bounding box of every admissible cluster (ref: node.cpp:289-305): min/max are exact
+  //      whatever the order, so runs (or points) fold into their cluster's box with LDS atomics.
+  //      The four arrays live where the centroids go afterwards (indexed by root here, by
+  //      cluster position there).
   uint32_t *bminx = (uint32_t *)L.ccx, *bmaxx = (uint32_t *)L.ccy, *bminy = (uint32_t *)L.ccz,
            *bmaxy = (uint32_t *)L.cce;
   for (uint32_t c = tid; c < n_c; c += FX_WG) {
@@ -434,17 +653,31 @@ __device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t sca
     bmaxy[root] = f2ord(-1000.0f);
   }
   __syncthreads();
-  for (uint32_t i = tid; i < n; i += FX_WG) {
-    const uint32_t root = L.parent[i];
-    const uint32_t sz = L.csize[root];
-    if (sz < P.min_count || sz > P.max_count) continue;
-    const uint32_t ox = f2ord(L.px[i]), oy = f2ord(L.py[i]);
-    atomicMin(&bminx[root], ox);
-    atomicMax(&bmaxx[root], ox);
-    atomicMin(&bminy[root], oy);
-    atomicMax(&bmaxy[root], oy);
+  if (n_runs <= FX_RUN_MAX && n_runs > 1) {
+    RunTable RT = run_table(L.s_w);
+    for (uint32_t r = tid; r < n_runs; r += FX_WG) {
+      const uint32_t root = L.parent[RT.start[r]];
+      const uint32_t sz = L.csize[root];
+      if (sz < P.min_count || sz > P.max_count) continue;
+      atomicMin(&bminx[root], f2ord(RT.minx[r]));
+      atomicMax(&bmaxx[root], f2ord(RT.maxx[r]));
+      atomicMin(&bminy[root], f2ord(RT.miny[r]));
+      atomicMax(&bmaxy[root], f2ord(RT.maxy[r]));
+    }
+  } else {
+    for (uint32_t i = tid; i < n; i += FX_WG) {
+      const uint32_t root = L.parent[i];
+      const uint32_t sz = L.csize[root];
+      if (sz < P.min_count || sz > P.max_count) continue;
+      const uint32_t ox = f2ord(L.px[i]), oy = f2ord(L.py[i]);
+      atomicMin(&bminx[root], ox);
+      atomicMax(&bmaxx[root], ox);
+      atomicMin(&bminy[root], oy);
+      atomicMax(&bmaxy[root], oy);
+    }
   }
   __syncthreads();
+  FX_STAMP(7);
   // ---- diameter gate per cluster, in PCL's cluster order (ref: node.cpp:314-316)
   for (uint32_t s = tid; s < n_c; s += FX_WG) {
     const uint32_t root = L.croot[L.crec[s] & 0xffffu];
@@ -456,6 +689,7 @@ __device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t sca
     L.cslot[s] = (diameter < P.gate_diameter) ? 1u : 0u;
   }
   __syncthreads();
+  FX_STAMP(8);
   // ---- centroid of the clusters that pass: fp64 sums in ascending member order
   //      (ref: node.cpp:293-297, 317-320); the walk also ranks the members for keypoint_cloud
   for (uint32_t s = tid; s < n_c; s += FX_WG) {
@@ -477,6 +711,7 @@ __device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t sca
     L.cce[s] = L.pe[root];
   }
   __syncthreads();
+  FX_STAMP(9);
 
   // ---- slots of the gate-passing clusters and offsets of their member runs
   uint32_t n_pass = 0, n_mem = 0;
@@ -495,6 +730,7 @@ __device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t sca
     n_mem += tot_m;
   }
   __syncthreads();
+  FX_STAMP(10);
 
   // ---- candidates of this ring (cylinderCentroids, ref: node.cpp:322)
   float4 *rc = B.ring_cand + ring_slot * P.max_ring_cands;
@@ -506,29 +742,17 @@ __device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t sca
       rcs[slot] = L.crec[s] >> 16;
     }
   }
-  // ---- member points (cylinderCloud, ref: node.cpp:310, 323) into a chunk of the scan's pool;
-  //      k_merge puts the chunks into ring order.
+  // ---- member points (cylinderCloud, ref: node.cpp:310, 323): the ring's chunk of the pool
+  //      starts where the ring's points start (members are a subset of them); k_merge lays
+  //      the chunks out back to back in ring order.
   if (tid == 0) {
-    uint32_t off = 0, cnt = n_mem;
     if (n_pass > P.max_ring_cands) atomicOr(&B.flags[scan], FX_FLAG_CAND_OVERFLOW);
-    if (n_mem) {
-      off = atomicAdd(&B.kpc_used[scan], n_mem);
-      if (off + n_mem > P.max_kpc) {
-        atomicOr(&B.flags[scan], FX_FLAG_KPC_OVERFLOW);
-        cnt = 0;
-      }
-    }
     B.ring_cand_cnt[ring_slot] = n_pass < P.max_ring_cands ? n_pass : P.max_ring_cands;
-    B.kpc_ring_off[ring_slot] = off;
-    B.kpc_ring_cnt[ring_slot] = cnt;
-    L.s_w[16] = off;
-    L.s_w[17] = cnt;
+    B.kpc_ring_cnt[ring_slot] = n_mem;
   }
-  __syncthreads();
-  const uint32_t off = L.s_w[16];
-  if (L.s_w[17]) {
-    float4 *pool = B.kpc_pool + (size_t)scan * P.max_kpc;
-    uint32_t *pool_c = B.kpc_pool_cand + (size_t)scan * P.max_kpc;
+  if (n_mem) {
+    float4 *pool = B.kpc_pool + (size_t)scan * P.ring_slot_cap + off;
+    uint32_t *pool_c = B.kpc_pool_cand + (size_t)scan * P.ring_slot_cap + off;
     for (uint32_t i = tid; i < n; i += FX_WG) {
       const uint32_t root = L.parent[i];
       const uint32_t sz = L.csize[root];
@@ -536,12 +760,13 @@ __device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t sca
       const uint32_t s = L.cpos[root];
       const uint32_t slot = L.cslot[s];
       if (slot == FX_NONE) continue;
-      const uint32_t dst = off + L.ckoff[s] + L.rank[i];
+      const uint32_t dst = L.ckoff[s] + L.rank[i];
       pool[dst] = make_float4(L.px[i], L.py[i], L.pz[i], L.pe[i]);
       pool_c[dst] = slot;
     }
   }
   __syncthreads();
+  FX_STAMP(11);
   return true;
 }
 
@@ -568,9 +793,9 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_rings_big(FxDevParams P, F
 // ====================================================================== stage 3: merge
 struct MergeLds {
   float *cx, *cy, *cz, *ce, *pz;
-  uint32_t *parent, *csize, *croot, *crec, *cpos, *rbase, *s_w;
+  uint32_t *parent, *csize, *croot, *crec, *cpos, *rid, *rbase, *s_w;
 };
-#define FX_MERGE_WORDS_PER_CAND 10
+#define FX_MERGE_WORDS_PER_CAND 11
 __device__ __forceinline__ MergeLds merge_carve(uint32_t *smem, uint32_t cap, uint32_t n_rings) {
   MergeLds L;
   L.s_w = smem;
@@ -585,6 +810,7 @@ __device__ __forceinline__ MergeLds merge_carve(uint32_t *smem, uint32_t cap, ui
   L.croot = p, p += cap;
   L.crec = p, p += cap;
   L.cpos = p, p += cap;
+  L.rid = p, p += cap;
   L.rbase = p, p += (n_rings + 1);
   return L;
 }
@@ -650,7 +876,7 @@ __device__ bool merge_body(const FxDevParams &P, const FxBuffers &B, uint32_t sc
 
   uint32_t K = 0;
   if (C > 0) {  // ref: node.cpp:209-210
-    cc_label(L.cx, L.cy, L.pz, C, P.r2_merge, L.parent, L.csize, L.s_w);
+    cc_label(L.cx, L.cy, L.pz, C, P.r2_merge, L.parent, L.csize, L.rid, L.s_w);
     const uint32_t n_c = cc_order(C, L.parent, L.csize, P.ndc, P.secondary_max, L.croot, L.crec, L.s_w);
     K = n_c < P.max_keypoints ? n_c : P.max_keypoints;
     if (n_c > P.max_keypoints && tid == 0) atomicOr(&B.flags[scan], FX_FLAG_KP_OVERFLOW);
@@ -688,15 +914,19 @@ __device__ bool merge_body(const FxDevParams &P, const FxBuffers &B, uint32_t sc
   }
 
   // ---- keypoint_cloud: chunks into ring order, candidate slot -> ordinal in keypoints_full
-  const uint32_t *koff = B.kpc_ring_off + (size_t)scan * R;
+  const uint32_t *koff = B.ring_off + (size_t)scan * R;
   const uint32_t *kcnt = B.kpc_ring_cnt + (size_t)scan * R;
-  const float4 *pool = B.kpc_pool + (size_t)scan * P.max_kpc;
-  const uint32_t *pool_c = B.kpc_pool_cand + (size_t)scan * P.max_kpc;
+  const float4 *pool = B.kpc_pool + (size_t)scan * P.ring_slot_cap;
+  const uint32_t *pool_c = B.kpc_pool_cand + (size_t)scan * P.ring_slot_cap;
   float4 *kpc = B.kpc + (size_t)scan * P.max_kpc;
   uint32_t *kpc_c = B.kpc_cand + (size_t)scan * P.max_kpc;
   uint32_t run = 0;
   for (uint32_t r = 0; r < R; ++r) {
     const uint32_t c = kcnt[r], o = koff[r], cb = L.rbase[r];
+    if (run + c > P.max_kpc) {
+      if (tid == 0) atomicOr(&B.flags[scan], FX_FLAG_KPC_OVERFLOW);
+      break;
+    }
     for (uint32_t j = tid; j < c; j += FX_WG) {
       kpc[run + j] = pool[o + j];
       kpc_c[run + j] = cb + pool_c[o + j];
@@ -1285,6 +1515,10 @@ hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t desc_big) {
 
 void fxk_prep(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch) {
   hipLaunchKernelGGL(k_prep, dim3(batch), dim3(FX_PREP_T), 0, s, P, B);
+}
+void fxk_bucket(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float el0, float inv_step) {
+  const size_t lds = (16 + (size_t)P.n_rings * (2 + FX_NWAVE) + 1) * 4;
+  hipLaunchKernelGGL(k_bucket, dim3(batch), dim3(FX_WG), lds, s, P, B, el0, inv_step);
 }
 void fxk_rings_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap) {
   hipLaunchKernelGGL(k_rings_small, dim3(batch * P.n_rings), dim3(FX_WG), fxk_ring_lds_bytes(cap), s, P, B, cap);

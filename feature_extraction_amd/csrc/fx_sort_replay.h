@@ -30,8 +30,8 @@ struct RevView {
   uint32_t *rec;
   int n;
   FX_HD uint32_t get(int i) const { return rec[n - 1 - i]; }
-  FX_HD void set(int i, uint32_t v) const { rec[n - 1 - i] = v; }
-  FX_HD void swap(int i, int j) const {
+  FX_HD void set(int i, uint32_t v) { rec[n - 1 - i] = v; }
+  FX_HD void swap(int i, int j) {
     uint32_t a = get(i), b = get(j);
     set(i, b);
     set(j, a);
@@ -39,7 +39,8 @@ struct RevView {
 };
 FX_HD inline bool less_size(uint32_t a, uint32_t b) { return (a >> 16) < (b >> 16); }
 
-FX_HD inline void push_heap(const RevView &v, int first, int hole, int top, uint32_t value) {
+template <class V>
+FX_HD inline void push_heap(V &v, int first, int hole, int top, uint32_t value) {
   int parent = (hole - 1) / 2;
   while (hole > top && less_size(v.get(first + parent), value)) {
     v.set(first + hole, v.get(first + parent));
@@ -48,7 +49,8 @@ FX_HD inline void push_heap(const RevView &v, int first, int hole, int top, uint
   }
   v.set(first + hole, value);
 }
-FX_HD inline void adjust_heap(const RevView &v, int first, int hole, int len, uint32_t value) {
+template <class V>
+FX_HD inline void adjust_heap(V &v, int first, int hole, int len, uint32_t value) {
   const int top = hole;
   int child = hole;
   while (child < (len - 1) / 2) {
@@ -65,7 +67,8 @@ FX_HD inline void adjust_heap(const RevView &v, int first, int hole, int len, ui
   push_heap(v, first, hole, top, value);
 }
 // partial_sort(first, last, last): make_heap + sort_heap over [first, last)
-FX_HD inline void heap_sort(const RevView &v, int first, int last) {
+template <class V>
+FX_HD inline void heap_sort(V &v, int first, int last) {
   const int len = last - first;
   if (len >= 2) {
     int parent = (len - 2) / 2;
@@ -84,7 +87,8 @@ FX_HD inline void heap_sort(const RevView &v, int first, int last) {
     adjust_heap(v, first, 0, l - first, value);
   }
 }
-FX_HD inline void median_to_first(const RevView &v, int result, int a, int b, int c) {
+template <class V>
+FX_HD inline void median_to_first(V &v, int result, int a, int b, int c) {
   const uint32_t va = v.get(a), vb = v.get(b), vc = v.get(c);
   if (less_size(va, vb)) {
     if (less_size(vb, vc))
@@ -100,7 +104,8 @@ FX_HD inline void median_to_first(const RevView &v, int result, int a, int b, in
   else
     v.swap(result, b);
 }
-FX_HD inline int partition_pivot(const RevView &v, int first, int last) {
+template <class V>
+FX_HD inline int partition_pivot(V &v, int first, int last) {
   const int mid = first + (last - first) / 2;
   median_to_first(v, first, first + 1, mid, last - 1);
   int lo = first + 1, hi = last;
@@ -114,7 +119,8 @@ FX_HD inline int partition_pivot(const RevView &v, int first, int last) {
     ++lo;
   }
 }
-FX_HD inline void linear_insert_unguarded(const RevView &v, int last) {
+template <class V>
+FX_HD inline void linear_insert_unguarded(V &v, int last) {
   const uint32_t val = v.get(last);
   int next = last - 1;
   while (less_size(val, v.get(next))) {
@@ -124,7 +130,8 @@ FX_HD inline void linear_insert_unguarded(const RevView &v, int last) {
   }
   v.set(last, val);
 }
-FX_HD inline void insertion_sort(const RevView &v, int first, int last) {
+template <class V>
+FX_HD inline void insertion_sort(V &v, int first, int last) {
   if (first == last) return;
   for (int i = first + 1; i != last; ++i) {
     if (less_size(v.get(i), v.get(first))) {
@@ -139,15 +146,14 @@ FX_HD inline void insertion_sort(const RevView &v, int first, int last) {
 
 }  // namespace fx_sort_detail
 
-// Sorts rec[0..n) into the order PCL hands clusters back: descending size, ties as
-// libstdc++'s introsort leaves them.
+// Sorts the n records behind view `v` (logical position i = reversed position) into the order
+// PCL hands clusters back: descending size, ties as libstdc++'s introsort leaves them.
+// stk: FX_SORT_STACK_WORDS ints of scratch.
 #define FX_SORT_STACK_WORDS 120
-// stk: FX_SORT_STACK_WORDS ints of scratch (LDS on the device, so the kernel needs no private memory)
-FX_HD inline void fx_sort_replay_desc(uint32_t *rec, uint32_t n_u, int *stk) {
+template <class V>
+FX_HD inline void fx_sort_replay_view(V &v, int n, int *stk) {
   using namespace fx_sort_detail;
-  const int n = (int)n_u;
   if (n < 2) return;
-  RevView v{rec, n};
   const int kThreshold = 16;
   int lg = 0;
   for (int t = n; t > 1; t >>= 1) ++lg;
@@ -182,6 +188,12 @@ FX_HD inline void fx_sort_replay_desc(uint32_t *rec, uint32_t n_u, int *stk) {
   } else {
     insertion_sort(v, 0, n);
   }
+}
+
+// Records in memory (LDS on the device, plain memory on the host).
+FX_HD inline void fx_sort_replay_desc(uint32_t *rec, uint32_t n, int *stk) {
+  fx_sort_detail::RevView v{rec, (int)n};
+  fx_sort_replay_view(v, (int)n, stk);
 }
 
 #endif  // FX_SORT_REPLAY_H_

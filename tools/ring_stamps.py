@@ -1,0 +1,31 @@
+"""Diagnostic: per-phase cycle shares of the ring kernel (needs lib/libfx_hip_stamps.so,
+built with -DFX_STAMPS; never the product build).  Usage on the GPU box:
+  python tools/ring_stamps.py [preset]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from feature_extraction_amd import capi
+
+capi.LIB_PATH = os.path.join(os.path.dirname(capi.LIB_PATH), "libfx_hip_stamps.so")
+lib = capi.load()
+preset = sys.argv[1] if len(sys.argv) > 1 else "launch"
+B = 256
+scans = [capi.synth_scan(capi.synth_cfg(1000 + b)) for b in range(B)]
+ctx = capi.Context(capi.params(preset), capi.limits(B, 28800))
+descs = ctx.make_descs([s.ctypes.data for s in scans], [len(s) for s in scans], 16, 0.02, -0.015)
+for _ in range(3):
+    ctx.process_raw(descs, B, 0)
+ctx.synchronize()
+out = (C.c_ulonglong * 32)()
+lib.fx_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
+capi.check(lib.fx_debug_stamps(ctx.handle, out))
+v = np.array(list(out), dtype=np.float64)
+names = {1: "ring split", 2: "run labelling", 3: "all pairs", 4: "find+sizes", 5: "discovery compaction",
+         6: "sort replay (1 lane)", 7: "bbox", 8: "gate", 9: "centroid walks", 10: "slot scans", 11: "outputs"}
+tot = v.sum()
+for k, nm in names.items():
+    print(f"{nm:24s} {v[k] / tot * 100:6.2f} %   {v[k] / (3 * B * 16):10.0f} cycles per ring")
