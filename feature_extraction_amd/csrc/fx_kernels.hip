@@ -343,15 +343,7 @@ __device__ uint32_t cc_order(uint32_t n, const uint32_t *parent, const uint32_t 
   }
   __syncthreads();
   FX_STAMP(5);
-  if (n_c > 1 && threadIdx.x < 64) {
-    if (n_c <= 64) {
-      WaveRegView v{threadIdx.x < n_c ? crec[threadIdx.x] : 0u, (int)n_c, (int)threadIdx.x};
-      fx_sort_replay_view(v, (int)n_c, (int *)(s_w + 32));
-      if (threadIdx.x < n_c) crec[threadIdx.x] = v.reg;
-    } else if (threadIdx.x == 0) {
-      fx_sort_replay_desc(crec, n_c, (int *)(s_w + 32));
-    }
-  }
+  if (n_c > 1 && threadIdx.x == 0) fx_sort_replay_desc(crec, n_c, (int *)(s_w + 32));
   __syncthreads();
   FX_STAMP(6);
   return n_c;
