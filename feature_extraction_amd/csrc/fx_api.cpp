@@ -23,8 +23,9 @@ size_t fxk_desc_lds_bytes(uint32_t cap);
 hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t desc_big);
 void fxk_prep(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
 void fxk_bucket(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float el0, float inv_step);
-void fxk_rings_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap);
-void fxk_rings_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t grid);
+void fxk_rings_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap,
+                     uint32_t mid_cap);
+void fxk_rings_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t grid, uint32_t huge);
 void fxk_merge_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap);
 void fxk_merge_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t grid);
 void fxk_offsets(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
@@ -56,7 +57,7 @@ fx_status fail(fx_status s, const std::string &msg) {
   } while (0)
 
 constexpr int kMetaSlots = 8;
-constexpr uint32_t kRingCapSmall = 512, kMergeCapSmall = 512, kListCap = 1024;
+constexpr uint32_t kRingCapSmall = 256, kRingCapMid = 1024, kMergeCapSmall = 512, kListCap = 1024;
 }  // namespace
 
 struct fx_ctx {
@@ -264,6 +265,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   FX_A(dev_alloc(c, &b.desc, (size_t)L.max_total_keypoints * FX_DESC_FLOATS));
   FX_A(dev_alloc(c, &b.flags, B));
   FX_A(dev_alloc(c, &b.big_rings, B * R));
+  FX_A(dev_alloc(c, &b.huge_rings, B * R));
   FX_A(dev_alloc(c, &b.big_merge, B));
   FX_A(dev_alloc(c, &b.big_desc, L.max_total_keypoints));
   FX_A(dev_alloc(c, &b.list_desc, L.max_total_keypoints));
@@ -448,9 +450,11 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
     fxk_prep(s, P, B, batch);
     fxk_bucket(s, P, B, batch, (float)c->params.el0_deg, (float)(1.0 / c->params.el_step_deg));
     FX_HIP(mark(1));
-    fxk_rings_small(s, P, B, batch, ring_small);
+    const uint32_t ring_mid = L.max_ring_points < kRingCapMid ? L.max_ring_points : kRingCapMid;
+    fxk_rings_small(s, P, B, batch, ring_small, ring_mid);
     FX_HIP(mark(2));
-    fxk_rings_big(s, P, B, L.max_ring_points, big_grid);
+    fxk_rings_big(s, P, B, ring_mid, big_grid * 2, 0);
+    fxk_rings_big(s, P, B, L.max_ring_points, big_grid, 1);
     FX_HIP(mark(3));
     fxk_merge_small(s, P, B, batch, merge_small);
     FX_HIP(mark(4));

@@ -79,7 +79,8 @@ struct FxBuffers {
   float *desc;            // [max_total_kp][1989]
   uint32_t *flags;        // [B]
   // work lists for the large-capacity tiers
-  uint32_t *big_rings;    // [B*n_rings]
+  uint32_t *big_rings;    // [B*n_rings]  rings for the mid workgroup tier
+  uint32_t *huge_rings;   // [B*n_rings]  rings for the large workgroup tier
   uint32_t *big_merge;    // [B]
   uint32_t *big_desc;     // [max_total_kp]  rows whose support list overflowed list_cap
   uint32_t *list_desc;    // [max_total_kp]  rows whose list is too long for one wavefront
@@ -87,7 +88,7 @@ struct FxBuffers {
   float4 *s_pts;          // [max_total_kp][list_cap]  (x, y, z rotated, point index as bits)
   uint32_t *s_cnt;        // [max_total_kp]
   unsigned long long *stamps;  // [32] diagnostic build only (-DFX_STAMPS)
-  uint32_t *counters;     // [8]: 0 big_rings, 1 big_merge, 2 big_desc, 3 need_rng_fix, 4 list_desc
+  uint32_t *counters;     // [8]: 0 big_rings, 1 big_merge, 2 big_desc, 3 need_rng_fix, 4 list_desc, 5 huge_rings
 };
 
 #endif

@@ -34,6 +34,7 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
 
 // Stable rank of the threads whose pred is true (order = thread index); total = number of them.
 // s_w: FX_NWAVE words of LDS scratch.  Contains two barriers.
+template <int NT>
 __device__ __forceinline__ uint32_t block_rank(bool pred, uint32_t *s_w, uint32_t &total) {
   const unsigned long long m = __ballot(pred);
   const uint32_t wave = threadIdx.x >> 6;
@@ -41,7 +42,7 @@ __device__ __forceinline__ uint32_t block_rank(bool pred, uint32_t *s_w, uint32_
   __syncthreads();
   uint32_t base = 0, tot = 0;
 #pragma unroll
-  for (int w = 0; w < FX_NWAVE; ++w) {
+  for (int w = 0; w < (NT / 64); ++w) {
     const uint32_t c = s_w[w];
     base += (w < (int)wave) ? c : 0u;
     tot += c;
@@ -52,6 +53,7 @@ __device__ __forceinline__ uint32_t block_rank(bool pred, uint32_t *s_w, uint32_
 }
 
 // Exclusive prefix sum of v over the block in thread order; total = block sum.
+template <int NT>
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_w, uint32_t &total) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t inc = v;
@@ -64,7 +66,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_w, u
   __syncthreads();
   uint32_t base = 0, tot = 0;
 #pragma unroll
-  for (int w = 0; w < FX_NWAVE; ++w) {
+  for (int w = 0; w < (NT / 64); ++w) {
     const uint32_t c = s_w[w];
     base += (w < (int)wave) ? c : 0u;
     tot += c;
@@ -172,13 +174,14 @@ __device__ __forceinline__ RunTable run_table(uint32_t *s_w) {
 //     every pair that could be an edge, so the result is exact for any input order.
 //  3. roots per run head, then per point; sizes per run.
 // Returns the number of runs.
+template <int NT>
 __device__ uint32_t cc_label(const float *px, const float *py, const float *pz, uint32_t n, float r2, uint32_t *parent,
                              uint32_t *csize, uint32_t *rid, uint32_t *s_w, unsigned long long *stamps = nullptr) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   FX_STAMP_INIT(stamps);
   RunTable RT = run_table(s_w);
   uint32_t carry = 0, n_runs = 0;
-  for (uint32_t b0 = 0; b0 < n; b0 += FX_WG) {
+  for (uint32_t b0 = 0; b0 < n; b0 += NT) {
     const uint32_t i = b0 + threadIdx.x;
     bool start = true;
     if (i < n) {
@@ -195,7 +198,7 @@ __device__ uint32_t cc_label(const float *px, const float *py, const float *pz, 
     const unsigned long long below = m & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
     uint32_t head = carry, last = carry, runs_before = 0, runs_chunk = 0;
 #pragma unroll
-    for (int w = 0; w < FX_NWAVE; ++w) {
+    for (int w = 0; w < (NT / 64); ++w) {
       const uint32_t v = s_w[w], c = s_w[4 + w];
       if (v != FX_NONE) {
         if (w < (int)wave) head = v;
@@ -218,7 +221,7 @@ __device__ uint32_t cc_label(const float *px, const float *py, const float *pz, 
   }
   const bool table = n_runs <= FX_RUN_MAX;
   if (table) {
-    for (uint32_t r = threadIdx.x; r < n_runs; r += FX_WG) {
+    for (uint32_t r = threadIdx.x; r < n_runs; r += NT) {
       RT.minx[r] = __uint_as_float(f2ord(INFINITY));
       RT.maxx[r] = __uint_as_float(f2ord(-INFINITY));
       RT.miny[r] = __uint_as_float(f2ord(INFINITY));
@@ -229,7 +232,7 @@ __device__ uint32_t cc_label(const float *px, const float *py, const float *pz, 
   __syncthreads();
   FX_STAMP(2);
   if (table && n_runs > 1) {
-    for (uint32_t i = threadIdx.x; i < n; i += FX_WG) {
+    for (uint32_t i = threadIdx.x; i < n; i += NT) {
       const uint32_t r = rid[i];
       const uint32_t ox = f2ord(px[i]), oy = f2ord(py[i]);
       atomicMin(reinterpret_cast<uint32_t *>(&RT.minx[r]), ox);
@@ -238,7 +241,7 @@ __device__ uint32_t cc_label(const float *px, const float *py, const float *pz, 
       atomicMax(reinterpret_cast<uint32_t *>(&RT.maxy[r]), oy);
     }
     __syncthreads();
-    for (uint32_t r = threadIdx.x; r < n_runs; r += FX_WG) {
+    for (uint32_t r = threadIdx.x; r < n_runs; r += NT) {
       RT.minx[r] = ord2f(__float_as_uint(RT.minx[r]));
       RT.maxx[r] = ord2f(__float_as_uint(RT.maxx[r]));
       RT.miny[r] = ord2f(__float_as_uint(RT.miny[r]));
@@ -246,7 +249,7 @@ __device__ uint32_t cc_label(const float *px, const float *py, const float *pz, 
     }
     __syncthreads();
     const float r2_pad = r2 * 1.001f;  // the box distance is a lower bound; pad it against fp32 rounding
-    for (uint32_t i = threadIdx.x; i < n; i += FX_WG) {
+    for (uint32_t i = threadIdx.x; i < n; i += NT) {
       const float qx = px[i], qy = py[i], qz = pz[i];
       for (uint32_t r = rid[i] + 1; r < n_runs; ++r) {
         const float dx = fmaxf(fmaxf(RT.minx[r] - qx, qx - RT.maxx[r]), 0.0f);
@@ -273,27 +276,27 @@ __device__ uint32_t cc_label(const float *px, const float *py, const float *pz, 
       if (i + 1 >= n) break;
       const uint32_t j = i + 1 + k;
       if (rid[i] != rid[j] && dist2(px[i], py[i], pz[i], px[j], py[j], pz[j]) < r2) uf_union(parent, j, i);
-      k += FX_WG;
+      k += NT;
     }
   }
   __syncthreads();
   FX_STAMP(3);
   // roots: run heads first (only heads are ever linked), then every point through its head
-  for (uint32_t i = threadIdx.x; i < n; i += FX_WG) {
+  for (uint32_t i = threadIdx.x; i < n; i += NT) {
     const bool is_head = i == 0 || rid[i] != rid[i - 1];
     if (is_head) parent[i] = uf_find(parent, i);
   }
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < n; i += FX_WG) {
+  for (uint32_t i = threadIdx.x; i < n; i += NT) {
     const bool is_head = i == 0 || rid[i] != rid[i - 1];
     if (!is_head) parent[i] = parent[parent[i]];
   }
   __syncthreads();
   // sizes: one atomic per run
   if (table) {
-    for (uint32_t r = threadIdx.x; r < n_runs; r += FX_WG) atomicAdd(&csize[parent[RT.start[r]]], RT.start[r + 1] - RT.start[r]);
+    for (uint32_t r = threadIdx.x; r < n_runs; r += NT) atomicAdd(&csize[parent[RT.start[r]]], RT.start[r + 1] - RT.start[r]);
   } else {
-    for (uint32_t i = threadIdx.x; i < n; i += FX_WG) atomicAdd(&csize[parent[i]], 1u);
+    for (uint32_t i = threadIdx.x; i < n; i += NT) atomicAdd(&csize[parent[i]], 1u);
   }
   __syncthreads();
   FX_STAMP(4);
@@ -319,12 +322,13 @@ struct WaveRegView {
 // Size-admissible components in discovery order (ascending smallest index), then PCL's
 // final std::sort replayed sequentially.  crec[s] = (size << 16) | discovery ordinal, in the
 // order PCL returns the clusters; croot[ordinal] = root index.  Returns the cluster count.
+template <int NT>
 __device__ uint32_t cc_order(uint32_t n, const uint32_t *parent, const uint32_t *csize, uint32_t min_sz,
                              uint32_t max_sz, uint32_t *croot, uint32_t *crec, uint32_t *s_w,
                              unsigned long long *stamps = nullptr) {
   FX_STAMP_INIT(stamps);
   uint32_t n_c = 0;
-  for (uint32_t b0 = 0; b0 < n; b0 += FX_WG) {
+  for (uint32_t b0 = 0; b0 < n; b0 += NT) {
     const uint32_t i = b0 + threadIdx.x;
     bool acc = false;
     uint32_t sz = 0;
@@ -333,7 +337,7 @@ __device__ uint32_t cc_order(uint32_t n, const uint32_t *parent, const uint32_t 
       acc = sz >= min_sz && sz <= max_sz;
     }
     uint32_t tot;
-    const uint32_t r = block_rank(acc, s_w, tot);
+    const uint32_t r = block_rank<NT>(acc, s_w, tot);
     if (acc) {
       const uint32_t c = n_c + r;
       croot[c] = i;
@@ -480,7 +484,7 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_bucket(FxDevParams P, FxBu
     const uint32_t r = b0 + tid;
     const uint32_t c = r < R ? cnt[r] : 0u;
     uint32_t tot;
-    const uint32_t ex = block_excl_scan(c, s_w, tot);
+    const uint32_t ex = block_excl_scan<FX_WG>(c, s_w, tot);
     if (r < R) off[r] = total + ex;
     total += tot;
   }
@@ -590,6 +594,7 @@ __device__ __forceinline__ RingLds ring_carve(uint32_t *smem, uint32_t cap) {
 // Euclidean clustering, centroid + diameter gate, candidates in PCL's cluster order, member
 // points for keypoint_cloud.  Returns false when the ring does not fit `cap` points (the
 // caller defers it to the large tier).
+template <int NT>
 __device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t scan, uint32_t ring, uint32_t cap,
                           uint32_t *smem, bool last_tier) {
   RingLds L = ring_carve(smem, cap);
@@ -614,7 +619,7 @@ __device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t sca
     return true;
   }
   const float4 *src = B.ring_pts + (size_t)scan * P.ring_slot_cap + off;
-  for (uint32_t i = tid; i < n; i += FX_WG) {
+  for (uint32_t i = tid; i < n; i += NT) {
     const float4 v = src[i];
     L.px[i] = v.x;
     L.py[i] = v.y;
@@ -625,8 +630,8 @@ __device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t sca
   FX_STAMP(1);
 
   // ---- pcl::EuclideanClusterExtraction (ref: node.cpp:269-276)
-  const uint32_t n_runs = cc_label(L.px, L.py, L.pz, n, P.r2_cluster, L.parent, L.csize, L.rank, L.s_w, B.stamps);
-  const uint32_t n_c = cc_order(n, L.parent, L.csize, P.min_count, P.max_count, L.croot, L.crec, L.s_w, B.stamps);
+  const uint32_t n_runs = cc_label<NT>(L.px, L.py, L.pz, n, P.r2_cluster, L.parent, L.csize, L.rank, L.s_w, B.stamps);
+  const uint32_t n_c = cc_order<NT>(n, L.parent, L.csize, P.min_count, P.max_count, L.croot, L.crec, L.s_w, B.stamps);
 #ifdef FX_STAMPS
   stamp_prev_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -637,7 +642,7 @@ __device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t sca
   //      cluster position there).
   uint32_t *bminx = (uint32_t *)L.ccx, *bmaxx = (uint32_t *)L.ccy, *bminy = (uint32_t *)L.ccz,
            *bmaxy = (uint32_t *)L.cce;
-  for (uint32_t c = tid; c < n_c; c += FX_WG) {
+  for (uint32_t c = tid; c < n_c; c += NT) {
     const uint32_t root = L.croot[c];
     bminx[root] = f2ord(1000.0f);  // ref: node.cpp:289-290 initial values
     bmaxx[root] = f2ord(-1000.0f);
@@ -647,7 +652,7 @@ __device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t sca
   __syncthreads();
   if (n_runs <= FX_RUN_MAX && n_runs > 1) {
     RunTable RT = run_table(L.s_w);
-    for (uint32_t r = tid; r < n_runs; r += FX_WG) {
+    for (uint32_t r = tid; r < n_runs; r += NT) {
       const uint32_t root = L.parent[RT.start[r]];
       const uint32_t sz = L.csize[root];
       if (sz < P.min_count || sz > P.max_count) continue;
@@ -657,7 +662,7 @@ __device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t sca
       atomicMax(&bmaxy[root], f2ord(RT.maxy[r]));
     }
   } else {
-    for (uint32_t i = tid; i < n; i += FX_WG) {
+    for (uint32_t i = tid; i < n; i += NT) {
       const uint32_t root = L.parent[i];
       const uint32_t sz = L.csize[root];
       if (sz < P.min_count || sz > P.max_count) continue;
@@ -671,7 +676,7 @@ __device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t sca
   __syncthreads();
   FX_STAMP(7);
   // ---- diameter gate per cluster, in PCL's cluster order (ref: node.cpp:314-316)
-  for (uint32_t s = tid; s < n_c; s += FX_WG) {
+  for (uint32_t s = tid; s < n_c; s += NT) {
     const uint32_t root = L.croot[L.crec[s] & 0xffffu];
     const double minx = ord2f(bminx[root]), maxx = ord2f(bmaxx[root]);
     const double miny = ord2f(bminy[root]), maxy = ord2f(bmaxy[root]);
@@ -684,7 +689,7 @@ __device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t sca
   FX_STAMP(8);
   // ---- centroid of the clusters that pass: fp64 sums in ascending member order
   //      (ref: node.cpp:293-297, 317-320); the walk also ranks the members for keypoint_cloud
-  for (uint32_t s = tid; s < n_c; s += FX_WG) {
+  for (uint32_t s = tid; s < n_c; s += NT) {
     if (L.cslot[s] == 0u) continue;
     const uint32_t rec = L.crec[s];
     const uint32_t sz = rec >> 16, root = L.croot[rec & 0xffffu];
@@ -707,13 +712,13 @@ __device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t sca
 
   // ---- slots of the gate-passing clusters and offsets of their member runs
   uint32_t n_pass = 0, n_mem = 0;
-  for (uint32_t b0 = 0; b0 < n_c; b0 += FX_WG) {
+  for (uint32_t b0 = 0; b0 < n_c; b0 += NT) {
     const uint32_t s = b0 + tid;
     const bool pass = s < n_c && L.cslot[s] != 0u;
     const uint32_t sz = pass ? (L.crec[s] >> 16) : 0u;
     uint32_t tot_p, tot_m;
-    const uint32_t slot = block_rank(pass, L.s_w, tot_p);
-    const uint32_t koff = block_excl_scan(sz, L.s_w, tot_m);
+    const uint32_t slot = block_rank<NT>(pass, L.s_w, tot_p);
+    const uint32_t koff = block_excl_scan<NT>(sz, L.s_w, tot_m);
     if (s < n_c) {
       L.cslot[s] = pass ? (n_pass + slot) : FX_NONE;
       L.ckoff[s] = n_mem + koff;
@@ -727,7 +732,7 @@ __device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t sca
   // ---- candidates of this ring (cylinderCentroids, ref: node.cpp:322)
   float4 *rc = B.ring_cand + ring_slot * P.max_ring_cands;
   uint32_t *rcs = B.ring_cand_size + ring_slot * P.max_ring_cands;
-  for (uint32_t s = tid; s < n_c; s += FX_WG) {
+  for (uint32_t s = tid; s < n_c; s += NT) {
     const uint32_t slot = L.cslot[s];
     if (slot < P.max_ring_cands) {
       rc[slot] = make_float4(L.ccx[s], L.ccy[s], L.ccz[s], L.cce[s]);
@@ -745,7 +750,7 @@ __device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t sca
   if (n_mem) {
     float4 *pool = B.kpc_pool + (size_t)scan * P.ring_slot_cap + off;
     uint32_t *pool_c = B.kpc_pool_cand + (size_t)scan * P.ring_slot_cap + off;
-    for (uint32_t i = tid; i < n; i += FX_WG) {
+    for (uint32_t i = tid; i < n; i += NT) {
       const uint32_t root = L.parent[i];
       const uint32_t sz = L.csize[root];
       if (sz < P.min_count || sz > P.max_count) continue;
@@ -762,22 +767,29 @@ __device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t sca
   return true;
 }
 
-extern "C" __global__ __launch_bounds__(FX_WG) void k_rings_small(FxDevParams P, FxBuffers B, uint32_t cap) {
+// small tier: ONE WAVEFRONT per (scan, ring) — every block-level step is wave-synchronous, so the
+// many short dependent phases of a ring cost no workgroup barriers
+#define FX_RING_SMALL_T 64
+extern "C" __global__ __launch_bounds__(FX_RING_SMALL_T) void k_rings_small(FxDevParams P, FxBuffers B, uint32_t cap,
+                                                                            uint32_t mid_cap) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const uint32_t scan = blockIdx.x / P.n_rings, ring = blockIdx.x % P.n_rings;
-  if (!ring_body(P, B, scan, ring, cap, smem, false)) {
+  if (!ring_body<FX_RING_SMALL_T>(P, B, scan, ring, cap, smem, false)) {
     if (threadIdx.x == 0) {
-      const uint32_t pos = atomicAdd(&B.counters[0], 1u);
-      B.big_rings[pos] = blockIdx.x;
+      // too many points for one wavefront: workgroup tiers (mid: fits mid_cap, else the large one)
+      const bool mid = B.ring_cnt[blockIdx.x] <= mid_cap;
+      const uint32_t pos = atomicAdd(&B.counters[mid ? 0 : 5], 1u);
+      (mid ? B.big_rings : B.huge_rings)[pos] = blockIdx.x;
     }
   }
 }
-extern "C" __global__ __launch_bounds__(FX_WG) void k_rings_big(FxDevParams P, FxBuffers B, uint32_t cap) {
+extern "C" __global__ __launch_bounds__(FX_WG) void k_rings_big(FxDevParams P, FxBuffers B, uint32_t cap, uint32_t huge) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  const uint32_t n_big = B.counters[0];
+  const uint32_t n_big = B.counters[huge ? 5 : 0];
+  const uint32_t *items = huge ? B.huge_rings : B.big_rings;
   for (uint32_t w = blockIdx.x; w < n_big; w += gridDim.x) {
-    const uint32_t item = B.big_rings[w];
-    ring_body(P, B, item / P.n_rings, item % P.n_rings, cap, smem, true);
+    const uint32_t item = items[w];
+    ring_body<FX_WG>(P, B, item / P.n_rings, item % P.n_rings, cap, smem, true);
     __syncthreads();
   }
 }
@@ -823,7 +835,7 @@ __device__ bool merge_body(const FxDevParams &P, const FxBuffers &B, uint32_t sc
     const uint32_t r = b0 + tid;
     const uint32_t c = r < R ? rcnt[r] : 0u;
     uint32_t tot;
-    const uint32_t ex = block_excl_scan(c, L.s_w, tot);
+    const uint32_t ex = block_excl_scan<FX_WG>(c, L.s_w, tot);
     if (r < R) L.rbase[r] = C + ex;
     C += tot;
   }
@@ -868,8 +880,8 @@ __device__ bool merge_body(const FxDevParams &P, const FxBuffers &B, uint32_t sc
 
   uint32_t K = 0;
   if (C > 0) {  // ref: node.cpp:209-210
-    cc_label(L.cx, L.cy, L.pz, C, P.r2_merge, L.parent, L.csize, L.rid, L.s_w);
-    const uint32_t n_c = cc_order(C, L.parent, L.csize, P.ndc, P.secondary_max, L.croot, L.crec, L.s_w);
+    cc_label<FX_WG>(L.cx, L.cy, L.pz, C, P.r2_merge, L.parent, L.csize, L.rid, L.s_w);
+    const uint32_t n_c = cc_order<FX_WG>(C, L.parent, L.csize, P.ndc, P.secondary_max, L.croot, L.crec, L.s_w);
     K = n_c < P.max_keypoints ? n_c : P.max_keypoints;
     if (n_c > P.max_keypoints && tid == 0) atomicOr(&B.flags[scan], FX_FLAG_KP_OVERFLOW);
     float4 *kp = B.keypoints + (size_t)scan * P.max_keypoints;
@@ -960,7 +972,7 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_offsets(FxDevParams P, FxB
     const uint32_t b = b0 + threadIdx.x;
     const uint32_t c = b < batch ? B.n_kp[b] : 0u;
     uint32_t tot;
-    const uint32_t ex = block_excl_scan(c, s_w, tot);
+    const uint32_t ex = block_excl_scan<FX_WG>(c, s_w, tot);
     if (b < batch) {
       const uint32_t off = run + ex;
       B.kp_offset[b] = off;
@@ -1512,11 +1524,13 @@ void fxk_bucket(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_
   const size_t lds = (16 + (size_t)P.n_rings * (2 + FX_NWAVE) + 1) * 4;
   hipLaunchKernelGGL(k_bucket, dim3(batch), dim3(FX_WG), lds, s, P, B, el0, inv_step);
 }
-void fxk_rings_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap) {
-  hipLaunchKernelGGL(k_rings_small, dim3(batch * P.n_rings), dim3(FX_WG), fxk_ring_lds_bytes(cap), s, P, B, cap);
+void fxk_rings_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap,
+                     uint32_t mid_cap) {
+  hipLaunchKernelGGL(k_rings_small, dim3(batch * P.n_rings), dim3(FX_RING_SMALL_T), fxk_ring_lds_bytes(cap), s, P, B, cap,
+                     mid_cap);
 }
-void fxk_rings_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t grid) {
-  hipLaunchKernelGGL(k_rings_big, dim3(grid), dim3(FX_WG), fxk_ring_lds_bytes(cap), s, P, B, cap);
+void fxk_rings_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t grid, uint32_t huge) {
+  hipLaunchKernelGGL(k_rings_big, dim3(grid), dim3(FX_WG), fxk_ring_lds_bytes(cap), s, P, B, cap, huge);
 }
 void fxk_merge_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap) {
   hipLaunchKernelGGL(k_merge_small, dim3(batch), dim3(FX_WG), fxk_merge_lds_bytes(cap, P.n_rings), s, P, B, cap);
