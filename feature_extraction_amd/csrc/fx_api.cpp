@@ -24,7 +24,7 @@ hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t desc_big);
 void fxk_prep(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
 void fxk_bucket(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float el0, float inv_step);
 void fxk_rings_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap,
-                     uint32_t mid_cap);
+                     uint32_t mid_cap, uint32_t grid);
 void fxk_rings_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t grid, uint32_t huge);
 void fxk_merge_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap);
 void fxk_merge_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t grid);
@@ -77,6 +77,7 @@ struct fx_ctx {
   int meta_next = 0;
   FxScanMeta *d_meta = nullptr;
   float box_margin = 0.f;
+  uint32_t ring_waves_per_cu = 8;
   // host-input staging
   float *d_stage = nullptr;
   std::vector<float> repack;
@@ -169,6 +170,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   c->params = *params;
   c->lim = L;
   c->device = device_id;
+  if (const char *e = getenv("FX_RING_WAVES_PER_CU")) c->ring_waves_per_cu = (uint32_t)atoi(e);
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->n_cu = prop.multiProcessorCount;
 
@@ -272,8 +274,8 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   FX_A(dev_alloc(c, &b.s_pts, (size_t)L.max_total_keypoints * P.list_cap));
   FX_A(dev_alloc(c, &b.s_cnt, L.max_total_keypoints));
   FX_A(dev_alloc(c, &b.counters, 8));
-  FX_A(dev_alloc(c, &b.stamps, 32));
-  if (hipMemset(b.stamps, 0, 32 * 8) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
+  FX_A(dev_alloc(c, &b.stamps, 64 * 32));
+  if (hipMemset(b.stamps, 0, 64 * 32 * 8) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
 
   // ---- tables
   {
@@ -451,7 +453,7 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
     fxk_bucket(s, P, B, batch, (float)c->params.el0_deg, (float)(1.0 / c->params.el_step_deg));
     FX_HIP(mark(1));
     const uint32_t ring_mid = L.max_ring_points < kRingCapMid ? L.max_ring_points : kRingCapMid;
-    fxk_rings_small(s, P, B, batch, ring_small, ring_mid);
+    fxk_rings_small(s, P, B, batch, ring_small, ring_mid, (uint32_t)c->n_cu * c->ring_waves_per_cu);
     FX_HIP(mark(2));
     fxk_rings_big(s, P, B, ring_mid, big_grid * 2, 0);
     fxk_rings_big(s, P, B, L.max_ring_points, big_grid, 1);
@@ -583,7 +585,12 @@ fx_status fx_debug_stamps(fx_ctx *c, unsigned long long *out32) {
   if (!c || !out32) return fail(FX_ERR_INVALID_ARG, "null argument");
   FX_HIP(hipSetDevice(c->device));
   FX_HIP(hipStreamSynchronize(c->stream));
-  FX_HIP(hipMemcpy(out32, c->buf.stamps, 32 * 8, hipMemcpyDeviceToHost));
+  std::vector<unsigned long long> all(64 * 32);
+  FX_HIP(hipMemcpy(all.data(), c->buf.stamps, all.size() * 8, hipMemcpyDeviceToHost));
+  for (int k = 0; k < 32; ++k) {
+    out32[k] = 0;
+    for (int w = 0; w < 64; ++w) out32[k] += all[(size_t)w * 32 + k];
+  }
   return FX_OK;
 }
 

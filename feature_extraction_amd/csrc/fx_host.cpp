@@ -238,5 +238,14 @@ void fx_test_sort_replay(const uint32_t *sizes, uint32_t n, uint32_t *perm_out) 
   for (uint32_t i = 0; i < n; ++i) perm_out[i] = rec[i] & 0xffffu;
   delete[] rec;
 }
+// The variant the kernels use: sequential partition phase + stable ranking.
+void fx_test_sort_replay_ranked(const uint32_t *sizes, uint32_t n, uint32_t *perm_out) {
+  uint32_t *rec = new uint32_t[2 * (n ? n : 1)];
+  for (uint32_t i = 0; i < n; ++i) rec[i] = (sizes[i] << 16) | i;
+  int stk[FX_SORT_STACK_WORDS];
+  fx_sort_replay_desc_ranked(rec, n, stk, rec + n);
+  for (uint32_t i = 0; i < n; ++i) perm_out[i] = rec[i] & 0xffffu;
+  delete[] rec;
+}
 
 }  // extern "C"

@@ -88,8 +88,11 @@ __device__ __forceinline__ float dist2(float qx, float qy, float qz, float px, f
 // ------------------------------------------------------------------ union-find in LDS
 // Links always go from the larger root to the smaller one, so a component's root is its
 // smallest member index — PCL's "indices[0]" and its discovery order.
+// The parent array is always LDS; addressing it through an explicit LDS pointer keeps these
+// loops on ds_read / ds_min instead of flat instructions.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
 __device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t i) {
-  volatile uint32_t *p = parent;
+  volatile lds_u32 *p = (volatile lds_u32 *)parent;
   uint32_t q = p[i];
   while (q != i) {
     const uint32_t g = p[q];
@@ -100,6 +103,7 @@ __device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t i) {
   return i;
 }
 __device__ __forceinline__ void uf_union(uint32_t *parent, uint32_t a, uint32_t b) {
+  lds_u32 *p = (lds_u32 *)parent;
   while (true) {
     a = uf_find(parent, a);
     b = uf_find(parent, b);
@@ -109,7 +113,7 @@ __device__ __forceinline__ void uf_union(uint32_t *parent, uint32_t a, uint32_t 
       a = b;
       b = t;
     }
-    const uint32_t old = atomicMin(&parent[a], b);
+    const uint32_t old = __hip_atomic_fetch_min(p + a, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (old == a) return;
     a = old;  // a stopped being a root meanwhile: its former parent must join b's set too
   }
@@ -118,13 +122,13 @@ __device__ __forceinline__ void uf_union(uint32_t *parent, uint32_t a, uint32_t 
 // Diagnostic build only (-DFX_STAMPS): per-phase cycle shares of the ring kernel, summed by
 // thread 0 of every workgroup into B.counters-adjacent debug words.  Never in the product build.
 #ifdef FX_STAMPS
-#define FX_STAMP(slot)                                                                     \
-  do {                                                                                     \
-    if (threadIdx.x == 0 && stamps_) {                                                     \
-      const unsigned long long now_ = __builtin_amdgcn_s_memtime();                        \
-      atomicAdd(&stamps_[slot], now_ - stamp_prev_);                                      \
-      stamp_prev_ = now_;                                                                  \
-    }                                                                                      \
+#define FX_STAMP(slot)                                                                      \
+  do {                                                                                      \
+    if (threadIdx.x == 0 && stamps_) {                                                      \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime();                         \
+      atomicAdd(&stamps_[((blockIdx.x & 63u) << 5) + (slot)], now_ - stamp_prev_);          \
+      stamp_prev_ = __builtin_amdgcn_s_memtime();                                           \
+    }                                                                                       \
   } while (0)
 #define FX_STAMP_INIT(ptr)                 \
   unsigned long long *stamps_ = (ptr);    \
@@ -134,10 +138,14 @@ __device__ __forceinline__ void uf_union(uint32_t *parent, uint32_t a, uint32_t 
 #define FX_STAMP_INIT(ptr)
 #endif
 
-// s_w[0..15] block helpers, [16..31] broadcast slots, [32..151] sort stack, [160..] run table
-#define FX_RUN_MAX 128
-#define FX_RUN_TABLE 160
-#define FX_SCRATCH_WORDS (FX_RUN_TABLE + (FX_RUN_MAX + 1) + 4 * FX_RUN_MAX + 7)  // 808: keeps the carve 16-byte aligned
+// Scratch words in front of the per-point arrays (NT = workgroup size of the tier):
+// [0..15] block helpers, [16..31] broadcast slots, [32..151] sort stack, [160..] segment table
+#define FX_SEG_TABLE 160
+template <int NT>
+struct SegCfg {
+  static constexpr uint32_t kMax = NT == 64 ? 64u : 128u;                        // segments the table holds
+  static constexpr uint32_t kWords = ((FX_SEG_TABLE + 11 * kMax + 2 + 3) / 4) * 4;  // keeps the carve 16-byte aligned
+};
 #define FX_NONE 0xffffffffu
 
 // order-preserving map float -> uint32 (for LDS atomicMin/Max on coordinates)
@@ -149,18 +157,45 @@ __device__ __forceinline__ float ord2f(uint32_t o) {
   return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
 }
 
-struct RunTable {  // lives in the scratch words; valid when n_runs <= FX_RUN_MAX
-  uint32_t *start;                    // [FX_RUN_MAX + 1] first point of each run, start[n_runs] = n
-  float *minx, *maxx, *miny, *maxy;   // xy bounding box of each run
+// Segment = up to `seg_len` consecutive points of one run; run = maximal chain of consecutive
+// points closer than the tolerance.  The table lives in the scratch words (plain uint32 words,
+// floats stored as bits) and is valid when the segment count fits SegCfg<NT>::kMax.
+template <int NT>
+struct SegTable {
+  static constexpr uint32_t M = SegCfg<NT>::kMax;
+  uint32_t *w;
+  __device__ __forceinline__ explicit SegTable(uint32_t *s_w) : w(s_w + FX_SEG_TABLE) {}
+  // segments: first point (start[n_segs] = n), run id, xy bounding box
+  __device__ __forceinline__ uint32_t &start(uint32_t i) const { return w[i]; }
+  __device__ __forceinline__ uint32_t &run(uint32_t i) const { return w[M + 1 + i]; }
+  __device__ __forceinline__ float box(uint32_t which, uint32_t i) const { return __uint_as_float(w[(2 + which) * M + 1 + i]); }
+  __device__ __forceinline__ void set_box(uint32_t which, uint32_t i, float v) const { w[(2 + which) * M + 1 + i] = __float_as_uint(v); }
+  // runs: first segment (rseg[n_runs] = n_segs), xy bounding box
+  __device__ __forceinline__ uint32_t &rseg(uint32_t r) const { return w[6 * M + 1 + r]; }
+  __device__ __forceinline__ float rbox(uint32_t which, uint32_t r) const { return __uint_as_float(w[(7 + which) * M + 2 + r]); }
+  __device__ __forceinline__ void set_rbox(uint32_t which, uint32_t r, float v) const { w[(7 + which) * M + 2 + r] = __float_as_uint(v); }
 };
-__device__ __forceinline__ RunTable run_table(uint32_t *s_w) {
-  RunTable t;
-  t.start = s_w + FX_RUN_TABLE;
-  t.minx = reinterpret_cast<float *>(t.start + FX_RUN_MAX + 1);
-  t.maxx = t.minx + FX_RUN_MAX;
-  t.miny = t.maxx + FX_RUN_MAX;
-  t.maxy = t.miny + FX_RUN_MAX;
-  return t;
+enum { FX_MINX = 0, FX_MAXX = 1, FX_MINY = 2, FX_MAXY = 3 };
+
+// Stable numbering of the flagged lanes across the block, chunk by chunk: returns the number
+// of flags at or before this thread in the current chunk (inclusive) and the chunk total.
+template <int NT>
+__device__ __forceinline__ uint32_t block_count_incl(bool flag, uint32_t *s_w, uint32_t &total) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long m = __ballot(flag);
+  if (lane == 0) s_w[8 + wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  uint32_t before = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) {
+    const uint32_t c = s_w[8 + w];
+    before += (w < (int)wave) ? c : 0u;
+    tot += c;
+  }
+  __syncthreads();
+  total = tot;
+  const unsigned long long incl = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+  return before + (uint32_t)__popcll(m & incl);
 }
 
 // Connected components of {d2(i,j) < r2} over n points held in LDS.  On return parent[i] is the
@@ -168,19 +203,22 @@ __device__ __forceinline__ RunTable run_table(uint32_t *s_w) {
 //  1. run labelling: consecutive points i-1, i closer than the tolerance form runs; a wave ballot
 //     + highest-set-bit gives every point its run head.  Sensor rings arrive azimuth ordered, so
 //     this one scan already finds almost every cluster, and only run heads ever get linked.
-//  2. cross-run edges.  Few runs: every point tests the xy bounding box of each later run and
-//     scans that run's points only when the box is within the tolerance and the two are not yet
-//     one component.  Many runs (unordered input): all pairs of different runs.  Both examine
-//     every pair that could be an edge, so the result is exact for any input order.
-//  3. roots per run head, then per point; sizes per run.
-// Returns the number of runs.
+//  2. cross-run edges.  Runs are cut into segments of <= seg_len points with an xy bounding box
+//     each; only segment pairs of different runs whose boxes are within the tolerance and that
+//     are not yet one component have their point pairs tested.  If the segments do not fit the
+//     table (unordered input) every point pair of different runs is tested instead.  Either way
+//     every pair that could be an edge is examined: exact for any input order.
+//  3. roots per run head, then per point; sizes per segment.
+// Returns the number of segments (the table is valid iff it is <= SegCfg<NT>::kMax).
 template <int NT>
 __device__ uint32_t cc_label(const float *px, const float *py, const float *pz, uint32_t n, float r2, uint32_t *parent,
                              uint32_t *csize, uint32_t *rid, uint32_t *s_w, unsigned long long *stamps = nullptr) {
+  constexpr uint32_t kSegMax = SegCfg<NT>::kMax;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   FX_STAMP_INIT(stamps);
-  RunTable RT = run_table(s_w);
-  uint32_t carry = 0, n_runs = 0;
+  const SegTable<NT> ST(s_w);
+  const uint32_t seg_len = max(8u, (n + 95u) / 96u);
+  uint32_t carry = 0, n_runs = 0, n_segs = 0;
   for (uint32_t b0 = 0; b0 < n; b0 += NT) {
     const uint32_t i = b0 + threadIdx.x;
     bool start = true;
@@ -189,94 +227,143 @@ __device__ uint32_t cc_label(const float *px, const float *py, const float *pz, 
       if (i > 0) start = !(dist2(px[i], py[i], pz[i], px[i - 1], py[i - 1], pz[i - 1]) < r2);
     }
     const unsigned long long m = __ballot(start);
-    const unsigned long long mreal = __ballot(start && i < n);
-    if (lane == 0) {
-      s_w[wave] = m ? (b0 + wave * 64 + (63u - (uint32_t)__clzll((long long)m))) : FX_NONE;
-      s_w[4 + wave] = (uint32_t)__popcll(mreal);
-    }
+    if (lane == 0) s_w[wave] = m ? (b0 + wave * 64 + (63u - (uint32_t)__clzll((long long)m))) : FX_NONE;
     __syncthreads();
     const unsigned long long below = m & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
-    uint32_t head = carry, last = carry, runs_before = 0, runs_chunk = 0;
+    uint32_t head = carry, last = carry;
 #pragma unroll
-    for (int w = 0; w < (NT / 64); ++w) {
-      const uint32_t v = s_w[w], c = s_w[4 + w];
+    for (int w = 0; w < NT / 64; ++w) {
+      const uint32_t v = s_w[w];
       if (v != FX_NONE) {
         if (w < (int)wave) head = v;
         last = v;
       }
-      runs_before += (w < (int)wave) ? c : 0u;
-      runs_chunk += c;
     }
     if (below) head = b0 + wave * 64 + (63u - (uint32_t)__clzll((long long)below));
-    if (i < n) {
-      parent[i] = head;
-      // run id = heads at or before me - 1
-      const uint32_t r = n_runs + runs_before + (uint32_t)__popcll(mreal & below) - 1u;
-      rid[i] = r;
-      if (start && r < FX_RUN_MAX) RT.start[r] = i;
-    }
     __syncthreads();
     carry = last;
-    n_runs += runs_chunk;
-  }
-  const bool table = n_runs <= FX_RUN_MAX;
-  if (table) {
-    for (uint32_t r = threadIdx.x; r < n_runs; r += NT) {
-      RT.minx[r] = __uint_as_float(f2ord(INFINITY));
-      RT.maxx[r] = __uint_as_float(f2ord(-INFINITY));
-      RT.miny[r] = __uint_as_float(f2ord(INFINITY));
-      RT.maxy[r] = __uint_as_float(f2ord(-INFINITY));
-    }
-    if (threadIdx.x == 0) RT.start[n_runs] = n;
-  }
-  __syncthreads();
-  FX_STAMP(2);
-  if (table && n_runs > 1) {
-    for (uint32_t i = threadIdx.x; i < n; i += NT) {
-      const uint32_t r = rid[i];
-      const uint32_t ox = f2ord(px[i]), oy = f2ord(py[i]);
-      atomicMin(reinterpret_cast<uint32_t *>(&RT.minx[r]), ox);
-      atomicMax(reinterpret_cast<uint32_t *>(&RT.maxx[r]), ox);
-      atomicMin(reinterpret_cast<uint32_t *>(&RT.miny[r]), oy);
-      atomicMax(reinterpret_cast<uint32_t *>(&RT.maxy[r]), oy);
-    }
-    __syncthreads();
-    for (uint32_t r = threadIdx.x; r < n_runs; r += NT) {
-      RT.minx[r] = ord2f(__float_as_uint(RT.minx[r]));
-      RT.maxx[r] = ord2f(__float_as_uint(RT.maxx[r]));
-      RT.miny[r] = ord2f(__float_as_uint(RT.miny[r]));
-      RT.maxy[r] = ord2f(__float_as_uint(RT.maxy[r]));
-    }
-    __syncthreads();
-    const float r2_pad = r2 * 1.001f;  // the box distance is a lower bound; pad it against fp32 rounding
-    for (uint32_t i = threadIdx.x; i < n; i += NT) {
-      const float qx = px[i], qy = py[i], qz = pz[i];
-      for (uint32_t r = rid[i] + 1; r < n_runs; ++r) {
-        const float dx = fmaxf(fmaxf(RT.minx[r] - qx, qx - RT.maxx[r]), 0.0f);
-        const float dy = fmaxf(fmaxf(RT.miny[r] - qy, qy - RT.maxy[r]), 0.0f);
-        if (dx * dx + dy * dy > r2_pad) continue;
-        const uint32_t s = RT.start[r], e = RT.start[r + 1];
-        if (uf_find(parent, i) == uf_find(parent, s)) continue;  // already one component
-        for (uint32_t j = s; j < e; ++j) {
-          if (dist2(qx, qy, qz, px[j], py[j], pz[j]) < r2) {
-            uf_union(parent, j, i);
-            break;  // the two components are one now; further edges into this run add nothing
-          }
+    // number the runs and the segments (a segment starts at a run head and every seg_len points)
+    const bool in = i < n;
+    uint32_t tot_r, tot_s;
+    const uint32_t r_incl = block_count_incl<NT>(in && start, s_w, tot_r);
+    const bool seg_start = in && (start || ((i - head) % seg_len) == 0u);
+    const uint32_t s_incl = block_count_incl<NT>(seg_start, s_w, tot_s);
+    if (in) {
+      parent[i] = head;
+      rid[i] = n_runs + r_incl - 1u;
+      if (seg_start) {
+        const uint32_t sg = n_segs + s_incl - 1u;
+        if (sg < kSegMax) {
+          ST.start(sg) = i;
+          ST.run(sg) = n_runs + r_incl - 1u;
         }
       }
     }
-  } else if (!table) {
-    // every pair (i, j > i) of different runs; pairs are dealt round-robin to the threads
-    uint32_t i = 0, k = threadIdx.x;  // k = j - (i + 1)
-    while (true) {
-      while (i + 1 < n && k >= n - 1 - i) {
-        k -= n - 1 - i;
-        ++i;
+    n_runs += tot_r;
+    n_segs += tot_s;
+  }
+  const bool table = n_segs <= kSegMax;
+  __syncthreads();
+  if (table && threadIdx.x == 0) ST.start(n_segs) = n;
+  __syncthreads();
+  FX_STAMP(2);
+  if (table) {
+    for (uint32_t sg = threadIdx.x; sg < n_segs; sg += NT) {
+      float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+      for (uint32_t i = ST.start(sg); i < ST.start(sg + 1); ++i) {
+        const float x = px[i], y = py[i];
+        x0 = fminf(x0, x);
+        x1 = fmaxf(x1, x);
+        y0 = fminf(y0, y);
+        y1 = fmaxf(y1, y);
       }
-      if (i + 1 >= n) break;
-      const uint32_t j = i + 1 + k;
-      if (rid[i] != rid[j] && dist2(px[i], py[i], pz[i], px[j], py[j], pz[j]) < r2) uf_union(parent, j, i);
-      k += NT;
+      ST.set_box(FX_MINX, sg, x0);
+      ST.set_box(FX_MAXX, sg, x1);
+      ST.set_box(FX_MINY, sg, y0);
+      ST.set_box(FX_MAXY, sg, y1);
+    }
+    __syncthreads();
+  }
+  if (n_runs > 1) {
+    if (table) {
+      // run level: first segment and box of every run
+      for (uint32_t sg = threadIdx.x; sg < n_segs; sg += NT)
+        if (sg == 0 || ST.run(sg) != ST.run(sg - 1)) ST.rseg(ST.run(sg)) = sg;
+      if (threadIdx.x == 0) ST.rseg(n_runs) = n_segs;
+      __syncthreads();
+      for (uint32_t r = threadIdx.x; r < n_runs; r += NT) {
+        float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+        for (uint32_t sg = ST.rseg(r); sg < ST.rseg(r + 1); ++sg) {
+          x0 = fminf(x0, ST.box(FX_MINX, sg));
+          x1 = fmaxf(x1, ST.box(FX_MAXX, sg));
+          y0 = fminf(y0, ST.box(FX_MINY, sg));
+          y1 = fmaxf(y1, ST.box(FX_MAXY, sg));
+        }
+        ST.set_rbox(FX_MINX, r, x0);
+        ST.set_rbox(FX_MAXX, r, x1);
+        ST.set_rbox(FX_MINY, r, y0);
+        ST.set_rbox(FX_MAXY, r, y1);
+      }
+      __syncthreads();
+      const float r2_pad = r2 * 1.001f;  // box distances are lower bounds; pad them against fp32 rounding
+      // every point against every later run: run box, then the run's segment boxes, then points.
+      // The run loop is wave-uniform (LDS broadcast reads, four boxes in flight per trip); the
+      // rare near runs are handled in the slow path below.
+      for (uint32_t i0 = 0; i0 < n; i0 += NT) {
+        const uint32_t i = i0 + threadIdx.x;
+        const bool live = i < n;
+        const float qx = live ? px[i] : 0.f, qy = live ? py[i] : 0.f, qz = live ? pz[i] : 0.f;
+        const uint32_t my_run = live ? rid[i] : FX_NONE;
+        // runs before the smallest run id of this wave cannot be "later" for any lane
+        uint32_t r_lo = my_run;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) r_lo = min(r_lo, (uint32_t)__shfl_xor((int)r_lo, d, 64));
+        if (r_lo == FX_NONE) continue;
+        for (uint32_t r0 = r_lo + 1; r0 < n_runs; r0 += 4) {
+          uint32_t near = 0;
+#pragma unroll
+          for (uint32_t u = 0; u < 4; ++u) {
+            const uint32_t r = min(r0 + u, n_runs - 1);
+            const float dx = fmaxf(fmaxf(ST.rbox(FX_MINX, r) - qx, qx - ST.rbox(FX_MAXX, r)), 0.0f);
+            const float dy = fmaxf(fmaxf(ST.rbox(FX_MINY, r) - qy, qy - ST.rbox(FX_MAXY, r)), 0.0f);
+            const bool ok = (r0 + u < n_runs) && (r0 + u > my_run) && !(dx * dx + dy * dy > r2_pad);
+            near |= ok ? (1u << u) : 0u;
+          }
+          while (near) {
+            const uint32_t u = (uint32_t)__ffs((int)near) - 1u;
+            near &= near - 1u;
+            const uint32_t r = r0 + u;
+            const uint32_t s0 = ST.rseg(r), s1 = ST.rseg(r + 1);
+            if (uf_find(parent, i) == uf_find(parent, ST.start(s0))) continue;  // already one component
+            bool linked = false;
+            for (uint32_t sg = s0; sg < s1 && !linked; ++sg) {
+              const float dx = fmaxf(fmaxf(ST.box(FX_MINX, sg) - qx, qx - ST.box(FX_MAXX, sg)), 0.0f);
+              const float dy = fmaxf(fmaxf(ST.box(FX_MINY, sg) - qy, qy - ST.box(FX_MAXY, sg)), 0.0f);
+              if (dx * dx + dy * dy > r2_pad) continue;
+              for (uint32_t j = ST.start(sg); j < ST.start(sg + 1); ++j) {
+                if (dist2(qx, qy, qz, px[j], py[j], pz[j]) < r2) {
+                  uf_union(parent, j, i);
+                  linked = true;  // the two runs are one component now; more edges add nothing
+                  break;
+                }
+              }
+            }
+          }
+        }
+      }
+    } else {
+      // every pair (i, j > i) of different runs; pairs are dealt round-robin to the threads
+      uint32_t i = 0, k = threadIdx.x;  // k = j - (i + 1)
+      while (true) {
+        while (i + 1 < n && k >= n - 1 - i) {
+          k -= n - 1 - i;
+          ++i;
+        }
+        if (i + 1 >= n) break;
+        const uint32_t j = i + 1 + k;
+        if (rid[i] != rid[j] && dist2(px[i], py[i], pz[i], px[j], py[j], pz[j]) < r2) uf_union(parent, j, i);
+        k += NT;
+      }
     }
   }
   __syncthreads();
@@ -292,39 +379,24 @@ __device__ uint32_t cc_label(const float *px, const float *py, const float *pz, 
     if (!is_head) parent[i] = parent[parent[i]];
   }
   __syncthreads();
-  // sizes: one atomic per run
   if (table) {
-    for (uint32_t r = threadIdx.x; r < n_runs; r += NT) atomicAdd(&csize[parent[RT.start[r]]], RT.start[r + 1] - RT.start[r]);
+    for (uint32_t sg = threadIdx.x; sg < n_segs; sg += NT) atomicAdd(&csize[parent[ST.start(sg)]], ST.start(sg + 1) - ST.start(sg));
   } else {
     for (uint32_t i = threadIdx.x; i < n; i += NT) atomicAdd(&csize[parent[i]], 1u);
   }
   __syncthreads();
   FX_STAMP(4);
-  return n_runs;
+  return n_segs;
 }
 
-// The sort records of up to 64 clusters held one per lane of a wavefront: the sequential
-// algorithm runs with wave-uniform control flow on v_readlane / v_writelane instead of
-// dependent LDS round trips.
-struct WaveRegView {
-  uint32_t reg;
-  int n;
-  int lane;
-  __device__ __forceinline__ uint32_t get(int i) const { return __builtin_amdgcn_readlane(reg, n - 1 - i); }
-  __device__ __forceinline__ void set(int i, uint32_t v) { reg = (lane == n - 1 - i) ? v : reg; }
-  __device__ __forceinline__ void swap(int i, int j) {
-    const uint32_t a = get(i), b = get(j);
-    set(i, b);
-    set(j, a);
-  }
-};
-
-// Size-admissible components in discovery order (ascending smallest index), then PCL's
-// final std::sort replayed sequentially.  crec[s] = (size << 16) | discovery ordinal, in the
-// order PCL returns the clusters; croot[ordinal] = root index.  Returns the cluster count.
+// Size-admissible components in discovery order (ascending smallest index), then PCL's final
+// std::sort(rbegin, rend, bySize): its partition phase is replayed sequentially by one lane
+// (only needed above 16 clusters), its insertion phase — a stable sort — as a parallel ranking
+// (csrc/fx_sort_replay.h).  crec[s] = (size << 16) | discovery ordinal, in the order PCL returns
+// the clusters; croot[ordinal] = root index; tmp: n words of scratch.  Returns the cluster count.
 template <int NT>
 __device__ uint32_t cc_order(uint32_t n, const uint32_t *parent, const uint32_t *csize, uint32_t min_sz,
-                             uint32_t max_sz, uint32_t *croot, uint32_t *crec, uint32_t *s_w,
+                             uint32_t max_sz, uint32_t *croot, uint32_t *crec, uint32_t *tmp, uint32_t *s_w,
                              unsigned long long *stamps = nullptr) {
   FX_STAMP_INIT(stamps);
   uint32_t n_c = 0;
@@ -347,8 +419,27 @@ __device__ uint32_t cc_order(uint32_t n, const uint32_t *parent, const uint32_t 
   }
   __syncthreads();
   FX_STAMP(5);
-  if (n_c > 1 && threadIdx.x == 0) fx_sort_replay_desc(crec, n_c, (int *)(s_w + 32));
-  __syncthreads();
+  if (n_c > FX_SORT_THRESHOLD) {
+    if (threadIdx.x == 0) {
+      fx_sort_detail::RevView v{crec, (int)n_c};
+      fx_sort_partition_phase(v, (int)n_c, (int *)(s_w + 32));
+    }
+    __syncthreads();
+  }
+  if (n_c > 1) {
+    for (uint32_t c = threadIdx.x; c < n_c; c += NT) {
+      const uint32_t rec = crec[c], sz = rec >> 16;
+      uint32_t pos = 0;
+      for (uint32_t d = 0; d < n_c; ++d) {
+        const uint32_t sd = crec[d] >> 16;
+        pos += (sd > sz || (sd == sz && d < c)) ? 1u : 0u;
+      }
+      tmp[pos] = rec;
+    }
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < n_c; c += NT) crec[c] = tmp[c];
+    __syncthreads();
+  }
   FX_STAMP(6);
   return n_c;
 }
@@ -566,10 +657,11 @@ struct RingLds {
   float *px, *py, *pz, *pe, *ccx, *ccy, *ccz, *cce;
   uint32_t *parent, *csize, *rank, *croot, *crec, *cpos, *cslot, *ckoff, *s_w;
 };
+template <int NT>
 __device__ __forceinline__ RingLds ring_carve(uint32_t *smem, uint32_t cap) {
   RingLds L;
   L.s_w = smem;
-  uint32_t *p = smem + FX_SCRATCH_WORDS;
+  uint32_t *p = smem + SegCfg<NT>::kWords;
   L.px = (float *)p, p += cap;
   L.py = (float *)p, p += cap;
   L.pz = (float *)p, p += cap;
@@ -597,8 +689,9 @@ __device__ __forceinline__ RingLds ring_carve(uint32_t *smem, uint32_t cap) {
 template <int NT>
 __device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t scan, uint32_t ring, uint32_t cap,
                           uint32_t *smem, bool last_tier) {
-  RingLds L = ring_carve(smem, cap);
-  FX_STAMP_INIT(B.stamps);
+  RingLds L = ring_carve<NT>(smem, cap);
+  unsigned long long *const stamp_base = B.stamps ? B.stamps + (NT == 64 ? 0 : 16) : nullptr;
+  FX_STAMP_INIT(stamp_base);
   const uint32_t tid = threadIdx.x;
   const size_t ring_slot = (size_t)scan * P.n_rings + ring;
   const uint32_t n = B.ring_cnt[ring_slot], off = B.ring_off[ring_slot];
@@ -630,8 +723,9 @@ __device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t sca
   FX_STAMP(1);
 
   // ---- pcl::EuclideanClusterExtraction (ref: node.cpp:269-276)
-  const uint32_t n_runs = cc_label<NT>(L.px, L.py, L.pz, n, P.r2_cluster, L.parent, L.csize, L.rank, L.s_w, B.stamps);
-  const uint32_t n_c = cc_order<NT>(n, L.parent, L.csize, P.min_count, P.max_count, L.croot, L.crec, L.s_w, B.stamps);
+  const uint32_t n_segs = cc_label<NT>(L.px, L.py, L.pz, n, P.r2_cluster, L.parent, L.csize, L.rank, L.s_w, stamp_base);
+  const uint32_t n_c =
+      cc_order<NT>(n, L.parent, L.csize, P.min_count, P.max_count, L.croot, L.crec, L.ckoff, L.s_w, stamp_base);
 #ifdef FX_STAMPS
   stamp_prev_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -650,16 +744,16 @@ __device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t sca
     bmaxy[root] = f2ord(-1000.0f);
   }
   __syncthreads();
-  if (n_runs <= FX_RUN_MAX && n_runs > 1) {
-    RunTable RT = run_table(L.s_w);
-    for (uint32_t r = tid; r < n_runs; r += NT) {
-      const uint32_t root = L.parent[RT.start[r]];
+  if (n_segs <= SegCfg<NT>::kMax) {
+    const SegTable<NT> ST(L.s_w);
+    for (uint32_t sg = tid; sg < n_segs; sg += NT) {
+      const uint32_t root = L.parent[ST.start(sg)];
       const uint32_t sz = L.csize[root];
       if (sz < P.min_count || sz > P.max_count) continue;
-      atomicMin(&bminx[root], f2ord(RT.minx[r]));
-      atomicMax(&bmaxx[root], f2ord(RT.maxx[r]));
-      atomicMin(&bminy[root], f2ord(RT.miny[r]));
-      atomicMax(&bmaxy[root], f2ord(RT.maxy[r]));
+      atomicMin(&bminx[root], f2ord(ST.box(FX_MINX, sg)));
+      atomicMax(&bmaxx[root], f2ord(ST.box(FX_MAXX, sg)));
+      atomicMin(&bminy[root], f2ord(ST.box(FX_MINY, sg)));
+      atomicMax(&bmaxy[root], f2ord(ST.box(FX_MAXY, sg)));
     }
   } else {
     for (uint32_t i = tid; i < n; i += NT) {
@@ -771,16 +865,20 @@ __device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t sca
 // many short dependent phases of a ring cost no workgroup barriers
 #define FX_RING_SMALL_T 64
 extern "C" __global__ __launch_bounds__(FX_RING_SMALL_T) void k_rings_small(FxDevParams P, FxBuffers B, uint32_t cap,
-                                                                            uint32_t mid_cap) {
+                                                                            uint32_t mid_cap, uint32_t n_items) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  const uint32_t scan = blockIdx.x / P.n_rings, ring = blockIdx.x % P.n_rings;
-  if (!ring_body<FX_RING_SMALL_T>(P, B, scan, ring, cap, smem, false)) {
-    if (threadIdx.x == 0) {
-      // too many points for one wavefront: workgroup tiers (mid: fits mid_cap, else the large one)
-      const bool mid = B.ring_cnt[blockIdx.x] <= mid_cap;
-      const uint32_t pos = atomicAdd(&B.counters[mid ? 0 : 5], 1u);
-      (mid ? B.big_rings : B.huge_rings)[pos] = blockIdx.x;
+  // persistent wavefronts: each strides over the (scan, ring) items
+  for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const uint32_t scan = item / P.n_rings, ring = item % P.n_rings;
+    if (!ring_body<FX_RING_SMALL_T>(P, B, scan, ring, cap, smem, false)) {
+      if (threadIdx.x == 0) {
+        // too many points for one wavefront: workgroup tiers (mid: fits mid_cap, else the large one)
+        const bool mid = B.ring_cnt[item] <= mid_cap;
+        const uint32_t pos = atomicAdd(&B.counters[mid ? 0 : 5], 1u);
+        (mid ? B.big_rings : B.huge_rings)[pos] = item;
+      }
     }
+    __syncthreads();
   }
 }
 extern "C" __global__ __launch_bounds__(FX_WG) void k_rings_big(FxDevParams P, FxBuffers B, uint32_t cap, uint32_t huge) {
@@ -803,7 +901,7 @@ struct MergeLds {
 __device__ __forceinline__ MergeLds merge_carve(uint32_t *smem, uint32_t cap, uint32_t n_rings) {
   MergeLds L;
   L.s_w = smem;
-  uint32_t *p = smem + FX_SCRATCH_WORDS;
+  uint32_t *p = smem + SegCfg<FX_WG>::kWords;
   L.cx = (float *)p, p += cap;
   L.cy = (float *)p, p += cap;
   L.cz = (float *)p, p += cap;
@@ -881,7 +979,7 @@ __device__ bool merge_body(const FxDevParams &P, const FxBuffers &B, uint32_t sc
   uint32_t K = 0;
   if (C > 0) {  // ref: node.cpp:209-210
     cc_label<FX_WG>(L.cx, L.cy, L.pz, C, P.r2_merge, L.parent, L.csize, L.rid, L.s_w);
-    const uint32_t n_c = cc_order<FX_WG>(C, L.parent, L.csize, P.ndc, P.secondary_max, L.croot, L.crec, L.s_w);
+    const uint32_t n_c = cc_order<FX_WG>(C, L.parent, L.csize, P.ndc, P.secondary_max, L.croot, L.crec, L.rid, L.s_w);
     K = n_c < P.max_keypoints ? n_c : P.max_keypoints;
     if (n_c > P.max_keypoints && tid == 0) atomicOr(&B.flags[scan], FX_FLAG_KP_OVERFLOW);
     float4 *kp = B.keypoints + (size_t)scan * P.max_keypoints;
@@ -1501,9 +1599,12 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_pack_kp_records(FxDevParam
 // ====================================================================== launchers
 extern "C" {
 
-size_t fxk_ring_lds_bytes(uint32_t cap) { return (size_t)(FX_SCRATCH_WORDS + FX_RING_WORDS_PER_POINT * cap) * 4; }
+size_t fxk_ring_lds_bytes(uint32_t cap) { return (size_t)(SegCfg<FX_WG>::kWords + FX_RING_WORDS_PER_POINT * cap) * 4; }
+size_t fxk_ring_wave_lds_bytes(uint32_t cap) {
+  return (size_t)(SegCfg<FX_RING_SMALL_T>::kWords + FX_RING_WORDS_PER_POINT * cap) * 4;
+}
 size_t fxk_merge_lds_bytes(uint32_t cap, uint32_t n_rings) {
-  return (size_t)(FX_SCRATCH_WORDS + FX_MERGE_WORDS_PER_CAND * cap + n_rings + 1) * 4;
+  return (size_t)(SegCfg<FX_WG>::kWords + FX_MERGE_WORDS_PER_CAND * cap + n_rings + 1) * 4;
 }
 size_t fxk_desc_lds_bytes(uint32_t cap) { return (size_t)(16 + FX_DESC_WORDS_PER_POINT * cap + FX_DESC_BINS) * 4; }
 
@@ -1525,9 +1626,11 @@ void fxk_bucket(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_
   hipLaunchKernelGGL(k_bucket, dim3(batch), dim3(FX_WG), lds, s, P, B, el0, inv_step);
 }
 void fxk_rings_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap,
-                     uint32_t mid_cap) {
-  hipLaunchKernelGGL(k_rings_small, dim3(batch * P.n_rings), dim3(FX_RING_SMALL_T), fxk_ring_lds_bytes(cap), s, P, B, cap,
-                     mid_cap);
+                     uint32_t mid_cap, uint32_t grid) {
+  const uint32_t n_items = batch * (uint32_t)P.n_rings;
+  if (grid > n_items) grid = n_items;
+  hipLaunchKernelGGL(k_rings_small, dim3(grid), dim3(FX_RING_SMALL_T), fxk_ring_wave_lds_bytes(cap), s, P, B, cap, mid_cap,
+                     n_items);
 }
 void fxk_rings_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t grid, uint32_t huge) {
   hipLaunchKernelGGL(k_rings_big, dim3(grid), dim3(FX_WG), fxk_ring_lds_bytes(cap), s, P, B, cap, huge);

@@ -146,15 +146,15 @@ FX_HD inline void insertion_sort(V &v, int first, int last) {
 
 }  // namespace fx_sort_detail
 
-// Sorts the n records behind view `v` (logical position i = reversed position) into the order
-// PCL hands clusters back: descending size, ties as libstdc++'s introsort leaves them.
-// stk: FX_SORT_STACK_WORDS ints of scratch.
+// Phase 1 of std::sort (std::__introsort_loop): median-of-3 quicksort partitions until every
+// pending range has <= 16 elements; heap sort for a range whose depth budget ran out.
+// Sequential by nature.  stk: FX_SORT_STACK_WORDS ints of scratch.
 #define FX_SORT_STACK_WORDS 120
+#define FX_SORT_THRESHOLD 16
 template <class V>
-FX_HD inline void fx_sort_replay_view(V &v, int n, int *stk) {
+FX_HD inline void fx_sort_partition_phase(V &v, int n, int *stk) {
   using namespace fx_sort_detail;
-  if (n < 2) return;
-  const int kThreshold = 16;
+  if (n <= FX_SORT_THRESHOLD) return;
   int lg = 0;
   for (int t = n; t > 1; t >>= 1) ++lg;
   // explicit stack for the recursion on the right-hand part; pending ranges are disjoint,
@@ -168,7 +168,7 @@ FX_HD inline void fx_sort_replay_view(V &v, int n, int *stk) {
   while (sp > 0) {
     --sp;
     int first = stk_first[sp], last = stk_last[sp], depth = stk_depth[sp];
-    while (last - first > kThreshold) {
+    while (last - first > FX_SORT_THRESHOLD) {
       if (depth == 0) {
         heap_sort(v, first, last);
         break;
@@ -182,18 +182,47 @@ FX_HD inline void fx_sort_replay_view(V &v, int n, int *stk) {
       last = cut;
     }
   }
-  if (n > kThreshold) {
-    insertion_sort(v, 0, kThreshold);
-    for (int i = kThreshold; i != n; ++i) linear_insert_unguarded(v, i);
+}
+
+// Phase 2 of std::sort (std::__final_insertion_sort): a guarded insertion sort of the first 16
+// elements and an unguarded one of the rest.  Both move an element left only past strictly
+// greater ones, i.e. together they are a STABLE sort of whatever phase 1 left behind — which is
+// why the kernels replace this phase by a parallel stable ranking (cc_order in fx_kernels.hip).
+template <class V>
+FX_HD inline void fx_sort_insertion_phase(V &v, int n) {
+  using namespace fx_sort_detail;
+  if (n > FX_SORT_THRESHOLD) {
+    insertion_sort(v, 0, FX_SORT_THRESHOLD);
+    for (int i = FX_SORT_THRESHOLD; i != n; ++i) linear_insert_unguarded(v, i);
   } else {
     insertion_sort(v, 0, n);
   }
 }
 
-// Records in memory (LDS on the device, plain memory on the host).
+// Records in memory, literal two-phase replay: descending size, ties as libstdc++ leaves them.
 FX_HD inline void fx_sort_replay_desc(uint32_t *rec, uint32_t n, int *stk) {
+  if (n < 2) return;
   fx_sort_detail::RevView v{rec, (int)n};
-  fx_sort_replay_view(v, (int)n, stk);
+  fx_sort_partition_phase(v, (int)n, stk);
+  fx_sort_insertion_phase(v, (int)n);
+}
+
+// Same result with phase 2 as a stable ranking (what the GPU does, O(n^2) here for the test):
+// in forward order, position = #larger + #equal-sized records in front.
+FX_HD inline void fx_sort_replay_desc_ranked(uint32_t *rec, uint32_t n, int *stk, uint32_t *tmp) {
+  if (n < 2) return;
+  fx_sort_detail::RevView v{rec, (int)n};
+  fx_sort_partition_phase(v, (int)n, stk);
+  for (uint32_t c = 0; c < n; ++c) {
+    const uint32_t sz = rec[c] >> 16;
+    uint32_t pos = 0;
+    for (uint32_t d = 0; d < n; ++d) {
+      const uint32_t sd = rec[d] >> 16;
+      pos += (sd > sz || (sd == sz && d < c)) ? 1u : 0u;
+    }
+    tmp[pos] = rec[c];
+  }
+  for (uint32_t c = 0; c < n; ++c) rec[c] = tmp[c];
 }
 
 #endif  // FX_SORT_REPLAY_H_

@@ -230,6 +230,8 @@ uint32_t fx_synth_scan(const fx_synth_cfg *c, float *xyzi_out, uint32_t capacity
 /* Test hook: host build of the cluster-order replay the kernels run on one GPU lane
  * (csrc/fx_sort_replay.h).  perm_out[s] = ordinal of the cluster PCL returns at position s. */
 void fx_test_sort_replay(const uint32_t *sizes, uint32_t n, uint32_t *perm_out);
+/* same, with the final insertion phase replaced by the stable ranking the kernels use */
+void fx_test_sort_replay_ranked(const uint32_t *sizes, uint32_t n, uint32_t *perm_out);
 
 #ifdef __cplusplus
 }
