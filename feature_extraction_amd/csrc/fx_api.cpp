@@ -34,6 +34,8 @@ void fxk_desc_wave(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint
                    uint32_t mode);
 void fxk_desc_wg(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t grid,
                  uint32_t mode, uint32_t from_list);
+void fxk_desc_spill(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t mode,
+                    uint32_t slab_pts);
 void fxk_pack_kp_records(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, void *dst,
                          uint32_t rec_kp);
 void fxk_rng_ord(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
@@ -78,6 +80,7 @@ struct fx_ctx {
   FxScanMeta *d_meta = nullptr;
   float box_margin = 0.f;
   uint32_t ring_waves_per_cu = 8;
+  uint32_t spill_grid = 0, spill_slab = 0;
   // host-input staging
   float *d_stage = nullptr;
   std::vector<float> repack;
@@ -160,7 +163,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   const size_t kLds = 160 * 1024;
   if (fxk_ring_lds_bytes(L.max_ring_points) > kLds) return fail(FX_ERR_INVALID_ARG, "max_ring_points exceeds the LDS budget (<= 2550)");
   if (fxk_merge_lds_bytes(L.max_candidates, params->n_rings) > kLds)
-    return fail(FX_ERR_INVALID_ARG, "max_candidates exceeds the LDS budget (<= ~4000)");
+    return fail(FX_ERR_INVALID_ARG, "max_candidates exceeds the LDS budget (<= ~3500)");
   if (fxk_desc_lds_bytes(L.max_neighbors) > kLds) return fail(FX_ERR_INVALID_ARG, "max_neighbors exceeds the LDS budget (<= ~4800)");
   if (L.max_keypoints > 65535 || L.max_candidates > 32768 || L.max_ring_points > 32768)
     return fail(FX_ERR_INVALID_ARG, "limit exceeds the 16-bit packing of the order replay");
@@ -215,7 +218,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   P.max_neighbors = L.max_neighbors;
   P.max_ring_points = L.max_ring_points;
   P.list_cap = L.max_neighbors < kListCap ? L.max_neighbors : kListCap;
-  P.ring_slot_cap = L.max_points + L.max_points / 8 + 64;  // a point on a window boundary sits in two rings
+  P.ring_slot_cap = 2 * L.max_points;  // worst case: every point on a window boundary, i.e. in two rings
 
   fx_status st = FX_OK;
   auto bail = [&](fx_status s) {
@@ -273,6 +276,20 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   FX_A(dev_alloc(c, &b.list_desc, L.max_total_keypoints));
   FX_A(dev_alloc(c, &b.s_pts, (size_t)L.max_total_keypoints * P.list_cap));
   FX_A(dev_alloc(c, &b.s_cnt, L.max_total_keypoints));
+  FX_A(dev_alloc(c, &b.spill_desc, L.max_total_keypoints));
+  {
+    // spill tier: a slab of pow2(max_points) entries per workgroup (36 B per entry)
+    uint32_t slab = 1;
+    while (slab < L.max_points) slab <<= 1;
+    c->spill_slab = slab;
+    c->spill_grid = 32;
+    const size_t n = (size_t)c->spill_grid * slab;
+    FX_A(dev_alloc(c, &b.spill_pts, n));
+    FX_A(dev_alloc(c, &b.spill_d2, n));
+    FX_A(dev_alloc(c, &b.spill_nlist, n));
+    FX_A(dev_alloc(c, &b.spill_key, n));
+    FX_A(dev_alloc(c, &b.spill_w, n));
+  }
   FX_A(dev_alloc(c, &b.counters, 8));
   FX_A(dev_alloc(c, &b.stamps, 64 * 32));
   if (hipMemset(b.stamps, 0, 64 * 32 * 8) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
@@ -471,11 +488,13 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
       FX_HIP(mark(7));
       fxk_desc_wg(s, P, B, batch, P.list_cap, big_grid, 0, 1);
       fxk_desc_wg(s, P, B, batch, L.max_neighbors, big_grid, 0, 0);
+      fxk_desc_spill(s, P, B, batch, c->spill_grid, 0, c->spill_slab);
       fxk_rng_ord(s, P, B, batch);
       // second pass: only keypoints whose RNG ordinal moved (an earlier keypoint had no neighbours)
       fxk_desc_wave(s, P, B, batch, desc_grid, 1);
       fxk_desc_wg(s, P, B, batch, P.list_cap, big_grid, 1, 1);
       fxk_desc_wg(s, P, B, batch, L.max_neighbors, big_grid, 1, 0);
+      fxk_desc_spill(s, P, B, batch, c->spill_grid, 1, c->spill_slab);
     } else {
       FX_HIP(mark(6));
       FX_HIP(mark(7));

@@ -84,11 +84,18 @@ struct FxBuffers {
   uint32_t *big_merge;    // [B]
   uint32_t *big_desc;     // [max_total_kp]  rows whose support list overflowed list_cap
   uint32_t *list_desc;    // [max_total_kp]  rows whose list is too long for one wavefront
+  uint32_t *spill_desc;   // [max_total_kp]  rows whose support set does not fit LDS
+  // spill tier slabs, one per workgroup of k_desc_spill (null when the context has none)
+  float4 *spill_pts;
+  float *spill_d2;
+  uint32_t *spill_nlist;
+  unsigned long long *spill_key;
+  float *spill_w;
   // per-keypoint support lists written by k_gather
   float4 *s_pts;          // [max_total_kp][list_cap]  (x, y, z rotated, point index as bits)
   uint32_t *s_cnt;        // [max_total_kp]
   unsigned long long *stamps;  // [32] diagnostic build only (-DFX_STAMPS)
-  uint32_t *counters;     // [8]: 0 big_rings, 1 big_merge, 2 big_desc, 3 need_rng_fix, 4 list_desc, 5 huge_rings
+  uint32_t *counters;     // [8]: 0 big_rings, 1 big_merge, 2 big_desc, 3 need_rng_fix, 4 list_desc, 5 huge_rings, 6 spill_desc
 };
 
 #endif

@@ -88,7 +88,7 @@ void fx_rotation_from_roll_pitch(double roll, double pitch, float R[9]) {
   const float hp = 0.5f * (float)pitch, hr = 0.5f * (float)roll;
   const float cy = std::cos(hp), sy = std::sin(hp);
   const float cx = std::cos(hr), sx = std::sin(hr);
-  const float w = cy * cx, x = cy * sx, y = sy * cx, z = -(sy * sx);
+  const float w = cy * cx, x = cy * sx, y = sy * cx, z = 0.0f - sy * sx;  // (0 - y1 x2: +0 at zero angles, as Eigen's product)
   const float tx = 2.0f * x, ty = 2.0f * y, tz = 2.0f * z;
   const float twx = tx * w, twy = ty * w, twz = tz * w;
   const float txx = tx * x, txy = ty * x, txz = tz * x;

@@ -1275,7 +1275,7 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_wave(FxDevParams P, F
       if (ord == k) continue;
     }
     const uint32_t nS = B.s_cnt[row];
-    if (nS > FX_WAVE_CAP) {  // long list: workgroup tiers
+    if (nS > FX_WAVE_CAP || nS > P.list_cap) {  // long (or truncated) list: workgroup tiers
       if (lane == 0) {
         const uint32_t pos = atomicAdd(&B.counters[nS > P.list_cap ? 2 : 4], 1u);
         (nS > P.list_cap ? B.big_desc : B.list_desc)[pos] = row;
@@ -1445,14 +1445,7 @@ __device__ bool desc_body(const FxDevParams &P, const FxBuffers &B, uint32_t row
     }
     __syncthreads();
     nS = L.s_w[0];
-    if (nS > cap) {
-      if (tid == 0) {
-        atomicOr(&B.flags[scan], FX_FLAG_NBR_OVERFLOW);
-        B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = FX_NONE;
-      }
-      desc_fill_nan(out, tid, FX_WG);
-      return false;
-    }
+    if (nS > cap) return false;  // the caller hands the keypoint to the spill tier
   }
   for (uint32_t t = tid; t < FX_DESC_BINS; t += FX_WG) L.img[t] = 0.0f;
 
@@ -1536,10 +1529,162 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_wg(FxDevParams P, FxB
     const uint32_t scan = scan_of_row(B.kp_offset, batch, row);
     const uint32_t k = row - B.kp_offset[scan];
     const uint32_t ord = mode == 1 ? B.rng_ord[(size_t)scan * P.max_keypoints + k] : k;
-    desc_body(P, B, row, scan, k, ord, cap, smem, from_list != 0);
+    if (!desc_body(P, B, row, scan, k, ord, cap, smem, from_list != 0)) {
+      if (threadIdx.x == 0) {
+        if (B.spill_pts) {
+          const uint32_t pos = atomicAdd(&B.counters[6], 1u);
+          B.spill_desc[pos] = row;
+        } else {  // context created without a spill slab (limits.max_neighbors is then a hard cap)
+          atomicOr(&B.flags[scan], FX_FLAG_NBR_OVERFLOW);
+          B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = FX_NONE;
+        }
+      }
+      if (!B.spill_pts) desc_fill_nan(B.desc + (size_t)row * FX_DESC_FLOATS, threadIdx.x, FX_WG);
+    }
     __syncthreads();
   }
 }
+
+// ---------------------------------------------------------------- spill tier
+// Keypoints whose support set does not fit LDS (dense scans: > max_neighbors points within
+// R + R/5).  Same algorithm, with the support set, the neighbour list and the sort in a
+// per-workgroup slab of global memory; the density count streams the support set through LDS
+// tiles.  Slow but exact and without a capacity limit below max_points.
+#define FX_SPILL_TILE 1024
+extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_spill(FxDevParams P, FxBuffers B, uint32_t batch, uint32_t mode,
+                                                                  uint32_t slab_pts) {
+  __shared__ float t_x[FX_SPILL_TILE], t_y[FX_SPILL_TILE], t_z[FX_SPILL_TILE];
+  __shared__ uint32_t s_cnt[4];
+  if (mode == 1 && B.counters[3] == 0) return;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t n_items = B.counters[6];
+  float4 *sp = B.spill_pts + (size_t)blockIdx.x * slab_pts;              // support set (x, y, z, index bits)
+  float *sd2 = B.spill_d2 + (size_t)blockIdx.x * slab_pts;               // its squared distances
+  uint32_t *nlist = B.spill_nlist + (size_t)blockIdx.x * slab_pts;       // support positions of the binned neighbours
+  unsigned long long *nkey = B.spill_key + (size_t)blockIdx.x * slab_pts;  // slab_pts is a power of two
+  float *nw = B.spill_w + (size_t)blockIdx.x * slab_pts;
+  const FxScTables *T = B.tables;
+  for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+    const uint32_t row = B.spill_desc[it];
+    const uint32_t scan = scan_of_row(B.kp_offset, batch, row);
+    const uint32_t k = row - B.kp_offset[scan];
+    const uint32_t ord = mode == 1 ? B.rng_ord[(size_t)scan * P.max_keypoints + k] : k;
+    const FxScanMeta M = B.meta[scan];
+    const float4 kp = B.keypoints[(size_t)scan * P.max_keypoints + k];
+    const float2 xa = B.xaxis[ord];
+    float *out = B.desc + (size_t)row * FX_DESC_FLOATS;
+    if (tid < 4) s_cnt[tid] = 0;
+    __syncthreads();
+    // ---- gather into the slab
+    const uint32_t n = M.n;
+    for (uint32_t i0 = 0; i0 < n; i0 += FX_WG * 4) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t i = i0 + u * FX_WG + tid;
+        v[u] = i < n ? *reinterpret_cast<const float4 *>(M.pts + (size_t)i * M.stride_f) : make_float4(NAN, NAN, NAN, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float x = v[u].x, y = v[u].y, z = v[u].z;
+        const float rx = ((M.R[0] * x + M.R[1] * y) + M.R[2] * z) + 0.0f;
+        const float ry = ((M.R[3] * x + M.R[4] * y) + M.R[5] * z) + 0.0f;
+        const float rz = ((M.R[6] * x + M.R[7] * y) + M.R[8] * z) + 0.0f;
+        const float d = dist2(kp.x, kp.y, kp.z, rx, ry, rz);
+        if (d < P.r2_support && isfinite(rx) && isfinite(ry) && isfinite(rz)) {
+          const uint32_t pos = atomicAdd(&s_cnt[0], 1u);
+          sp[pos] = make_float4(rx, ry, rz, __uint_as_float(i0 + u * FX_WG + tid));
+          sd2[pos] = d;
+          if (d < P.r2_search) {
+            atomicAdd(&s_cnt[2], 1u);
+            if (!(fabsf(d - 0.0f) < FLT_EPSILON)) nlist[atomicAdd(&s_cnt[1], 1u)] = pos;
+          }
+        }
+      }
+    }
+    __threadfence();  // the slab is re-read by other waves of this workgroup: release + L1 invalidate
+    __syncthreads();
+    const uint32_t nS = s_cnt[0], nM = s_cnt[1], nAll = s_cnt[2];
+    if (tid == 0) B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = nAll;
+    if (nAll == 0) {
+      desc_fill_nan(out, tid, FX_WG);
+      __syncthreads();
+      continue;
+    }
+    // ---- neighbours in batches of one per thread; density = support points within R/5, counted
+    //      while the support set streams through LDS tiles
+    for (uint32_t m0 = 0; m0 < nM; m0 += FX_WG) {
+      const uint32_t m = m0 + tid;
+      const bool live = m < nM;
+      const uint32_t e = live ? nlist[m] : 0u;
+      const float4 b = live ? sp[e] : make_float4(0, 0, 0, 0);
+      uint32_t dens = 0;
+      for (uint32_t q0 = 0; q0 < nS; q0 += FX_SPILL_TILE) {
+        __syncthreads();
+        for (uint32_t q = tid; q < FX_SPILL_TILE; q += FX_WG) {
+          const float4 v = q0 + q < nS ? sp[q0 + q] : make_float4(INFINITY, INFINITY, INFINITY, 0);
+          t_x[q] = v.x;
+          t_y[q] = v.y;
+          t_z[q] = v.z;
+        }
+        __syncthreads();
+        const uint32_t lim = min((uint32_t)FX_SPILL_TILE, nS - q0);
+        for (uint32_t q = 0; q < lim; ++q) dens += (dist2(b.x, b.y, b.z, t_x[q], t_y[q], t_z[q]) < P.r2_density) ? 1u : 0u;
+      }
+      if (live) {
+        const float d2 = sd2[e];
+        float lut;
+        const uint32_t bin = sc3d_bin(kp, b.x, b.y, b.z, d2, xa, T, lut);
+        nkey[m] = sc3d_key(bin, d2, __float_as_uint(b.w));
+        nw[m] = (1.0f / (float)dens) * lut;
+      }
+    }
+    // ---- bitonic sort by (bin, d2, index) in the slab
+    uint32_t p2 = 1;
+    while (p2 < nM) p2 <<= 1;
+    for (uint32_t t = nM + tid; t < p2; t += FX_WG) nkey[t] = ~0ull;
+    __threadfence();
+    __syncthreads();
+    for (uint32_t kb = 2; kb <= p2; kb <<= 1) {
+      for (uint32_t jb = kb >> 1; jb > 0; jb >>= 1) {
+        for (uint32_t t = tid; t < p2; t += FX_WG) {
+          const uint32_t x = t ^ jb;
+          if (x > t) {
+            const unsigned long long a = nkey[t], c = nkey[x];
+            const bool up = (t & kb) == 0;
+            if ((a > c) == up) {
+              nkey[t] = c;
+              nkey[x] = a;
+              const float wa = nw[t];
+              nw[t] = nw[x];
+              nw[x] = wa;
+            }
+          }
+        }
+        __threadfence();
+        __syncthreads();
+      }
+    }
+    // ---- zero the row, then one lane per bin run adds its weights in order
+    for (uint32_t t = tid; t < FX_DESC_FLOATS; t += FX_WG) out[t] = 0.0f;
+    __threadfence();
+    __syncthreads();
+    for (uint32_t t = tid; t < nM; t += FX_WG) {
+      const uint32_t bin = (uint32_t)(nkey[t] >> 52);
+      if (t > 0 && (uint32_t)(nkey[t - 1] >> 52) == bin) continue;
+      float acc = 0.0f;
+      uint32_t e = t;
+      do {
+        acc += nw[e];
+        ++e;
+      } while (e < nM && (uint32_t)(nkey[e] >> 52) == bin);
+      out[bin] = acc;
+    }
+    __threadfence();
+    __syncthreads();
+  }
+}
+
 
 // RNG ordinals: 3DSC draws its three numbers only for keypoints that have neighbours.
 extern "C" __global__ __launch_bounds__(FX_WG) void k_rng_ord(FxDevParams P, FxBuffers B, uint32_t batch) {
@@ -1655,6 +1800,10 @@ void fxk_desc_wave(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint
 void fxk_desc_wg(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t grid,
                  uint32_t mode, uint32_t from_list) {
   hipLaunchKernelGGL(k_desc_wg, dim3(grid), dim3(FX_WG), fxk_desc_lds_bytes(cap), s, P, B, batch, cap, mode, from_list);
+}
+void fxk_desc_spill(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t mode,
+                    uint32_t slab_pts) {
+  hipLaunchKernelGGL(k_desc_spill, dim3(grid), dim3(FX_WG), 0, s, P, B, batch, mode, slab_pts);
 }
 void fxk_rng_ord(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch) {
   hipLaunchKernelGGL(k_rng_ord, dim3((batch + FX_WG - 1) / FX_WG), dim3(FX_WG), 0, s, P, B, batch);

@@ -47,7 +47,7 @@ typedef enum fx_status {
 #define FX_FLAG_RING_OVERFLOW 0x1u      /* a ring held more points than limits.max_ring_points */
 #define FX_FLAG_CAND_OVERFLOW 0x2u      /* more per-ring candidates than limits.max_candidates */
 #define FX_FLAG_KP_OVERFLOW 0x4u        /* more keypoints than limits.max_keypoints */
-#define FX_FLAG_NBR_OVERFLOW 0x8u       /* a keypoint's support set exceeded limits.max_neighbors */
+#define FX_FLAG_NBR_OVERFLOW 0x8u       /* support set too large and the context has no spill slab (not raised by default) */
 #define FX_FLAG_TOTAL_KP_OVERFLOW 0x10u /* batch-wide keypoint pool exhausted */
 #define FX_FLAG_KPC_OVERFLOW 0x20u      /* keypoint_cloud exceeded its pool */
 
@@ -83,7 +83,7 @@ typedef struct fx_limits {
   uint32_t max_ring_candidates; /* candidates one ring may emit          (def 256)  */
   uint32_t max_candidates;      /* per-ring candidates per scan, all rings (def 2048) */
   uint32_t max_keypoints;       /* keypoints per scan                    (def 256)  */
-  uint32_t max_neighbors;       /* support-set points per keypoint       (def 4096) */
+  uint32_t max_neighbors;       /* support-set points per keypoint held in LDS (def 4096); larger sets spill to HBM */
   uint32_t max_total_keypoints; /* keypoints per batch (descriptor pool) (def max_batch*64) */
   uint32_t max_kpc_points;      /* keypoint_cloud points per scan        (def 4096) */
 } fx_limits;

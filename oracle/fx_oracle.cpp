@@ -679,4 +679,32 @@ void fxo_sort_by_size_desc(const uint32_t *sizes, uint32_t n, uint32_t *perm_out
 }
 float fxo_elevation_deg(float x, float y, float z) { return elevation_deg(x, y, z); }
 
+/* McIlroy's "killer adversary for quicksort" run against the very std::sort call of A.6: returns
+ * a size sequence that drives libstdc++'s introsort into its depth limit (heap-sort fallback),
+ * so the tests can exercise that branch of the replay too. */
+void fxo_antiqsort(uint32_t n, uint32_t *sizes_out) {
+  std::vector<int> val(n), ptr(n);
+  const int gas = (int)n - 1;
+  int nsolid = 0, candidate = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    ptr[i] = (int)i;
+    val[i] = gas;
+  }
+  auto less = [&](int x, int y) {
+    if (val[x] == gas && val[y] == gas) {
+      if (x == candidate)
+        val[x] = nsolid++;
+      else
+        val[y] = nsolid++;
+    }
+    if (val[x] == gas)
+      candidate = x;
+    else if (val[y] == gas)
+      candidate = y;
+    return val[x] < val[y];
+  };
+  std::sort(ptr.rbegin(), ptr.rend(), less);
+  for (uint32_t i = 0; i < n; ++i) sizes_out[i] = (uint32_t)val[i] + 1u;
+}
+
 } /* extern "C" */

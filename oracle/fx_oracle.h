@@ -56,6 +56,7 @@ float fxo_radius2(double r);              /* (float)(r*r), r as the caller's dou
 float fxo_cluster_radius2(double tol);    /* EuclideanClusterExtraction narrows tol to float first */
 void fxo_sort_by_size_desc(const uint32_t *sizes, uint32_t n, uint32_t *perm_out); /* libstdc++ std::sort(rbegin,rend) */
 float fxo_elevation_deg(float x, float y, float z); /* ref: node.cpp:150-154 */
+void fxo_antiqsort(uint32_t n, uint32_t *sizes_out); /* adversarial size sequence for std::sort(rbegin, rend) */
 
 #ifdef __cplusplus
 }

@@ -53,6 +53,7 @@ def load():
     lib.fxo_sort_by_size_desc.argtypes = [_U32P, C.c_uint32, _U32P]
     lib.fxo_elevation_deg.restype = C.c_float
     lib.fxo_elevation_deg.argtypes = [C.c_float, C.c_float, C.c_float]
+    lib.fxo_antiqsort.argtypes = [C.c_uint32, _U32P]
     _lib = lib
     return lib
 
@@ -132,3 +133,10 @@ def sort_by_size_desc(sizes):
     perm = np.zeros(len(s), np.uint32)
     load().fxo_sort_by_size_desc(_u(s), len(s), _u(perm))
     return perm
+
+
+def antiqsort(n):
+    """Size sequence that drives libstdc++'s introsort to its heap-sort fallback."""
+    out = np.zeros(n, np.uint32)
+    load().fxo_antiqsort(n, _u(out))
+    return out

@@ -1,0 +1,184 @@
+"""Edge cases of the hot path on the GPU: empty / tiny / ragged scans, non-finite points,
+elevation-window boundaries, unordered input, strides, device-resident input, determinism,
+capacity flags."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from feature_extraction_amd import capi
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _cmp(oracle, p, lim, scans, roll=0.0, pitch=0.0, tag=""):
+    ctx = capi.Context(p, lim)
+    got = ctx.process_host(scans, roll=roll, pitch=pitch)
+    for b, s in enumerate(scans):
+        ora = oracle.run(p, s, roll=roll, pitch=pitch)
+        util.compare_scan(got[b], ora, tag=f"{tag} scan {b}")
+    ctx.close()
+    return got
+
+
+def test_empty_and_ragged_batch(fxlib, oracle):
+    """Empty scans give K = 0 (ref: node.cpp:209-210, 263-264, 331-332 early returns)."""
+    full = util.vlp16_scan(1000)
+    scans = [np.zeros((0, 4), np.float32), full[:1], full[:17], full[:16 * 100], full, np.zeros((0, 4), np.float32),
+             full[5000:9000]]
+    got = _cmp(oracle, capi.params("launch"), capi.limits(len(scans), 28800), scans, 0.02, -0.015, "ragged")
+    assert got[0]["n_keypoints"] == 0 and len(got[0]["filtered"]) == 0 and got[4]["n_keypoints"] > 0
+
+
+def test_empty_batch_call(fxlib):
+    ctx = capi.Context(capi.params("default"), capi.limits(4, 1024))
+    v = ctx.process_raw(ctx.make_descs([], []), 0, capi.FX_OUT_HOST)
+    assert v.batch == 0 and v.total_keypoints == 0
+    ctx.close()
+
+
+def test_everything_filtered_out(fxlib, oracle):
+    s = util.vlp16_scan(3)
+    s[:, 0] = -np.abs(s[:, 0]) - 1.0  # x_min = 0 removes every point
+    got = _cmp(oracle, capi.params("default"), capi.limits(1, 28800), [s], tag="all filtered")
+    assert got[0]["n_keypoints"] == 0 and len(got[0]["filtered"]) == 0
+
+
+def test_non_finite_points_are_dropped(fxlib, oracle):
+    """PassThrough removes non-finite points (A.3); they are not part of the 3DSC search surface."""
+    s = util.vlp16_scan(1000)
+    rng = np.random.default_rng(0)
+    bad = rng.choice(len(s), 600, replace=False)
+    s[bad[:200], 0] = np.nan
+    s[bad[200:400], 1] = np.inf
+    s[bad[400:], 2] = -np.inf
+    _cmp(oracle, capi.params("launch"), capi.limits(1, 28800), [s], 0.02, -0.015, "NaN/Inf injection")
+
+
+def test_points_on_window_boundaries_belong_to_two_rings(fxlib, oracle):
+    """Inclusive ring windows (ref: node.cpp:201): an even-degree elevation sits in two rings."""
+    n = 48  # 8 groups of 6 points, groups 1.2 m apart, points 3 cm apart
+    rho = 8.0
+    pts = np.zeros((4 * n, 4), np.float32)
+    for i, el_deg in enumerate((0.0, 2.0, -4.0, 1.0)):
+        el = np.radians(el_deg)
+        a = 0.1 + 0.15 * (np.arange(n) // 6) + (np.arange(n) % 6) * 0.004
+        pts[i * n:(i + 1) * n, 0] = rho * np.cos(a)
+        pts[i * n:(i + 1) * n, 1] = rho * np.sin(a)
+        pts[i * n:(i + 1) * n, 2] = rho * np.tan(el)
+    p = capi.params("default", z_min=-3.0)
+    got = _cmp(oracle, p, capi.limits(1, 4 * n), [pts], tag="boundary elevations")
+    ora = oracle.run(p, pts, want_labels=True)
+    assert ((ora["ring_labels"] >= 0).sum(axis=0) == 2).sum() >= 2 * n  # points really are in two rings
+    assert got[0]["n_keypoints"] > 0
+
+
+def test_unordered_input_takes_the_all_pairs_path(fxlib, oracle):
+    """Shuffled points: no azimuth order, one run per point — exactness must not depend on order."""
+    rng = np.random.default_rng(4)
+    s = util.vlp16_scan(1000)
+    s = s[rng.permutation(len(s))]
+    _cmp(oracle, capi.params("launch"), capi.limits(1, 28800), [s], 0.02, -0.015, "shuffled")
+    _cmp(oracle, capi.params("default"), capi.limits(1, 28800), [s], 0.02, -0.015, "shuffled default")
+
+
+def test_pcl_stride32_and_device_input(fxlib, oracle):
+    import torch
+    p = capi.params("launch")
+    s = util.vlp16_scan(1000)
+    ora = oracle.run(p, s, roll=0.02, pitch=-0.015)
+    ctx = capi.Context(p, capi.limits(2, 28800))
+    # pcl::PointXYZI in-memory layout: x y z pad intensity pad pad pad (32 bytes)
+    wide = np.zeros((len(s), 8), np.float32)
+    wide[:, :3] = s[:, :3]
+    wide[:, 3] = 1.0
+    wide[:, 4] = 123.0
+    got = ctx.process_host([wide], roll=0.02, pitch=-0.015)[0]
+    util.compare_scan(got, ora, tag="host stride 32")
+    for arr, stride in ((s, 16), (wide, 32)):
+        d = torch.from_numpy(arr).cuda()
+        descs = ctx.make_descs([d.data_ptr()], [len(arr)], stride, 0.02, -0.015)
+        flags = capi.FX_IN_DEVICE | capi.FX_OUT_HOST | capi.FX_OUT_CLOUDS | capi.FX_OUT_DEBUG
+        got = ctx.unpack(ctx.process_raw(descs, 1, flags))[0]
+        util.compare_scan(got, ora, tag=f"device stride {stride}")
+    ctx.close()
+
+
+def test_argument_errors(fxlib):
+    ctx = capi.Context(capi.params("default"), capi.limits(2, 1000))
+    s = util.vlp16_scan(1)[:500]
+    v = capi.FxBatchView()
+    assert fxlib.fx_process_batch(ctx.handle, ctx.make_descs([s.ctypes.data] * 3, [500] * 3), 3, 0, C.byref(v)) == 5
+    assert fxlib.fx_process_batch(ctx.handle, ctx.make_descs([s.ctypes.data], [5000]), 1, 0, C.byref(v)) == 5
+    assert fxlib.fx_process_batch(ctx.handle, ctx.make_descs([s.ctypes.data], [500], stride_bytes=12), 1, 0, C.byref(v)) == 1
+    assert fxlib.fx_process_batch(ctx.handle, ctx.make_descs([s.ctypes.data + 4], [400]), 1, 0, C.byref(v)) == 1
+    ctx.close()
+    with pytest.raises(capi.FxError):
+        capi.Context(capi.params("default", n_rings=0), capi.limits(2, 1000))
+    with pytest.raises(capi.FxError):
+        capi.Context(capi.params("default"), capi.limits(2, 1000, max_ring_points=100000))
+
+
+def test_determinism_and_context_reuse(fxlib):
+    """Same input twice, and through a second context: bit-identical (no float atomics anywhere)."""
+    scans = [util.vlp16_scan(1000 + b) for b in range(4)]
+    p, lim = capi.params("launch"), capi.limits(4, 28800)
+    ctx = capi.Context(p, lim)
+    a = ctx.process_host(scans, roll=0.02, pitch=-0.015)
+    ctx.process_host(scans[::-1], roll=0.0, pitch=0.0)  # different batch in between
+    b = ctx.process_host(scans, roll=0.02, pitch=-0.015)
+    ctx2 = capi.Context(p, lim)
+    c = ctx2.process_host(scans, roll=0.02, pitch=-0.015)
+    for x, y, z in zip(a, b, c):
+        for k in ("filtered", "candidates", "keypoints", "descriptors", "kpc", "cand_keypoint", "kp_neighbors"):
+            util.assert_bit_equal(x[k], y[k], k)
+            util.assert_bit_equal(x[k], z[k], k)
+    ctx.close()
+    ctx2.close()
+
+
+def test_streaming_batch_of_one(fxlib, oracle):
+    """B = 1 at sensor rate (the ROS shell's mode) through one long-lived context."""
+    p = capi.params("launch")
+    ctx = capi.Context(p, capi.limits(1, 28800))
+    for seed in (1, 2, 3):
+        s = util.vlp16_scan(seed)
+        got = ctx.process_host([s], roll=0.01 * seed, pitch=-0.01)[0]
+        util.compare_scan(got, oracle.run(p, s, roll=0.01 * seed, pitch=-0.01), tag=f"stream {seed}")
+    ctx.close()
+
+
+def test_capacity_overflow_is_flagged_never_silent(fxlib, oracle):
+    s = util.vlp16_scan(1000)
+    p = capi.params("launch")
+    ora = oracle.run(p, s, roll=0.02, pitch=-0.015)
+    for over, bit in ((dict(max_keypoints=8), 0x4), (dict(max_ring_candidates=4), 0x2), (dict(max_candidates=64), 0x2),
+                      (dict(max_ring_points=128), 0x1), (dict(max_total_keypoints=10), 0x10),
+                      (dict(max_kpc_points=100), 0x20)):
+        ctx = capi.Context(p, capi.limits(1, 28800, **over))
+        got = ctx.process_host([s], roll=0.02, pitch=-0.015)[0]
+        assert got["flags"] & bit, (over, hex(got["flags"]))
+        ctx.close()
+    # and with room for everything the flags stay clear
+    ctx = capi.Context(p, capi.limits(1, 28800))
+    got = ctx.process_host([s], roll=0.02, pitch=-0.015)[0]
+    assert got["flags"] == 0 and got["n_keypoints"] == ora["n_keypoints"]
+    ctx.close()
+
+
+def test_support_sets_beyond_lds_use_the_spill_tier(fxlib, oracle):
+    """max_neighbors only sizes the LDS tiers: larger support sets go through global-memory slabs."""
+    s = util.vlp16_scan(1000)
+    p = capi.params("launch")
+    _cmp(oracle, p, capi.limits(1, 28800, max_neighbors=64), [s], 0.02, -0.015, "spill tier (tiny LDS cap)")
+    _cmp(oracle, capi.params("default"), capi.limits(1, 28800, max_neighbors=128), [s], 0.02, -0.015, "spill tier default")
+
+
+def test_long_support_lists_use_the_workgroup_tiers(fxlib, oracle):
+    """Keypoints with > 256 and > 1024 support points (list tier and re-gather tier)."""
+    s = util.vlp16_scan(1000, n_poles=8, x_lo=3.0, x_hi=8.0, y_lo=-4.0, y_hi=4.0)
+    p = capi.params("default", descriptor_radius=4.0)
+    ora = oracle.run(p, s)
+    assert ora["kp_neighbors"].max() > 1100
+    _cmp(oracle, p, capi.limits(1, 28800), [s], tag="dense neighbourhoods")

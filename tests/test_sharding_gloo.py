@@ -1,0 +1,62 @@
+"""N > 1 path on CPU: two gloo ranks shard a scan stream, each builds the keypoint records of its
+block, one all-gather assembles the table; rank 0 checks it against the unsharded result.
+(The record producer here is the oracle — the GPU producer is checked in test_gpu_*.)"""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from feature_extraction_amd import capi, sharding
+from oracle import oracle_py
+from tests import util
+
+TOTAL = 6
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _records_for(span):
+    p = capi.params("launch")
+    kps, flags = [], []
+    for b in range(*span):
+        r = oracle_py.run(p, util.vlp16_scan(1000 + b, n_az=450), roll=0.02, pitch=-0.015)
+        kps.append(r["keypoints"])
+        flags.append(0)
+    return sharding.pack_records(kps, flags)
+
+
+def _worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    span = sharding.shard_range(TOTAL, world, rank)
+    rec = torch.from_numpy(_records_for(span))
+    gathered = sharding.all_gather_records(rec, world)
+    # max-over-ranks timing plumbing used by bench.py
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        np.save(out_path, gathered.numpy())
+        assert t.item() == float(world)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_equals_unsharded(tmp_path):
+    out = str(tmp_path / "gathered.npy")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    want = _records_for((0, TOTAL))
+    assert got.shape == want.shape == (TOTAL, 1 + sharding.REC_KP, 4)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    per_scan = sharding.unpack_records(got)
+    assert sum(k for k, _, _ in per_scan) > 0 and all(f == 0 for _, f, _ in per_scan)

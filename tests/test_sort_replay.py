@@ -1,0 +1,44 @@
+"""The kernels' cluster-order replay (csrc/fx_sort_replay.h, host build through the C-ABI test
+hooks) against the oracle's literal std::sort(rbegin, rend, bySize) call."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from feature_extraction_amd import capi
+
+
+def _replay(lib, sizes, ranked):
+    s = np.ascontiguousarray(sizes, dtype=np.uint32)
+    out = np.zeros(len(s), np.uint32)
+    fn = lib.fx_test_sort_replay_ranked if ranked else lib.fx_test_sort_replay
+    fn(s.ctypes.data_as(capi._U32P), len(s), out.ctypes.data_as(capi._U32P))
+    return out
+
+
+@pytest.mark.parametrize("ranked", [False, True])
+def test_random_sequences(fxlib, oracle, ranked):
+    rng = np.random.default_rng(11)
+    for trial in range(1500):
+        n = int(rng.integers(0, 300)) if trial % 12 else int(rng.integers(1000, 4000))
+        hi = int(rng.choice([1, 2, 3, 5, 16, 50, 1000]))
+        s = rng.integers(1, hi + 1, n)
+        assert np.array_equal(_replay(fxlib, s, ranked), oracle.sort_by_size_desc(s)), (trial, n, hi)
+
+
+@pytest.mark.parametrize("ranked", [False, True])
+def test_structured_sequences(fxlib, oracle, ranked):
+    for n in (0, 1, 2, 16, 17, 33, 100, 1000, 5000):
+        idx = np.arange(n)
+        for s in (idx % 60000 + 1, idx[::-1] % 60000 + 1, np.ones(n), np.minimum(idx, idx[::-1]) + 1,
+                  (idx * 7919) % 13 + 1):
+            assert np.array_equal(_replay(fxlib, s, ranked), oracle.sort_by_size_desc(s)), n
+
+
+@pytest.mark.parametrize("ranked", [False, True])
+def test_heap_sort_fallback_is_replayed(fxlib, oracle, ranked):
+    # McIlroy's adversary built against the very std::sort call drives introsort to its depth limit
+    for n in (64, 500, 5000, 30000):
+        s = oracle.antiqsort(n)
+        assert len(np.unique(s)) == n
+        assert np.array_equal(_replay(fxlib, s, ranked), oracle.sort_by_size_desc(s)), n
