@@ -28,14 +28,32 @@ def stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not stale():
-        return LIB
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    cmd = [hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+CLI = os.path.join(HERE, "bin", "fx_cli")
+CLI_SOURCES = ["fx_cli.cpp", "fx_node.hpp", "fx_pcd.hpp"]
+
+
+def build_cli(force=False, verbose=False):
+    """C++ host front end (csrc/fx_node.hpp mirror of the reference class + .pcd CLI) over the C-ABI."""
+    deps = [os.path.join(CSRC, s) for s in CLI_SOURCES] + [LIB]
+    if not force and os.path.exists(CLI) and all(os.path.getmtime(d) <= os.path.getmtime(CLI) for d in deps):
+        return CLI
+    os.makedirs(os.path.dirname(CLI), exist_ok=True)
+    cmd = ["g++", "-O2", "-std=c++17", "-o", CLI, os.path.join(CSRC, "fx_cli.cpp"), "-L" + os.path.dirname(LIB), "-lfx_hip",
+           "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath," + os.path.dirname(LIB)]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    return CLI
+
+
+def build(force=False, verbose=False):
+    if force or stale():
+        os.makedirs(os.path.dirname(LIB), exist_ok=True)
+        cmd = [hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    build_cli(force, verbose)
     return LIB
 
 
