@@ -486,13 +486,13 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
       FX_HIP(mark(6));
       fxk_desc_wave(s, P, B, batch, desc_grid, 0);
       FX_HIP(mark(7));
-      fxk_desc_wg(s, P, B, batch, P.list_cap, big_grid, 0, 1);
+      fxk_desc_wg(s, P, B, batch, P.list_cap, big_grid * 4, 0, 1);
       fxk_desc_wg(s, P, B, batch, L.max_neighbors, big_grid, 0, 0);
       fxk_desc_spill(s, P, B, batch, c->spill_grid, 0, c->spill_slab);
       fxk_rng_ord(s, P, B, batch);
       // second pass: only keypoints whose RNG ordinal moved (an earlier keypoint had no neighbours)
       fxk_desc_wave(s, P, B, batch, desc_grid, 1);
-      fxk_desc_wg(s, P, B, batch, P.list_cap, big_grid, 1, 1);
+      fxk_desc_wg(s, P, B, batch, P.list_cap, big_grid * 4, 1, 1);
       fxk_desc_wg(s, P, B, batch, L.max_neighbors, big_grid, 1, 0);
       fxk_desc_spill(s, P, B, batch, c->spill_grid, 1, c->spill_slab);
     } else {

@@ -1176,10 +1176,14 @@ __device__ __forceinline__ unsigned long long sc3d_key(uint32_t bin, float d2, u
 
 // ---------------------------------------------------------------- k_gather
 #define FX_GATHER_SLICES 4
+#define FX_GATHER_BINS 64
 extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBuffers B, float box_margin) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  float4 *s_kp = reinterpret_cast<float4 *>(smem + 16);
+  // LDS: [0..15] scratch, [16..16+BINS] bin starts, then keypoints (float4) and their x-sorted order
   uint32_t *s_w = smem;
+  uint32_t *s_bin = smem + 16;                                    // [FX_GATHER_BINS + 1]
+  float4 *s_kp = reinterpret_cast<float4 *>(smem + 16 + 80);      // 16-byte aligned
+  uint32_t *s_ord = smem + 16 + 80 + 4 * P.max_keypoints;         // keypoint ids sorted by x bin
   const uint32_t scan = blockIdx.y, slice = blockIdx.x, tid = threadIdx.x;
   uint32_t K = B.n_kp[scan];
   if (K == 0) return;
@@ -1189,6 +1193,7 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
   const FxScanMeta M = B.meta[scan];
   // keypoints of the scan -> LDS; their bounding box (ordered-uint atomics) for a cheap reject
   if (tid < 6) s_w[tid] = (tid & 1) ? f2ord(-INFINITY) : f2ord(INFINITY);
+  for (uint32_t b = tid; b <= FX_GATHER_BINS; b += FX_WG) s_bin[b] = 0;
   __syncthreads();
   for (uint32_t k = tid; k < K; k += FX_WG) {
     const float4 kp = B.keypoints[(size_t)scan * P.max_keypoints + k];
@@ -1201,9 +1206,36 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
     atomicMax(&s_w[5], f2ord(kp.z));
   }
   __syncthreads();
-  const float bx0 = ord2f(s_w[0]) - box_margin, bx1 = ord2f(s_w[1]) + box_margin;
+  const float kx0 = ord2f(s_w[0]), kx1 = ord2f(s_w[1]);
+  const float bx0 = kx0 - box_margin, bx1 = kx1 + box_margin;
   const float by0 = ord2f(s_w[2]) - box_margin, by1 = ord2f(s_w[3]) + box_margin;
   const float bz0 = ord2f(s_w[4]) - box_margin, bz1 = ord2f(s_w[5]) + box_margin;
+  // keypoints binned along x; bin width >= the support radius (+ margin), so a point only has to
+  // look at the keypoints of its own bin and the two next to it
+  const float width = fmaxf(box_margin, (kx1 - kx0) / (float)(FX_GATHER_BINS - 1) * 1.0001f + 1e-6f);
+  const float inv_w = 1.0f / width;
+  for (uint32_t k = tid; k < K; k += FX_WG) {
+    const int b = min(max((int)((s_kp[k].x - kx0) * inv_w), 0), FX_GATHER_BINS - 1);
+    atomicAdd(&s_bin[b + 1], 1u);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t run = 0;
+    for (int b = 0; b <= FX_GATHER_BINS; ++b) {
+      run += s_bin[b];
+      s_bin[b] = run;  // s_bin[b] = first slot of bin b (counts were stored one up)
+    }
+  }
+  __syncthreads();
+  uint32_t *s_fill = s_w + 8;  // unused scratch words are too few: fill cursors live behind the order array
+  s_fill = s_ord + P.max_keypoints;
+  for (uint32_t b = tid; b < FX_GATHER_BINS; b += FX_WG) s_fill[b] = 0;
+  __syncthreads();
+  for (uint32_t k = tid; k < K; k += FX_WG) {
+    const int b = min(max((int)((s_kp[k].x - kx0) * inv_w), 0), FX_GATHER_BINS - 1);
+    s_ord[s_bin[b] + atomicAdd(&s_fill[b], 1u)] = k;
+  }
+  __syncthreads();
 
   const uint32_t n = M.n;
   uint32_t chunk = (n + FX_GATHER_SLICES - 1) / FX_GATHER_SLICES;
@@ -1228,7 +1260,10 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
                         isfinite(rx) && isfinite(ry) && isfinite(rz);
       if (!near) continue;
       const uint32_t idx = i0 + u * FX_WG + tid;
-      for (uint32_t k = 0; k < K; ++k) {
+      const int b = min(max((int)floorf((rx - kx0) * inv_w), -1), FX_GATHER_BINS);
+      const uint32_t s0 = s_bin[max(b - 1, 0)], s1 = s_bin[min(b + 2, FX_GATHER_BINS)];
+      for (uint32_t kk = s0; kk < s1; ++kk) {
+        const uint32_t k = s_ord[kk];
         const float4 kp = s_kp[k];
         const float d = dist2(kp.x, kp.y, kp.z, rx, ry, rz);
         if (d < P.r2_support) {
@@ -1790,7 +1825,8 @@ void fxk_offsets(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32
   hipLaunchKernelGGL(k_offsets, dim3(1), dim3(FX_WG), 0, s, P, B, batch);
 }
 void fxk_gather(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float box_margin) {
-  hipLaunchKernelGGL(k_gather, dim3(FX_GATHER_SLICES, batch), dim3(FX_WG), (16 + 4 * (size_t)P.max_keypoints) * 4, s, P, B,
+  hipLaunchKernelGGL(k_gather, dim3(FX_GATHER_SLICES, batch), dim3(FX_WG),
+                     (16 + 80 + 5 * (size_t)P.max_keypoints + FX_GATHER_BINS) * 4, s, P, B,
                      box_margin);
 }
 void fxk_desc_wave(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid,
