@@ -133,7 +133,12 @@ __device__ __forceinline__ void uf_union(uint32_t *parent, uint32_t a, uint32_t 
 #define FX_STAMP_INIT(ptr)                 \
   unsigned long long *stamps_ = (ptr);    \
   unsigned long long stamp_prev_ = __builtin_amdgcn_s_memtime()
+#define FX_COUNT(slot, v)                                                             \
+  do {                                                                                \
+    if (stamps_) atomicAdd(&stamps_[((blockIdx.x & 63u) << 5) + (slot)], (unsigned long long)(v)); \
+  } while (0)
 #else
+#define FX_COUNT(slot, v)
 #define FX_STAMP(slot)
 #define FX_STAMP_INIT(ptr)
 #endif
@@ -267,6 +272,11 @@ __device__ uint32_t cc_label(const float *px, const float *py, const float *pz, 
   if (table && threadIdx.x == 0) ST.start(n_segs) = n;
   __syncthreads();
   FX_STAMP(2);
+  if (threadIdx.x == 0) {
+    FX_COUNT(12, 1);
+    FX_COUNT(13, n_runs);
+    FX_COUNT(14, n_segs);
+  }
   if (table) {
     for (uint32_t sg = threadIdx.x; sg < n_segs; sg += NT) {
       float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
@@ -334,12 +344,15 @@ __device__ uint32_t cc_label(const float *px, const float *py, const float *pz, 
             near &= near - 1u;
             const uint32_t r = r0 + u;
             const uint32_t s0 = ST.rseg(r), s1 = ST.rseg(r + 1);
+            FX_COUNT(15, 1);
             if (uf_find(parent, i) == uf_find(parent, ST.start(s0))) continue;  // already one component
+            FX_COUNT(11 + 5, 0);
             bool linked = false;
             for (uint32_t sg = s0; sg < s1 && !linked; ++sg) {
               const float dx = fmaxf(fmaxf(ST.box(FX_MINX, sg) - qx, qx - ST.box(FX_MAXX, sg)), 0.0f);
               const float dy = fmaxf(fmaxf(ST.box(FX_MINY, sg) - qy, qy - ST.box(FX_MAXY, sg)), 0.0f);
               if (dx * dx + dy * dy > r2_pad) continue;
+              FX_COUNT(0, 1);
               for (uint32_t j = ST.start(sg); j < ST.start(sg + 1); ++j) {
                 if (dist2(qx, qy, qz, px[j], py[j], pz[j]) < r2) {
                   uf_union(parent, j, i);

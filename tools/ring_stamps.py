@@ -31,3 +31,7 @@ for tier, base in (("wave tier (n <= 256)", 0), ("workgroup tiers", 16)):
     print(f"-- {tier}: {tot / (3 * B * 16):.0f} cycles per (scan, ring) slot")
     for k, nm in names.items():
         print(f"   {nm:24s} {v[base + k] / max(tot, 1) * 100:6.2f} %   {v[base + k] / (3 * B * 16):10.0f}")
+    cnt = v[base + 12]
+    if cnt:
+        print(f"   rings {cnt / 3:.0f}/batch  runs/ring {v[base + 13] / cnt:.1f}  segs/ring {v[base + 14] / cnt:.1f}  "
+              f"near (point,run) pairs/ring {v[base + 15] / cnt:.1f}  near segments scanned/ring {v[base + 0] / cnt:.1f}")
