@@ -17,15 +17,16 @@
 #include "fx_device.h"
 
 extern "C" {
-size_t fxk_ring_lds_bytes(uint32_t cap);
+size_t fxk_ring_lds_bytes(uint32_t cap, uint32_t ccap);
 size_t fxk_merge_lds_bytes(uint32_t cap, uint32_t n_rings);
 size_t fxk_desc_lds_bytes(uint32_t cap);
 hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t desc_big);
 void fxk_prep(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
 void fxk_bucket(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float el0, float inv_step);
-void fxk_rings_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap,
+void fxk_rings_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t ccap,
                      uint32_t mid_cap, uint32_t grid);
-void fxk_rings_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t grid, uint32_t huge);
+void fxk_rings_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t ccap, uint32_t grid,
+                   uint32_t huge);
 void fxk_merge_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap);
 void fxk_merge_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t grid);
 void fxk_offsets(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
@@ -79,7 +80,7 @@ struct fx_ctx {
   int meta_next = 0;
   FxScanMeta *d_meta = nullptr;
   float box_margin = 0.f;
-  uint32_t ring_waves_per_cu = 8;
+  uint32_t ring_waves_per_cu = 12;
   uint32_t spill_grid = 0, spill_slab = 0;
   // host-input staging
   float *d_stage = nullptr;
@@ -161,7 +162,8 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   if (L.max_ring_candidates > L.max_ring_points) L.max_ring_candidates = L.max_ring_points;
   // LDS budget of the large tiers (160 KiB per workgroup on gfx950)
   const size_t kLds = 160 * 1024;
-  if (fxk_ring_lds_bytes(L.max_ring_points) > kLds) return fail(FX_ERR_INVALID_ARG, "max_ring_points exceeds the LDS budget (<= 2550)");
+  if (fxk_ring_lds_bytes(L.max_ring_points, L.max_ring_points) > kLds)
+    return fail(FX_ERR_INVALID_ARG, "max_ring_points exceeds the LDS budget (<= 2600)");
   if (fxk_merge_lds_bytes(L.max_candidates, params->n_rings) > kLds)
     return fail(FX_ERR_INVALID_ARG, "max_candidates exceeds the LDS budget (<= ~3500)");
   if (fxk_desc_lds_bytes(L.max_neighbors) > kLds) return fail(FX_ERR_INVALID_ARG, "max_neighbors exceeds the LDS budget (<= ~4800)");
@@ -332,7 +334,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
     return bail(fail(FX_ERR_HIP, "hipStreamCreate"));
   c->stream = c->own_stream;
   {
-    hipError_t ce = fxk_configure(fxk_ring_lds_bytes(L.max_ring_points), fxk_merge_lds_bytes(L.max_candidates, params->n_rings),
+    hipError_t ce = fxk_configure(fxk_ring_lds_bytes(L.max_ring_points, L.max_ring_points), fxk_merge_lds_bytes(L.max_candidates, params->n_rings),
                                   fxk_desc_lds_bytes(L.max_neighbors));
     if (ce != hipSuccess) return bail(fail(FX_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(ce)));
   }
@@ -470,10 +472,10 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
     fxk_bucket(s, P, B, batch, (float)c->params.el0_deg, (float)(1.0 / c->params.el_step_deg));
     FX_HIP(mark(1));
     const uint32_t ring_mid = L.max_ring_points < kRingCapMid ? L.max_ring_points : kRingCapMid;
-    fxk_rings_small(s, P, B, batch, ring_small, ring_mid, (uint32_t)c->n_cu * c->ring_waves_per_cu);
+    fxk_rings_small(s, P, B, batch, ring_small, ring_small / 4, ring_mid, (uint32_t)c->n_cu * c->ring_waves_per_cu);
     FX_HIP(mark(2));
-    fxk_rings_big(s, P, B, ring_mid, big_grid * 2, 0);
-    fxk_rings_big(s, P, B, L.max_ring_points, big_grid, 1);
+    fxk_rings_big(s, P, B, ring_mid, ring_mid / 4, big_grid * 3, 0);
+    fxk_rings_big(s, P, B, L.max_ring_points, L.max_ring_points, big_grid, 1);
     FX_HIP(mark(3));
     fxk_merge_small(s, P, B, batch, merge_small);
     FX_HIP(mark(4));

@@ -203,33 +203,53 @@ __device__ __forceinline__ uint32_t block_count_incl(bool flag, uint32_t *s_w, u
   return before + (uint32_t)__popcll(m & incl);
 }
 
-// Connected components of {d2(i,j) < r2} over n points held in LDS.  On return parent[i] is the
-// smallest index of i's component, csize[root] the component size, rid[i] the run of point i.
+// Connected components of {d2(i,j) < r2} over n points held in LDS as float4 (x, y, z, *).
+// On return parent[i] is the smallest index of i's component, csize[root] the component size,
+// rid[i] the run of point i.
 //  1. run labelling: consecutive points i-1, i closer than the tolerance form runs; a wave ballot
 //     + highest-set-bit gives every point its run head.  Sensor rings arrive azimuth ordered, so
 //     this one scan already finds almost every cluster, and only run heads ever get linked.
-//  2. cross-run edges.  Runs are cut into segments of <= seg_len points with an xy bounding box
-//     each; only segment pairs of different runs whose boxes are within the tolerance and that
-//     are not yet one component have their point pairs tested.  If the segments do not fit the
-//     table (unordered input) every point pair of different runs is tested instead.  Either way
-//     every pair that could be an edge is examined: exact for any input order.
+//     The same pass numbers runs and segments (<= seg_len points of one run) and folds every
+//     point into its segment's xy bounding box with LDS atomics.
+//  2. cross-run edges: every point against every later run — run box, then the boxes of the run's
+//     segments, then the segment's points — skipping runs already in the point's component.  If
+//     the segments do not fit the table (unordered input) every point pair of different runs is
+//     tested instead.  Either way every pair that could be an edge is examined: exact for any
+//     input order.
 //  3. roots per run head, then per point; sizes per segment.
 // Returns the number of segments (the table is valid iff it is <= SegCfg<NT>::kMax).
 template <int NT>
-__device__ uint32_t cc_label(const float *px, const float *py, const float *pz, uint32_t n, float r2, uint32_t *parent,
-                             uint32_t *csize, uint32_t *rid, uint32_t *s_w, unsigned long long *stamps = nullptr) {
+__device__ uint32_t cc_label(const float4 *pt, uint32_t n, float r2, uint32_t *parent, uint32_t *csize, uint32_t *rid,
+                             uint32_t *s_w, unsigned long long *stamps = nullptr) {
   constexpr uint32_t kSegMax = SegCfg<NT>::kMax;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   FX_STAMP_INIT(stamps);
   const SegTable<NT> ST(s_w);
   const uint32_t seg_len = max(8u, (n + 95u) / 96u);
+  for (uint32_t t = threadIdx.x; t < kSegMax; t += NT) {
+    ST.set_box(FX_MINX, t, __uint_as_float(f2ord(INFINITY)));
+    ST.set_box(FX_MAXX, t, __uint_as_float(f2ord(-INFINITY)));
+    ST.set_box(FX_MINY, t, __uint_as_float(f2ord(INFINITY)));
+    ST.set_box(FX_MAXY, t, __uint_as_float(f2ord(-INFINITY)));
+    ST.set_rbox(FX_MINX, t, __uint_as_float(f2ord(INFINITY)));
+    ST.set_rbox(FX_MAXX, t, __uint_as_float(f2ord(-INFINITY)));
+    ST.set_rbox(FX_MINY, t, __uint_as_float(f2ord(INFINITY)));
+    ST.set_rbox(FX_MAXY, t, __uint_as_float(f2ord(-INFINITY)));
+  }
+  __syncthreads();
   uint32_t carry = 0, n_runs = 0, n_segs = 0;
   for (uint32_t b0 = 0; b0 < n; b0 += NT) {
     const uint32_t i = b0 + threadIdx.x;
+    const bool in = i < n;
     bool start = true;
-    if (i < n) {
+    float4 q = make_float4(0, 0, 0, 0);
+    if (in) {
+      q = pt[i];
       csize[i] = 0;
-      if (i > 0) start = !(dist2(px[i], py[i], pz[i], px[i - 1], py[i - 1], pz[i - 1]) < r2);
+      if (i > 0) {
+        const float4 p = pt[i - 1];
+        start = !(dist2(q.x, q.y, q.z, p.x, p.y, p.z) < r2);
+      }
     }
     const unsigned long long m = __ballot(start);
     if (lane == 0) s_w[wave] = m ? (b0 + wave * 64 + (63u - (uint32_t)__clzll((long long)m))) : FX_NONE;
@@ -248,28 +268,31 @@ __device__ uint32_t cc_label(const float *px, const float *py, const float *pz, 
     __syncthreads();
     carry = last;
     // number the runs and the segments (a segment starts at a run head and every seg_len points)
-    const bool in = i < n;
     uint32_t tot_r, tot_s;
     const uint32_t r_incl = block_count_incl<NT>(in && start, s_w, tot_r);
     const bool seg_start = in && (start || ((i - head) % seg_len) == 0u);
     const uint32_t s_incl = block_count_incl<NT>(seg_start, s_w, tot_s);
     if (in) {
+      const uint32_t r = n_runs + r_incl - 1u, sg = n_segs + s_incl - 1u;
       parent[i] = head;
-      rid[i] = n_runs + r_incl - 1u;
-      if (seg_start) {
-        const uint32_t sg = n_segs + s_incl - 1u;
-        if (sg < kSegMax) {
+      rid[i] = r;
+      if (sg < kSegMax) {
+        if (seg_start) {
           ST.start(sg) = i;
-          ST.run(sg) = n_runs + r_incl - 1u;
+          ST.run(sg) = r;
+          if (start) ST.rseg(r) = sg;
         }
+        const uint32_t ox = f2ord(q.x), oy = f2ord(q.y);
+        atomicMin(&ST.w[(2 + FX_MINX) * kSegMax + 1 + sg], ox);
+        atomicMax(&ST.w[(2 + FX_MAXX) * kSegMax + 1 + sg], ox);
+        atomicMin(&ST.w[(2 + FX_MINY) * kSegMax + 1 + sg], oy);
+        atomicMax(&ST.w[(2 + FX_MAXY) * kSegMax + 1 + sg], oy);
       }
     }
     n_runs += tot_r;
     n_segs += tot_s;
   }
   const bool table = n_segs <= kSegMax;
-  __syncthreads();
-  if (table && threadIdx.x == 0) ST.start(n_segs) = n;
   __syncthreads();
   FX_STAMP(2);
   if (threadIdx.x == 0) {
@@ -278,51 +301,39 @@ __device__ uint32_t cc_label(const float *px, const float *py, const float *pz, 
     FX_COUNT(14, n_segs);
   }
   if (table) {
+    // segment boxes -> floats, folded into the run boxes
     for (uint32_t sg = threadIdx.x; sg < n_segs; sg += NT) {
-      float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
-      for (uint32_t i = ST.start(sg); i < ST.start(sg + 1); ++i) {
-        const float x = px[i], y = py[i];
-        x0 = fminf(x0, x);
-        x1 = fmaxf(x1, x);
-        y0 = fminf(y0, y);
-        y1 = fmaxf(y1, y);
+      const uint32_t r = ST.run(sg);
+#pragma unroll
+      for (uint32_t k = 0; k < 4; ++k) {
+        const uint32_t o = ST.w[(2 + k) * kSegMax + 1 + sg];
+        ST.w[(2 + k) * kSegMax + 1 + sg] = __float_as_uint(ord2f(o));
+        if (k & 1)
+          atomicMax(&ST.w[(7 + k) * kSegMax + 2 + r], o);
+        else
+          atomicMin(&ST.w[(7 + k) * kSegMax + 2 + r], o);
       }
-      ST.set_box(FX_MINX, sg, x0);
-      ST.set_box(FX_MAXX, sg, x1);
-      ST.set_box(FX_MINY, sg, y0);
-      ST.set_box(FX_MAXY, sg, y1);
+    }
+    if (threadIdx.x == 0) {
+      ST.start(n_segs) = n;
+      ST.rseg(n_runs) = n_segs;
+    }
+    __syncthreads();
+    for (uint32_t r = threadIdx.x; r < n_runs; r += NT) {
+#pragma unroll
+      for (uint32_t k = 0; k < 4; ++k) ST.w[(7 + k) * kSegMax + 2 + r] = __float_as_uint(ord2f(ST.w[(7 + k) * kSegMax + 2 + r]));
     }
     __syncthreads();
   }
   if (n_runs > 1) {
     if (table) {
-      // run level: first segment and box of every run
-      for (uint32_t sg = threadIdx.x; sg < n_segs; sg += NT)
-        if (sg == 0 || ST.run(sg) != ST.run(sg - 1)) ST.rseg(ST.run(sg)) = sg;
-      if (threadIdx.x == 0) ST.rseg(n_runs) = n_segs;
-      __syncthreads();
-      for (uint32_t r = threadIdx.x; r < n_runs; r += NT) {
-        float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
-        for (uint32_t sg = ST.rseg(r); sg < ST.rseg(r + 1); ++sg) {
-          x0 = fminf(x0, ST.box(FX_MINX, sg));
-          x1 = fmaxf(x1, ST.box(FX_MAXX, sg));
-          y0 = fminf(y0, ST.box(FX_MINY, sg));
-          y1 = fmaxf(y1, ST.box(FX_MAXY, sg));
-        }
-        ST.set_rbox(FX_MINX, r, x0);
-        ST.set_rbox(FX_MAXX, r, x1);
-        ST.set_rbox(FX_MINY, r, y0);
-        ST.set_rbox(FX_MAXY, r, y1);
-      }
-      __syncthreads();
       const float r2_pad = r2 * 1.001f;  // box distances are lower bounds; pad them against fp32 rounding
-      // every point against every later run: run box, then the run's segment boxes, then points.
       // The run loop is wave-uniform (LDS broadcast reads, four boxes in flight per trip); the
       // rare near runs are handled in the slow path below.
       for (uint32_t i0 = 0; i0 < n; i0 += NT) {
         const uint32_t i = i0 + threadIdx.x;
         const bool live = i < n;
-        const float qx = live ? px[i] : 0.f, qy = live ? py[i] : 0.f, qz = live ? pz[i] : 0.f;
+        const float4 q = live ? pt[i] : make_float4(0, 0, 0, 0);
         const uint32_t my_run = live ? rid[i] : FX_NONE;
         // runs before the smallest run id of this wave cannot be "later" for any lane
         uint32_t r_lo = my_run;
@@ -334,8 +345,8 @@ __device__ uint32_t cc_label(const float *px, const float *py, const float *pz, 
 #pragma unroll
           for (uint32_t u = 0; u < 4; ++u) {
             const uint32_t r = min(r0 + u, n_runs - 1);
-            const float dx = fmaxf(fmaxf(ST.rbox(FX_MINX, r) - qx, qx - ST.rbox(FX_MAXX, r)), 0.0f);
-            const float dy = fmaxf(fmaxf(ST.rbox(FX_MINY, r) - qy, qy - ST.rbox(FX_MAXY, r)), 0.0f);
+            const float dx = fmaxf(fmaxf(ST.rbox(FX_MINX, r) - q.x, q.x - ST.rbox(FX_MAXX, r)), 0.0f);
+            const float dy = fmaxf(fmaxf(ST.rbox(FX_MINY, r) - q.y, q.y - ST.rbox(FX_MAXY, r)), 0.0f);
             const bool ok = (r0 + u < n_runs) && (r0 + u > my_run) && !(dx * dx + dy * dy > r2_pad);
             near |= ok ? (1u << u) : 0u;
           }
@@ -346,15 +357,15 @@ __device__ uint32_t cc_label(const float *px, const float *py, const float *pz, 
             const uint32_t s0 = ST.rseg(r), s1 = ST.rseg(r + 1);
             FX_COUNT(15, 1);
             if (uf_find(parent, i) == uf_find(parent, ST.start(s0))) continue;  // already one component
-            FX_COUNT(11 + 5, 0);
             bool linked = false;
             for (uint32_t sg = s0; sg < s1 && !linked; ++sg) {
-              const float dx = fmaxf(fmaxf(ST.box(FX_MINX, sg) - qx, qx - ST.box(FX_MAXX, sg)), 0.0f);
-              const float dy = fmaxf(fmaxf(ST.box(FX_MINY, sg) - qy, qy - ST.box(FX_MAXY, sg)), 0.0f);
+              const float dx = fmaxf(fmaxf(ST.box(FX_MINX, sg) - q.x, q.x - ST.box(FX_MAXX, sg)), 0.0f);
+              const float dy = fmaxf(fmaxf(ST.box(FX_MINY, sg) - q.y, q.y - ST.box(FX_MAXY, sg)), 0.0f);
               if (dx * dx + dy * dy > r2_pad) continue;
               FX_COUNT(0, 1);
               for (uint32_t j = ST.start(sg); j < ST.start(sg + 1); ++j) {
-                if (dist2(qx, qy, qz, px[j], py[j], pz[j]) < r2) {
+                const float4 p = pt[j];
+                if (dist2(q.x, q.y, q.z, p.x, p.y, p.z) < r2) {
                   uf_union(parent, j, i);
                   linked = true;  // the two runs are one component now; more edges add nothing
                   break;
@@ -374,7 +385,10 @@ __device__ uint32_t cc_label(const float *px, const float *py, const float *pz, 
         }
         if (i + 1 >= n) break;
         const uint32_t j = i + 1 + k;
-        if (rid[i] != rid[j] && dist2(px[i], py[i], pz[i], px[j], py[j], pz[j]) < r2) uf_union(parent, j, i);
+        if (rid[i] != rid[j]) {
+          const float4 a = pt[i], b = pt[j];
+          if (dist2(a.x, a.y, a.z, b.x, b.y, b.z) < r2) uf_union(parent, j, i);
+        }
         k += NT;
       }
     }
@@ -406,11 +420,13 @@ __device__ uint32_t cc_label(const float *px, const float *py, const float *pz, 
 // std::sort(rbegin, rend, bySize): its partition phase is replayed sequentially by one lane
 // (only needed above 16 clusters), its insertion phase — a stable sort — as a parallel ranking
 // (csrc/fx_sort_replay.h).  crec[s] = (size << 16) | discovery ordinal, in the order PCL returns
-// the clusters; croot[ordinal] = root index; tmp: n words of scratch.  Returns the cluster count.
+// the clusters; croot[ordinal] = root index; tmp: scratch.  croot / crec / tmp hold ccap entries;
+// returns the cluster count, which the caller must check against ccap (nothing is written past it,
+// and nothing is ordered, when it does not fit).
 template <int NT>
 __device__ uint32_t cc_order(uint32_t n, const uint32_t *parent, const uint32_t *csize, uint32_t min_sz,
-                             uint32_t max_sz, uint32_t *croot, uint32_t *crec, uint32_t *tmp, uint32_t *s_w,
-                             unsigned long long *stamps = nullptr) {
+                             uint32_t max_sz, uint32_t *croot, uint32_t *crec, uint32_t *tmp, uint32_t ccap,
+                             uint32_t *s_w, unsigned long long *stamps = nullptr) {
   FX_STAMP_INIT(stamps);
   uint32_t n_c = 0;
   for (uint32_t b0 = 0; b0 < n; b0 += NT) {
@@ -425,13 +441,16 @@ __device__ uint32_t cc_order(uint32_t n, const uint32_t *parent, const uint32_t 
     const uint32_t r = block_rank<NT>(acc, s_w, tot);
     if (acc) {
       const uint32_t c = n_c + r;
-      croot[c] = i;
-      crec[c] = (sz << 16) | c;
+      if (c < ccap) {
+        croot[c] = i;
+        crec[c] = (sz << 16) | c;
+      }
     }
     n_c += tot;
   }
   __syncthreads();
   FX_STAMP(5);
+  if (n_c > ccap) return n_c;
   if (n_c > FX_SORT_THRESHOLD) {
     if (threadIdx.x == 0) {
       fx_sort_detail::RevView v{crec, (int)n_c};
@@ -666,43 +685,39 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_bucket(FxDevParams P, FxBu
 }
 
 // ====================================================================== stage 2b: rings
+// LDS of one ring: 7 words per point (float4 point, parent, size|position, run / member rank)
+// + 8 words per cluster (root, sort record, scratch / member offset, slot, float4 centroid).
 struct RingLds {
-  float *px, *py, *pz, *pe, *ccx, *ccy, *ccz, *cce;
-  uint32_t *parent, *csize, *rank, *croot, *crec, *cpos, *cslot, *ckoff, *s_w;
+  float4 *pt, *cc;
+  uint32_t *parent, *csize, *rank, *croot, *crec, *ckoff, *cslot, *s_w;
 };
+#define FX_RING_WORDS_PER_POINT 7
+#define FX_RING_WORDS_PER_CLUSTER 8
 template <int NT>
-__device__ __forceinline__ RingLds ring_carve(uint32_t *smem, uint32_t cap) {
+__device__ __forceinline__ RingLds ring_carve(uint32_t *smem, uint32_t cap, uint32_t ccap) {
   RingLds L;
   L.s_w = smem;
-  uint32_t *p = smem + SegCfg<NT>::kWords;
-  L.px = (float *)p, p += cap;
-  L.py = (float *)p, p += cap;
-  L.pz = (float *)p, p += cap;
-  L.pe = (float *)p, p += cap;
-  L.ccx = (float *)p, p += cap;
-  L.ccy = (float *)p, p += cap;
-  L.ccz = (float *)p, p += cap;
-  L.cce = (float *)p, p += cap;
+  uint32_t *p = smem + SegCfg<NT>::kWords;  // multiple of 4 words: the float4 arrays stay 16-byte aligned
+  L.pt = reinterpret_cast<float4 *>(p), p += 4 * cap;
+  L.cc = reinterpret_cast<float4 *>(p), p += 4 * ccap;
   L.parent = p, p += cap;
   L.csize = p, p += cap;
   L.rank = p, p += cap;
-  L.croot = p, p += cap;
-  L.crec = p, p += cap;
-  L.cpos = p, p += cap;
-  L.cslot = p, p += cap;
-  L.ckoff = p, p += cap;
+  L.croot = p, p += ccap;
+  L.crec = p, p += ccap;
+  L.ckoff = p, p += ccap;
+  L.cslot = p, p += ccap;
   return L;
 }
-#define FX_RING_WORDS_PER_POINT 16
 
 // One (scan, ring): getCylinderSegments (ref: node.cpp:261-327) on the ring's points:
 // Euclidean clustering, centroid + diameter gate, candidates in PCL's cluster order, member
-// points for keypoint_cloud.  Returns false when the ring does not fit `cap` points (the
-// caller defers it to the large tier).
+// points for keypoint_cloud.  Returns false when the ring does not fit this tier (more than
+// `cap` points or more than `ccap` size-admissible clusters): the caller defers it to a larger one.
 template <int NT>
 __device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t scan, uint32_t ring, uint32_t cap,
-                          uint32_t *smem, bool last_tier) {
-  RingLds L = ring_carve<NT>(smem, cap);
+                          uint32_t ccap, uint32_t *smem, bool last_tier) {
+  RingLds L = ring_carve<NT>(smem, cap, ccap);
   unsigned long long *const stamp_base = B.stamps ? B.stamps + (NT == 64 ? 0 : 16) : nullptr;
   FX_STAMP_INIT(stamp_base);
   const uint32_t tid = threadIdx.x;
@@ -725,71 +740,62 @@ __device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t sca
     return true;
   }
   const float4 *src = B.ring_pts + (size_t)scan * P.ring_slot_cap + off;
-  for (uint32_t i = tid; i < n; i += NT) {
-    const float4 v = src[i];
-    L.px[i] = v.x;
-    L.py[i] = v.y;
-    L.pz[i] = v.z;
-    L.pe[i] = v.w;
-  }
+  for (uint32_t i = tid; i < n; i += NT) L.pt[i] = src[i];
   __syncthreads();
   FX_STAMP(1);
 
   // ---- pcl::EuclideanClusterExtraction (ref: node.cpp:269-276)
-  const uint32_t n_segs = cc_label<NT>(L.px, L.py, L.pz, n, P.r2_cluster, L.parent, L.csize, L.rank, L.s_w, stamp_base);
-  const uint32_t n_c =
-      cc_order<NT>(n, L.parent, L.csize, P.min_count, P.max_count, L.croot, L.crec, L.ckoff, L.s_w, stamp_base);
+  const uint32_t n_segs = cc_label<NT>(L.pt, n, P.r2_cluster, L.parent, L.csize, L.rank, L.s_w, stamp_base);
+  const uint32_t n_c = cc_order<NT>(n, L.parent, L.csize, P.min_count, P.max_count, L.croot, L.crec, L.ckoff, ccap, L.s_w,
+                                    stamp_base);
+  if (n_c > ccap) return false;  // (ccap == cap in the last tier, so this cannot happen there)
 #ifdef FX_STAMPS
   stamp_prev_ = __builtin_amdgcn_s_memtime();
 #endif
-
-  // ---- xy bounding box of every admissible cluster (ref: node.cpp:289-305): min/max are exact
-  //      whatever the order, so runs (or points) fold into their cluster's box with LDS atomics.
-  //      The four arrays live where the centroids go afterwards (indexed by root here, by
-  //      cluster position there).
-  uint32_t *bminx = (uint32_t *)L.ccx, *bmaxx = (uint32_t *)L.ccy, *bminy = (uint32_t *)L.ccz,
-           *bmaxy = (uint32_t *)L.cce;
-  for (uint32_t c = tid; c < n_c; c += NT) {
-    const uint32_t root = L.croot[c];
-    bminx[root] = f2ord(1000.0f);  // ref: node.cpp:289-290 initial values
-    bmaxx[root] = f2ord(-1000.0f);
-    bminy[root] = f2ord(1000.0f);
-    bmaxy[root] = f2ord(-1000.0f);
+  // ---- cluster position in PCL's order, packed next to the size: csize[root] = size | (s + 1) << 16;
+  //      xy bounding box per cluster (ref: node.cpp:289-305) starts at the reference's +-1000
+  uint32_t *bb = reinterpret_cast<uint32_t *>(L.cc);  // [s][minx, maxx, miny, maxy] until the centroids go there
+  for (uint32_t s = tid; s < n_c; s += NT) {
+    const uint32_t root = L.croot[L.crec[s] & 0xffffu];
+    L.csize[root] |= (s + 1u) << 16;
+    bb[4 * s + 0] = f2ord(1000.0f);
+    bb[4 * s + 1] = f2ord(-1000.0f);
+    bb[4 * s + 2] = f2ord(1000.0f);
+    bb[4 * s + 3] = f2ord(-1000.0f);
   }
   __syncthreads();
+  // min/max are exact whatever the order, so segments (or points) fold into their cluster's box
   if (n_segs <= SegCfg<NT>::kMax) {
     const SegTable<NT> ST(L.s_w);
     for (uint32_t sg = tid; sg < n_segs; sg += NT) {
-      const uint32_t root = L.parent[ST.start(sg)];
-      const uint32_t sz = L.csize[root];
-      if (sz < P.min_count || sz > P.max_count) continue;
-      atomicMin(&bminx[root], f2ord(ST.box(FX_MINX, sg)));
-      atomicMax(&bmaxx[root], f2ord(ST.box(FX_MAXX, sg)));
-      atomicMin(&bminy[root], f2ord(ST.box(FX_MINY, sg)));
-      atomicMax(&bmaxy[root], f2ord(ST.box(FX_MAXY, sg)));
+      const uint32_t pos = L.csize[L.parent[ST.start(sg)]] >> 16;
+      if (pos == 0) continue;  // not a size-admissible cluster
+      uint32_t *b = bb + 4 * (pos - 1u);
+      atomicMin(&b[0], f2ord(ST.box(FX_MINX, sg)));
+      atomicMax(&b[1], f2ord(ST.box(FX_MAXX, sg)));
+      atomicMin(&b[2], f2ord(ST.box(FX_MINY, sg)));
+      atomicMax(&b[3], f2ord(ST.box(FX_MAXY, sg)));
     }
   } else {
     for (uint32_t i = tid; i < n; i += NT) {
-      const uint32_t root = L.parent[i];
-      const uint32_t sz = L.csize[root];
-      if (sz < P.min_count || sz > P.max_count) continue;
-      const uint32_t ox = f2ord(L.px[i]), oy = f2ord(L.py[i]);
-      atomicMin(&bminx[root], ox);
-      atomicMax(&bmaxx[root], ox);
-      atomicMin(&bminy[root], oy);
-      atomicMax(&bmaxy[root], oy);
+      const uint32_t pos = L.csize[L.parent[i]] >> 16;
+      if (pos == 0) continue;
+      uint32_t *b = bb + 4 * (pos - 1u);
+      const float4 q = L.pt[i];
+      atomicMin(&b[0], f2ord(q.x));
+      atomicMax(&b[1], f2ord(q.x));
+      atomicMin(&b[2], f2ord(q.y));
+      atomicMax(&b[3], f2ord(q.y));
     }
   }
   __syncthreads();
   FX_STAMP(7);
   // ---- diameter gate per cluster, in PCL's cluster order (ref: node.cpp:314-316)
   for (uint32_t s = tid; s < n_c; s += NT) {
-    const uint32_t root = L.croot[L.crec[s] & 0xffffu];
-    const double minx = ord2f(bminx[root]), maxx = ord2f(bmaxx[root]);
-    const double miny = ord2f(bminy[root]), maxy = ord2f(bmaxy[root]);
+    const double minx = ord2f(bb[4 * s + 0]), maxx = ord2f(bb[4 * s + 1]);
+    const double miny = ord2f(bb[4 * s + 2]), maxy = ord2f(bb[4 * s + 3]);
     const double ddx = maxx - minx, ddy = maxy - miny;
     const double diameter = sqrt(ddx * ddx + ddy * ddy);
-    L.cpos[root] = s;
     L.cslot[s] = (diameter < P.gate_diameter) ? 1u : 0u;
   }
   __syncthreads();
@@ -804,15 +810,13 @@ __device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t sca
     uint32_t cnt = 0;
     for (uint32_t i = root; i < n && cnt < sz; ++i) {
       if (L.parent[i] != root) continue;
-      sumx += (double)L.px[i];
-      sumy += (double)L.py[i];
-      sumz += (double)L.pz[i];
+      const float4 q = L.pt[i];
+      sumx += (double)q.x;
+      sumy += (double)q.y;
+      sumz += (double)q.z;
       L.rank[i] = cnt++;
     }
-    L.ccx[s] = (float)(sumx / (double)sz);
-    L.ccy[s] = (float)(sumy / (double)sz);
-    L.ccz[s] = (float)(sumz / (double)sz);
-    L.cce[s] = L.pe[root];
+    L.cc[s] = make_float4((float)(sumx / (double)sz), (float)(sumy / (double)sz), (float)(sumz / (double)sz), L.pt[root].w);
   }
   __syncthreads();
   FX_STAMP(9);
@@ -842,7 +846,7 @@ __device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t sca
   for (uint32_t s = tid; s < n_c; s += NT) {
     const uint32_t slot = L.cslot[s];
     if (slot < P.max_ring_cands) {
-      rc[slot] = make_float4(L.ccx[s], L.ccy[s], L.ccz[s], L.cce[s]);
+      rc[slot] = L.cc[s];
       rcs[slot] = L.crec[s] >> 16;
     }
   }
@@ -858,14 +862,13 @@ __device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t sca
     float4 *pool = B.kpc_pool + (size_t)scan * P.ring_slot_cap + off;
     uint32_t *pool_c = B.kpc_pool_cand + (size_t)scan * P.ring_slot_cap + off;
     for (uint32_t i = tid; i < n; i += NT) {
-      const uint32_t root = L.parent[i];
-      const uint32_t sz = L.csize[root];
-      if (sz < P.min_count || sz > P.max_count) continue;
-      const uint32_t s = L.cpos[root];
+      const uint32_t pos = L.csize[L.parent[i]] >> 16;
+      if (pos == 0) continue;
+      const uint32_t s = pos - 1u;
       const uint32_t slot = L.cslot[s];
       if (slot == FX_NONE) continue;
       const uint32_t dst = L.ckoff[s] + L.rank[i];
-      pool[dst] = make_float4(L.px[i], L.py[i], L.pz[i], L.pe[i]);
+      pool[dst] = L.pt[i];
       pool_c[dst] = slot;
     }
   }
@@ -878,14 +881,14 @@ __device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t sca
 // many short dependent phases of a ring cost no workgroup barriers
 #define FX_RING_SMALL_T 64
 extern "C" __global__ __launch_bounds__(FX_RING_SMALL_T) void k_rings_small(FxDevParams P, FxBuffers B, uint32_t cap,
-                                                                            uint32_t mid_cap, uint32_t n_items) {
+                                                                            uint32_t ccap, uint32_t mid_cap, uint32_t n_items) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   // persistent wavefronts: each strides over the (scan, ring) items
   for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
     const uint32_t scan = item / P.n_rings, ring = item % P.n_rings;
-    if (!ring_body<FX_RING_SMALL_T>(P, B, scan, ring, cap, smem, false)) {
+    if (!ring_body<FX_RING_SMALL_T>(P, B, scan, ring, cap, ccap, smem, false)) {
       if (threadIdx.x == 0) {
-        // too many points for one wavefront: workgroup tiers (mid: fits mid_cap, else the large one)
+        // too big for one wavefront: workgroup tiers (mid: fits mid_cap points, else the large one)
         const bool mid = B.ring_cnt[item] <= mid_cap;
         const uint32_t pos = atomicAdd(&B.counters[mid ? 0 : 5], 1u);
         (mid ? B.big_rings : B.huge_rings)[pos] = item;
@@ -894,38 +897,41 @@ extern "C" __global__ __launch_bounds__(FX_RING_SMALL_T) void k_rings_small(FxDe
     __syncthreads();
   }
 }
-extern "C" __global__ __launch_bounds__(FX_WG) void k_rings_big(FxDevParams P, FxBuffers B, uint32_t cap, uint32_t huge) {
+extern "C" __global__ __launch_bounds__(FX_WG) void k_rings_big(FxDevParams P, FxBuffers B, uint32_t cap, uint32_t ccap,
+                                                                 uint32_t huge) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const uint32_t n_big = B.counters[huge ? 5 : 0];
   const uint32_t *items = huge ? B.huge_rings : B.big_rings;
   for (uint32_t w = blockIdx.x; w < n_big; w += gridDim.x) {
     const uint32_t item = items[w];
-    ring_body<FX_WG>(P, B, item / P.n_rings, item % P.n_rings, cap, smem, true);
+    if (!ring_body<FX_WG>(P, B, item / P.n_rings, item % P.n_rings, cap, ccap, smem, huge != 0)) {
+      if (threadIdx.x == 0) {  // mid tier only: more clusters than it holds
+        const uint32_t pos = atomicAdd(&B.counters[5], 1u);
+        B.huge_rings[pos] = item;
+      }
+    }
     __syncthreads();
   }
 }
 
 // ====================================================================== stage 3: merge
 struct MergeLds {
-  float *cx, *cy, *cz, *ce, *pz;
-  uint32_t *parent, *csize, *croot, *crec, *cpos, *rid, *rbase, *s_w;
+  float4 *pt;  // (x, y, pseudo z, elevation) of each candidate
+  float *cz;   // true z
+  uint32_t *parent, *csize, *rid, *croot, *crec, *rbase, *s_w;
 };
-#define FX_MERGE_WORDS_PER_CAND 11
+#define FX_MERGE_WORDS_PER_CAND 10
 __device__ __forceinline__ MergeLds merge_carve(uint32_t *smem, uint32_t cap, uint32_t n_rings) {
   MergeLds L;
   L.s_w = smem;
   uint32_t *p = smem + SegCfg<FX_WG>::kWords;
-  L.cx = (float *)p, p += cap;
-  L.cy = (float *)p, p += cap;
+  L.pt = reinterpret_cast<float4 *>(p), p += 4 * cap;
   L.cz = (float *)p, p += cap;
-  L.ce = (float *)p, p += cap;
-  L.pz = (float *)p, p += cap;
   L.parent = p, p += cap;
   L.csize = p, p += cap;
+  L.rid = p, p += cap;
   L.croot = p, p += cap;
   L.crec = p, p += cap;
-  L.cpos = p, p += cap;
-  L.rid = p, p += cap;
   L.rbase = p, p += (n_rings + 1);
   return L;
 }
@@ -962,10 +968,7 @@ __device__ bool merge_body(const FxDevParams &P, const FxBuffers &B, uint32_t sc
     }
     return true;
   }
-  if (C > cap) {
-    if (!last_tier) return false;
-    // cap == max_candidates in the last tier, so this cannot happen
-  }
+  if (C > cap && !last_tier) return false;  // (cap == max_candidates in the last tier)
 
   float4 *cand = B.cand + (size_t)scan * P.max_candidates;
   uint32_t *cand_size = B.cand_size + (size_t)scan * P.max_candidates;
@@ -977,12 +980,9 @@ __device__ bool merge_body(const FxDevParams &P, const FxBuffers &B, uint32_t sc
     for (uint32_t j = tid; j < c; j += FX_WG) {
       const float4 v = rc[j];
       const uint32_t idx = base + j;
-      L.cx[idx] = v.x;
-      L.cy[idx] = v.y;
-      L.cz[idx] = v.z;
-      L.ce[idx] = v.w;
       // ref: node.cpp:217  z = intensity*0.75*clusterRadiusThreshold/2  (double, left to right)
-      L.pz[idx] = (float)((double)v.w * 0.75 * P.crt / 2);
+      L.pt[idx] = make_float4(v.x, v.y, (float)((double)v.w * 0.75 * P.crt / 2), v.w);
+      L.cz[idx] = v.z;
       cand[idx] = v;
       cand_size[idx] = rcs[j];
     }
@@ -991,8 +991,8 @@ __device__ bool merge_body(const FxDevParams &P, const FxBuffers &B, uint32_t sc
 
   uint32_t K = 0;
   if (C > 0) {  // ref: node.cpp:209-210
-    cc_label<FX_WG>(L.cx, L.cy, L.pz, C, P.r2_merge, L.parent, L.csize, L.rid, L.s_w);
-    const uint32_t n_c = cc_order<FX_WG>(C, L.parent, L.csize, P.ndc, P.secondary_max, L.croot, L.crec, L.rid, L.s_w);
+    cc_label<FX_WG>(L.pt, C, P.r2_merge, L.parent, L.csize, L.rid, L.s_w);
+    const uint32_t n_c = cc_order<FX_WG>(C, L.parent, L.csize, P.ndc, P.secondary_max, L.croot, L.crec, L.rid, cap, L.s_w);
     K = n_c < P.max_keypoints ? n_c : P.max_keypoints;
     if (n_c > P.max_keypoints && tid == 0) atomicOr(&B.flags[scan], FX_FLAG_KP_OVERFLOW);
     float4 *kp = B.keypoints + (size_t)scan * P.max_keypoints;
@@ -1000,31 +1000,26 @@ __device__ bool merge_body(const FxDevParams &P, const FxBuffers &B, uint32_t sc
     for (uint32_t s = tid; s < n_c; s += FX_WG) {
       const uint32_t rec = L.crec[s];
       const uint32_t sz = rec >> 16, root = L.croot[rec & 0xffffu];
-      L.cpos[root] = s;
+      L.csize[root] |= (s + 1u) << 16;  // position in PCL's order, next to the size
       if (s >= K) continue;
       double sumx = 0.0, sumy = 0.0, sumz = 0.0;
       uint32_t cnt = 0;
       for (uint32_t i = root; i < C && cnt < sz; ++i) {
         if (L.parent[i] != root) continue;
-        sumx += (double)L.cx[i];
-        sumy += (double)L.cy[i];
+        const float4 q = L.pt[i];
+        sumx += (double)q.x;
+        sumy += (double)q.y;
         sumz += (double)L.cz[i];
         ++cnt;
       }
       kp[s] = make_float4((float)(sumx / (double)sz), (float)(sumy / (double)sz), (float)(sumz / (double)sz),
-                          L.ce[root]);
+                          L.pt[root].w);
       kps[s] = sz;
     }
     __syncthreads();
     for (uint32_t i = tid; i < C; i += FX_WG) {
-      const uint32_t root = L.parent[i];
-      const uint32_t sz = L.csize[root];
-      int32_t k = -1;
-      if (sz >= P.ndc && sz <= P.secondary_max) {
-        const uint32_t s = L.cpos[root];
-        if (s < K) k = (int32_t)s;
-      }
-      cand_kp[i] = k;
+      const uint32_t pos = L.csize[L.parent[i]] >> 16;
+      cand_kp[i] = (pos != 0 && pos - 1u < K) ? (int32_t)(pos - 1u) : -1;
     }
   }
 
@@ -1792,9 +1787,11 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_pack_kp_records(FxDevParam
 // ====================================================================== launchers
 extern "C" {
 
-size_t fxk_ring_lds_bytes(uint32_t cap) { return (size_t)(SegCfg<FX_WG>::kWords + FX_RING_WORDS_PER_POINT * cap) * 4; }
-size_t fxk_ring_wave_lds_bytes(uint32_t cap) {
-  return (size_t)(SegCfg<FX_RING_SMALL_T>::kWords + FX_RING_WORDS_PER_POINT * cap) * 4;
+size_t fxk_ring_lds_bytes(uint32_t cap, uint32_t ccap) {
+  return (size_t)(SegCfg<FX_WG>::kWords + FX_RING_WORDS_PER_POINT * cap + FX_RING_WORDS_PER_CLUSTER * ccap) * 4;
+}
+size_t fxk_ring_wave_lds_bytes(uint32_t cap, uint32_t ccap) {
+  return (size_t)(SegCfg<FX_RING_SMALL_T>::kWords + FX_RING_WORDS_PER_POINT * cap + FX_RING_WORDS_PER_CLUSTER * ccap) * 4;
 }
 size_t fxk_merge_lds_bytes(uint32_t cap, uint32_t n_rings) {
   return (size_t)(SegCfg<FX_WG>::kWords + FX_MERGE_WORDS_PER_CAND * cap + n_rings + 1) * 4;
@@ -1818,15 +1815,16 @@ void fxk_bucket(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_
   const size_t lds = (16 + (size_t)P.n_rings * (2 + FX_NWAVE) + 1) * 4;
   hipLaunchKernelGGL(k_bucket, dim3(batch), dim3(FX_WG), lds, s, P, B, el0, inv_step);
 }
-void fxk_rings_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap,
+void fxk_rings_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t ccap,
                      uint32_t mid_cap, uint32_t grid) {
   const uint32_t n_items = batch * (uint32_t)P.n_rings;
   if (grid > n_items) grid = n_items;
-  hipLaunchKernelGGL(k_rings_small, dim3(grid), dim3(FX_RING_SMALL_T), fxk_ring_wave_lds_bytes(cap), s, P, B, cap, mid_cap,
-                     n_items);
+  hipLaunchKernelGGL(k_rings_small, dim3(grid), dim3(FX_RING_SMALL_T), fxk_ring_wave_lds_bytes(cap, ccap), s, P, B, cap, ccap,
+                     mid_cap, n_items);
 }
-void fxk_rings_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t grid, uint32_t huge) {
-  hipLaunchKernelGGL(k_rings_big, dim3(grid), dim3(FX_WG), fxk_ring_lds_bytes(cap), s, P, B, cap, huge);
+void fxk_rings_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t ccap, uint32_t grid,
+                   uint32_t huge) {
+  hipLaunchKernelGGL(k_rings_big, dim3(grid), dim3(FX_WG), fxk_ring_lds_bytes(cap, ccap), s, P, B, cap, ccap, huge);
 }
 void fxk_merge_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap) {
   hipLaunchKernelGGL(k_merge_small, dim3(batch), dim3(FX_WG), fxk_merge_lds_bytes(cap, P.n_rings), s, P, B, cap);
