@@ -918,7 +918,7 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_rings_big(FxDevParams P, F
 struct MergeLds {
   float4 *pt;  // (x, y, pseudo z, elevation) of each candidate
   float *cz;   // true z
-  uint32_t *parent, *csize, *rid, *croot, *crec, *rbase, *s_w;
+  uint32_t *parent, *csize, *rid, *croot, *crec, *rbase, *kbase, *s_w;
 };
 #define FX_MERGE_WORDS_PER_CAND 10
 __device__ __forceinline__ MergeLds merge_carve(uint32_t *smem, uint32_t cap, uint32_t n_rings) {
@@ -933,7 +933,21 @@ __device__ __forceinline__ MergeLds merge_carve(uint32_t *smem, uint32_t cap, ui
   L.croot = p, p += cap;
   L.crec = p, p += cap;
   L.rbase = p, p += (n_rings + 1);
+  L.kbase = p, p += (n_rings + 1);
   return L;
+}
+
+// largest r with base[r] <= idx, base = exclusive prefix with base[R] = total > idx
+__device__ __forceinline__ uint32_t prefix_owner(const uint32_t *base, uint32_t R, uint32_t idx) {
+  uint32_t lo = 0, hi = R;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (base[mid] <= idx)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return lo;
 }
 
 // One scan: keypoints_full = per-ring candidates in ring order (ref: node.cpp:205), pseudo-z,
@@ -973,19 +987,15 @@ __device__ bool merge_body(const FxDevParams &P, const FxBuffers &B, uint32_t sc
   float4 *cand = B.cand + (size_t)scan * P.max_candidates;
   uint32_t *cand_size = B.cand_size + (size_t)scan * P.max_candidates;
   int32_t *cand_kp = B.cand_kp + (size_t)scan * P.max_candidates;
-  for (uint32_t r = 0; r < R; ++r) {
-    const uint32_t c = rcnt[r], base = L.rbase[r];
-    const float4 *rc = B.ring_cand + ((size_t)scan * R + r) * P.max_ring_cands;
-    const uint32_t *rcs = B.ring_cand_size + ((size_t)scan * R + r) * P.max_ring_cands;
-    for (uint32_t j = tid; j < c; j += FX_WG) {
-      const float4 v = rc[j];
-      const uint32_t idx = base + j;
-      // ref: node.cpp:217  z = intensity*0.75*clusterRadiusThreshold/2  (double, left to right)
-      L.pt[idx] = make_float4(v.x, v.y, (float)((double)v.w * 0.75 * P.crt / 2), v.w);
-      L.cz[idx] = v.z;
-      cand[idx] = v;
-      cand_size[idx] = rcs[j];
-    }
+  // all candidates in parallel (each finds its ring in the prefix table)
+  for (uint32_t idx = tid; idx < C; idx += FX_WG) {
+    const uint32_t r = prefix_owner(L.rbase, R, idx), j = idx - L.rbase[r];
+    const float4 v = B.ring_cand[((size_t)scan * R + r) * P.max_ring_cands + j];
+    // ref: node.cpp:217  z = intensity*0.75*clusterRadiusThreshold/2  (double, left to right)
+    L.pt[idx] = make_float4(v.x, v.y, (float)((double)v.w * 0.75 * P.crt / 2), v.w);
+    L.cz[idx] = v.z;
+    cand[idx] = v;
+    cand_size[idx] = B.ring_cand_size[((size_t)scan * R + r) * P.max_ring_cands + j];
   }
   __syncthreads();
 
@@ -1031,17 +1041,24 @@ __device__ bool merge_body(const FxDevParams &P, const FxBuffers &B, uint32_t sc
   float4 *kpc = B.kpc + (size_t)scan * P.max_kpc;
   uint32_t *kpc_c = B.kpc_cand + (size_t)scan * P.max_kpc;
   uint32_t run = 0;
-  for (uint32_t r = 0; r < R; ++r) {
-    const uint32_t c = kcnt[r], o = koff[r], cb = L.rbase[r];
-    if (run + c > P.max_kpc) {
-      if (tid == 0) atomicOr(&B.flags[scan], FX_FLAG_KPC_OVERFLOW);
-      break;
-    }
-    for (uint32_t j = tid; j < c; j += FX_WG) {
-      kpc[run + j] = pool[o + j];
-      kpc_c[run + j] = cb + pool_c[o + j];
-    }
-    run += c;
+  for (uint32_t b0 = 0; b0 < R; b0 += FX_WG) {
+    const uint32_t r = b0 + tid;
+    const uint32_t c = r < R ? kcnt[r] : 0u;
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan<FX_WG>(c, L.s_w, tot);
+    if (r < R) L.kbase[r] = run + ex;
+    run += tot;
+  }
+  if (tid == 0) L.kbase[R] = run;
+  __syncthreads();
+  if (run > P.max_kpc) {
+    if (tid == 0) atomicOr(&B.flags[scan], FX_FLAG_KPC_OVERFLOW);
+    run = 0;
+  }
+  for (uint32_t t = tid; t < run; t += FX_WG) {
+    const uint32_t r = prefix_owner(L.kbase, R, t), j = t - L.kbase[r];
+    kpc[t] = pool[koff[r] + j];
+    kpc_c[t] = L.rbase[r] + pool_c[koff[r] + j];
   }
   if (tid == 0) {
     B.n_cand[scan] = C;
@@ -1794,7 +1811,7 @@ size_t fxk_ring_wave_lds_bytes(uint32_t cap, uint32_t ccap) {
   return (size_t)(SegCfg<FX_RING_SMALL_T>::kWords + FX_RING_WORDS_PER_POINT * cap + FX_RING_WORDS_PER_CLUSTER * ccap) * 4;
 }
 size_t fxk_merge_lds_bytes(uint32_t cap, uint32_t n_rings) {
-  return (size_t)(SegCfg<FX_WG>::kWords + FX_MERGE_WORDS_PER_CAND * cap + n_rings + 1) * 4;
+  return (size_t)(SegCfg<FX_WG>::kWords + FX_MERGE_WORDS_PER_CAND * cap + 2 * (n_rings + 1)) * 4;
 }
 size_t fxk_desc_lds_bytes(uint32_t cap) { return (size_t)(16 + FX_DESC_WORDS_PER_POINT * cap + FX_DESC_BINS) * 4; }
 
