@@ -293,8 +293,8 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
     FX_A(dev_alloc(c, &b.spill_w, n));
   }
   FX_A(dev_alloc(c, &b.counters, 8));
-  FX_A(dev_alloc(c, &b.stamps, 64 * 32));
-  if (hipMemset(b.stamps, 0, 64 * 32 * 8) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
+  FX_A(dev_alloc(c, &b.stamps, 64 * 64));
+  if (hipMemset(b.stamps, 0, 64 * 64 * 8) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
 
   // ---- tables
   {
@@ -602,15 +602,15 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
 }
 
 // Diagnostic (-DFX_STAMPS builds): cumulative per-phase cycle counters of the ring kernel.
-fx_status fx_debug_stamps(fx_ctx *c, unsigned long long *out32) {
+fx_status fx_debug_stamps(fx_ctx *c, unsigned long long *out32 /* 64 words */) {
   if (!c || !out32) return fail(FX_ERR_INVALID_ARG, "null argument");
   FX_HIP(hipSetDevice(c->device));
   FX_HIP(hipStreamSynchronize(c->stream));
-  std::vector<unsigned long long> all(64 * 32);
+  std::vector<unsigned long long> all(64 * 64);
   FX_HIP(hipMemcpy(all.data(), c->buf.stamps, all.size() * 8, hipMemcpyDeviceToHost));
-  for (int k = 0; k < 32; ++k) {
+  for (int k = 0; k < 64; ++k) {
     out32[k] = 0;
-    for (int w = 0; w < 64; ++w) out32[k] += all[(size_t)w * 32 + k];
+    for (int w = 0; w < 64; ++w) out32[k] += all[(size_t)w * 64 + k];
   }
   return FX_OK;
 }

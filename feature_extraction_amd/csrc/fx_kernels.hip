@@ -102,6 +102,17 @@ __device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t i) {
   }
   return i;
 }
+// Read-only variant for the final root pass: there each owner overwrites parent[i] with its root,
+// and a concurrent path-halving write from another lane could put a non-root ancestor back.
+__device__ __forceinline__ uint32_t uf_find_ro(uint32_t *parent, uint32_t i) {
+  volatile lds_u32 *p = (volatile lds_u32 *)parent;
+  uint32_t q = p[i];
+  while (q != i) {
+    i = q;
+    q = p[i];
+  }
+  return i;
+}
 __device__ __forceinline__ void uf_union(uint32_t *parent, uint32_t a, uint32_t b) {
   lds_u32 *p = (lds_u32 *)parent;
   while (true) {
@@ -126,7 +137,7 @@ __device__ __forceinline__ void uf_union(uint32_t *parent, uint32_t a, uint32_t 
   do {                                                                                      \
     if (threadIdx.x == 0 && stamps_) {                                                      \
       const unsigned long long now_ = __builtin_amdgcn_s_memtime();                         \
-      atomicAdd(&stamps_[((blockIdx.x & 63u) << 5) + (slot)], now_ - stamp_prev_);          \
+      atomicAdd(&stamps_[((blockIdx.x & 63u) << 6) + (slot)], now_ - stamp_prev_);          \
       stamp_prev_ = __builtin_amdgcn_s_memtime();                                           \
     }                                                                                       \
   } while (0)
@@ -135,7 +146,7 @@ __device__ __forceinline__ void uf_union(uint32_t *parent, uint32_t a, uint32_t 
   unsigned long long stamp_prev_ = __builtin_amdgcn_s_memtime()
 #define FX_COUNT(slot, v)                                                             \
   do {                                                                                \
-    if (stamps_) atomicAdd(&stamps_[((blockIdx.x & 63u) << 5) + (slot)], (unsigned long long)(v)); \
+    if (stamps_) atomicAdd(&stamps_[((blockIdx.x & 63u) << 6) + (slot)], (unsigned long long)(v)); \
   } while (0)
 #else
 #define FX_COUNT(slot, v)
@@ -146,10 +157,12 @@ __device__ __forceinline__ void uf_union(uint32_t *parent, uint32_t a, uint32_t 
 // Scratch words in front of the per-point arrays (NT = workgroup size of the tier):
 // [0..15] block helpers, [16..31] broadcast slots, [32..151] sort stack, [160..] segment table
 #define FX_SEG_TABLE 160
+#define FX_WAVE_QUEUE 256  // work items one wavefront can park before it drains them
 template <int NT>
 struct SegCfg {
   static constexpr uint32_t kMax = NT == 64 ? 64u : 128u;                        // segments the table holds
-  static constexpr uint32_t kWords = ((FX_SEG_TABLE + 11 * kMax + 2 + 3) / 4) * 4;  // keeps the carve 16-byte aligned
+  static constexpr uint32_t kQueue = ((FX_SEG_TABLE + 11 * kMax + 2 + 3) / 4) * 4;    // per-wave work queues start here
+  static constexpr uint32_t kWords = kQueue + (NT / 64) * FX_WAVE_QUEUE;               // multiple of 4: the carve stays 16-byte aligned
 };
 #define FX_NONE 0xffffffffu
 
@@ -326,10 +339,57 @@ __device__ uint32_t cc_label(const float4 *pt, uint32_t n, float r2, uint32_t *p
     __syncthreads();
   }
   if (n_runs > 1) {
+    // Candidate generation is wave-uniform and cheap; the expensive part (finds, segment and
+    // point scans, unions) would serialise the wavefront if done in place, one lane at a time.
+    // So each wavefront parks its (point, run) / (point, point) work items in a small LDS queue
+    // and drains it with all lanes busy on different items.
+    uint32_t *wq = s_w + SegCfg<NT>::kQueue + wave * FX_WAVE_QUEUE;
+    uint32_t wq_n = 0;
+    const float r2_pad = r2 * 1.001f;  // box distances are lower bounds; pad them against fp32 rounding
+    auto drain = [&]() {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (uint32_t t = lane; t < wq_n; t += 64) {
+        const uint32_t item = wq[t];
+        const uint32_t i = item >> 16, x = item & 0xffffu;
+        if (!table) {
+          uf_union(parent, x, i);  // (i, j) is an edge
+          continue;
+        }
+        // (point i, later run x): its segments' boxes, then their points
+        const uint32_t s0 = ST.rseg(x), s1 = ST.rseg(x + 1);
+        if (uf_find(parent, i) == uf_find(parent, ST.start(s0))) continue;  // already one component
+        const float4 q = pt[i];
+        bool linked = false;
+        for (uint32_t sg = s0; sg < s1 && !linked; ++sg) {
+          const float dx = fmaxf(fmaxf(ST.box(FX_MINX, sg) - q.x, q.x - ST.box(FX_MAXX, sg)), 0.0f);
+          const float dy = fmaxf(fmaxf(ST.box(FX_MINY, sg) - q.y, q.y - ST.box(FX_MAXY, sg)), 0.0f);
+          if (dx * dx + dy * dy > r2_pad) continue;
+          for (uint32_t j = ST.start(sg); j < ST.start(sg + 1); ++j) {
+            const float4 p = pt[j];
+            if (dist2(q.x, q.y, q.z, p.x, p.y, p.z) < r2) {
+              uf_union(parent, j, i);
+              linked = true;  // the two runs are one component now; more edges add nothing
+              break;
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      wq_n = 0;
+    };
+    auto park = [&](bool has, uint32_t item) {
+      const unsigned long long m = __ballot(has);
+      if (m) {  // wave-uniform: nothing to do in the common case
+        if (has) wq[wq_n + lanes_below(m)] = item;
+        wq_n += (uint32_t)__popcll(m);
+        if (wq_n > FX_WAVE_QUEUE - 64) drain();
+      }
+    };
     if (table) {
-      const float r2_pad = r2 * 1.001f;  // box distances are lower bounds; pad them against fp32 rounding
-      // The run loop is wave-uniform (LDS broadcast reads, four boxes in flight per trip); the
-      // rare near runs are handled in the slow path below.
+      // every point against the box of every later run; the run loop is wave-uniform (LDS
+      // broadcast reads, four boxes in flight per trip)
       for (uint32_t i0 = 0; i0 < n; i0 += NT) {
         const uint32_t i = i0 + threadIdx.x;
         const bool live = i < n;
@@ -341,64 +401,39 @@ __device__ uint32_t cc_label(const float4 *pt, uint32_t n, float r2, uint32_t *p
         for (int d = 32; d > 0; d >>= 1) r_lo = min(r_lo, (uint32_t)__shfl_xor((int)r_lo, d, 64));
         if (r_lo == FX_NONE) continue;
         for (uint32_t r0 = r_lo + 1; r0 < n_runs; r0 += 4) {
-          uint32_t near = 0;
 #pragma unroll
           for (uint32_t u = 0; u < 4; ++u) {
             const uint32_t r = min(r0 + u, n_runs - 1);
             const float dx = fmaxf(fmaxf(ST.rbox(FX_MINX, r) - q.x, q.x - ST.rbox(FX_MAXX, r)), 0.0f);
             const float dy = fmaxf(fmaxf(ST.rbox(FX_MINY, r) - q.y, q.y - ST.rbox(FX_MAXY, r)), 0.0f);
             const bool ok = (r0 + u < n_runs) && (r0 + u > my_run) && !(dx * dx + dy * dy > r2_pad);
-            near |= ok ? (1u << u) : 0u;
-          }
-          while (near) {
-            const uint32_t u = (uint32_t)__ffs((int)near) - 1u;
-            near &= near - 1u;
-            const uint32_t r = r0 + u;
-            const uint32_t s0 = ST.rseg(r), s1 = ST.rseg(r + 1);
-            FX_COUNT(15, 1);
-            if (uf_find(parent, i) == uf_find(parent, ST.start(s0))) continue;  // already one component
-            bool linked = false;
-            for (uint32_t sg = s0; sg < s1 && !linked; ++sg) {
-              const float dx = fmaxf(fmaxf(ST.box(FX_MINX, sg) - q.x, q.x - ST.box(FX_MAXX, sg)), 0.0f);
-              const float dy = fmaxf(fmaxf(ST.box(FX_MINY, sg) - q.y, q.y - ST.box(FX_MAXY, sg)), 0.0f);
-              if (dx * dx + dy * dy > r2_pad) continue;
-              FX_COUNT(0, 1);
-              for (uint32_t j = ST.start(sg); j < ST.start(sg + 1); ++j) {
-                const float4 p = pt[j];
-                if (dist2(q.x, q.y, q.z, p.x, p.y, p.z) < r2) {
-                  uf_union(parent, j, i);
-                  linked = true;  // the two runs are one component now; more edges add nothing
-                  break;
-                }
-              }
-            }
+            park(ok, (i << 16) | (r0 + u));
           }
         }
       }
     } else {
-      // every pair (i, j > i) of different runs; pairs are dealt round-robin to the threads
-      uint32_t i = 0, k = threadIdx.x;  // k = j - (i + 1)
-      while (true) {
-        while (i + 1 < n && k >= n - 1 - i) {
-          k -= n - 1 - i;
-          ++i;
+      // every pair (i, j > i) of different runs: each lane keeps its point i in registers and all
+      // lanes walk j together (LDS broadcast reads), a dozen instructions per 64 pairs
+      for (uint32_t i0 = 0; i0 < n; i0 += NT) {
+        const uint32_t i = i0 + threadIdx.x;
+        const bool live = i < n;
+        const float4 q = live ? pt[i] : make_float4(0, 0, 0, 0);
+        const uint32_t my_run = live ? rid[i] : FX_NONE;
+        for (uint32_t j = i0 + wave * 64 + 1; j < n; ++j) {
+          const float4 p = pt[j];
+          const bool edge = live && j > i && rid[j] != my_run && dist2(q.x, q.y, q.z, p.x, p.y, p.z) < r2;
+          park(edge, (i << 16) | j);
         }
-        if (i + 1 >= n) break;
-        const uint32_t j = i + 1 + k;
-        if (rid[i] != rid[j]) {
-          const float4 a = pt[i], b = pt[j];
-          if (dist2(a.x, a.y, a.z, b.x, b.y, b.z) < r2) uf_union(parent, j, i);
-        }
-        k += NT;
       }
     }
+    drain();
   }
   __syncthreads();
   FX_STAMP(3);
   // roots: run heads first (only heads are ever linked), then every point through its head
   for (uint32_t i = threadIdx.x; i < n; i += NT) {
     const bool is_head = i == 0 || rid[i] != rid[i - 1];
-    if (is_head) parent[i] = uf_find(parent, i);
+    if (is_head) parent[i] = uf_find_ro(parent, i);
   }
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < n; i += NT) {
@@ -956,6 +991,8 @@ __device__ __forceinline__ uint32_t prefix_owner(const uint32_t *base, uint32_t 
 __device__ bool merge_body(const FxDevParams &P, const FxBuffers &B, uint32_t scan, uint32_t cap, uint32_t *smem,
                            bool last_tier) {
   MergeLds L = merge_carve(smem, cap, (uint32_t)P.n_rings);
+  unsigned long long *const stamp_base = B.stamps ? B.stamps + 32 : nullptr;
+  FX_STAMP_INIT(stamp_base);
   const uint32_t tid = threadIdx.x;
   const uint32_t R = (uint32_t)P.n_rings;
   const uint32_t *rcnt = B.ring_cand_cnt + (size_t)scan * R;
@@ -999,10 +1036,15 @@ __device__ bool merge_body(const FxDevParams &P, const FxBuffers &B, uint32_t sc
   }
   __syncthreads();
 
+  FX_STAMP(1);
   uint32_t K = 0;
   if (C > 0) {  // ref: node.cpp:209-210
-    cc_label<FX_WG>(L.pt, C, P.r2_merge, L.parent, L.csize, L.rid, L.s_w);
-    const uint32_t n_c = cc_order<FX_WG>(C, L.parent, L.csize, P.ndc, P.secondary_max, L.croot, L.crec, L.rid, cap, L.s_w);
+    cc_label<FX_WG>(L.pt, C, P.r2_merge, L.parent, L.csize, L.rid, L.s_w, stamp_base);
+    const uint32_t n_c =
+        cc_order<FX_WG>(C, L.parent, L.csize, P.ndc, P.secondary_max, L.croot, L.crec, L.rid, cap, L.s_w, stamp_base);
+#ifdef FX_STAMPS
+    stamp_prev_ = __builtin_amdgcn_s_memtime();
+#endif
     K = n_c < P.max_keypoints ? n_c : P.max_keypoints;
     if (n_c > P.max_keypoints && tid == 0) atomicOr(&B.flags[scan], FX_FLAG_KP_OVERFLOW);
     float4 *kp = B.keypoints + (size_t)scan * P.max_keypoints;
@@ -1027,6 +1069,7 @@ __device__ bool merge_body(const FxDevParams &P, const FxBuffers &B, uint32_t sc
       kps[s] = sz;
     }
     __syncthreads();
+    FX_STAMP(9);
     for (uint32_t i = tid; i < C; i += FX_WG) {
       const uint32_t pos = L.csize[L.parent[i]] >> 16;
       cand_kp[i] = (pos != 0 && pos - 1u < K) ? (int32_t)(pos - 1u) : -1;
@@ -1066,6 +1109,7 @@ __device__ bool merge_body(const FxDevParams &P, const FxBuffers &B, uint32_t sc
     B.n_kpc[scan] = run;
   }
   __syncthreads();
+  FX_STAMP(11);
   return true;
 }
 
