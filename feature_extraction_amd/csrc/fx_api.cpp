@@ -31,8 +31,9 @@ void fxk_merge_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, ui
 void fxk_merge_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t grid);
 void fxk_offsets(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
 void fxk_gather(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float box_margin);
-void fxk_desc_wave(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid,
-                   uint32_t mode);
+void fxk_desc_zero(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid);
+void fxk_desc_wave(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid_fast,
+                   uint32_t grid_exact, uint32_t mode);
 void fxk_desc_wg(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t grid,
                  uint32_t mode, uint32_t from_list);
 void fxk_desc_spill(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t mode,
@@ -269,7 +270,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   FX_A(dev_alloc(c, &b.kpc, B * L.max_kpc_points));
   FX_A(dev_alloc(c, &b.kpc_cand, B * L.max_kpc_points));
   FX_A(dev_alloc(c, &b.n_kpc, B));
-  FX_A(dev_alloc(c, &b.desc, (size_t)L.max_total_keypoints * FX_DESC_FLOATS));
+  FX_A(dev_alloc(c, &b.desc, (size_t)L.max_total_keypoints * FX_DESC_FLOATS + 4));
   FX_A(dev_alloc(c, &b.flags, B));
   FX_A(dev_alloc(c, &b.big_rings, B * R));
   FX_A(dev_alloc(c, &b.huge_rings, B * R));
@@ -278,7 +279,9 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   FX_A(dev_alloc(c, &b.list_desc, L.max_total_keypoints));
   FX_A(dev_alloc(c, &b.s_pts, (size_t)L.max_total_keypoints * P.list_cap));
   FX_A(dev_alloc(c, &b.s_cnt, L.max_total_keypoints));
+  FX_A(dev_alloc(c, &b.row_map, L.max_total_keypoints));
   FX_A(dev_alloc(c, &b.spill_desc, L.max_total_keypoints));
+  FX_A(dev_alloc(c, &b.exact_desc, L.max_total_keypoints));
   {
     // spill tier: a slab of pow2(max_points) entries per workgroup (36 B per entry)
     uint32_t slab = 1;
@@ -485,15 +488,16 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
     if (P.estimate_descriptors) {
       FX_HIP(hipMemsetAsync(B.s_cnt, 0, (size_t)L.max_total_keypoints * sizeof(uint32_t), s));
       fxk_gather(s, P, B, batch, c->box_margin);
+      fxk_desc_zero(s, P, B, batch, (uint32_t)c->n_cu * 8u);
       FX_HIP(mark(6));
-      fxk_desc_wave(s, P, B, batch, desc_grid, 0);
+      fxk_desc_wave(s, P, B, batch, desc_grid, big_grid, 0);
       FX_HIP(mark(7));
       fxk_desc_wg(s, P, B, batch, P.list_cap, big_grid * 4, 0, 1);
       fxk_desc_wg(s, P, B, batch, L.max_neighbors, big_grid, 0, 0);
       fxk_desc_spill(s, P, B, batch, c->spill_grid, 0, c->spill_slab);
       fxk_rng_ord(s, P, B, batch);
       // second pass: only keypoints whose RNG ordinal moved (an earlier keypoint had no neighbours)
-      fxk_desc_wave(s, P, B, batch, desc_grid, 1);
+      fxk_desc_wave(s, P, B, batch, desc_grid, big_grid, 1);
       fxk_desc_wg(s, P, B, batch, P.list_cap, big_grid * 4, 1, 1);
       fxk_desc_wg(s, P, B, batch, L.max_neighbors, big_grid, 1, 0);
       fxk_desc_spill(s, P, B, batch, c->spill_grid, 1, c->spill_slab);

@@ -1175,8 +1175,18 @@ __device__ __forceinline__ uint32_t scan_of_row(const uint32_t *kp_offset, uint3
 
 // (j, k, l) bin and lookup-table weight of one neighbour.
 // kp = keypoint (origin), b = neighbour, xa = the keypoint's 3DSC x-axis (z component is -0).
+// FAST = false: phi / theta through fp64 atan2 / acos rounded once to fp32 (the oracle's policy).
+// FAST = true: fp32 atan2f / acosf; `amb` is raised when an angle is within FX_FAST_EPS_DEG of a
+// bin edge, i.e. when fp32 could put the neighbour into another bin than the exact evaluation
+// (everywhere else the two agree on the bin, and the bin is all that is used downstream).
+#define FX_FAST_EPS_DEG 2e-3f
+__device__ __forceinline__ bool near_multiple(float v, float step, float inv_step) {
+  const float t = v * inv_step;
+  return fabsf(t - rintf(t)) * step < FX_FAST_EPS_DEG;
+}
+template <bool FAST>
 __device__ __forceinline__ uint32_t sc3d_bin(const float4 kp, float bx, float by, float bz, float d2, const float2 xa,
-                                             const FxScTables *T, float &lut) {
+                                             const FxScTables *T, float &lut, bool &amb) {
   const float nx = 0.0f, ny = 0.0f, nz = 1.0f;  // every normal is +z (ref: node.cpp:337-340)
   const float ax = xa.x, ay = xa.y, az = -0.0f;
   const float r = sqrtf(d2);
@@ -1201,7 +1211,7 @@ __device__ __forceinline__ uint32_t sc3d_bin(const float4 kp, float bx, float by
   const float c2 = ax * p1 - ay * p0;
   const float cn = sqrtf(c0 * c0 + (c1 * c1 + c2 * c2));
   const float xd = ax * p0 + (ay * p1 + az * p2);
-  float phi = (float)atan2((double)cn, (double)xd) * 57.29578f;
+  float phi = (FAST ? atan2f(cn, xd) : (float)atan2((double)cn, (double)xd)) * 57.29578f;
   const float cdn = c0 * nx + (c1 * ny + c2 * nz);
   phi = cdn < 0.f ? (360.0f - phi) : phi;
   // theta = acos(clamp(normal . normalized(neighbour - origin))) in degrees
@@ -1218,7 +1228,12 @@ __device__ __forceinline__ uint32_t sc3d_bin(const float4 kp, float bx, float by
   float theta = nx * n0 + (ny * n1 + nz * n2);
   const float mx = (-1.0f < theta) ? theta : -1.0f;  // std::max(-1.0f, theta)
   const float tc = (mx < 1.0f) ? mx : 1.0f;          // std::min(1.0f, .)
-  theta = (float)acos((double)tc) * 57.29578f;
+  theta = (FAST ? acosf(tc) : (float)acos((double)tc)) * 57.29578f;
+  if (FAST) {
+    // edges: phi_div = 30 l, theta_div = l * (180/11) (A.8-2); non-finite angles go the exact way too
+    amb = amb || !(phi == phi) || !(theta == theta) || near_multiple(phi, 30.0f, 1.0f / 30.0f) ||
+          near_multiple(theta, 180.0f / 11.0f, 11.0f / 180.0f);
+  }
 
   uint32_t j = 0, kk = 0, l = 0;
   for (uint32_t rad = 1; rad < 16; ++rad)
@@ -1244,7 +1259,7 @@ __device__ __forceinline__ unsigned long long sc3d_key(uint32_t bin, float d2, u
 }
 
 // ---------------------------------------------------------------- k_gather
-#define FX_GATHER_SLICES 4
+#define FX_GATHER_SLICES 2
 #define FX_GATHER_BINS 64
 extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBuffers B, float box_margin) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -1260,6 +1275,9 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
   if (row0 >= P.max_total_kp) return;
   if (row0 + K > P.max_total_kp) K = P.max_total_kp - row0;
   const FxScanMeta M = B.meta[scan];
+  // row -> (scan, keypoint) map for the per-keypoint kernels (one load instead of a binary search)
+  if (slice == 0)
+    for (uint32_t k = tid; k < K; k += FX_WG) B.row_map[row0 + k] = make_uint2(scan, k);
   // keypoints of the scan -> LDS; their bounding box (ordered-uint atomics) for a cheap reject
   if (tid < 6) s_w[tid] = (tid & 1) ? f2ord(-INFINITY) : f2ord(INFINITY);
   for (uint32_t b = tid; b <= FX_GATHER_BINS; b += FX_WG) s_bin[b] = 0;
@@ -1344,35 +1362,52 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
   }
 }
 
-// ---------------------------------------------------------------- k_desc_wave
+// ---------------------------------------------------------------- k_desc_zero
+// Descriptors are sparse (a few dozen of 1980 bins): the rows of the batch are zeroed in one
+// streaming pass (16 B per lane, coalesced) and the keypoint kernels only write non-empty bins.
+extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_zero(FxDevParams P, FxBuffers B, uint32_t batch) {
+  uint32_t total = B.kp_offset[batch];
+  if (total > P.max_total_kp) total = P.max_total_kp;
+  const size_t n4 = ((size_t)total * FX_DESC_FLOATS + 3) / 4;  // B.desc is 256-byte aligned; capacity is padded
+  float4 *d = reinterpret_cast<float4 *>(B.desc);
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (size_t i = (size_t)blockIdx.x * FX_WG + threadIdx.x; i < n4; i += (size_t)gridDim.x * FX_WG) d[i] = z;
+}
+
+// ---------------------------------------------------------------- k_desc_fast / k_desc_wave
 #define FX_WAVE_CAP 256
 #define FX_WAVE_WORDS (FX_WAVE_CAP * 8)
 __device__ __forceinline__ void desc_fill_nan(float *out, uint32_t lane, uint32_t stride) {
   for (uint32_t t = lane; t < FX_DESC_FLOATS; t += stride) out[t] = t < FX_DESC_BINS ? NAN : 0.0f;
 }
 
-extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_wave(FxDevParams P, FxBuffers B, uint32_t batch,
-                                                                 uint32_t mode) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+// One wavefront per keypoint.  FAST: angles in fp32; a keypoint with any neighbour whose angle
+// lies within FX_FAST_EPS_DEG of a bin edge is not finished here but handed to the exact
+// kernel (same code with FAST = false, fp64 angles), so the result is the exact one either way.
+// from_list = 0: all keypoint rows;  1: the rows in B.exact_desc.
+template <bool FAST>
+__device__ __forceinline__ void desc_wave_body(const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t mode,
+                                               uint32_t *smem) {
   if (mode == 1 && B.counters[3] == 0) return;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t *base = smem + wave * FX_WAVE_WORDS;
-  // per-wave LDS: support set (5 arrays) + unsorted (key, weight); the sorted (key, weight)
-  // arrays reuse the support-set storage once the density counts are done
-  unsigned long long *nkey = reinterpret_cast<unsigned long long *>(base);  // 2 * CAP words
-  float *nw = reinterpret_cast<float *>(base + 2 * FX_WAVE_CAP);
-  float *sx = reinterpret_cast<float *>(base + 3 * FX_WAVE_CAP);
-  float *sy = sx + FX_WAVE_CAP, *sz = sy + FX_WAVE_CAP, *sd2 = sz + FX_WAVE_CAP;
-  uint32_t *sidx = reinterpret_cast<uint32_t *>(sd2 + FX_WAVE_CAP);
-  unsigned long long *skey = reinterpret_cast<unsigned long long *>(sx);  // aliases sx, sy
-  float *sw = sz;                                                         // aliases sz
+  // per-wave LDS: support set as float4 (x, y, z, d2) + point index, unsorted (key, weight); the
+  // sorted (key, weight) arrays reuse the support-set storage once the density counts are done
+  float4 *sp = reinterpret_cast<float4 *>(base);                                                  // 4 * CAP words
+  unsigned long long *nkey = reinterpret_cast<unsigned long long *>(base + 4 * FX_WAVE_CAP);     // 2 * CAP words
+  float *nw = reinterpret_cast<float *>(base + 6 * FX_WAVE_CAP);
+  uint32_t *sidx = base + 7 * FX_WAVE_CAP;
+  unsigned long long *skey = reinterpret_cast<unsigned long long *>(base);  // aliases sp
+  float *sw = reinterpret_cast<float *>(base + 2 * FX_WAVE_CAP);            // aliases sp
   const FxScTables *T = B.tables;
 
   uint32_t total = B.kp_offset[batch];
   if (total > P.max_total_kp) total = P.max_total_kp;
-  for (uint32_t row = blockIdx.x * FX_NWAVE + wave; row < total; row += gridDim.x * FX_NWAVE) {
-    const uint32_t scan = scan_of_row(B.kp_offset, batch, row);
-    const uint32_t k = row - B.kp_offset[scan];
+  const uint32_t n_items = FAST ? total : B.counters[7];
+  for (uint32_t it = blockIdx.x * FX_NWAVE + wave; it < n_items; it += gridDim.x * FX_NWAVE) {
+    const uint32_t row = FAST ? it : B.exact_desc[it];
+    const uint2 rm = B.row_map[row];
+    const uint32_t scan = rm.x, k = rm.y;
     uint32_t ord = k;
     if (mode == 1) {
       ord = B.rng_ord[(size_t)scan * P.max_keypoints + k];
@@ -1380,7 +1415,7 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_wave(FxDevParams P, F
     }
     const uint32_t nS = B.s_cnt[row];
     if (nS > FX_WAVE_CAP || nS > P.list_cap) {  // long (or truncated) list: workgroup tiers
-      if (lane == 0) {
+      if (FAST && lane == 0) {
         const uint32_t pos = atomicAdd(&B.counters[nS > P.list_cap ? 2 : 4], 1u);
         (nS > P.list_cap ? B.big_desc : B.list_desc)[pos] = row;
       }
@@ -1392,33 +1427,32 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_wave(FxDevParams P, F
     __builtin_amdgcn_wave_barrier();
     for (uint32_t e = lane; e < nS; e += 64) {
       const float4 v = B.s_pts[(size_t)row * P.list_cap + e];
-      sx[e] = v.x;
-      sy[e] = v.y;
-      sz[e] = v.z;
+      sp[e] = make_float4(v.x, v.y, v.z, dist2(kp.x, kp.y, kp.z, v.x, v.y, v.z));
       sidx[e] = __float_as_uint(v.w);
-      sd2[e] = dist2(kp.x, kp.y, kp.z, v.x, v.y, v.z);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // zero the output row now; the bin sums are scattered into it at the end
-    for (uint32_t t = lane; t < FX_DESC_FLOATS; t += 64) out[t] = 0.0f;
 
     uint32_t nAll = 0, nM = 0;
+    bool amb = false;
     for (uint32_t e0 = 0; e0 < nS; e0 += 64) {
       const uint32_t e = e0 + lane;
-      const float d2 = e < nS ? sd2[e] : INFINITY;
+      const float4 b = e < nS ? sp[e] : make_float4(0, 0, 0, INFINITY);
+      const float d2 = b.w;
       const bool nb = d2 < P.r2_search;
       nAll += (uint32_t)__popcll(__ballot(nb));
       const bool use = nb && !(fabsf(d2 - 0.0f) < FLT_EPSILON);  // pcl::utils::equal(nn_dists[ne], 0.0f)
       unsigned long long key = 0;
       float w = 0.f;
       if (use) {
-        const float bx = sx[e], by = sy[e], bz = sz[e];
         float lut;
-        const uint32_t bin = sc3d_bin(kp, bx, by, bz, d2, xa, T, lut);
+        const uint32_t bin = sc3d_bin<FAST>(kp, b.x, b.y, b.z, d2, xa, T, lut, amb);
         uint32_t dens = 0;  // support points within R/5 of this neighbour (itself included)
-        for (uint32_t q = 0; q < nS; ++q) dens += (dist2(bx, by, bz, sx[q], sy[q], sz[q]) < P.r2_density) ? 1u : 0u;
+        for (uint32_t q = 0; q < nS; ++q) {
+          const float4 s = sp[q];
+          dens += (dist2(b.x, b.y, b.z, s.x, s.y, s.z) < P.r2_density) ? 1u : 0u;
+        }
         w = (1.0f / (float)dens) * lut;
         key = sc3d_key(bin, d2, sidx[e]);
       }
@@ -1430,11 +1464,20 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_wave(FxDevParams P, F
       }
       nM += (uint32_t)__popcll(um);
     }
+    if (FAST && __ballot(amb)) {  // some angle too close to a bin edge for fp32: the exact kernel redoes this keypoint
+      if (lane == 0) B.exact_desc[atomicAdd(&B.counters[7], 1u)] = row;
+      continue;
+    }
     if (lane == 0) B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = nAll;
     if (nAll == 0) {  // no neighbours: NaN descriptor, no RNG draw (A.8-3)
-      __builtin_amdgcn_s_waitcnt(0);  // the zero fill first
       desc_fill_nan(out, lane, 64);
       continue;
+    }
+    // the output rows were zeroed in bulk by k_desc_zero; only the non-empty bins are written here.
+    // (second pass: the row holds the first pass's bins, so it is cleared again first)
+    if (mode == 1) {
+      for (uint32_t t = lane; t < FX_DESC_FLOATS; t += 64) out[t] = 0.0f;
+      __builtin_amdgcn_s_waitcnt(0);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1453,8 +1496,6 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_wave(FxDevParams P, F
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // the zero fill must have landed before the sums go on top of it
-    __builtin_amdgcn_s_waitcnt(0);
     for (uint32_t e0 = 0; e0 < nM; e0 += 64) {
       const uint32_t e = e0 + lane;
       if (e >= nM) continue;
@@ -1470,6 +1511,14 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_wave(FxDevParams P, F
     }
     __builtin_amdgcn_wave_barrier();
   }
+}
+extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_fast(FxDevParams P, FxBuffers B, uint32_t batch, uint32_t mode) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  desc_wave_body<true>(P, B, batch, mode, smem);
+}
+extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_wave(FxDevParams P, FxBuffers B, uint32_t batch, uint32_t mode) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  desc_wave_body<false>(P, B, batch, mode, smem);
 }
 
 // ---------------------------------------------------------------- workgroup tiers
@@ -1562,7 +1611,8 @@ __device__ bool desc_body(const FxDevParams &P, const FxBuffers &B, uint32_t row
     if (fabsf(d2 - 0.0f) < FLT_EPSILON) continue;  // pcl::utils::equal(nn_dists[ne], 0.0f)
     const float bx = L.sx[e], by = L.sy[e], bz = L.sz[e];
     float lut;
-    const uint32_t bin = sc3d_bin(kp, bx, by, bz, d2, xa, T, lut);
+    bool amb_unused = false;
+    const uint32_t bin = sc3d_bin<false>(kp, bx, by, bz, d2, xa, T, lut, amb_unused);
     uint32_t dens = 0;
     for (uint32_t q = 0; q < nS; ++q)
       dens += (dist2(bx, by, bz, L.sx[q], L.sy[q], L.sz[q]) < P.r2_density) ? 1u : 0u;
@@ -1630,8 +1680,8 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_wg(FxDevParams P, FxB
   const uint32_t *items = from_list ? B.list_desc : B.big_desc;
   for (uint32_t i = blockIdx.x; i < n_items; i += gridDim.x) {
     const uint32_t row = items[i];
-    const uint32_t scan = scan_of_row(B.kp_offset, batch, row);
-    const uint32_t k = row - B.kp_offset[scan];
+    const uint2 rm = B.row_map[row];
+    const uint32_t scan = rm.x, k = rm.y;
     const uint32_t ord = mode == 1 ? B.rng_ord[(size_t)scan * P.max_keypoints + k] : k;
     if (!desc_body(P, B, row, scan, k, ord, cap, smem, from_list != 0)) {
       if (threadIdx.x == 0) {
@@ -1670,8 +1720,8 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_spill(FxDevParams P, 
   const FxScTables *T = B.tables;
   for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
     const uint32_t row = B.spill_desc[it];
-    const uint32_t scan = scan_of_row(B.kp_offset, batch, row);
-    const uint32_t k = row - B.kp_offset[scan];
+    const uint2 rm = B.row_map[row];
+    const uint32_t scan = rm.x, k = rm.y;
     const uint32_t ord = mode == 1 ? B.rng_ord[(size_t)scan * P.max_keypoints + k] : k;
     const FxScanMeta M = B.meta[scan];
     const float4 kp = B.keypoints[(size_t)scan * P.max_keypoints + k];
@@ -1738,7 +1788,8 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_spill(FxDevParams P, 
       if (live) {
         const float d2 = sd2[e];
         float lut;
-        const uint32_t bin = sc3d_bin(kp, b.x, b.y, b.z, d2, xa, T, lut);
+        bool amb_unused = false;
+        const uint32_t bin = sc3d_bin<false>(kp, b.x, b.y, b.z, d2, xa, T, lut, amb_unused);
         nkey[m] = sc3d_key(bin, d2, __float_as_uint(b.w));
         nw[m] = (1.0f / (float)dens) * lut;
       }
@@ -1901,9 +1952,13 @@ void fxk_gather(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_
                      (16 + 80 + 5 * (size_t)P.max_keypoints + FX_GATHER_BINS) * 4, s, P, B,
                      box_margin);
 }
-void fxk_desc_wave(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid,
-                   uint32_t mode) {
-  hipLaunchKernelGGL(k_desc_wave, dim3(grid), dim3(FX_WG), (size_t)FX_NWAVE * FX_WAVE_WORDS * 4, s, P, B, batch, mode);
+void fxk_desc_zero(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid) {
+  hipLaunchKernelGGL(k_desc_zero, dim3(grid), dim3(FX_WG), 0, s, P, B, batch);
+}
+void fxk_desc_wave(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid_fast,
+                   uint32_t grid_exact, uint32_t mode) {
+  hipLaunchKernelGGL(k_desc_fast, dim3(grid_fast), dim3(FX_WG), (size_t)FX_NWAVE * FX_WAVE_WORDS * 4, s, P, B, batch, mode);
+  hipLaunchKernelGGL(k_desc_wave, dim3(grid_exact), dim3(FX_WG), (size_t)FX_NWAVE * FX_WAVE_WORDS * 4, s, P, B, batch, mode);
 }
 void fxk_desc_wg(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t grid,
                  uint32_t mode, uint32_t from_list) {
