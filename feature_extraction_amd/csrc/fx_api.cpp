@@ -18,6 +18,7 @@
 
 extern "C" {
 size_t fxk_ring_lds_bytes(uint32_t cap, uint32_t ccap);
+size_t fxk_ring_wave_lds_bytes(uint32_t cap, uint32_t ccap);
 size_t fxk_merge_lds_bytes(uint32_t cap, uint32_t n_rings);
 size_t fxk_desc_lds_bytes(uint32_t cap);
 hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t desc_big);
@@ -81,7 +82,8 @@ struct fx_ctx {
   int meta_next = 0;
   FxScanMeta *d_meta = nullptr;
   float box_margin = 0.f;
-  uint32_t ring_waves_per_cu = 12;
+  uint32_t ring_waves_per_cu = 16;
+  uint32_t desc_wgs_per_cu = 10;
   uint32_t spill_grid = 0, spill_slab = 0;
   // host-input staging
   float *d_stage = nullptr;
@@ -177,6 +179,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   c->lim = L;
   c->device = device_id;
   if (const char *e = getenv("FX_RING_WAVES_PER_CU")) c->ring_waves_per_cu = (uint32_t)atoi(e);
+  if (const char *e = getenv("FX_DESC_WGS_PER_CU")) c->desc_wgs_per_cu = (uint32_t)atoi(e);
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->n_cu = prop.multiProcessorCount;
 
@@ -470,12 +473,17 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
   if (batch) {
     const uint32_t ring_small = L.max_ring_points < kRingCapSmall ? L.max_ring_points : kRingCapSmall;
     const uint32_t merge_small = L.max_candidates < kMergeCapSmall ? L.max_candidates : kMergeCapSmall;
-    const uint32_t desc_grid = (uint32_t)c->n_cu * 8u;
+    const uint32_t desc_grid = (uint32_t)c->n_cu * c->desc_wgs_per_cu;  // resident all at once (32 KB LDS each)
     fxk_prep(s, P, B, batch);
     fxk_bucket(s, P, B, batch, (float)c->params.el0_deg, (float)(1.0 / c->params.el_step_deg));
     FX_HIP(mark(1));
     const uint32_t ring_mid = L.max_ring_points < kRingCapMid ? L.max_ring_points : kRingCapMid;
-    fxk_rings_small(s, P, B, batch, ring_small, ring_small / 4, ring_mid, (uint32_t)c->n_cu * c->ring_waves_per_cu);
+    {
+      // persistent one-wave workgroups: as many per CU as their LDS footprint admits
+      uint32_t per_cu = (uint32_t)(160 * 1024 / fxk_ring_wave_lds_bytes(ring_small, ring_small / 4));
+      if (per_cu > c->ring_waves_per_cu) per_cu = c->ring_waves_per_cu;
+      fxk_rings_small(s, P, B, batch, ring_small, ring_small / 4, ring_mid, (uint32_t)c->n_cu * per_cu);
+    }
     FX_HIP(mark(2));
     fxk_rings_big(s, P, B, ring_mid, ring_mid / 4, big_grid * 3, 0);
     fxk_rings_big(s, P, B, L.max_ring_points, L.max_ring_points, big_grid, 1);

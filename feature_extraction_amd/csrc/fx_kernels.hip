@@ -401,13 +401,18 @@ __device__ uint32_t cc_label(const float4 *pt, uint32_t n, float r2, uint32_t *p
         for (int d = 32; d > 0; d >>= 1) r_lo = min(r_lo, (uint32_t)__shfl_xor((int)r_lo, d, 64));
         if (r_lo == FX_NONE) continue;
         for (uint32_t r0 = r_lo + 1; r0 < n_runs; r0 += 4) {
+          uint32_t near = 0;
 #pragma unroll
           for (uint32_t u = 0; u < 4; ++u) {
             const uint32_t r = min(r0 + u, n_runs - 1);
             const float dx = fmaxf(fmaxf(ST.rbox(FX_MINX, r) - q.x, q.x - ST.rbox(FX_MAXX, r)), 0.0f);
             const float dy = fmaxf(fmaxf(ST.rbox(FX_MINY, r) - q.y, q.y - ST.rbox(FX_MAXY, r)), 0.0f);
             const bool ok = (r0 + u < n_runs) && (r0 + u > my_run) && !(dx * dx + dy * dy > r2_pad);
-            park(ok, (i << 16) | (r0 + u));
+            near |= ok ? (1u << u) : 0u;
+          }
+          if (__ballot(near != 0u)) {  // wave-uniform and rare
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) park((near >> u) & 1u, (i << 16) | (r0 + u));
           }
         }
       }

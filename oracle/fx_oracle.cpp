@@ -24,6 +24,9 @@
 #include <limits>
 #include <memory>
 #include <random>
+#include <atomic>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -678,6 +681,32 @@ void fxo_sort_by_size_desc(const uint32_t *sizes, uint32_t n, uint32_t *perm_out
   for (uint32_t i = 0; i < n; ++i) perm_out[i] = v[i].id;
 }
 float fxo_elevation_deg(float x, float y, float z) { return elevation_deg(x, y, z); }
+
+/* CPU baseline: `threads` host threads run the whole pipeline (kd-tree search) on the given scans,
+ * cycled, one scan per thread at a time, for about `seconds` of wall time.  Returns elapsed seconds. */
+double fxo_bench_throughput(const fx_params *p, const float *points, uint32_t n_scans, uint32_t n, uint32_t stride_floats,
+                            double roll, double pitch, uint32_t threads, double seconds, uint64_t *scans_done,
+                            uint64_t *keypoints) {
+  std::atomic<uint64_t> next(0), done(0), kps(0);
+  const auto t0 = std::chrono::steady_clock::now();
+  auto elapsed = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+  auto worker = [&]() {
+    while (elapsed() < seconds) {
+      const uint64_t i = next.fetch_add(1);
+      Result *r = run(*p, points + (size_t)(i % n_scans) * n * stride_floats, n, stride_floats, roll, pitch,
+                      FXO_SEARCH_KDTREE, FXO_TRIG_F64_ROUNDED);
+      kps.fetch_add(r->keypoints.size());
+      done.fetch_add(1);
+      delete r;
+    }
+  };
+  std::vector<std::thread> pool;
+  for (uint32_t t = 0; t < threads; ++t) pool.emplace_back(worker);
+  for (auto &t : pool) t.join();
+  *scans_done = done.load();
+  *keypoints = kps.load();
+  return elapsed();
+}
 
 /* McIlroy's "killer adversary for quicksort" run against the very std::sort call of A.6: returns
  * a size sequence that drives libstdc++'s introsort into its depth limit (heap-sort fallback),

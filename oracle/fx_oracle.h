@@ -58,6 +58,11 @@ void fxo_sort_by_size_desc(const uint32_t *sizes, uint32_t n, uint32_t *perm_out
 float fxo_elevation_deg(float x, float y, float z); /* ref: node.cpp:150-154 */
 void fxo_antiqsort(uint32_t n, uint32_t *sizes_out); /* adversarial size sequence for std::sort(rbegin, rend) */
 
+/* CPU baseline: whole pipeline (kd-tree) on cycled scans with `threads` host threads for ~`seconds`; returns elapsed s */
+double fxo_bench_throughput(const fx_params *p, const float *points, uint32_t n_scans, uint32_t n, uint32_t stride_floats,
+                            double roll, double pitch, uint32_t threads, double seconds, uint64_t *scans_done,
+                            uint64_t *keypoints);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,9 @@ def load():
     lib.fxo_elevation_deg.restype = C.c_float
     lib.fxo_elevation_deg.argtypes = [C.c_float, C.c_float, C.c_float]
     lib.fxo_antiqsort.argtypes = [C.c_uint32, _U32P]
+    lib.fxo_bench_throughput.restype = C.c_double
+    lib.fxo_bench_throughput.argtypes = [C.c_void_p, _F32P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double,
+                                         C.c_uint32, C.c_double, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     _lib = lib
     return lib
 
@@ -140,3 +143,13 @@ def antiqsort(n):
     out = np.zeros(n, np.uint32)
     load().fxo_antiqsort(n, _u(out))
     return out
+
+
+def bench_throughput(params, scans, roll, pitch, threads, seconds):
+    """(scans/s, scans done, keypoints, elapsed s) of the whole CPU pipeline on `threads` host threads."""
+    pts = np.ascontiguousarray(scans, dtype=np.float32)  # [S, N, stride]
+    S, n, stride = pts.shape
+    done, kps = C.c_uint64(0), C.c_uint64(0)
+    dt = load().fxo_bench_throughput(C.byref(params), _f(pts), S, n, stride, roll, pitch, threads, seconds,
+                                     C.byref(done), C.byref(kps))
+    return done.value / dt, done.value, kps.value, dt
