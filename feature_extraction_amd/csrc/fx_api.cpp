@@ -33,10 +33,12 @@ void fxk_merge_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint
 void fxk_offsets(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
 void fxk_gather(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float box_margin);
 void fxk_desc_zero(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid);
-void fxk_desc_wave(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid_fast,
-                   uint32_t grid_exact, uint32_t mode);
+void fxk_desc_fast(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t mode);
+void fxk_desc_exact(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t mode);
 void fxk_desc_wg(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t grid,
-                 uint32_t mode, uint32_t from_list);
+                 uint32_t mode, uint32_t src);
+void fxk_desc_wg_fast(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t grid,
+                      uint32_t mode);
 void fxk_desc_spill(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t mode,
                     uint32_t slab_pts);
 void fxk_pack_kp_records(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, void *dst,
@@ -62,7 +64,7 @@ fx_status fail(fx_status s, const std::string &msg) {
   } while (0)
 
 constexpr int kMetaSlots = 8;
-constexpr uint32_t kRingCapSmall = 256, kRingCapMid = 1024, kMergeCapSmall = 512, kListCap = 1024;
+constexpr uint32_t kRingCapSmall = 256, kRingCapMid = 640, kMergeCapSmall = 512, kListCap = 1024;
 }  // namespace
 
 struct fx_ctx {
@@ -475,45 +477,56 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
     const uint32_t merge_small = L.max_candidates < kMergeCapSmall ? L.max_candidates : kMergeCapSmall;
     const uint32_t desc_grid = (uint32_t)c->n_cu * c->desc_wgs_per_cu;  // resident all at once (32 KB LDS each)
     fxk_prep(s, P, B, batch);
-    fxk_bucket(s, P, B, batch, (float)c->params.el0_deg, (float)(1.0 / c->params.el_step_deg));
     FX_HIP(mark(1));
+    fxk_bucket(s, P, B, batch, (float)c->params.el0_deg, (float)(1.0 / c->params.el_step_deg));
+    FX_HIP(mark(2));
     const uint32_t ring_mid = L.max_ring_points < kRingCapMid ? L.max_ring_points : kRingCapMid;
     {
       // persistent one-wave workgroups: as many per CU as their LDS footprint admits
-      uint32_t per_cu = (uint32_t)(160 * 1024 / fxk_ring_wave_lds_bytes(ring_small, ring_small / 4));
+      // (LDS appears to be handed out in 2 KiB granules: a workgroup too many per CU queues behind the others)
+      uint32_t per_cu = (uint32_t)(160 * 1024 / ((fxk_ring_wave_lds_bytes(ring_small, ring_small / 4) + 2047) / 2048 * 2048));
       if (per_cu > c->ring_waves_per_cu) per_cu = c->ring_waves_per_cu;
       fxk_rings_small(s, P, B, batch, ring_small, ring_small / 4, ring_mid, (uint32_t)c->n_cu * per_cu);
     }
-    FX_HIP(mark(2));
-    fxk_rings_big(s, P, B, ring_mid, ring_mid / 4, big_grid * 3, 0);
-    fxk_rings_big(s, P, B, L.max_ring_points, L.max_ring_points, big_grid, 1);
     FX_HIP(mark(3));
-    fxk_merge_small(s, P, B, batch, merge_small);
+    {
+      uint32_t per_cu = (uint32_t)(160 * 1024 / ((fxk_ring_lds_bytes(ring_mid, ring_mid / 4) + 2047) / 2048 * 2048));
+      if (per_cu > 8) per_cu = 8;
+      if (per_cu < 1) per_cu = 1;
+      fxk_rings_big(s, P, B, ring_mid, ring_mid / 4, big_grid * per_cu, 0);
+    }
     FX_HIP(mark(4));
+    fxk_rings_big(s, P, B, L.max_ring_points, L.max_ring_points, big_grid, 1);
+    fxk_merge_small(s, P, B, batch, merge_small);
+    FX_HIP(mark(5));
     fxk_merge_big(s, P, B, L.max_candidates, big_grid);
     fxk_offsets(s, P, B, batch);
-    FX_HIP(mark(5));
     if (P.estimate_descriptors) {
       FX_HIP(hipMemsetAsync(B.s_cnt, 0, (size_t)L.max_total_keypoints * sizeof(uint32_t), s));
-      fxk_gather(s, P, B, batch, c->box_margin);
-      fxk_desc_zero(s, P, B, batch, (uint32_t)c->n_cu * 8u);
       FX_HIP(mark(6));
-      fxk_desc_wave(s, P, B, batch, desc_grid, big_grid, 0);
+      fxk_gather(s, P, B, batch, c->box_margin);
       FX_HIP(mark(7));
-      fxk_desc_wg(s, P, B, batch, P.list_cap, big_grid * 4, 0, 1);
+      fxk_desc_zero(s, P, B, batch, (uint32_t)c->n_cu * 8u);
+      FX_HIP(mark(8));
+      fxk_desc_fast(s, P, B, batch, desc_grid, 0);
+      FX_HIP(mark(9));
+      FX_HIP(mark(10));
+      fxk_desc_wg_fast(s, P, B, batch, P.list_cap, big_grid * 8, 0);
+      fxk_desc_wg(s, P, B, batch, P.list_cap, big_grid, 0, 2);
+      FX_HIP(mark(11));
       fxk_desc_wg(s, P, B, batch, L.max_neighbors, big_grid, 0, 0);
       fxk_desc_spill(s, P, B, batch, c->spill_grid, 0, c->spill_slab);
       fxk_rng_ord(s, P, B, batch);
       // second pass: only keypoints whose RNG ordinal moved (an earlier keypoint had no neighbours)
-      fxk_desc_wave(s, P, B, batch, desc_grid, big_grid, 1);
-      fxk_desc_wg(s, P, B, batch, P.list_cap, big_grid * 4, 1, 1);
+      fxk_desc_fast(s, P, B, batch, desc_grid, 1);
+      fxk_desc_wg_fast(s, P, B, batch, P.list_cap, big_grid * 8, 1);
+      fxk_desc_wg(s, P, B, batch, P.list_cap, big_grid, 1, 2);
       fxk_desc_wg(s, P, B, batch, L.max_neighbors, big_grid, 1, 0);
       fxk_desc_spill(s, P, B, batch, c->spill_grid, 1, c->spill_slab);
     } else {
-      FX_HIP(mark(6));
-      FX_HIP(mark(7));
+      for (int i = 6; i <= 11; ++i) FX_HIP(mark(i));
     }
-    FX_HIP(mark(8));
+    FX_HIP(mark(12));
     FX_HIP(hipGetLastError());
   } else {
     for (int i = 1; i <= FX_N_STAGES; ++i) FX_HIP(mark(i));
@@ -610,6 +623,15 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
   out->h_flags = c->h_flags;
   out->h_n_filtered = c->h_n_filt;
   out->h_n_kpc = c->h_n_kpc;
+  return FX_OK;
+}
+
+// Diagnostic: the work-list counters of the last batch (rings / scans / keypoint rows deferred to larger tiers).
+fx_status fx_debug_counters(fx_ctx *c, uint32_t *out8) {
+  if (!c || !out8) return fail(FX_ERR_INVALID_ARG, "null argument");
+  FX_HIP(hipSetDevice(c->device));
+  FX_HIP(hipStreamSynchronize(c->stream));
+  FX_HIP(hipMemcpy(out8, c->buf.counters, 8 * 4, hipMemcpyDeviceToHost));
   return FX_OK;
 }
 

@@ -157,7 +157,7 @@ __device__ __forceinline__ void uf_union(uint32_t *parent, uint32_t a, uint32_t 
 // Scratch words in front of the per-point arrays (NT = workgroup size of the tier):
 // [0..15] block helpers, [16..31] broadcast slots, [32..151] sort stack, [160..] segment table
 #define FX_SEG_TABLE 160
-#define FX_WAVE_QUEUE 256  // work items one wavefront can park before it drains them
+#define FX_WAVE_QUEUE 128  // work items one wavefront can park before it drains them
 template <int NT>
 struct SegCfg {
   static constexpr uint32_t kMax = NT == 64 ? 64u : 128u;                        // segments the table holds
@@ -1184,7 +1184,7 @@ __device__ __forceinline__ uint32_t scan_of_row(const uint32_t *kp_offset, uint3
 // FAST = true: fp32 atan2f / acosf; `amb` is raised when an angle is within FX_FAST_EPS_DEG of a
 // bin edge, i.e. when fp32 could put the neighbour into another bin than the exact evaluation
 // (everywhere else the two agree on the bin, and the bin is all that is used downstream).
-#define FX_FAST_EPS_DEG 2e-3f
+#define FX_FAST_EPS_DEG 5e-4f
 __device__ __forceinline__ bool near_multiple(float v, float step, float inv_step) {
   const float t = v * inv_step;
   return fabsf(t - rintf(t)) * step < FX_FAST_EPS_DEG;
@@ -1470,7 +1470,7 @@ __device__ __forceinline__ void desc_wave_body(const FxDevParams &P, const FxBuf
       nM += (uint32_t)__popcll(um);
     }
     if (FAST && __ballot(amb)) {  // some angle too close to a bin edge for fp32: the exact kernel redoes this keypoint
-      if (lane == 0) B.exact_desc[atomicAdd(&B.counters[7], 1u)] = row;
+      if (lane == 0) B.exact_desc[atomicAdd(&B.counters[7], 1u)] = row;  // the exact workgroup kernel redoes it
       continue;
     }
     if (lane == 0) B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = nAll;
@@ -1529,7 +1529,8 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_wave(FxDevParams P, F
 // ---------------------------------------------------------------- workgroup tiers
 struct DescLds {
   unsigned long long *nkey;
-  float *nw, *sx, *sy, *sz, *sd2, *img;
+  float4 *sp;  // support set (x, y, z, d2)
+  float *nw, *img;
   uint32_t *sidx, *s_w;
 };
 #define FX_DESC_WORDS_PER_POINT 8
@@ -1537,12 +1538,9 @@ __device__ __forceinline__ DescLds desc_carve(uint32_t *smem, uint32_t cap) {
   DescLds L;
   L.s_w = smem;  // 16 words
   uint32_t *p = smem + 16;
-  L.nkey = (unsigned long long *)p, p += 2 * cap;  // 8-byte aligned: 16 words in front
+  L.sp = (float4 *)p, p += 4 * cap;                // 16-byte aligned: 16 words in front
+  L.nkey = (unsigned long long *)p, p += 2 * cap;
   L.nw = (float *)p, p += cap;
-  L.sx = (float *)p, p += cap;
-  L.sy = (float *)p, p += cap;
-  L.sz = (float *)p, p += cap;
-  L.sd2 = (float *)p, p += cap;
   L.sidx = p, p += cap;
   L.img = (float *)p;  // FX_DESC_BINS floats
   return L;
@@ -1551,6 +1549,7 @@ __device__ __forceinline__ DescLds desc_carve(uint32_t *smem, uint32_t cap) {
 // One keypoint by a whole workgroup.  from_list: the support set comes from k_gather's list;
 // otherwise it is re-gathered from the scan (lists that overflowed P.list_cap).
 // Returns false if the support set does not fit `cap` (only possible when !from_list).
+template <bool FAST>
 __device__ bool desc_body(const FxDevParams &P, const FxBuffers &B, uint32_t row, uint32_t scan, uint32_t k,
                           uint32_t ord, uint32_t cap, uint32_t *smem, bool from_list) {
   DescLds L = desc_carve(smem, cap);
@@ -1566,11 +1565,8 @@ __device__ bool desc_body(const FxDevParams &P, const FxBuffers &B, uint32_t row
     nS = B.s_cnt[row];
     for (uint32_t e = tid; e < nS; e += FX_WG) {
       const float4 v = B.s_pts[(size_t)row * P.list_cap + e];
-      L.sx[e] = v.x;
-      L.sy[e] = v.y;
-      L.sz[e] = v.z;
+      L.sp[e] = make_float4(v.x, v.y, v.z, dist2(kp.x, kp.y, kp.z, v.x, v.y, v.z));
       L.sidx[e] = __float_as_uint(v.w);
-      L.sd2[e] = dist2(kp.x, kp.y, kp.z, v.x, v.y, v.z);
     }
     __syncthreads();
   } else {
@@ -1592,10 +1588,7 @@ __device__ bool desc_body(const FxDevParams &P, const FxBuffers &B, uint32_t row
         if (d < P.r2_support && isfinite(rx) && isfinite(ry) && isfinite(rz)) {
           const uint32_t pos = atomicAdd(&L.s_w[0], 1u);
           if (pos < cap) {
-            L.sx[pos] = rx;
-            L.sy[pos] = ry;
-            L.sz[pos] = rz;
-            L.sd2[pos] = d;
+            L.sp[pos] = make_float4(rx, ry, rz, d);
             L.sidx[pos] = i0 + u * FX_WG + tid;
           }
         }
@@ -1610,23 +1603,32 @@ __device__ bool desc_body(const FxDevParams &P, const FxBuffers &B, uint32_t row
   const FxScTables *T = B.tables;
   const float2 xa = B.xaxis[ord];
   for (uint32_t e = tid; e < nS; e += FX_WG) {
-    const float d2 = L.sd2[e];
+    const float4 bq = L.sp[e];
+    const float d2 = bq.w;
     if (!(d2 < P.r2_search)) continue;
     atomicAdd(&L.s_w[2], 1u);
     if (fabsf(d2 - 0.0f) < FLT_EPSILON) continue;  // pcl::utils::equal(nn_dists[ne], 0.0f)
-    const float bx = L.sx[e], by = L.sy[e], bz = L.sz[e];
+    const float bx = bq.x, by = bq.y, bz = bq.z;
     float lut;
-    bool amb_unused = false;
-    const uint32_t bin = sc3d_bin<false>(kp, bx, by, bz, d2, xa, T, lut, amb_unused);
+    bool amb = false;
+    const uint32_t bin = sc3d_bin<FAST>(kp, bx, by, bz, d2, xa, T, lut, amb);
+    if (FAST && amb) L.s_w[3] = 1u;  // some angle too close to a bin edge for fp32
     uint32_t dens = 0;
-    for (uint32_t q = 0; q < nS; ++q)
-      dens += (dist2(bx, by, bz, L.sx[q], L.sy[q], L.sz[q]) < P.r2_density) ? 1u : 0u;
+    for (uint32_t q = 0; q < nS; ++q) {
+      const float4 sq = L.sp[q];
+      dens += (dist2(bx, by, bz, sq.x, sq.y, sq.z) < P.r2_density) ? 1u : 0u;
+    }
     const uint32_t pos = atomicAdd(&L.s_w[1], 1u);
     L.nkey[pos] = sc3d_key(bin, d2, L.sidx[e]);
     L.nw[pos] = (1.0f / (float)dens) * lut;
   }
   __syncthreads();
   const uint32_t nM = L.s_w[1], nAll = L.s_w[2];
+  if (FAST && L.s_w[3]) {  // hand the keypoint to the exact kernel
+    if (tid == 0) B.exact_desc[atomicAdd(&B.counters[7], 1u)] = row;
+    __syncthreads();
+    return true;
+  }
   if (tid == 0) B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = nAll;
   if (nAll == 0) {  // no neighbours: NaN descriptor, no RNG draw (A.8-3)
     desc_fill_nan(out, tid, FX_WG);
@@ -1675,20 +1677,22 @@ __device__ bool desc_body(const FxDevParams &P, const FxBuffers &B, uint32_t row
   return true;
 }
 
-// tier 2: rows whose list is longer than a wavefront handles (list_desc), support set from the list
-// tier 3: rows whose list overflowed (big_desc), support set re-gathered from the scan
-extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_wg(FxDevParams P, FxBuffers B, uint32_t batch, uint32_t cap,
-                                                               uint32_t mode, uint32_t from_list) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+// src 0: rows whose list overflowed (big_desc): support set re-gathered from the scan, exact angles
+// src 1: rows whose list is longer than a wavefront handles (list_desc): from the list, fp32 angles
+// src 2: rows with an angle near a bin edge (exact_desc): from the list, exact angles
+template <bool FAST>
+__device__ __forceinline__ void desc_wg_loop(const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap,
+                                             uint32_t mode, uint32_t src, uint32_t *smem) {
   if (mode == 1 && B.counters[3] == 0) return;
-  const uint32_t n_items = B.counters[from_list ? 4 : 2];
-  const uint32_t *items = from_list ? B.list_desc : B.big_desc;
+  const uint32_t n_items = B.counters[src == 0 ? 2 : (src == 1 ? 4 : 7)];
+  const uint32_t *items = src == 0 ? B.big_desc : (src == 1 ? B.list_desc : B.exact_desc);
   for (uint32_t i = blockIdx.x; i < n_items; i += gridDim.x) {
     const uint32_t row = items[i];
     const uint2 rm = B.row_map[row];
     const uint32_t scan = rm.x, k = rm.y;
     const uint32_t ord = mode == 1 ? B.rng_ord[(size_t)scan * P.max_keypoints + k] : k;
-    if (!desc_body(P, B, row, scan, k, ord, cap, smem, from_list != 0)) {
+    if (B.s_cnt[row] > P.list_cap && src != 0) continue;  // (exact_desc rows always fit; list rows too)
+    if (!desc_body<FAST>(P, B, row, scan, k, ord, cap, smem, src != 0)) {
       if (threadIdx.x == 0) {
         if (B.spill_pts) {
           const uint32_t pos = atomicAdd(&B.counters[6], 1u);
@@ -1702,6 +1706,16 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_wg(FxDevParams P, FxB
     }
     __syncthreads();
   }
+}
+extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_wg(FxDevParams P, FxBuffers B, uint32_t batch, uint32_t cap,
+                                                               uint32_t mode, uint32_t src) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  desc_wg_loop<false>(P, B, batch, cap, mode, src, smem);
+}
+extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_wg_fast(FxDevParams P, FxBuffers B, uint32_t batch, uint32_t cap,
+                                                                    uint32_t mode) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  desc_wg_loop<true>(P, B, batch, cap, mode, 1u, smem);
 }
 
 // ---------------------------------------------------------------- spill tier
@@ -1960,14 +1974,19 @@ void fxk_gather(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_
 void fxk_desc_zero(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid) {
   hipLaunchKernelGGL(k_desc_zero, dim3(grid), dim3(FX_WG), 0, s, P, B, batch);
 }
-void fxk_desc_wave(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid_fast,
-                   uint32_t grid_exact, uint32_t mode) {
-  hipLaunchKernelGGL(k_desc_fast, dim3(grid_fast), dim3(FX_WG), (size_t)FX_NWAVE * FX_WAVE_WORDS * 4, s, P, B, batch, mode);
-  hipLaunchKernelGGL(k_desc_wave, dim3(grid_exact), dim3(FX_WG), (size_t)FX_NWAVE * FX_WAVE_WORDS * 4, s, P, B, batch, mode);
+void fxk_desc_fast(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t mode) {
+  hipLaunchKernelGGL(k_desc_fast, dim3(grid), dim3(FX_WG), (size_t)FX_NWAVE * FX_WAVE_WORDS * 4, s, P, B, batch, mode);
+}
+void fxk_desc_exact(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t mode) {
+  hipLaunchKernelGGL(k_desc_wave, dim3(grid), dim3(FX_WG), (size_t)FX_NWAVE * FX_WAVE_WORDS * 4, s, P, B, batch, mode);
 }
 void fxk_desc_wg(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t grid,
-                 uint32_t mode, uint32_t from_list) {
-  hipLaunchKernelGGL(k_desc_wg, dim3(grid), dim3(FX_WG), fxk_desc_lds_bytes(cap), s, P, B, batch, cap, mode, from_list);
+                 uint32_t mode, uint32_t src) {
+  hipLaunchKernelGGL(k_desc_wg, dim3(grid), dim3(FX_WG), fxk_desc_lds_bytes(cap), s, P, B, batch, cap, mode, src);
+}
+void fxk_desc_wg_fast(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t grid,
+                      uint32_t mode) {
+  hipLaunchKernelGGL(k_desc_wg_fast, dim3(grid), dim3(FX_WG), fxk_desc_lds_bytes(cap), s, P, B, batch, cap, mode);
 }
 void fxk_desc_spill(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t mode,
                     uint32_t slab_pts) {
