@@ -33,6 +33,7 @@ void fxk_merge_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint
 void fxk_offsets(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
 void fxk_gather(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float box_margin);
 void fxk_desc_zero(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid);
+void fxk_desc_group(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t mode);
 void fxk_desc_fast(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t mode);
 void fxk_desc_exact(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t mode);
 void fxk_desc_wg(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t grid,
@@ -287,6 +288,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   FX_A(dev_alloc(c, &b.row_map, L.max_total_keypoints));
   FX_A(dev_alloc(c, &b.spill_desc, L.max_total_keypoints));
   FX_A(dev_alloc(c, &b.exact_desc, L.max_total_keypoints));
+  FX_A(dev_alloc(c, &b.wave_desc, L.max_total_keypoints));
   {
     // spill tier: a slab of pow2(max_points) entries per workgroup (36 B per entry)
     uint32_t slab = 1;
@@ -300,7 +302,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
     FX_A(dev_alloc(c, &b.spill_key, n));
     FX_A(dev_alloc(c, &b.spill_w, n));
   }
-  FX_A(dev_alloc(c, &b.counters, 8));
+  FX_A(dev_alloc(c, &b.counters, 16));
   FX_A(dev_alloc(c, &b.stamps, 64 * 64));
   if (hipMemset(b.stamps, 0, 64 * 64 * 8) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
 
@@ -346,7 +348,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
                                   fxk_desc_lds_bytes(L.max_neighbors));
     if (ce != hipSuccess) return bail(fail(FX_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(ce)));
   }
-  if (hipMemset(b.counters, 0, 8 * sizeof(uint32_t)) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
+  if (hipMemset(b.counters, 0, 16 * sizeof(uint32_t)) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
   if (hipMemset(b.kp_offset, 0, (B + 1) * sizeof(uint32_t)) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
   if (hipMemset(b.n_kp, 0, B * sizeof(uint32_t)) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
 #undef FX_A
@@ -471,7 +473,7 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
   if (prof) c->ev = &c->ev_ring[(size_t)(c->ev_count % c->ev_depth) * (FX_N_STAGES + 1)];
   auto mark = [&](int i) -> hipError_t { return prof ? hipEventRecord(c->ev[i], s) : hipSuccess; };
   FX_HIP(mark(0));
-  FX_HIP(hipMemsetAsync(B.counters, 0, 8 * sizeof(uint32_t), s));
+  FX_HIP(hipMemsetAsync(B.counters, 0, 16 * sizeof(uint32_t), s));
   if (batch) {
     const uint32_t ring_small = L.max_ring_points < kRingCapSmall ? L.max_ring_points : kRingCapSmall;
     const uint32_t merge_small = L.max_candidates < kMergeCapSmall ? L.max_candidates : kMergeCapSmall;
@@ -508,8 +510,9 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
       FX_HIP(mark(7));
       fxk_desc_zero(s, P, B, batch, (uint32_t)c->n_cu * 8u);
       FX_HIP(mark(8));
-      fxk_desc_fast(s, P, B, batch, desc_grid, 0);
+      fxk_desc_group(s, P, B, batch, desc_grid, 0);
       FX_HIP(mark(9));
+      fxk_desc_fast(s, P, B, batch, big_grid * 4, 0);
       FX_HIP(mark(10));
       fxk_desc_wg_fast(s, P, B, batch, P.list_cap, big_grid * 8, 0);
       fxk_desc_wg(s, P, B, batch, P.list_cap, big_grid, 0, 2);
@@ -518,7 +521,8 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
       fxk_desc_spill(s, P, B, batch, c->spill_grid, 0, c->spill_slab);
       fxk_rng_ord(s, P, B, batch);
       // second pass: only keypoints whose RNG ordinal moved (an earlier keypoint had no neighbours)
-      fxk_desc_fast(s, P, B, batch, desc_grid, 1);
+      fxk_desc_group(s, P, B, batch, desc_grid, 1);
+      fxk_desc_fast(s, P, B, batch, big_grid * 4, 1);
       fxk_desc_wg_fast(s, P, B, batch, P.list_cap, big_grid * 8, 1);
       fxk_desc_wg(s, P, B, batch, P.list_cap, big_grid, 1, 2);
       fxk_desc_wg(s, P, B, batch, L.max_neighbors, big_grid, 1, 0);
@@ -627,11 +631,11 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
 }
 
 // Diagnostic: the work-list counters of the last batch (rings / scans / keypoint rows deferred to larger tiers).
-fx_status fx_debug_counters(fx_ctx *c, uint32_t *out8) {
+fx_status fx_debug_counters(fx_ctx *c, uint32_t *out8 /* 16 words */) {
   if (!c || !out8) return fail(FX_ERR_INVALID_ARG, "null argument");
   FX_HIP(hipSetDevice(c->device));
   FX_HIP(hipStreamSynchronize(c->stream));
-  FX_HIP(hipMemcpy(out8, c->buf.counters, 8 * 4, hipMemcpyDeviceToHost));
+  FX_HIP(hipMemcpy(out8, c->buf.counters, 16 * 4, hipMemcpyDeviceToHost));
   return FX_OK;
 }
 

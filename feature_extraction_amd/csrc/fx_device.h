@@ -85,6 +85,7 @@ struct FxBuffers {
   uint32_t *big_desc;     // [max_total_kp]  rows whose support list overflowed list_cap
   uint32_t *list_desc;    // [max_total_kp]  rows whose list is too long for one wavefront
   uint32_t *spill_desc;   // [max_total_kp]  rows whose support set does not fit LDS
+  uint32_t *wave_desc;    // [max_total_kp]  rows with 65..256 support points (one wavefront each)
   uint32_t *exact_desc;   // [max_total_kp]  rows with an angle too close to a bin edge for the fp32 pass
   // spill tier slabs, one per workgroup of k_desc_spill (null when the context has none)
   float4 *spill_pts;
@@ -97,7 +98,7 @@ struct FxBuffers {
   uint32_t *s_cnt;        // [max_total_kp]
   uint2 *row_map;         // [max_total_kp]  (scan, keypoint ordinal) of each descriptor row
   unsigned long long *stamps;  // [32] diagnostic build only (-DFX_STAMPS)
-  uint32_t *counters;     // [8]: 0 big_rings, 1 big_merge, 2 big_desc, 3 need_rng_fix, 4 list_desc, 5 huge_rings, 6 spill_desc, 7 exact_desc
+  uint32_t *counters;     // [16]: 0 big_rings, 1 big_merge, 2 big_desc, 3 need_rng_fix, 4 list_desc, 5 huge_rings, 6 spill_desc, 7 exact_desc, 8 wave_desc
 };
 
 #endif

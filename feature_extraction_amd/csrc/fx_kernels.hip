@@ -1389,7 +1389,7 @@ __device__ __forceinline__ void desc_fill_nan(float *out, uint32_t lane, uint32_
 // One wavefront per keypoint.  FAST: angles in fp32; a keypoint with any neighbour whose angle
 // lies within FX_FAST_EPS_DEG of a bin edge is not finished here but handed to the exact
 // kernel (same code with FAST = false, fp64 angles), so the result is the exact one either way.
-// from_list = 0: all keypoint rows;  1: the rows in B.exact_desc.
+// FAST: the rows in B.wave_desc (support sets of 65..256 points); exact: the rows in B.exact_desc.
 template <bool FAST>
 __device__ __forceinline__ void desc_wave_body(const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t mode,
                                                uint32_t *smem) {
@@ -1408,9 +1408,9 @@ __device__ __forceinline__ void desc_wave_body(const FxDevParams &P, const FxBuf
 
   uint32_t total = B.kp_offset[batch];
   if (total > P.max_total_kp) total = P.max_total_kp;
-  const uint32_t n_items = FAST ? total : B.counters[7];
+  const uint32_t n_items = FAST ? B.counters[8] : B.counters[7];
   for (uint32_t it = blockIdx.x * FX_NWAVE + wave; it < n_items; it += gridDim.x * FX_NWAVE) {
-    const uint32_t row = FAST ? it : B.exact_desc[it];
+    const uint32_t row = FAST ? B.wave_desc[it] : B.exact_desc[it];
     const uint2 rm = B.row_map[row];
     const uint32_t scan = rm.x, k = rm.y;
     uint32_t ord = k;
@@ -1524,6 +1524,156 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_fast(FxDevParams P, F
 extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_wave(FxDevParams P, FxBuffers B, uint32_t batch, uint32_t mode) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   desc_wave_body<false>(P, B, batch, mode, smem);
+}
+
+// ---------------------------------------------------------------- k_desc_group
+// Most keypoints have a small support set (median < 10 points on the VLP-16 scenes, 90 % < 64):
+// a whole wavefront per keypoint leaves its lanes idle and pays the per-keypoint latency 64-wide.
+// Here a wavefront works on FX_GROUPS keypoints at once, FX_GLANES lanes each (fp32 angles, same
+// exactness contract as k_desc_fast).  Rows with more than FX_GROUP_CAP support points go to the
+// wave list, rows with an angle near a bin edge to the exact list.
+#define FX_GLANES 16
+#define FX_GROUPS (64 / FX_GLANES)
+#define FX_GROUP_CAP 64
+#define FX_GROUP_WORDS (FX_GROUP_CAP * 8 + 8)  // per group: support float4, keys, weights, indices + 8 counters
+extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_group(FxDevParams P, FxBuffers B, uint32_t batch, uint32_t mode) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  if (mode == 1 && B.counters[3] == 0) return;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t gl = lane % FX_GLANES, g = lane / FX_GLANES;
+  uint32_t *base = smem + (wave * FX_GROUPS + g) * FX_GROUP_WORDS;
+  float4 *sp = reinterpret_cast<float4 *>(base);                                                   // 4 * CAP words
+  unsigned long long *nkey = reinterpret_cast<unsigned long long *>(base + 4 * FX_GROUP_CAP);      // 2 * CAP
+  float *nw = reinterpret_cast<float *>(base + 6 * FX_GROUP_CAP);
+  uint32_t *sidx = base + 7 * FX_GROUP_CAP;
+  uint32_t *cnt = base + 8 * FX_GROUP_CAP;  // [0] neighbours, [1] binned neighbours, [2] ambiguous
+  unsigned long long *skey = reinterpret_cast<unsigned long long *>(base);  // aliases sp
+  float *sw = reinterpret_cast<float *>(base + 2 * FX_GROUP_CAP);           // aliases sp
+  const FxScTables *T = B.tables;
+
+  uint32_t total = B.kp_offset[batch];
+  if (total > P.max_total_kp) total = P.max_total_kp;
+  const uint32_t stride = gridDim.x * FX_NWAVE * FX_GROUPS;
+  // all groups of a wavefront make the same number of trips (wave-level fences inside)
+  for (uint32_t r0 = (blockIdx.x * FX_NWAVE + wave) * FX_GROUPS; r0 < total; r0 += stride) {
+    const uint32_t row = r0 + g;
+    bool live = row < total;
+    uint32_t scan = 0, k = 0, ord = 0, nS = 0;
+    if (live) {
+      const uint2 rm = B.row_map[row];
+      scan = rm.x, k = rm.y, ord = k;
+      if (mode == 1) {
+        ord = B.rng_ord[(size_t)scan * P.max_keypoints + k];
+        live = ord != k;
+      }
+    }
+    if (live) {
+      nS = B.s_cnt[row];
+      if (nS > FX_GROUP_CAP || nS > P.list_cap) {  // too long for a group (or truncated): wavefront / workgroup / re-gather tiers
+        if (gl == 0) {
+          const uint32_t c = nS > P.list_cap ? 2u : (nS > FX_WAVE_CAP ? 4u : 8u);
+          uint32_t *list = nS > P.list_cap ? B.big_desc : (nS > FX_WAVE_CAP ? B.list_desc : B.wave_desc);
+          list[atomicAdd(&B.counters[c], 1u)] = row;
+        }
+        live = false;
+      }
+    }
+    const float4 kp = live ? B.keypoints[(size_t)scan * P.max_keypoints + k] : make_float4(0, 0, 0, 0);
+    const float2 xa = live ? B.xaxis[ord] : make_float2(1.f, 0.f);
+    float *out = B.desc + (size_t)row * FX_DESC_FLOATS;
+    if (!live) nS = 0;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t e = gl; e < nS; e += FX_GLANES) {
+      const float4 v = B.s_pts[(size_t)row * P.list_cap + e];
+      sp[e] = make_float4(v.x, v.y, v.z, dist2(kp.x, kp.y, kp.z, v.x, v.y, v.z));
+      sidx[e] = __float_as_uint(v.w);
+    }
+    if (gl < 3) cnt[gl] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (uint32_t e = gl; e < nS; e += FX_GLANES) {
+      const float4 b = sp[e];
+      const float d2 = b.w;
+      if (!(d2 < P.r2_search)) continue;
+      atomicAdd(&cnt[0], 1u);
+      if (fabsf(d2 - 0.0f) < FLT_EPSILON) continue;  // pcl::utils::equal(nn_dists[ne], 0.0f)
+      float lut;
+      bool amb = false;
+      const uint32_t bin = sc3d_bin<true>(kp, b.x, b.y, b.z, d2, xa, T, lut, amb);
+      if (amb) cnt[2] = 1u;
+      uint32_t dens = 0;  // support points within R/5 of this neighbour (itself included)
+      for (uint32_t q = 0; q < nS; ++q) {
+        const float4 s = sp[q];
+        dens += (dist2(b.x, b.y, b.z, s.x, s.y, s.z) < P.r2_density) ? 1u : 0u;
+      }
+      const uint32_t pos = atomicAdd(&cnt[1], 1u);
+      nkey[pos] = sc3d_key(bin, d2, sidx[e]);
+      nw[pos] = (1.0f / (float)dens) * lut;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t nAll = live ? cnt[0] : 0u;
+    uint32_t nM = live ? cnt[1] : 0u;
+    if (live && cnt[2]) {  // an angle too close to a bin edge for fp32: the exact kernel redoes this keypoint
+      if (gl == 0) B.exact_desc[atomicAdd(&B.counters[7], 1u)] = row;
+      live = false;
+      nM = 0;
+    }
+    if (live) {
+      if (gl == 0) B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = nAll;
+      if (nAll == 0) {  // no neighbours: NaN descriptor, no RNG draw (A.8-3)
+        desc_fill_nan(out, gl, FX_GLANES);
+        nM = 0;
+      } else if (mode == 1) {  // second pass: clear the first pass's bins
+        for (uint32_t t = gl; t < FX_DESC_FLOATS; t += FX_GLANES) out[t] = 0.0f;
+      }
+    }
+    if (mode == 1) __builtin_amdgcn_s_waitcnt(0);
+    // rank sort (keys are unique: they end in the point index); the sorted arrays reuse the support storage
+    unsigned long long my_key[FX_GROUP_CAP / FX_GLANES];
+    float my_w[FX_GROUP_CAP / FX_GLANES];
+    uint32_t my_rank[FX_GROUP_CAP / FX_GLANES];
+#pragma unroll
+    for (uint32_t u = 0; u < FX_GROUP_CAP / FX_GLANES; ++u) {
+      const uint32_t e = gl + u * FX_GLANES;
+      my_rank[u] = FX_NONE;
+      if (e < nM) {
+        my_key[u] = nkey[e];
+        my_w[u] = nw[e];
+        uint32_t rank = 0;
+        for (uint32_t q = 0; q < nM; ++q) rank += (nkey[q] < my_key[u]) ? 1u : 0u;
+        my_rank[u] = rank;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (uint32_t u = 0; u < FX_GROUP_CAP / FX_GLANES; ++u)
+      if (my_rank[u] != FX_NONE) {
+        skey[my_rank[u]] = my_key[u];
+        sw[my_rank[u]] = my_w[u];
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // one lane per bin run adds its weights in sorted order (the rows were zeroed by k_desc_zero)
+    for (uint32_t e = gl; e < nM; e += FX_GLANES) {
+      const uint32_t bin = (uint32_t)(skey[e] >> 52);
+      if (e > 0 && (uint32_t)(skey[e - 1] >> 52) == bin) continue;
+      float acc = 0.0f;
+      uint32_t q = e;
+      do {
+        acc += sw[q];
+        ++q;
+      } while (q < nM && (uint32_t)(skey[q] >> 52) == bin);
+      out[bin] = acc;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
 }
 
 // ---------------------------------------------------------------- workgroup tiers
@@ -1973,6 +2123,10 @@ void fxk_gather(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_
 }
 void fxk_desc_zero(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid) {
   hipLaunchKernelGGL(k_desc_zero, dim3(grid), dim3(FX_WG), 0, s, P, B, batch);
+}
+void fxk_desc_group(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t mode) {
+  hipLaunchKernelGGL(k_desc_group, dim3(grid), dim3(FX_WG), (size_t)FX_NWAVE * FX_GROUPS * FX_GROUP_WORDS * 4, s, P, B, batch,
+                     mode);
 }
 void fxk_desc_fast(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t mode) {
   hipLaunchKernelGGL(k_desc_fast, dim3(grid), dim3(FX_WG), (size_t)FX_NWAVE * FX_WAVE_WORDS * 4, s, P, B, batch, mode);

@@ -10,11 +10,11 @@ scans = [capi.synth_scan(capi.synth_cfg(1000 + b)) for b in range(B)]
 ctx = capi.Context(capi.params(preset), capi.limits(B, 28800))
 descs = ctx.make_descs([s.ctypes.data for s in scans], [len(s) for s in scans], 16, 0.02, -0.015)
 v = ctx.process_raw(descs, B, capi.FX_OUT_HOST)
-out = (C.c_uint32 * 8)()
+out = (C.c_uint32 * 16)()
 lib.fx_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
 capi.check(lib.fx_debug_counters(ctx.handle, out))
 names = ["rings -> mid tier", "scans -> big merge", "rows -> re-gather tier", "scans needing RNG fix", "rows -> list tier",
-         "rings -> large tier", "rows -> spill tier", "rows -> exact angle pass"]
+         "rings -> large tier", "rows -> spill tier", "rows -> exact angle pass", "rows -> wavefront tier"]
 print(f"batch {B} scans, {v.total_keypoints} keypoint rows, {B * 16} rings")
 for n, c in zip(names, out):
     print(f"  {n:28s} {c}")
