@@ -515,8 +515,9 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
       fxk_desc_fast(s, P, B, batch, big_grid * 4, 0);
       FX_HIP(mark(10));
       fxk_desc_wg_fast(s, P, B, batch, P.list_cap, big_grid * 8, 0);
-      fxk_desc_wg(s, P, B, batch, P.list_cap, big_grid, 0, 2);
       FX_HIP(mark(11));
+      fxk_desc_wg(s, P, B, batch, P.list_cap, big_grid, 0, 2);
+      FX_HIP(mark(12));
       fxk_desc_wg(s, P, B, batch, L.max_neighbors, big_grid, 0, 0);
       fxk_desc_spill(s, P, B, batch, c->spill_grid, 0, c->spill_slab);
       fxk_rng_ord(s, P, B, batch);
@@ -528,9 +529,9 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
       fxk_desc_wg(s, P, B, batch, L.max_neighbors, big_grid, 1, 0);
       fxk_desc_spill(s, P, B, batch, c->spill_grid, 1, c->spill_slab);
     } else {
-      for (int i = 6; i <= 11; ++i) FX_HIP(mark(i));
+      for (int i = 6; i <= 12; ++i) FX_HIP(mark(i));
     }
-    FX_HIP(mark(12));
+    FX_HIP(mark(13));
     FX_HIP(hipGetLastError());
   } else {
     for (int i = 1; i <= FX_N_STAGES; ++i) FX_HIP(mark(i));

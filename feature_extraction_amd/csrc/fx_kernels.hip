@@ -1699,10 +1699,11 @@ __device__ __forceinline__ DescLds desc_carve(uint32_t *smem, uint32_t cap) {
 // One keypoint by a whole workgroup.  from_list: the support set comes from k_gather's list;
 // otherwise it is re-gathered from the scan (lists that overflowed P.list_cap).
 // Returns false if the support set does not fit `cap` (only possible when !from_list).
-template <bool FAST>
+template <bool FAST, int NT>
 __device__ bool desc_body(const FxDevParams &P, const FxBuffers &B, uint32_t row, uint32_t scan, uint32_t k,
                           uint32_t ord, uint32_t cap, uint32_t *smem, bool from_list) {
   DescLds L = desc_carve(smem, cap);
+  FX_STAMP_INIT(B.stamps && FAST ? B.stamps + 48 : nullptr);
   const uint32_t tid = threadIdx.x;
   const FxScanMeta M = B.meta[scan];
   const float4 kp = B.keypoints[(size_t)scan * P.max_keypoints + k];
@@ -1713,7 +1714,7 @@ __device__ bool desc_body(const FxDevParams &P, const FxBuffers &B, uint32_t row
   uint32_t nS;
   if (from_list) {
     nS = B.s_cnt[row];
-    for (uint32_t e = tid; e < nS; e += FX_WG) {
+    for (uint32_t e = tid; e < nS; e += NT) {
       const float4 v = B.s_pts[(size_t)row * P.list_cap + e];
       L.sp[e] = make_float4(v.x, v.y, v.z, dist2(kp.x, kp.y, kp.z, v.x, v.y, v.z));
       L.sidx[e] = __float_as_uint(v.w);
@@ -1721,11 +1722,11 @@ __device__ bool desc_body(const FxDevParams &P, const FxBuffers &B, uint32_t row
     __syncthreads();
   } else {
     const uint32_t n = M.n;
-    for (uint32_t i0 = 0; i0 < n; i0 += FX_WG * 4) {
+    for (uint32_t i0 = 0; i0 < n; i0 += NT * 4) {
       float4 v[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const uint32_t i = i0 + u * FX_WG + tid;
+        const uint32_t i = i0 + u * NT + tid;
         v[u] = i < n ? *reinterpret_cast<const float4 *>(M.pts + (size_t)i * M.stride_f) : make_float4(NAN, NAN, NAN, 0);
       }
 #pragma unroll
@@ -1739,7 +1740,7 @@ __device__ bool desc_body(const FxDevParams &P, const FxBuffers &B, uint32_t row
           const uint32_t pos = atomicAdd(&L.s_w[0], 1u);
           if (pos < cap) {
             L.sp[pos] = make_float4(rx, ry, rz, d);
-            L.sidx[pos] = i0 + u * FX_WG + tid;
+            L.sidx[pos] = i0 + u * NT + tid;
           }
         }
       }
@@ -1748,32 +1749,66 @@ __device__ bool desc_body(const FxDevParams &P, const FxBuffers &B, uint32_t row
     nS = L.s_w[0];
     if (nS > cap) return false;  // the caller hands the keypoint to the spill tier
   }
-  for (uint32_t t = tid; t < FX_DESC_BINS; t += FX_WG) L.img[t] = 0.0f;
+  FX_STAMP(1);
+  for (uint32_t t = tid; t < FX_DESC_BINS; t += NT) L.img[t] = 0.0f;
 
   const FxScTables *T = B.tables;
   const float2 xa = B.xaxis[ord];
-  for (uint32_t e = tid; e < nS; e += FX_WG) {
-    const float4 bq = L.sp[e];
-    const float d2 = bq.w;
+  // ---- neighbours (d2 < R^2, not the keypoint itself) packed densely: nlist[m] = support position.
+  //      The list lives in the weight array and the density counters in the key array until the
+  //      per-neighbour pass below overwrites slot m with the real key and weight.
+  uint32_t *nlist = reinterpret_cast<uint32_t *>(L.nw);
+  uint32_t *dens = reinterpret_cast<uint32_t *>(L.nkey);  // dens[2 * m]
+  for (uint32_t e = tid; e < nS; e += NT) {
+    const float d2 = L.sp[e].w;
     if (!(d2 < P.r2_search)) continue;
     atomicAdd(&L.s_w[2], 1u);
     if (fabsf(d2 - 0.0f) < FLT_EPSILON) continue;  // pcl::utils::equal(nn_dists[ne], 0.0f)
-    const float bx = bq.x, by = bq.y, bz = bq.z;
-    float lut;
-    bool amb = false;
-    const uint32_t bin = sc3d_bin<FAST>(kp, bx, by, bz, d2, xa, T, lut, amb);
-    if (FAST && amb) L.s_w[3] = 1u;  // some angle too close to a bin edge for fp32
-    uint32_t dens = 0;
-    for (uint32_t q = 0; q < nS; ++q) {
-      const float4 sq = L.sp[q];
-      dens += (dist2(bx, by, bz, sq.x, sq.y, sq.z) < P.r2_density) ? 1u : 0u;
-    }
-    const uint32_t pos = atomicAdd(&L.s_w[1], 1u);
-    L.nkey[pos] = sc3d_key(bin, d2, L.sidx[e]);
-    L.nw[pos] = (1.0f / (float)dens) * lut;
+    const uint32_t m = atomicAdd(&L.s_w[1], 1u);
+    nlist[m] = e;
+    dens[2 * m] = 0u;
   }
   __syncthreads();
+  {
+    // ---- local point density = support points within R/5 of the neighbour (itself included): every
+    //      neighbour's count is split over `parts` lanes so that the whole workgroup is busy
+    const uint32_t nMq = L.s_w[1];
+    uint32_t parts = 1;
+    while (parts < 32 && nMq * parts * 2 <= (uint32_t)NT) parts <<= 1;
+    const uint32_t chunk = (nS + parts - 1) / parts;
+    for (uint32_t t = tid; t < nMq * parts; t += NT) {
+      const uint32_t m = t / parts, part = t % parts;
+      const float4 bq = L.sp[nlist[m]];
+      const uint32_t q0 = part * chunk, q1 = min(q0 + chunk, nS);
+      uint32_t c = 0;
+      for (uint32_t q = q0; q < q1; ++q) {
+        const float4 sq = L.sp[q];
+        c += (dist2(bq.x, bq.y, bq.z, sq.x, sq.y, sq.z) < P.r2_density) ? 1u : 0u;
+      }
+      if (c) atomicAdd(&dens[2 * m], c);
+    }
+    __syncthreads();
+    // ---- bins and weights, one neighbour per lane
+    for (uint32_t m = tid; m < nMq; m += NT) {
+      const uint32_t e = nlist[m];
+      const float4 bq = L.sp[e];
+      float lut;
+      bool amb = false;
+      const uint32_t bin = sc3d_bin<FAST>(kp, bq.x, bq.y, bq.z, bq.w, xa, T, lut, amb);
+      if (FAST && amb) L.s_w[3] = 1u;  // some angle too close to a bin edge for fp32
+      const uint32_t d = dens[2 * m];
+      L.nkey[m] = sc3d_key(bin, bq.w, L.sidx[e]);
+      L.nw[m] = (1.0f / (float)d) * lut;
+    }
+  }
+  __syncthreads();
+  FX_STAMP(2);
   const uint32_t nM = L.s_w[1], nAll = L.s_w[2];
+  if (tid == 0) {
+    FX_COUNT(12, 1);
+    FX_COUNT(13, nS);
+    FX_COUNT(14, nM);
+  }
   if (FAST && L.s_w[3]) {  // hand the keypoint to the exact kernel
     if (tid == 0) B.exact_desc[atomicAdd(&B.counters[7], 1u)] = row;
     __syncthreads();
@@ -1781,56 +1816,90 @@ __device__ bool desc_body(const FxDevParams &P, const FxBuffers &B, uint32_t row
   }
   if (tid == 0) B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = nAll;
   if (nAll == 0) {  // no neighbours: NaN descriptor, no RNG draw (A.8-3)
-    desc_fill_nan(out, tid, FX_WG);
+    desc_fill_nan(out, tid, NT);
     __syncthreads();
     return true;
   }
-  // ---- sort by (bin, d2, index): bitonic network in LDS
-  uint32_t p2 = 1;
-  while (p2 < nM) p2 <<= 1;
-  for (uint32_t t = nM + tid; t < p2; t += FX_WG) L.nkey[t] = ~0ull;
-  __syncthreads();
-  for (uint32_t kb = 2; kb <= p2; kb <<= 1) {
-    for (uint32_t jb = kb >> 1; jb > 0; jb >>= 1) {
-      for (uint32_t t = tid; t < p2; t += FX_WG) {
-        const uint32_t x = t ^ jb;
-        if (x > t) {
-          const unsigned long long a = L.nkey[t], b = L.nkey[x];
-          const bool up = (t & kb) == 0;
-          if ((a > b) == up) {
-            L.nkey[t] = b;
-            L.nkey[x] = a;
-            const float wa = L.nw[t];
-            L.nw[t] = L.nw[x];
-            L.nw[x] = wa;
+  // ---- sort by (bin, d2, index).  Up to 512 neighbours: ranking (every key counts the smaller
+  //      ones, the count split over lanes like the density above; keys are unique); beyond that a
+  //      bitonic network.  Either way sk / sv end up holding the sorted keys and weights.
+  const unsigned long long *sk = L.nkey;
+  const float *sv = L.nw;
+  if (nM <= 512) {
+    unsigned long long *skey = reinterpret_cast<unsigned long long *>(L.sp);  // the support set is done with
+    float *sw = reinterpret_cast<float *>(L.sp) + 2 * cap;
+    uint32_t *rank = L.sidx;
+    for (uint32_t m = tid; m < nM; m += NT) rank[m] = 0;
+    __syncthreads();
+    uint32_t parts = 1;
+    while (parts < 32 && nM * parts * 2 <= (uint32_t)NT) parts <<= 1;
+    const uint32_t chunk = (nM + parts - 1) / parts;
+    for (uint32_t t = tid; t < nM * parts; t += NT) {
+      const uint32_t m = t / parts, part = t % parts;
+      const unsigned long long key = L.nkey[m];
+      const uint32_t q0 = part * chunk, q1 = min(q0 + chunk, nM);
+      uint32_t c = 0;
+      for (uint32_t q = q0; q < q1; ++q) c += (L.nkey[q] < key) ? 1u : 0u;
+      if (c) atomicAdd(&rank[m], c);
+    }
+    __syncthreads();
+    for (uint32_t m = tid; m < nM; m += NT) {
+      skey[rank[m]] = L.nkey[m];
+      sw[rank[m]] = L.nw[m];
+    }
+    __syncthreads();
+    sk = skey;
+    sv = sw;
+  } else {
+    uint32_t p2 = 1;
+    while (p2 < nM) p2 <<= 1;
+    for (uint32_t t = nM + tid; t < p2; t += NT) L.nkey[t] = ~0ull;
+    __syncthreads();
+    for (uint32_t kb = 2; kb <= p2; kb <<= 1) {
+      for (uint32_t jb = kb >> 1; jb > 0; jb >>= 1) {
+        for (uint32_t t = tid; t < p2; t += NT) {
+          const uint32_t x = t ^ jb;
+          if (x > t) {
+            const unsigned long long a = L.nkey[t], b = L.nkey[x];
+            const bool up = (t & kb) == 0;
+            if ((a > b) == up) {
+              L.nkey[t] = b;
+              L.nkey[x] = a;
+              const float wa = L.nw[t];
+              L.nw[t] = L.nw[x];
+              L.nw[x] = wa;
+            }
           }
         }
+        __syncthreads();
       }
-      __syncthreads();
     }
   }
+  FX_STAMP(3);
   // ---- sequential fp32 accumulation per bin, in sorted order
-  for (uint32_t t = tid; t < nM; t += FX_WG) {
-    const uint32_t bin = (uint32_t)(L.nkey[t] >> 52);
-    if (t > 0 && (uint32_t)(L.nkey[t - 1] >> 52) == bin) continue;
+  for (uint32_t t = tid; t < nM; t += NT) {
+    const uint32_t bin = (uint32_t)(sk[t] >> 52);
+    if (t > 0 && (uint32_t)(sk[t - 1] >> 52) == bin) continue;
     float acc = 0.0f;
     uint32_t e = t;
     do {
-      acc += L.nw[e];
+      acc += sv[e];
       ++e;
-    } while (e < nM && (uint32_t)(L.nkey[e] >> 52) == bin);
+    } while (e < nM && (uint32_t)(sk[e] >> 52) == bin);
     L.img[bin] = acc;
   }
   __syncthreads();
-  for (uint32_t t = tid; t < FX_DESC_FLOATS; t += FX_WG) out[t] = t < FX_DESC_BINS ? L.img[t] : 0.0f;  // rf = 0
+  FX_STAMP(4);
+  for (uint32_t t = tid; t < FX_DESC_FLOATS; t += NT) out[t] = t < FX_DESC_BINS ? L.img[t] : 0.0f;  // rf = 0
   __syncthreads();
+  FX_STAMP(5);
   return true;
 }
 
 // src 0: rows whose list overflowed (big_desc): support set re-gathered from the scan, exact angles
 // src 1: rows whose list is longer than a wavefront handles (list_desc): from the list, fp32 angles
 // src 2: rows with an angle near a bin edge (exact_desc): from the list, exact angles
-template <bool FAST>
+template <bool FAST, int NT>
 __device__ __forceinline__ void desc_wg_loop(const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap,
                                              uint32_t mode, uint32_t src, uint32_t *smem) {
   if (mode == 1 && B.counters[3] == 0) return;
@@ -1842,7 +1911,7 @@ __device__ __forceinline__ void desc_wg_loop(const FxDevParams &P, const FxBuffe
     const uint32_t scan = rm.x, k = rm.y;
     const uint32_t ord = mode == 1 ? B.rng_ord[(size_t)scan * P.max_keypoints + k] : k;
     if (B.s_cnt[row] > P.list_cap && src != 0) continue;  // (exact_desc rows always fit; list rows too)
-    if (!desc_body<FAST>(P, B, row, scan, k, ord, cap, smem, src != 0)) {
+    if (!desc_body<FAST, NT>(P, B, row, scan, k, ord, cap, smem, src != 0)) {
       if (threadIdx.x == 0) {
         if (B.spill_pts) {
           const uint32_t pos = atomicAdd(&B.counters[6], 1u);
@@ -1852,20 +1921,24 @@ __device__ __forceinline__ void desc_wg_loop(const FxDevParams &P, const FxBuffe
           B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = FX_NONE;
         }
       }
-      if (!B.spill_pts) desc_fill_nan(B.desc + (size_t)row * FX_DESC_FLOATS, threadIdx.x, FX_WG);
+      if (!B.spill_pts) desc_fill_nan(B.desc + (size_t)row * FX_DESC_FLOATS, threadIdx.x, NT);
     }
     __syncthreads();
   }
 }
-extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_wg(FxDevParams P, FxBuffers B, uint32_t batch, uint32_t cap,
-                                                               uint32_t mode, uint32_t src) {
+// A long-list keypoint is a chain of dependent phases (density counts, bitonic sort, ...); wide
+// workgroups shorten the chain: 1024 threads for the fp32 pass, 512 for the register-heavier exact one.
+#define FX_DESC_WG_FAST_T 1024
+#define FX_DESC_WG_EXACT_T 512
+extern "C" __global__ __launch_bounds__(FX_DESC_WG_EXACT_T) void k_desc_wg(FxDevParams P, FxBuffers B, uint32_t batch,
+                                                                            uint32_t cap, uint32_t mode, uint32_t src) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  desc_wg_loop<false>(P, B, batch, cap, mode, src, smem);
+  desc_wg_loop<false, FX_DESC_WG_EXACT_T>(P, B, batch, cap, mode, src, smem);
 }
-extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_wg_fast(FxDevParams P, FxBuffers B, uint32_t batch, uint32_t cap,
-                                                                    uint32_t mode) {
+extern "C" __global__ __launch_bounds__(FX_DESC_WG_FAST_T) void k_desc_wg_fast(FxDevParams P, FxBuffers B, uint32_t batch,
+                                                                                uint32_t cap, uint32_t mode) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  desc_wg_loop<true>(P, B, batch, cap, mode, 1u, smem);
+  desc_wg_loop<true, FX_DESC_WG_FAST_T>(P, B, batch, cap, mode, 1u, smem);
 }
 
 // ---------------------------------------------------------------- spill tier
@@ -2136,11 +2209,11 @@ void fxk_desc_exact(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uin
 }
 void fxk_desc_wg(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t grid,
                  uint32_t mode, uint32_t src) {
-  hipLaunchKernelGGL(k_desc_wg, dim3(grid), dim3(FX_WG), fxk_desc_lds_bytes(cap), s, P, B, batch, cap, mode, src);
+  hipLaunchKernelGGL(k_desc_wg, dim3(grid), dim3(FX_DESC_WG_EXACT_T), fxk_desc_lds_bytes(cap), s, P, B, batch, cap, mode, src);
 }
 void fxk_desc_wg_fast(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t grid,
                       uint32_t mode) {
-  hipLaunchKernelGGL(k_desc_wg_fast, dim3(grid), dim3(FX_WG), fxk_desc_lds_bytes(cap), s, P, B, batch, cap, mode);
+  hipLaunchKernelGGL(k_desc_wg_fast, dim3(grid), dim3(FX_DESC_WG_FAST_T), fxk_desc_lds_bytes(cap), s, P, B, batch, cap, mode);
 }
 void fxk_desc_spill(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t mode,
                     uint32_t slab_pts) {

@@ -35,3 +35,11 @@ for tier, base in (("wave tier (n <= 256)", 0), ("workgroup tiers", 16), ("merge
     if cnt:
         print(f"   rings {cnt / 3:.0f}/batch  runs/ring {v[base + 13] / cnt:.1f}  segs/ring {v[base + 14] / cnt:.1f}  "
               f"near (point,run) pairs/ring {v[base + 15] / cnt:.1f}  near segments scanned/ring {v[base + 0] / cnt:.1f}")
+
+base = 48
+tot = v[base:base + 12].sum()
+rows = max(v[base + 12], 1)
+print(f"-- long-list descriptor tier (fp32 pass): {rows / 3:.0f} rows/batch, support {v[base + 13] / rows:.0f}, neighbours {v[base + 14] / rows:.0f}, "
+      f"{tot / rows:.0f} cycles per row")
+for k, nm in {1: "load list", 2: "bins + density", 3: "bitonic sort", 4: "bin sums", 5: "row write"}.items():
+    print(f"   {nm:24s} {v[base + k] / max(tot, 1) * 100:6.2f} %   {v[base + k] / rows:10.0f}")
