@@ -69,6 +69,11 @@ class FxBatchView(C.Structure):
                 ("h_kp_neighbors", _U32P)]
 
 
+class FxPc2Layout(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in
+                ("point_step", "offset_x", "offset_y", "offset_z", "offset_intensity", "is_bigendian")]
+
+
 class FxTimings(C.Structure):
     _fields_ = [("ms", C.c_float * FX_N_STAGES), ("total_ms", C.c_float)]
 
@@ -85,7 +90,8 @@ EXPORTS = ("fx_version", "fx_status_str", "fx_last_error", "fx_params_default", 
            "fx_limits_default", "fx_create", "fx_destroy", "fx_set_stream", "fx_set_profiling", "fx_get_timings",
            "fx_get_limits", "fx_process_batch", "fx_synchronize", "fx_pack_features", "fx_pack_keypoint_records",
            "fx_rotation_from_roll_pitch", "fx_sc3d_tables", "fx_sc3d_xaxis", "fx_synth_cfg_vlp16",
-           "fx_synth_scan", "fx_test_sort_replay", "fx_test_sort_replay_ranked")
+           "fx_synth_scan", "fx_test_sort_replay", "fx_test_sort_replay_ranked", "fx_unpack_pointcloud2",
+           "fx_pack_pointxyzi")
 
 _lib = None
 
@@ -95,6 +101,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # When torch is going to be used in the same process (tests, bench.py) it must be imported
+        # before libfx_hip.so is loaded: both link libamdhip64 and the process must end up with ONE HIP
+        # runtime; with the other order the second runtime to initialise finds no device.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -131,6 +144,8 @@ def load():
     lib.fx_synth_cfg_vlp16.restype = None
     lib.fx_synth_scan.argtypes = [C.POINTER(FxSynthCfg), _F32P, C.c_uint32]
     lib.fx_synth_scan.restype = C.c_uint32
+    lib.fx_unpack_pointcloud2.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(FxPc2Layout), C.c_void_p]
+    lib.fx_pack_pointxyzi.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, _U32P]
     lib.fx_test_sort_replay.argtypes = [_U32P, C.c_uint32, _U32P]
     lib.fx_test_sort_replay.restype = None
     lib.fx_test_sort_replay_ranked.argtypes = [_U32P, C.c_uint32, _U32P]

@@ -45,6 +45,9 @@ void fxk_desc_spill(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uin
 void fxk_pack_kp_records(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, void *dst,
                          uint32_t rec_kp);
 void fxk_rng_ord(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
+void fxk_unpack_pc2(hipStream_t s, const void *src, uint32_t n, uint32_t point_step, uint32_t ox, uint32_t oy, uint32_t oz,
+                    uint32_t oi, uint32_t big_endian, void *dst, uint32_t grid);
+void fxk_pack_xyzi32(hipStream_t s, const void *src, uint32_t n, void *dst, uint32_t grid);
 void fxk_pack_features(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, void *dst,
                        uint32_t capacity, uint32_t grid);
 }
@@ -659,6 +662,49 @@ fx_status fx_pack_keypoint_records(fx_ctx *c, void *dst_device, uint32_t rec_key
   FX_HIP(hipSetDevice(c->device));
   if (c->last_batch) fxk_pack_kp_records(c->stream, c->dp, c->buf, c->last_batch, dst_device, rec_keypoints);
   FX_HIP(hipGetLastError());
+  return FX_OK;
+}
+
+fx_status fx_unpack_pointcloud2(fx_ctx *c, const void *data_device, uint32_t n_points, const fx_pc2_layout *lay,
+                                void *dst_device_xyzi) {
+  if (!c || !lay || (n_points && (!data_device || !dst_device_xyzi))) return fail(FX_ERR_INVALID_ARG, "null argument");
+  const uint32_t offs[3] = {lay->offset_x, lay->offset_y, lay->offset_z};
+  for (uint32_t o : offs)
+    if (o + 4 > lay->point_step) return fail(FX_ERR_INVALID_ARG, "field offset outside the point record");
+  if (lay->offset_intensity != 0xffffffffu && lay->offset_intensity + 4 > lay->point_step)
+    return fail(FX_ERR_INVALID_ARG, "intensity offset outside the point record");
+  if (((uintptr_t)dst_device_xyzi % 16) != 0) return fail(FX_ERR_INVALID_ARG, "dst must be 16-byte aligned");
+  FX_HIP(hipSetDevice(c->device));
+  if (n_points)
+    fxk_unpack_pc2(c->stream, data_device, n_points, lay->point_step, lay->offset_x, lay->offset_y, lay->offset_z,
+                   lay->offset_intensity, lay->is_bigendian, dst_device_xyzi, (uint32_t)c->n_cu * 8u);
+  FX_HIP(hipGetLastError());
+  return FX_OK;
+}
+
+fx_status fx_pack_pointxyzi(fx_ctx *c, uint32_t which, uint32_t scan, void *dst_device, uint32_t capacity_points,
+                            uint32_t *n_points_out) {
+  if (!c || !dst_device || !n_points_out) return fail(FX_ERR_INVALID_ARG, "null argument");
+  if (scan >= c->last_batch) return fail(FX_ERR_INVALID_ARG, "scan index outside the last batch");
+  if (((uintptr_t)dst_device % 16) != 0) return fail(FX_ERR_INVALID_ARG, "dst must be 16-byte aligned");
+  FX_HIP(hipSetDevice(c->device));
+  const FxBuffers &B = c->buf;
+  const fx_limits &L = c->lim;
+  const float4 *src = nullptr;
+  const uint32_t *cnt = nullptr;
+  switch (which) {
+    case FX_CLOUD_KEYPOINTS: src = B.keypoints + (size_t)scan * L.max_keypoints, cnt = B.n_kp + scan; break;
+    case FX_CLOUD_FILTERED: src = B.filt + (size_t)scan * L.max_points, cnt = B.n_filt + scan; break;
+    case FX_CLOUD_KEYPOINT_CLOUD: src = B.kpc + (size_t)scan * L.max_kpc_points, cnt = B.n_kpc + scan; break;
+    default: return fail(FX_ERR_INVALID_ARG, "unknown cloud selector");
+  }
+  uint32_t n = 0;
+  FX_HIP(hipMemcpyAsync(&n, cnt, 4, hipMemcpyDeviceToHost, c->stream));
+  FX_HIP(hipStreamSynchronize(c->stream));
+  if (n > capacity_points) return fail(FX_ERR_TOO_LARGE, "destination too small for the cloud");
+  if (n) fxk_pack_xyzi32(c->stream, src, n, dst_device, (uint32_t)c->n_cu * 4u);
+  FX_HIP(hipGetLastError());
+  *n_points_out = n;
   return FX_OK;
 }
 

@@ -2138,6 +2138,36 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_pack_kp_records(FxDevParam
   for (uint32_t k = threadIdx.x; k < rec_kp; k += FX_WG) rec[1 + k] = k < K ? kp[k] : make_float4(0, 0, 0, 0);
 }
 
+// ====================================================================== PointCloud2 wire formats
+// Ingress: pcl::fromPCLPointCloud2 (ref: node.cpp:79-81) picks the float32 fields x, y, z by name
+// out of point_step-byte records (velodyne driver clouds carry extra fields such as `ring`, and
+// point_step need not be a multiple of 4) — here as a byte-offset gather into packed float4.
+extern "C" __global__ __launch_bounds__(FX_WG) void k_unpack_pc2(const uint8_t *src, uint32_t n, uint32_t point_step,
+                                                                  uint32_t off_x, uint32_t off_y, uint32_t off_z,
+                                                                  uint32_t off_i, uint32_t big_endian, float4 *dst) {
+  for (uint32_t i = blockIdx.x * FX_WG + threadIdx.x; i < n; i += gridDim.x * FX_WG) {
+    const uint8_t *rec = src + (size_t)i * point_step;
+    auto rd = [&](uint32_t off) -> float {
+      uint32_t u = (uint32_t)rec[off] | ((uint32_t)rec[off + 1] << 8) | ((uint32_t)rec[off + 2] << 16) |
+                   ((uint32_t)rec[off + 3] << 24);
+      if (big_endian) u = __builtin_bswap32(u);
+      return __uint_as_float(u);
+    };
+    dst[i] = make_float4(rd(off_x), rd(off_y), rd(off_z), off_i != 0xffffffffu ? rd(off_i) : 0.0f);
+  }
+}
+// Egress: a pcl::PointCloud<pcl::PointXYZI> as pcl_ros serialises it — 32-byte records, x@0 y@4 z@8
+// (pad 1.0f @12) intensity@16 — from the context's float4 (x, y, z, intensity) arrays
+// (ref: node.cpp:129-139 publishes keypoints, keypoint_cloud and cloud this way).
+extern "C" __global__ __launch_bounds__(FX_WG) void k_pack_xyzi32(const float4 *src, uint32_t n, float *dst) {
+  for (uint32_t i = blockIdx.x * FX_WG + threadIdx.x; i < n; i += gridDim.x * FX_WG) {
+    const float4 v = src[i];
+    float4 *o = reinterpret_cast<float4 *>(dst + (size_t)i * 8);
+    o[0] = make_float4(v.x, v.y, v.z, 1.0f);
+    o[1] = make_float4(v.w, 0.0f, 0.0f, 0.0f);
+  }
+}
+
 // ====================================================================== launchers
 extern "C" {
 
@@ -2225,6 +2255,14 @@ void fxk_rng_ord(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32
 void fxk_pack_kp_records(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, void *dst,
                          uint32_t rec_kp) {
   hipLaunchKernelGGL(k_pack_kp_records, dim3(batch), dim3(FX_WG), 0, s, P, B, batch, (float4 *)dst, rec_kp);
+}
+void fxk_unpack_pc2(hipStream_t s, const void *src, uint32_t n, uint32_t point_step, uint32_t ox, uint32_t oy, uint32_t oz,
+                    uint32_t oi, uint32_t big_endian, void *dst, uint32_t grid) {
+  hipLaunchKernelGGL(k_unpack_pc2, dim3(grid), dim3(FX_WG), 0, s, (const uint8_t *)src, n, point_step, ox, oy, oz, oi,
+                     big_endian, (float4 *)dst);
+}
+void fxk_pack_xyzi32(hipStream_t s, const void *src, uint32_t n, void *dst, uint32_t grid) {
+  hipLaunchKernelGGL(k_pack_xyzi32, dim3(grid), dim3(FX_WG), 0, s, (const float4 *)src, n, (float *)dst);
 }
 void fxk_pack_features(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, void *dst,
                        uint32_t capacity, uint32_t grid) {

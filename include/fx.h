@@ -198,6 +198,29 @@ fx_status fx_synchronize(fx_ctx *ctx);
  * the device.  dst_device must hold total_keypoints records. */
 fx_status fx_pack_features(fx_ctx *ctx, void *dst_device, uint32_t capacity_records);
 
+/* ---- PointCloud2 wire formats ----
+ * Ingress: what pcl_conversions::toPCL + pcl::fromPCLPointCloud2 do for the node (ref: node.cpp:79-81):
+ * pick the float32 fields x, y, z (and optionally intensity) by their byte offsets out of
+ * point_step-byte records (extra fields such as `ring` are skipped; point_step may be any size) into
+ * the packed float4 layout fx_scan_desc takes.  data_device and dst_device_xyzi are device pointers;
+ * dst holds n_points * 16 bytes.  The offsets come from the message's PointField list. */
+typedef struct fx_pc2_layout {
+  uint32_t point_step;
+  uint32_t offset_x, offset_y, offset_z;
+  uint32_t offset_intensity; /* 0xffffffff: no such field (the path ignores incoming intensity anyway) */
+  uint32_t is_bigendian;
+} fx_pc2_layout;
+fx_status fx_unpack_pointcloud2(fx_ctx *ctx, const void *data_device, uint32_t n_points, const fx_pc2_layout *layout,
+                                void *dst_device_xyzi);
+/* Egress: one scan's cloud of the last batch as pcl_ros serialises a PointCloud<PointXYZI>
+ * (ref: node.cpp:129-139): 32-byte records, x@0 y@4 z@8 intensity@16 (fields x, y, z, intensity;
+ * point_step 32).  dst_device holds capacity_points * 32 bytes; *n_points_out = points written. */
+#define FX_CLOUD_KEYPOINTS 0u      /* ~keypoints      */
+#define FX_CLOUD_FILTERED 1u       /* ~cloud          */
+#define FX_CLOUD_KEYPOINT_CLOUD 2u /* ~keypoint_cloud */
+fx_status fx_pack_pointxyzi(fx_ctx *ctx, uint32_t which, uint32_t scan, void *dst_device, uint32_t capacity_points,
+                            uint32_t *n_points_out);
+
 /* Fixed-stride keypoint records of the last batch for the cross-GPU gather (one RCCL
  * collective per batch): per scan (1 + rec_keypoints) float4 = {n_kp, flags, 0, 0 as u32}
  * followed by rec_keypoints (x, y, z, elevation) entries, zero padded.  dst_device must hold
