@@ -1,12 +1,15 @@
 // fx_kernels.hip — gfx950 kernels of the per-scan detector/descriptor hot path.
 //
 // Stage map (reference: src/feature_extraction_node.cpp):
-//   k_prep     rotateCloud :159-167 + filterCloud :169-183 + getElevationAngles :147-156
-//              (elevation only for points that survive the filter: it is dead otherwise)
-//   k_rings    estimateKeypoints ring loop :195-207 + getCylinderSegments :261-327
-//   k_merge    secondary merge :209-257 (+ ring-order assembly of keypoints_full / keypoint_cloud)
-//   k_offsets  batch-wide keypoint offsets
-//   k_desc     estimateDescriptors :329-355 == pcl::ShapeContext3DEstimation
+//   k_prep       rotateCloud :159-167 + filterCloud :169-183 + getElevationAngles :147-156
+//                (elevation only for points that survive the filter: it is dead otherwise)
+//   k_bucket     estimateKeypoints ring loop :195-207 (the 16 PassThrough filters as one stable split)
+//   k_rings_*    getCylinderSegments :261-327 (one wavefront per ring; workgroup tiers for big rings)
+//   k_merge_*    secondary merge :209-257 (+ ring-order assembly of keypoints_full / keypoint_cloud)
+//   k_offsets    batch-wide keypoint offsets
+//   k_gather, k_desc_*   estimateDescriptors :329-355 == pcl::ShapeContext3DEstimation
+// Every stage has a fast tier sized for the common case and larger tiers fed through device-side
+// work lists, so no input is ever truncated silently (flags) and the common case stays small in LDS.
 //
 // Numerics contract: every result-bearing float expression is evaluated in the operation
 // order PCL / FLANN / Eigen use and is never contracted into an FMA (this TU is built with
@@ -1156,14 +1159,20 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_offsets(FxDevParams P, FxB
 }
 
 // ====================================================================== stage 5: descriptors
-// pcl::ShapeContext3DEstimation (ref: node.cpp:329-355), in three steps:
-//   k_gather     one pass over each scan tests every (rotated) point against ALL keypoints of the
-//                scan and appends the points within R + R/5 of a keypoint to that keypoint's
-//                support list (a superset of the neighbour query and of every density query)
-//   k_desc_wave  one wavefront per keypoint: bins + density + weight per neighbour, rank sort by
-//                (bin, d2, index) == PCL's accumulation order, sequential fp32 sum per bin
-//   k_desc_list / k_desc_full   workgroup-per-keypoint tiers for long lists / lists that
-//                overflowed the global list capacity (full re-gather into LDS)
+// pcl::ShapeContext3DEstimation (ref: node.cpp:329-355):
+//   k_gather        one pass over each scan tests every (rotated) point against the keypoints of the
+//                   scan (binned along x) and appends the points within R + R/5 of a keypoint to that
+//                   keypoint's support list (a superset of the neighbour query and of every density query)
+//   k_desc_zero     clears the descriptor rows of the batch in one streaming pass
+//   k_desc_group    4 keypoints per wavefront: support sets of <= 64 points (the bulk)
+//   k_desc_fast     one wavefront per keypoint: 65..256 support points
+//   k_desc_wg_fast  one 1024-thread workgroup per keypoint: up to list_cap support points
+//                   -- all three: bins + density + weight per neighbour, sort by (bin, d2, index) ==
+//                      PCL's accumulation order, sequential fp32 sum per bin; angles in fp32 --
+//   k_desc_wg       exact fp64-angle redo of keypoints the fp32 passes flagged (angle near a bin
+//                   edge), and re-gather tier for lists that overflowed list_cap
+//   k_desc_spill    support sets beyond LDS: slabs in HBM
+//   k_rng_ord       3DSC's RNG ordinal rule; a second pass redoes the (rare) affected keypoints
 
 // Which scan does global keypoint row w belong to?  kp_offset is an exclusive prefix.
 __device__ __forceinline__ uint32_t scan_of_row(const uint32_t *kp_offset, uint32_t batch, uint32_t w) {
@@ -1379,17 +1388,17 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_zero(FxDevParams P, F
   for (size_t i = (size_t)blockIdx.x * FX_WG + threadIdx.x; i < n4; i += (size_t)gridDim.x * FX_WG) d[i] = z;
 }
 
-// ---------------------------------------------------------------- k_desc_fast / k_desc_wave
+// ---------------------------------------------------------------- k_desc_fast
 #define FX_WAVE_CAP 256
 #define FX_WAVE_WORDS (FX_WAVE_CAP * 8)
 __device__ __forceinline__ void desc_fill_nan(float *out, uint32_t lane, uint32_t stride) {
   for (uint32_t t = lane; t < FX_DESC_FLOATS; t += stride) out[t] = t < FX_DESC_BINS ? NAN : 0.0f;
 }
 
-// One wavefront per keypoint.  FAST: angles in fp32; a keypoint with any neighbour whose angle
-// lies within FX_FAST_EPS_DEG of a bin edge is not finished here but handed to the exact
-// kernel (same code with FAST = false, fp64 angles), so the result is the exact one either way.
-// FAST: the rows in B.wave_desc (support sets of 65..256 points); exact: the rows in B.exact_desc.
+// One wavefront per keypoint, for the rows in B.wave_desc (support sets of 65..256 points).
+// Angles in fp32; a keypoint with any neighbour whose angle lies within FX_FAST_EPS_DEG of a bin
+// edge is not finished here but handed to the exact workgroup kernel (k_desc_wg, fp64 angles), so
+// the result is the exact one either way.
 template <bool FAST>
 __device__ __forceinline__ void desc_wave_body(const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t mode,
                                                uint32_t *smem) {
@@ -1520,10 +1529,6 @@ __device__ __forceinline__ void desc_wave_body(const FxDevParams &P, const FxBuf
 extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_fast(FxDevParams P, FxBuffers B, uint32_t batch, uint32_t mode) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   desc_wave_body<true>(P, B, batch, mode, smem);
-}
-extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_wave(FxDevParams P, FxBuffers B, uint32_t batch, uint32_t mode) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  desc_wave_body<false>(P, B, batch, mode, smem);
 }
 
 // ---------------------------------------------------------------- k_desc_group
@@ -2233,9 +2238,6 @@ void fxk_desc_group(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uin
 }
 void fxk_desc_fast(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t mode) {
   hipLaunchKernelGGL(k_desc_fast, dim3(grid), dim3(FX_WG), (size_t)FX_NWAVE * FX_WAVE_WORDS * 4, s, P, B, batch, mode);
-}
-void fxk_desc_exact(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t mode) {
-  hipLaunchKernelGGL(k_desc_wave, dim3(grid), dim3(FX_WG), (size_t)FX_NWAVE * FX_WAVE_WORDS * 4, s, P, B, batch, mode);
 }
 void fxk_desc_wg(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t grid,
                  uint32_t mode, uint32_t src) {
