@@ -90,8 +90,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("FX_BENCH_FORCE_DIST") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     B, N = args.batch, N_RINGS * N_AZ
@@ -108,17 +109,34 @@ def main():
     ctx.set_stream(stream.cuda_stream)
     base = d_in.data_ptr()
     descs = ctx.make_descs([base + b * N * 16 for b in range(B)], [N] * B, 16, roll, pitch)
-    rec = torch.zeros((B, 1 + REC_KP, 4), dtype=torch.float32, device=dev)
-    gathered = torch.zeros((world * B, 1 + REC_KP, 4), dtype=torch.float32, device=dev) if world > 1 else None
+    # keypoint records: double-buffered so that the gather of batch i (RCCL, its own stream) overlaps
+    # the kernels of batch i + 1; a buffer is reused only after its collective has completed
+    use_dist = world > 1 or os.environ.get("FX_BENCH_FORCE_DIST") == "1"
+    recs = [torch.zeros((B, 1 + REC_KP, 4), dtype=torch.float32, device=dev) for _ in range(2)]
+    gathered = [torch.zeros((world * B, 1 + REC_KP, 4), dtype=torch.float32, device=dev) for _ in range(2)] if use_dist else None
+    pending = [None, None]
+    counter = [0]
 
     def step():
+        j = counter[0] & 1
+        counter[0] += 1
+        if pending[j] is not None:
+            pending[j].wait()  # stream-level wait: rec[j] / gathered[j] are free again
+            pending[j] = None
         ctx.process_raw(descs, B, capi.FX_IN_DEVICE)
-        ctx.pack_keypoint_records(rec.data_ptr(), REC_KP)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered.view(-1), rec.view(-1))
+        ctx.pack_keypoint_records(recs[j].data_ptr(), REC_KP)
+        if use_dist:
+            pending[j] = dist.all_gather_into_tensor(gathered[j].view(-1), recs[j].view(-1), async_op=True)
+
+    def drain():
+        for j in range(2):
+            if pending[j] is not None:
+                pending[j].wait()
+                pending[j] = None
 
     for _ in range(args.warmup):
         step()
+    drain()
     ctx.set_profiling(max(args.steps, 1))  # HIP events around every stage kernel, on the launch stream
     if world > 1:
         dist.barrier()
@@ -126,6 +144,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -159,6 +178,7 @@ def main():
     else:
         k_all = k_total
 
+    result_line = None
     if rank == 0:
         parity = None
         if n_chk:
@@ -203,11 +223,19 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["h2d_inclusive_scans_per_s"] = h2d_inclusive(ctx, capi, host, B, N, roll, pitch)
             out["cpu_baseline"] = cpu_baseline(params, host, roll, pitch, threads)
-        print(json.dumps(out), flush=True)
+        result_line = json.dumps(out)
+    if use_dist and rank == 0:
+        # the gathered table holds every rank's records in stream order: check this rank's block
+        g = gathered[(counter[0] - 1) & 1][rank * B:(rank + 1) * B]
+        assert torch.equal(g, recs[(counter[0] - 1) & 1]), "gathered keypoint records differ from the local ones"
     ctx.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    if result_line is not None:
+        # the one JSON line goes out last, after RCCL's own start-up/tear-down chatter
+        sys.stdout.flush()
+        print(result_line, flush=True)
 
 
 if __name__ == "__main__":
