@@ -233,8 +233,11 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if result_line is not None:
-        # the one JSON line goes out last, after RCCL's own start-up/tear-down chatter
+        # the one JSON line goes out last: RCCL writes a version banner through C stdio, which sits in
+        # libc's buffer until flushed when stdout is a pipe
+        import ctypes
         sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
         print(result_line, flush=True)
 
 
