@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/fx.h"
@@ -106,6 +107,9 @@ struct fx_ctx {
   uint32_t ev_depth = 0, ev_count = 0;
   hipEvent_t *ev = nullptr;  // set of the batch being enqueued
   uint32_t last_batch = 0;
+  // HIP graphs of the stage sequence, one per batch size (batches up to graph_max_batch)
+  std::vector<std::pair<uint32_t, hipGraphExec_t>> graphs;
+  uint32_t graph_max_batch = 0;
 };
 
 namespace {
@@ -137,6 +141,114 @@ fx_status host_alloc(fx_ctx *c, T **p, size_t count) {
     if (s_ != FX_OK) return s_;   \
   } while (0)
 
+}  // namespace
+
+namespace {
+// Enqueues the stage kernels of one batch on stream s (the whole device-side pipeline between the
+// scan-table upload and the result copies).  Also what a HIP graph of the batch is captured from.
+fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof) {
+  const fx_limits &L = c->lim;
+  const FxDevParams &P = c->dp;
+  const FxBuffers &B = c->buf;
+  const uint32_t big_grid = (uint32_t)c->n_cu;
+  if (prof) c->ev = &c->ev_ring[(size_t)(c->ev_count % c->ev_depth) * (FX_N_STAGES + 1)];
+  auto mark = [&](int i) -> hipError_t { return prof ? hipEventRecord(c->ev[i], s) : hipSuccess; };
+  FX_HIP(mark(0));
+  FX_HIP(hipMemsetAsync(B.counters, 0, 16 * sizeof(uint32_t), s));
+  if (batch) {
+    const uint32_t ring_small = L.max_ring_points < kRingCapSmall ? L.max_ring_points : kRingCapSmall;
+    const uint32_t merge_small = L.max_candidates < kMergeCapSmall ? L.max_candidates : kMergeCapSmall;
+    const uint32_t desc_grid = (uint32_t)c->n_cu * c->desc_wgs_per_cu;  // resident all at once (32 KB LDS each)
+    fxk_prep(s, P, B, batch);
+    FX_HIP(mark(1));
+    fxk_bucket(s, P, B, batch, (float)c->params.el0_deg, (float)(1.0 / c->params.el_step_deg));
+    FX_HIP(mark(2));
+    const uint32_t ring_mid = L.max_ring_points < kRingCapMid ? L.max_ring_points : kRingCapMid;
+    {
+      // persistent one-wave workgroups: as many per CU as their LDS footprint admits
+      // (LDS appears to be handed out in 2 KiB granules: a workgroup too many per CU queues behind the others)
+      uint32_t per_cu = (uint32_t)(160 * 1024 / ((fxk_ring_wave_lds_bytes(ring_small, ring_small / 4) + 2047) / 2048 * 2048));
+      if (per_cu > c->ring_waves_per_cu) per_cu = c->ring_waves_per_cu;
+      fxk_rings_small(s, P, B, batch, ring_small, ring_small / 4, ring_mid, (uint32_t)c->n_cu * per_cu);
+    }
+    FX_HIP(mark(3));
+    {
+      uint32_t per_cu = (uint32_t)(160 * 1024 / ((fxk_ring_lds_bytes(ring_mid, ring_mid / 4) + 2047) / 2048 * 2048));
+      if (per_cu > 8) per_cu = 8;
+      if (per_cu < 1) per_cu = 1;
+      fxk_rings_big(s, P, B, ring_mid, ring_mid / 4, big_grid * per_cu, 0);
+    }
+    FX_HIP(mark(4));
+    fxk_rings_big(s, P, B, L.max_ring_points, L.max_ring_points, big_grid, 1);
+    fxk_merge_small(s, P, B, batch, merge_small);
+    FX_HIP(mark(5));
+    fxk_merge_big(s, P, B, L.max_candidates, big_grid);
+    fxk_offsets(s, P, B, batch);
+    if (P.estimate_descriptors) {
+      FX_HIP(hipMemsetAsync(B.s_cnt, 0, (size_t)L.max_total_keypoints * sizeof(uint32_t), s));
+      FX_HIP(mark(6));
+      fxk_gather(s, P, B, batch, c->box_margin);
+      FX_HIP(mark(7));
+      fxk_desc_zero(s, P, B, batch, (uint32_t)c->n_cu * 8u);
+      FX_HIP(mark(8));
+      fxk_desc_group(s, P, B, batch, desc_grid, 0);
+      FX_HIP(mark(9));
+      fxk_desc_fast(s, P, B, batch, big_grid * 4, 0);
+      FX_HIP(mark(10));
+      fxk_desc_wg_fast(s, P, B, batch, P.list_cap, big_grid * 8, 0);
+      FX_HIP(mark(11));
+      fxk_desc_wg(s, P, B, batch, P.list_cap, big_grid, 0, 2);
+      FX_HIP(mark(12));
+      fxk_desc_wg(s, P, B, batch, L.max_neighbors, big_grid, 0, 0);
+      fxk_desc_spill(s, P, B, batch, c->spill_grid, 0, c->spill_slab);
+      fxk_rng_ord(s, P, B, batch);
+      // second pass: only keypoints whose RNG ordinal moved (an earlier keypoint had no neighbours)
+      fxk_desc_group(s, P, B, batch, desc_grid, 1);
+      fxk_desc_fast(s, P, B, batch, big_grid * 4, 1);
+      fxk_desc_wg_fast(s, P, B, batch, P.list_cap, big_grid * 8, 1);
+      fxk_desc_wg(s, P, B, batch, P.list_cap, big_grid, 1, 2);
+      fxk_desc_wg(s, P, B, batch, L.max_neighbors, big_grid, 1, 0);
+      fxk_desc_spill(s, P, B, batch, c->spill_grid, 1, c->spill_slab);
+    } else {
+      for (int i = 6; i <= 12; ++i) FX_HIP(mark(i));
+    }
+    FX_HIP(mark(13));
+    FX_HIP(hipGetLastError());
+  } else {
+    for (int i = 1; i <= FX_N_STAGES; ++i) FX_HIP(mark(i));
+  }
+  return FX_OK;
+}
+
+// Small batches are launch-bound (about 30 launches for a few hundred microseconds of work): replay the
+// sequence as one HIP graph per batch size.  Kernel arguments depend on the batch size only; the scan
+// table lives in the fixed d_meta buffer and is uploaded before the graph runs.
+fx_status launch_graph(fx_ctx *c, hipStream_t s, uint32_t batch) {
+  hipGraphExec_t exec = nullptr;
+  for (auto &g : c->graphs)
+    if (g.first == batch) exec = g.second;
+  if (!exec) {
+    hipGraph_t graph = nullptr;
+    FX_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    fx_status st = enqueue_stages(c, s, batch, false);
+    hipError_t e = hipStreamEndCapture(s, &graph);
+    if (st != FX_OK) {
+      if (graph) (void)hipGraphDestroy(graph);
+      return st;
+    }
+    FX_HIP(e);
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    FX_HIP(e);
+    if (c->graphs.size() >= 8) {  // bounded cache: drop the oldest batch size
+      (void)hipGraphExecDestroy(c->graphs.front().second);
+      c->graphs.erase(c->graphs.begin());
+    }
+    c->graphs.emplace_back(batch, exec);
+  }
+  FX_HIP(hipGraphLaunch(exec, s));
+  return FX_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -185,6 +297,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   c->device = device_id;
   if (const char *e = getenv("FX_RING_WAVES_PER_CU")) c->ring_waves_per_cu = (uint32_t)atoi(e);
   if (const char *e = getenv("FX_DESC_WGS_PER_CU")) c->desc_wgs_per_cu = (uint32_t)atoi(e);
+  if (const char *e = getenv("FX_GRAPH_MAX_BATCH")) c->graph_max_batch = (uint32_t)atoi(e);
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->n_cu = prop.multiProcessorCount;
 
@@ -369,6 +482,7 @@ void fx_destroy(fx_ctx *c) {
   for (int i = 0; i < kMetaSlots; ++i)
     if (c->meta_ev[i]) (void)hipEventDestroy(c->meta_ev[i]);
   for (hipEvent_t e : c->ev_ring) (void)hipEventDestroy(e);
+  for (auto &g : c->graphs) (void)hipGraphExecDestroy(g.second);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -378,6 +492,12 @@ fx_status fx_set_stream(fx_ctx *c, void *hip_stream) {
   c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
   return FX_OK;
 }
+fx_status fx_set_graph_batch(fx_ctx *c, uint32_t max_batch) {
+  if (!c) return fail(FX_ERR_INVALID_ARG, "null ctx");
+  c->graph_max_batch = max_batch;
+  return FX_OK;
+}
+
 fx_status fx_set_profiling(fx_ctx *c, int depth) {
   if (!c || depth < 0) return fail(FX_ERR_INVALID_ARG, "bad argument");
   FX_HIP(hipSetDevice(c->device));
@@ -471,73 +591,10 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
   const FxDevParams &P = c->dp;
   const FxBuffers &B = c->buf;
   const bool prof = c->profiling;
-  const uint32_t big_grid = (uint32_t)c->n_cu;
-  if (prof) c->ev = &c->ev_ring[(size_t)(c->ev_count % c->ev_depth) * (FX_N_STAGES + 1)];
-  auto mark = [&](int i) -> hipError_t { return prof ? hipEventRecord(c->ev[i], s) : hipSuccess; };
-  FX_HIP(mark(0));
-  FX_HIP(hipMemsetAsync(B.counters, 0, 16 * sizeof(uint32_t), s));
-  if (batch) {
-    const uint32_t ring_small = L.max_ring_points < kRingCapSmall ? L.max_ring_points : kRingCapSmall;
-    const uint32_t merge_small = L.max_candidates < kMergeCapSmall ? L.max_candidates : kMergeCapSmall;
-    const uint32_t desc_grid = (uint32_t)c->n_cu * c->desc_wgs_per_cu;  // resident all at once (32 KB LDS each)
-    fxk_prep(s, P, B, batch);
-    FX_HIP(mark(1));
-    fxk_bucket(s, P, B, batch, (float)c->params.el0_deg, (float)(1.0 / c->params.el_step_deg));
-    FX_HIP(mark(2));
-    const uint32_t ring_mid = L.max_ring_points < kRingCapMid ? L.max_ring_points : kRingCapMid;
-    {
-      // persistent one-wave workgroups: as many per CU as their LDS footprint admits
-      // (LDS appears to be handed out in 2 KiB granules: a workgroup too many per CU queues behind the others)
-      uint32_t per_cu = (uint32_t)(160 * 1024 / ((fxk_ring_wave_lds_bytes(ring_small, ring_small / 4) + 2047) / 2048 * 2048));
-      if (per_cu > c->ring_waves_per_cu) per_cu = c->ring_waves_per_cu;
-      fxk_rings_small(s, P, B, batch, ring_small, ring_small / 4, ring_mid, (uint32_t)c->n_cu * per_cu);
-    }
-    FX_HIP(mark(3));
-    {
-      uint32_t per_cu = (uint32_t)(160 * 1024 / ((fxk_ring_lds_bytes(ring_mid, ring_mid / 4) + 2047) / 2048 * 2048));
-      if (per_cu > 8) per_cu = 8;
-      if (per_cu < 1) per_cu = 1;
-      fxk_rings_big(s, P, B, ring_mid, ring_mid / 4, big_grid * per_cu, 0);
-    }
-    FX_HIP(mark(4));
-    fxk_rings_big(s, P, B, L.max_ring_points, L.max_ring_points, big_grid, 1);
-    fxk_merge_small(s, P, B, batch, merge_small);
-    FX_HIP(mark(5));
-    fxk_merge_big(s, P, B, L.max_candidates, big_grid);
-    fxk_offsets(s, P, B, batch);
-    if (P.estimate_descriptors) {
-      FX_HIP(hipMemsetAsync(B.s_cnt, 0, (size_t)L.max_total_keypoints * sizeof(uint32_t), s));
-      FX_HIP(mark(6));
-      fxk_gather(s, P, B, batch, c->box_margin);
-      FX_HIP(mark(7));
-      fxk_desc_zero(s, P, B, batch, (uint32_t)c->n_cu * 8u);
-      FX_HIP(mark(8));
-      fxk_desc_group(s, P, B, batch, desc_grid, 0);
-      FX_HIP(mark(9));
-      fxk_desc_fast(s, P, B, batch, big_grid * 4, 0);
-      FX_HIP(mark(10));
-      fxk_desc_wg_fast(s, P, B, batch, P.list_cap, big_grid * 8, 0);
-      FX_HIP(mark(11));
-      fxk_desc_wg(s, P, B, batch, P.list_cap, big_grid, 0, 2);
-      FX_HIP(mark(12));
-      fxk_desc_wg(s, P, B, batch, L.max_neighbors, big_grid, 0, 0);
-      fxk_desc_spill(s, P, B, batch, c->spill_grid, 0, c->spill_slab);
-      fxk_rng_ord(s, P, B, batch);
-      // second pass: only keypoints whose RNG ordinal moved (an earlier keypoint had no neighbours)
-      fxk_desc_group(s, P, B, batch, desc_grid, 1);
-      fxk_desc_fast(s, P, B, batch, big_grid * 4, 1);
-      fxk_desc_wg_fast(s, P, B, batch, P.list_cap, big_grid * 8, 1);
-      fxk_desc_wg(s, P, B, batch, P.list_cap, big_grid, 1, 2);
-      fxk_desc_wg(s, P, B, batch, L.max_neighbors, big_grid, 1, 0);
-      fxk_desc_spill(s, P, B, batch, c->spill_grid, 1, c->spill_slab);
-    } else {
-      for (int i = 6; i <= 12; ++i) FX_HIP(mark(i));
-    }
-    FX_HIP(mark(13));
-    FX_HIP(hipGetLastError());
-  } else {
-    for (int i = 1; i <= FX_N_STAGES; ++i) FX_HIP(mark(i));
-  }
+  if (!prof && batch && batch <= c->graph_max_batch && s != nullptr)
+    FX_TRY(launch_graph(c, s, batch));
+  else
+    FX_TRY(enqueue_stages(c, s, batch, prof));
   if (prof) ++c->ev_count;
   c->last_batch = batch;
 

@@ -177,6 +177,10 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
 void fx_destroy(fx_ctx *ctx);
 /* hipStream_t to launch on (NULL = the context's own stream). */
 fx_status fx_set_stream(fx_ctx *ctx, void *hip_stream);
+/* Streaming mode: batches of up to max_batch scans are replayed as one HIP graph per
+ * batch size instead of ~30 separate launches (0 = never).  Needs a non-NULL stream; ignored while
+ * profiling is on.  Results are identical either way. */
+fx_status fx_set_graph_batch(fx_ctx *ctx, uint32_t max_batch);
 /* depth > 0: record HIP events around every stage kernel for the next batches, keeping the
  * last `depth` batches; 0 disables.  fx_get_timings reads the batch `back` calls ago
  * (0 = most recent) and waits for it to finish. */

@@ -87,3 +87,27 @@ def test_stage_timings_are_reported(fxlib):
     with pytest.raises(capi.FxError):
         ctx.timings(4)
     ctx.close()
+
+
+def test_graph_replay_matches_plain_launches(fxlib, oracle):
+    """Streaming mode: small batches replayed as one HIP graph per batch size give
+    the same bits as separate launches, across changing inputs and batch sizes."""
+    p = capi.params("launch")
+    scans = [util.vlp16_scan(2000 + b) for b in range(6)] + [np.zeros((0, 4), np.float32)]
+    plain = capi.Context(p, capi.limits(4, 28800))
+    graph = capi.Context(p, capi.limits(4, 28800))
+    graph.set_graph_batch(4)
+    want0 = oracle.run(p, scans[0], roll=0.02, pitch=-0.015)
+    for rep, part in enumerate(([0], [1], [2, 3], [6], [4, 5, 0, 6], [0], [3, 2])):
+        batch = [scans[i] for i in part]
+        a = plain.process_host(batch, roll=0.02, pitch=-0.015)
+        g = graph.process_host(batch, roll=0.02, pitch=-0.015)
+        for x, y in zip(a, g):
+            assert x["n_keypoints"] == y["n_keypoints"] and x["flags"] == y["flags"]
+            np.testing.assert_array_equal(x["keypoints"], y["keypoints"])
+            np.testing.assert_array_equal(x["descriptors"], y["descriptors"])
+            np.testing.assert_array_equal(x["filtered"], y["filtered"])
+        if part[0] == 0:
+            util.compare_scan(g[0], want0, tag=f"graph rep {rep}")
+    plain.close()
+    graph.close()
