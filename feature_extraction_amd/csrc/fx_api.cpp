@@ -110,6 +110,7 @@ struct fx_ctx {
   // HIP graphs of the stage sequence, one per batch size (batches up to graph_max_batch)
   std::vector<std::pair<uint32_t, hipGraphExec_t>> graphs;
   uint32_t graph_max_batch = 0;
+  bool debug_sync = false;
 };
 
 namespace {
@@ -152,7 +153,14 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof) {
   const FxBuffers &B = c->buf;
   const uint32_t big_grid = (uint32_t)c->n_cu;
   if (prof) c->ev = &c->ev_ring[(size_t)(c->ev_count % c->ev_depth) * (FX_N_STAGES + 1)];
-  auto mark = [&](int i) -> hipError_t { return prof ? hipEventRecord(c->ev[i], s) : hipSuccess; };
+  auto mark = [&](int i) -> hipError_t {
+    if (c->debug_sync) {  // FX_DEBUG_SYNC=1: name the stage a device fault belongs to
+      fprintf(stderr, "[fx] stage %d enqueued\n", i);
+      hipError_t e = hipStreamSynchronize(s);
+      if (e != hipSuccess) return e;
+    }
+    return prof ? hipEventRecord(c->ev[i], s) : hipSuccess;
+  };
   FX_HIP(mark(0));
   FX_HIP(hipMemsetAsync(B.counters, 0, 16 * sizeof(uint32_t), s));
   if (batch) {
@@ -297,6 +305,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   c->device = device_id;
   if (const char *e = getenv("FX_RING_WAVES_PER_CU")) c->ring_waves_per_cu = (uint32_t)atoi(e);
   if (const char *e = getenv("FX_DESC_WGS_PER_CU")) c->desc_wgs_per_cu = (uint32_t)atoi(e);
+  if (const char *e = getenv("FX_DEBUG_SYNC")) c->debug_sync = atoi(e) != 0;
   if (const char *e = getenv("FX_GRAPH_MAX_BATCH")) c->graph_max_batch = (uint32_t)atoi(e);
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->n_cu = prop.multiProcessorCount;
@@ -591,7 +600,7 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
   const FxDevParams &P = c->dp;
   const FxBuffers &B = c->buf;
   const bool prof = c->profiling;
-  if (!prof && batch && batch <= c->graph_max_batch && s != nullptr)
+  if (!prof && !c->debug_sync && batch && batch <= c->graph_max_batch && s != nullptr)
     FX_TRY(launch_graph(c, s, batch));
   else
     FX_TRY(enqueue_stages(c, s, batch, prof));

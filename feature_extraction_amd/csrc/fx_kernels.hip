@@ -235,7 +235,7 @@ __device__ __forceinline__ uint32_t block_count_incl(bool flag, uint32_t *s_w, u
 //  3. roots per run head, then per point; sizes per segment.
 // Returns the number of segments (the table is valid iff it is <= SegCfg<NT>::kMax).
 template <int NT>
-__device__ uint32_t cc_label(const float4 *pt, uint32_t n, float r2, uint32_t *parent, uint32_t *csize, uint32_t *rid,
+__device__ __forceinline__ uint32_t cc_label(const float4 *pt, uint32_t n, float r2, uint32_t *parent, uint32_t *csize, uint32_t *rid,
                              uint32_t *s_w, unsigned long long *stamps = nullptr) {
   constexpr uint32_t kSegMax = SegCfg<NT>::kMax;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -360,7 +360,7 @@ __device__ uint32_t cc_label(const float4 *pt, uint32_t n, float r2, uint32_t *p
           uf_union(parent, x, i);  // (i, j) is an edge
           continue;
         }
-        // (point i, later run x): its segments' boxes, then their points
+        // (point i, other run x): its segments' boxes, then their points
         const uint32_t s0 = ST.rseg(x), s1 = ST.rseg(x + 1);
         if (uf_find(parent, i) == uf_find(parent, ST.start(s0))) continue;  // already one component
         const float4 q = pt[i];
@@ -391,31 +391,73 @@ __device__ uint32_t cc_label(const float4 *pt, uint32_t n, float r2, uint32_t *p
       }
     };
     if (table) {
-      // every point against the box of every later run; the run loop is wave-uniform (LDS
-      // broadcast reads, four boxes in flight per trip)
-      for (uint32_t i0 = 0; i0 < n; i0 += NT) {
-        const uint32_t i = i0 + threadIdx.x;
-        const bool live = i < n;
-        const float4 q = live ? pt[i] : make_float4(0, 0, 0, 0);
-        const uint32_t my_run = live ? rid[i] : FX_NONE;
-        // runs before the smallest run id of this wave cannot be "later" for any lane
-        uint32_t r_lo = my_run;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) r_lo = min(r_lo, (uint32_t)__shfl_xor((int)r_lo, d, 64));
-        if (r_lo == FX_NONE) continue;
-        for (uint32_t r0 = r_lo + 1; r0 < n_runs; r0 += 4) {
-          uint32_t near = 0;
-#pragma unroll
-          for (uint32_t u = 0; u < 4; ++u) {
-            const uint32_t r = min(r0 + u, n_runs - 1);
-            const float dx = fmaxf(fmaxf(ST.rbox(FX_MINX, r) - q.x, q.x - ST.rbox(FX_MAXX, r)), 0.0f);
-            const float dy = fmaxf(fmaxf(ST.rbox(FX_MINY, r) - q.y, q.y - ST.rbox(FX_MAXY, r)), 0.0f);
-            const bool ok = (r0 + u < n_runs) && (r0 + u > my_run) && !(dx * dx + dy * dy > r2_pad);
-            near |= ok ? (1u << u) : 0u;
+      // Run pairs whose boxes come within the tolerance: azimuth-ordered rings have few or none, so
+      // listing them first (one box-box test per pair, pairs spread over all lanes) replaces
+      // the points x runs sweep.  The list borrows the sort stack, which is idle until cc_order.
+      uint32_t *rp = s_w + 32;
+      constexpr uint32_t kPairCap = FX_SORT_STACK_WORDS;
+      if (threadIdx.x == 0) s_w[16] = 0;
+      __syncthreads();
+      const float inv_runs = 1.0f / (float)n_runs;
+      for (uint32_t p = threadIdx.x; p < n_runs * n_runs; p += NT) {
+        // p = a * n_runs + b; (p + 0.5) / n_runs is never within rounding distance of an integer (p < 2^14)
+        const uint32_t a = (uint32_t)(((float)p + 0.5f) * inv_runs), b = p - a * n_runs;
+        if (b <= a) continue;
+        const float dx = fmaxf(fmaxf(ST.rbox(FX_MINX, b) - ST.rbox(FX_MAXX, a), ST.rbox(FX_MINX, a) - ST.rbox(FX_MAXX, b)), 0.0f);
+        const float dy = fmaxf(fmaxf(ST.rbox(FX_MINY, b) - ST.rbox(FX_MAXY, a), ST.rbox(FX_MINY, a) - ST.rbox(FX_MAXY, b)), 0.0f);
+        if (dx * dx + dy * dy > r2_pad) continue;
+        const uint32_t slot = atomicAdd(&s_w[16], 1u);
+        if (slot < kPairCap) rp[slot] = (a << 16) | b;
+      }
+      __syncthreads();
+      const uint32_t n_rp = s_w[16];
+      if (threadIdx.x == 0) {
+        FX_COUNT(15, n_rp);
+      }
+      if (n_rp <= kPairCap) {
+        // the points of the earlier run against the later run's box, one near pair per wavefront at a time
+        for (uint32_t t = wave; t < n_rp; t += NT / 64) {
+          const uint32_t a = rp[t] >> 16, b = rp[t] & 0xffffu;
+          const uint32_t i_end = ST.start(ST.rseg(a + 1));
+          for (uint32_t i0 = ST.start(ST.rseg(a)); i0 < i_end; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            bool ok = false;
+            if (i < i_end) {
+              const float4 q = pt[i];
+              const float dx = fmaxf(fmaxf(ST.rbox(FX_MINX, b) - q.x, q.x - ST.rbox(FX_MAXX, b)), 0.0f);
+              const float dy = fmaxf(fmaxf(ST.rbox(FX_MINY, b) - q.y, q.y - ST.rbox(FX_MAXY, b)), 0.0f);
+              ok = !(dx * dx + dy * dy > r2_pad);
+            }
+            park(ok, (i << 16) | b);
           }
-          if (__ballot(near != 0u)) {  // wave-uniform and rare
+        }
+      } else {
+        // every point against the box of every later run; the run loop is wave-uniform (LDS
+        // broadcast reads, four boxes in flight per trip)
+        for (uint32_t i0 = 0; i0 < n; i0 += NT) {
+          const uint32_t i = i0 + threadIdx.x;
+          const bool live = i < n;
+          const float4 q = live ? pt[i] : make_float4(0, 0, 0, 0);
+          const uint32_t my_run = live ? rid[i] : FX_NONE;
+          // runs before the smallest run id of this wave cannot be "later" for any lane
+          uint32_t r_lo = my_run;
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) park((near >> u) & 1u, (i << 16) | (r0 + u));
+          for (int d = 32; d > 0; d >>= 1) r_lo = min(r_lo, (uint32_t)__shfl_xor((int)r_lo, d, 64));
+          if (r_lo == FX_NONE) continue;
+          for (uint32_t r0 = r_lo + 1; r0 < n_runs; r0 += 4) {
+            uint32_t near = 0;
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+              const uint32_t r = min(r0 + u, n_runs - 1);
+              const float dx = fmaxf(fmaxf(ST.rbox(FX_MINX, r) - q.x, q.x - ST.rbox(FX_MAXX, r)), 0.0f);
+              const float dy = fmaxf(fmaxf(ST.rbox(FX_MINY, r) - q.y, q.y - ST.rbox(FX_MAXY, r)), 0.0f);
+              const bool ok = (r0 + u < n_runs) && (r0 + u > my_run) && !(dx * dx + dy * dy > r2_pad);
+              near |= ok ? (1u << u) : 0u;
+            }
+            if (__ballot(near != 0u)) {  // wave-uniform and rare
+#pragma unroll
+              for (uint32_t u = 0; u < 4; ++u) park((near >> u) & 1u, (i << 16) | (r0 + u));
+            }
           }
         }
       }
@@ -467,7 +509,7 @@ __device__ uint32_t cc_label(const float4 *pt, uint32_t n, float r2, uint32_t *p
 // returns the cluster count, which the caller must check against ccap (nothing is written past it,
 // and nothing is ordered, when it does not fit).
 template <int NT>
-__device__ uint32_t cc_order(uint32_t n, const uint32_t *parent, const uint32_t *csize, uint32_t min_sz,
+__device__ __forceinline__ uint32_t cc_order(uint32_t n, const uint32_t *parent, const uint32_t *csize, uint32_t min_sz,
                              uint32_t max_sz, uint32_t *croot, uint32_t *crec, uint32_t *tmp, uint32_t ccap,
                              uint32_t *s_w, unsigned long long *stamps = nullptr) {
   FX_STAMP_INIT(stamps);
@@ -523,52 +565,62 @@ __device__ uint32_t cc_order(uint32_t n, const uint32_t *parent, const uint32_t 
 
 // ====================================================================== stage 1: prep
 // One workgroup per scan streams the scan once: rotate (fp32, PCL's scalar order), apply
-// the three PassThrough predicates at once, compact the survivors in input order (wave
-// ballot + prefix), and compute the elevation angle (fp64) for survivors only.
+// the three PassThrough predicates at once and compact the survivors of a tile, in input
+// order (wave ballot + prefix), into LDS.  The elevation angle (fp64 atan2) is then computed
+// by a dense sweep over the compacted survivors only — about one point in ten survives, and
+// in firing order the survivors are spread over every wavefront.
 #define FX_PREP_T 512
 #define FX_PREP_U 4
+typedef float __attribute__((address_space(1))) gfloat;
 __global__ __launch_bounds__(FX_PREP_T) void k_prep(FxDevParams P, FxBuffers B) {
   const uint32_t scan = blockIdx.x;
   const FxScanMeta M = B.meta[scan];
   __shared__ uint32_t s_cnt[FX_PREP_U * (FX_PREP_T / 64)];
+  __shared__ float4 s_keep[FX_PREP_T * FX_PREP_U];  // un-rotated survivors of the tile
   float4 *out = B.filt + (size_t)scan * P.max_points;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int NW = FX_PREP_T / 64;
   uint32_t base = 0;
   const uint32_t n = M.n;
-  for (uint32_t t0 = 0; t0 < n; t0 += FX_PREP_T * FX_PREP_U) {
-    float4 v[FX_PREP_U];
+  // the loads of the next tile are issued before this tile's barriers, so the memory pipe stays full
+  // while the tile is compacted
+  // (global address space stated: a generic-pointer load would be a flat load, which also counts as an
+  //  LDS access and gets waited for at the next LDS instruction)
+  const gfloat *gpts = (const gfloat *)M.pts;
+  auto load_tile = [&](uint32_t t0, float4 (&v)[FX_PREP_U]) {
 #pragma unroll
     for (int u = 0; u < FX_PREP_U; ++u) {
       const uint32_t i = t0 + u * FX_PREP_T + tid;
-      if (i < n)
-        v[u] = *reinterpret_cast<const float4 *>(M.pts + (size_t)i * M.stride_f);
-      else
-        v[u] = make_float4(NAN, NAN, NAN, 0.f);
+      const gfloat *q = gpts + (size_t)min(i, n - 1u) * M.stride_f;  // clamped: no branch around the load
+      const float4 w = make_float4(q[0], q[1], q[2], q[3]);
+      v[u] = i < n ? w : make_float4(NAN, NAN, NAN, 0.f);
     }
-    float rx[FX_PREP_U], ry[FX_PREP_U], rz[FX_PREP_U];
+  };
+  float4 v[FX_PREP_U], nv[FX_PREP_U];
+  load_tile(0, v);
+  for (uint32_t t0 = 0; t0 < n; t0 += FX_PREP_T * FX_PREP_U) {
+    load_tile(t0 + FX_PREP_T * FX_PREP_U, nv);
     bool keep[FX_PREP_U];
     unsigned long long mask[FX_PREP_U];
 #pragma unroll
     for (int u = 0; u < FX_PREP_U; ++u) {
       const float x = v[u].x, y = v[u].y, z = v[u].z;
       // pcl::transformPointCloud, dense branch: ((m0 x + m1 y) + m2 z) + t, t = 0
-      rx[u] = ((M.R[0] * x + M.R[1] * y) + M.R[2] * z) + 0.0f;
-      ry[u] = ((M.R[3] * x + M.R[4] * y) + M.R[5] * z) + 0.0f;
-      rz[u] = ((M.R[6] * x + M.R[7] * y) + M.R[8] * z) + 0.0f;
-      bool k = isfinite(rx[u]) && isfinite(ry[u]) && isfinite(rz[u]);
-      k = k && !(rz[u] < P.z_min || rz[u] > P.z_max);
-      k = k && !(ry[u] < P.y_min || ry[u] > P.y_max);
-      k = k && !(rx[u] < P.x_min || rx[u] > P.x_max);
+      const float rx = ((M.R[0] * x + M.R[1] * y) + M.R[2] * z) + 0.0f;
+      const float ry = ((M.R[3] * x + M.R[4] * y) + M.R[5] * z) + 0.0f;
+      const float rz = ((M.R[6] * x + M.R[7] * y) + M.R[8] * z) + 0.0f;
+      bool k = isfinite(rx) && isfinite(ry) && isfinite(rz);
+      k = k && !(rz < P.z_min || rz > P.z_max);
+      k = k && !(ry < P.y_min || ry > P.y_max);
+      k = k && !(rx < P.x_min || rx > P.x_max);
       keep[u] = k;
       mask[u] = __ballot(k);
       if (lane == 0) s_cnt[u * NW + wave] = (uint32_t)__popcll(mask[u]);
     }
     __syncthreads();
-    // output slot = survivors before this tile + survivors of earlier slices of the tile
-    //             + survivors of earlier waves in my slice + earlier lanes of my wave
+    // tile slot = survivors of earlier slices of the tile + survivors of earlier waves in my
+    //             slice + earlier lanes of my wave
     uint32_t tile_total = 0;
-    uint32_t my_base[FX_PREP_U];
 #pragma unroll
     for (int u = 0; u < FX_PREP_U; ++u) {
       uint32_t before = 0, slice = 0;
@@ -578,22 +630,25 @@ __global__ __launch_bounds__(FX_PREP_T) void k_prep(FxDevParams P, FxBuffers B) 
         before += (w < (int)wave) ? c : 0u;
         slice += c;
       }
-      my_base[u] = tile_total + before;
+      if (keep[u]) s_keep[tile_total + before + lanes_below(mask[u])] = v[u];
       tile_total += slice;
     }
     __syncthreads();
-#pragma unroll
-    for (int u = 0; u < FX_PREP_U; ++u) {
-      if (keep[u]) {
-        // getElevationAngles on the un-rotated point: atan2(z, |xy|) in degrees, fp64 -> fp32.
-        // (cos(az) x + sin(az) y equals |xy| to within fp64 rounding)
-        const double x = v[u].x, y = v[u].y, z = v[u].z;
-        const double el = atan2(z, sqrt(x * x + y * y)) * 180 / M_PI;
-        const uint32_t pos = base + my_base[u] + lanes_below(mask[u]);
-        out[pos] = make_float4(rx[u], ry[u], rz[u], (float)el);
-      }
+    for (uint32_t j = tid; j < tile_total; j += FX_PREP_T) {
+      const float4 q = s_keep[j];
+      const float rx = ((M.R[0] * q.x + M.R[1] * q.y) + M.R[2] * q.z) + 0.0f;
+      const float ry = ((M.R[3] * q.x + M.R[4] * q.y) + M.R[5] * q.z) + 0.0f;
+      const float rz = ((M.R[6] * q.x + M.R[7] * q.y) + M.R[8] * q.z) + 0.0f;
+      // getElevationAngles on the un-rotated point: atan2(z, |xy|) in degrees, fp64 -> fp32.
+      // (cos(az) x + sin(az) y equals |xy| to within fp64 rounding)
+      const double x = q.x, y = q.y, z = q.z;
+      const double el = atan2(z, sqrt(x * x + y * y)) * 180 / M_PI;
+      out[base + j] = make_float4(rx, ry, rz, (float)el);
     }
     base += tile_total;
+    // (the next tile's s_keep writes come after its first barrier, i.e. after every lane left this sweep)
+#pragma unroll
+    for (int u = 0; u < FX_PREP_U; ++u) v[u] = nv[u];
   }
   if (tid == 0) {
     B.n_filt[scan] = base;
@@ -758,7 +813,7 @@ __device__ __forceinline__ RingLds ring_carve(uint32_t *smem, uint32_t cap, uint
 // points for keypoint_cloud.  Returns false when the ring does not fit this tier (more than
 // `cap` points or more than `ccap` size-admissible clusters): the caller defers it to a larger one.
 template <int NT>
-__device__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t scan, uint32_t ring, uint32_t cap,
+__device__ __forceinline__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t scan, uint32_t ring, uint32_t cap,
                           uint32_t ccap, uint32_t *smem, bool last_tier) {
   RingLds L = ring_carve<NT>(smem, cap, ccap);
   unsigned long long *const stamp_base = B.stamps ? B.stamps + (NT == 64 ? 0 : 16) : nullptr;
@@ -996,7 +1051,7 @@ __device__ __forceinline__ uint32_t prefix_owner(const uint32_t *base, uint32_t 
 // One scan: keypoints_full = per-ring candidates in ring order (ref: node.cpp:205), pseudo-z,
 // second Euclidean clustering, centroids -> keypoints (ref: node.cpp:212-257); then the
 // scan's keypoint_cloud chunks are laid out in ring order (ref: node.cpp:206).
-__device__ bool merge_body(const FxDevParams &P, const FxBuffers &B, uint32_t scan, uint32_t cap, uint32_t *smem,
+__device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers &B, uint32_t scan, uint32_t cap, uint32_t *smem,
                            bool last_tier) {
   MergeLds L = merge_carve(smem, cap, (uint32_t)P.n_rings);
   unsigned long long *const stamp_base = B.stamps ? B.stamps + 32 : nullptr;
@@ -1705,7 +1760,7 @@ __device__ __forceinline__ DescLds desc_carve(uint32_t *smem, uint32_t cap) {
 // otherwise it is re-gathered from the scan (lists that overflowed P.list_cap).
 // Returns false if the support set does not fit `cap` (only possible when !from_list).
 template <bool FAST, int NT>
-__device__ bool desc_body(const FxDevParams &P, const FxBuffers &B, uint32_t row, uint32_t scan, uint32_t k,
+__device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers &B, uint32_t row, uint32_t scan, uint32_t k,
                           uint32_t ord, uint32_t cap, uint32_t *smem, bool from_list) {
   DescLds L = desc_carve(smem, cap);
   FX_STAMP_INIT(B.stamps && FAST ? B.stamps + 48 : nullptr);

@@ -34,7 +34,7 @@ for tier, base in (("wave tier (n <= 256)", 0), ("workgroup tiers", 16), ("merge
     cnt = v[base + 12]
     if cnt:
         print(f"   rings {cnt / 3:.0f}/batch  runs/ring {v[base + 13] / cnt:.1f}  segs/ring {v[base + 14] / cnt:.1f}  "
-              f"near (point,run) pairs/ring {v[base + 15] / cnt:.1f}  near segments scanned/ring {v[base + 0] / cnt:.1f}")
+              f"near run pairs/ring {v[base + 15] / cnt:.1f}  near segments scanned/ring {v[base + 0] / cnt:.1f}")
 
 base = 48
 tot = v[base:base + 12].sum()
