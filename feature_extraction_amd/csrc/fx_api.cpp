@@ -22,6 +22,7 @@ size_t fxk_ring_lds_bytes(uint32_t cap, uint32_t ccap);
 size_t fxk_ring_wave_lds_bytes(uint32_t cap, uint32_t ccap);
 size_t fxk_merge_lds_bytes(uint32_t cap, uint32_t n_rings);
 size_t fxk_desc_lds_bytes(uint32_t cap);
+size_t fxk_gather_lds_bytes(uint32_t max_keypoints);
 hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t desc_big);
 void fxk_prep(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
 void fxk_bucket(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float el0, float inv_step);
@@ -294,6 +295,8 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
     return fail(FX_ERR_INVALID_ARG, "max_ring_points exceeds the LDS budget (<= 2600)");
   if (fxk_merge_lds_bytes(L.max_candidates, params->n_rings) > kLds)
     return fail(FX_ERR_INVALID_ARG, "max_candidates exceeds the LDS budget (<= ~3500)");
+  if (fxk_gather_lds_bytes(L.max_keypoints) > 64 * 1024)
+    return fail(FX_ERR_INVALID_ARG, "max_keypoints exceeds the LDS budget of the support gather (<= ~1500)");
   if (fxk_desc_lds_bytes(L.max_neighbors) > kLds) return fail(FX_ERR_INVALID_ARG, "max_neighbors exceeds the LDS budget (<= ~4800)");
   if (L.max_keypoints > 65535 || L.max_candidates > 32768 || L.max_ring_points > 32768)
     return fail(FX_ERR_INVALID_ARG, "limit exceeds the 16-bit packing of the order replay");

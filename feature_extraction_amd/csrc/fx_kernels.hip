@@ -1328,8 +1328,13 @@ __device__ __forceinline__ unsigned long long sc3d_key(uint32_t bin, float d2, u
 }
 
 // ---------------------------------------------------------------- k_gather
+#ifndef FX_GATHER_SLICES
 #define FX_GATHER_SLICES 2
+#endif
 #define FX_GATHER_BINS 64
+#ifndef FX_GATHER_STAGE
+#define FX_GATHER_STAGE 512  // hits one workgroup stages between flushes (a larger stage costs more in occupancy than it saves in flushes)
+#endif
 extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBuffers B, float box_margin) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   // LDS: [0..15] scratch, [16..16+BINS] bin starts, then keypoints (float4) and their x-sorted order
@@ -1337,6 +1342,12 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
   uint32_t *s_bin = smem + 16;                                    // [FX_GATHER_BINS + 1]
   float4 *s_kp = reinterpret_cast<float4 *>(smem + 16 + 80);      // 16-byte aligned
   uint32_t *s_ord = smem + 16 + 80 + 4 * P.max_keypoints;         // keypoint ids sorted by x bin
+  // hits are staged in LDS and appended to the keypoints' lists in bulk: one global atomic per
+  // (keypoint, flush) reserves the slots instead of one returning atomic per hit
+  uint32_t *s_kcnt = s_ord + P.max_keypoints + FX_GATHER_BINS;    // [max_keypoints] staged hits per keypoint
+  uint32_t *s_kbase = s_kcnt + P.max_keypoints;                   // [max_keypoints] reserved list position
+  uint32_t *s_smeta = s_kbase + P.max_keypoints;                  // [FX_GATHER_STAGE] keypoint << 16 | staged ordinal
+  float4 *s_spt = reinterpret_cast<float4 *>(smem + ((16 + 80 + 7 * P.max_keypoints + FX_GATHER_BINS + FX_GATHER_STAGE + 3) & ~3u));
   const uint32_t scan = blockIdx.y, slice = blockIdx.x, tid = threadIdx.x;
   uint32_t K = B.n_kp[scan];
   if (K == 0) return;
@@ -1386,6 +1397,8 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
   uint32_t *s_fill = s_w + 8;  // unused scratch words are too few: fill cursors live behind the order array
   s_fill = s_ord + P.max_keypoints;
   for (uint32_t b = tid; b < FX_GATHER_BINS; b += FX_WG) s_fill[b] = 0;
+  for (uint32_t k = tid; k < K; k += FX_WG) s_kcnt[k] = 0;
+  if (tid == 0) s_w[8] = 0;  // staged hits
   __syncthreads();
   for (uint32_t k = tid; k < K; k += FX_WG) {
     const int b = min(max((int)((s_kp[k].x - kx0) * inv_w), 0), FX_GATHER_BINS - 1);
@@ -1398,12 +1411,35 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
   chunk = (chunk + FX_WG * 4 - 1) / (FX_WG * 4) * (FX_WG * 4);
   const uint32_t lo = slice * chunk;
   const uint32_t hi = lo + chunk < n ? lo + chunk : n;
+  // called by the whole workgroup, after a barrier: reserve list positions, write the staged hits out
+  auto flush = [&](uint32_t staged) {
+    staged = min(staged, (uint32_t)FX_GATHER_STAGE);
+    for (uint32_t k = tid; k < K; k += FX_WG) {
+      const uint32_t c = s_kcnt[k];
+      if (c) s_kbase[k] = atomicAdd(&B.s_cnt[row0 + k], c);
+      s_kcnt[k] = 0;
+    }
+    __syncthreads();
+    for (uint32_t e = tid; e < staged; e += FX_WG) {
+      const uint32_t meta = s_smeta[e], k = meta >> 16;
+      const uint32_t pos = s_kbase[k] + (meta & 0xffffu);
+      if (pos < P.list_cap) B.s_pts[(size_t)(row0 + k) * P.list_cap + pos] = s_spt[e];
+    }
+    if (tid == 0) s_w[8] = 0;
+    __syncthreads();
+  };
   for (uint32_t i0 = lo; i0 < hi; i0 += FX_WG * 4) {
     float4 v[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const uint32_t i = i0 + u * FX_WG + tid;
       v[u] = i < hi ? *reinterpret_cast<const float4 *>(M.pts + (size_t)i * M.stride_f) : make_float4(NAN, NAN, NAN, 0);
+    }
+    if (i0 != lo) {  // flush when the next tile might not fit any more (workgroup-uniform decision)
+      __syncthreads();
+      const uint32_t staged = s_w[8];
+      __syncthreads();
+      if (staged > FX_GATHER_STAGE / 2) flush(staged);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -1423,12 +1459,21 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
         const float4 kp = s_kp[k];
         const float d = dist2(kp.x, kp.y, kp.z, rx, ry, rz);
         if (d < P.r2_support) {
-          const uint32_t pos = atomicAdd(&B.s_cnt[row0 + k], 1u);
-          if (pos < P.list_cap) B.s_pts[(size_t)(row0 + k) * P.list_cap + pos] = make_float4(rx, ry, rz, __uint_as_float(idx));
+          const float4 hit = make_float4(rx, ry, rz, __uint_as_float(idx));
+          const uint32_t slot = atomicAdd(&s_w[8], 1u);
+          if (slot < FX_GATHER_STAGE) {
+            s_spt[slot] = hit;
+            s_smeta[slot] = (k << 16) | atomicAdd(&s_kcnt[k], 1u);
+          } else {  // stage full (a burst of hits within one tile): append directly
+            const uint32_t pos = atomicAdd(&B.s_cnt[row0 + k], 1u);
+            if (pos < P.list_cap) B.s_pts[(size_t)(row0 + k) * P.list_cap + pos] = hit;
+          }
         }
       }
     }
   }
+  __syncthreads();
+  flush(s_w[8]);
 }
 
 // ---------------------------------------------------------------- k_desc_zero
@@ -2240,6 +2285,9 @@ size_t fxk_ring_wave_lds_bytes(uint32_t cap, uint32_t ccap) {
 size_t fxk_merge_lds_bytes(uint32_t cap, uint32_t n_rings) {
   return (size_t)(SegCfg<FX_WG>::kWords + FX_MERGE_WORDS_PER_CAND * cap + 2 * (n_rings + 1)) * 4;
 }
+size_t fxk_gather_lds_bytes(uint32_t max_keypoints) {
+  return (16 + 80 + 7 * (size_t)max_keypoints + FX_GATHER_BINS + FX_GATHER_STAGE + 4 + 4 * FX_GATHER_STAGE) * 4;
+}
 size_t fxk_desc_lds_bytes(uint32_t cap) { return (size_t)(16 + FX_DESC_WORDS_PER_POINT * cap + FX_DESC_BINS) * 4; }
 
 hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t desc_big) {
@@ -2281,8 +2329,7 @@ void fxk_offsets(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32
 }
 void fxk_gather(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float box_margin) {
   hipLaunchKernelGGL(k_gather, dim3(FX_GATHER_SLICES, batch), dim3(FX_WG),
-                     (16 + 80 + 5 * (size_t)P.max_keypoints + FX_GATHER_BINS) * 4, s, P, B,
-                     box_margin);
+                     fxk_gather_lds_bytes(P.max_keypoints), s, P, B, box_margin);
 }
 void fxk_desc_zero(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid) {
   hipLaunchKernelGGL(k_desc_zero, dim3(grid), dim3(FX_WG), 0, s, P, B, batch);
