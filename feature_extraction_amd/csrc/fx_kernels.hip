@@ -469,7 +469,28 @@ __device__ __forceinline__ uint32_t cc_label(const float4 *pt, uint32_t n, float
         const bool live = i < n;
         const float4 q = live ? pt[i] : make_float4(0, 0, 0, 0);
         const uint32_t my_run = live ? rid[i] : FX_NONE;
-        for (uint32_t j = i0 + wave * 64 + 1; j < n; ++j) {
+        // (eight points per trip, loaded before any of them is used: a trip costs one LDS round trip, not eight)
+        uint32_t j = i0 + wave * 64 + 1;
+        for (; j + 8 <= n; j += 8) {
+          float4 p[8];
+          uint32_t rj[8];
+#pragma unroll
+          for (uint32_t u = 0; u < 8; ++u) {
+            p[u] = pt[j + u];
+            rj[u] = rid[j + u];
+          }
+          uint32_t edges = 0;
+#pragma unroll
+          for (uint32_t u = 0; u < 8; ++u) {
+            const bool edge = live && j + u > i && rj[u] != my_run && dist2(q.x, q.y, q.z, p[u].x, p[u].y, p[u].z) < r2;
+            edges |= edge ? (1u << u) : 0u;
+          }
+          if (__ballot(edges != 0u)) {  // wave-uniform
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) park((edges >> u) & 1u, (i << 16) | (j + u));
+          }
+        }
+        for (; j < n; ++j) {
           const float4 p = pt[j];
           const bool edge = live && j > i && rid[j] != my_run && dist2(q.x, q.y, q.z, p.x, p.y, p.z) < r2;
           park(edge, (i << 16) | j);
@@ -547,6 +568,7 @@ __device__ __forceinline__ uint32_t cc_order(uint32_t n, const uint32_t *parent,
     for (uint32_t c = threadIdx.x; c < n_c; c += NT) {
       const uint32_t rec = crec[c], sz = rec >> 16;
       uint32_t pos = 0;
+#pragma unroll 8
       for (uint32_t d = 0; d < n_c; ++d) {
         const uint32_t sd = crec[d] >> 16;
         pos += (sd > sz || (sd == sz && d < c)) ? 1u : 0u;
@@ -1563,6 +1585,7 @@ __device__ __forceinline__ void desc_wave_body(const FxDevParams &P, const FxBuf
         float lut;
         const uint32_t bin = sc3d_bin<FAST>(kp, b.x, b.y, b.z, d2, xa, T, lut, amb);
         uint32_t dens = 0;  // support points within R/5 of this neighbour (itself included)
+#pragma unroll 8
         for (uint32_t q = 0; q < nS; ++q) {
           const float4 s = sp[q];
           dens += (dist2(b.x, b.y, b.z, s.x, s.y, s.z) < P.r2_density) ? 1u : 0u;
@@ -1602,6 +1625,7 @@ __device__ __forceinline__ void desc_wave_body(const FxDevParams &P, const FxBuf
       if (e < nM) {
         const unsigned long long key = nkey[e];
         uint32_t rank = 0;
+#pragma unroll 8
         for (uint32_t q = 0; q < nM; ++q) rank += (nkey[q] < key) ? 1u : 0u;
         skey[rank] = key;
         sw[rank] = nw[e];
@@ -1708,6 +1732,7 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_group(FxDevParams P, 
       const uint32_t bin = sc3d_bin<true>(kp, b.x, b.y, b.z, d2, xa, T, lut, amb);
       if (amb) cnt[2] = 1u;
       uint32_t dens = 0;  // support points within R/5 of this neighbour (itself included)
+#pragma unroll 8
       for (uint32_t q = 0; q < nS; ++q) {
         const float4 s = sp[q];
         dens += (dist2(b.x, b.y, b.z, s.x, s.y, s.z) < P.r2_density) ? 1u : 0u;
@@ -1748,6 +1773,7 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_group(FxDevParams P, 
         my_key[u] = nkey[e];
         my_w[u] = nw[e];
         uint32_t rank = 0;
+#pragma unroll 8
         for (uint32_t q = 0; q < nM; ++q) rank += (nkey[q] < my_key[u]) ? 1u : 0u;
         my_rank[u] = rank;
       }
@@ -1886,6 +1912,7 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
       const float4 bq = L.sp[nlist[m]];
       const uint32_t q0 = part * chunk, q1 = min(q0 + chunk, nS);
       uint32_t c = 0;
+#pragma unroll 8
       for (uint32_t q = q0; q < q1; ++q) {
         const float4 sq = L.sp[q];
         c += (dist2(bq.x, bq.y, bq.z, sq.x, sq.y, sq.z) < P.r2_density) ? 1u : 0u;
@@ -1944,6 +1971,7 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
       const unsigned long long key = L.nkey[m];
       const uint32_t q0 = part * chunk, q1 = min(q0 + chunk, nM);
       uint32_t c = 0;
+#pragma unroll 8
       for (uint32_t q = q0; q < q1; ++q) c += (L.nkey[q] < key) ? 1u : 0u;
       if (c) atomicAdd(&rank[m], c);
     }
