@@ -928,13 +928,25 @@ __device__ __forceinline__ bool ring_body(const FxDevParams &P, const FxBuffers 
     const uint32_t sz = rec >> 16, root = L.croot[rec & 0xffffu];
     double sumx = 0.0, sumy = 0.0, sumz = 0.0;
     uint32_t cnt = 0;
-    for (uint32_t i = root; i < n && cnt < sz; ++i) {
-      if (L.parent[i] != root) continue;
-      const float4 q = L.pt[i];
-      sumx += (double)q.x;
-      sumy += (double)q.y;
-      sumz += (double)q.z;
-      L.rank[i] = cnt++;
+    // (four points per LDS round trip: label and coordinates loaded before either is used; the
+    //  members of a ring cluster are almost always consecutive)
+    for (uint32_t i = root; i < n && cnt < sz; i += 4) {
+      uint32_t pr[4];
+      float4 q[4];
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u) {
+        const uint32_t iu = min(i + u, n - 1u);
+        pr[u] = L.parent[iu];
+        q[u] = L.pt[iu];
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u) {
+        if (i + u >= n || pr[u] != root) continue;
+        sumx += (double)q[u].x;
+        sumy += (double)q[u].y;
+        sumz += (double)q[u].z;
+        L.rank[i + u] = cnt++;
+      }
     }
     L.cc[s] = make_float4((float)(sumx / (double)sz), (float)(sumy / (double)sz), (float)(sumz / (double)sz), L.pt[root].w);
   }
@@ -1141,13 +1153,20 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
       if (s >= K) continue;
       double sumx = 0.0, sumy = 0.0, sumz = 0.0;
       uint32_t cnt = 0;
-      for (uint32_t i = root; i < C && cnt < sz; ++i) {
-        if (L.parent[i] != root) continue;
-        const float4 q = L.pt[i];
-        sumx += (double)q.x;
-        sumy += (double)q.y;
-        sumz += (double)L.cz[i];
-        ++cnt;
+      // (members are scattered over the candidate list: eight labels per LDS round trip)
+      for (uint32_t i = root; i < C && cnt < sz; i += 8) {
+        uint32_t pr[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) pr[u] = L.parent[min(i + u, C - 1u)];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+          if (i + u >= C || pr[u] != root) continue;
+          const float4 q = L.pt[i + u];
+          sumx += (double)q.x;
+          sumy += (double)q.y;
+          sumz += (double)L.cz[i + u];
+          ++cnt;
+        }
       }
       kp[s] = make_float4((float)(sumx / (double)sz), (float)(sumy / (double)sz), (float)(sumz / (double)sz),
                           L.pt[root].w);
