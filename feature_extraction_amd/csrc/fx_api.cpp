@@ -204,7 +204,7 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof) {
       FX_HIP(mark(9));
       fxk_desc_fast(s, P, B, batch, big_grid * 4, 0);
       FX_HIP(mark(10));
-      fxk_desc_wg_fast(s, P, B, batch, P.list_cap, big_grid * 8, 0);
+      fxk_desc_wg_fast(s, P, B, batch, P.list_cap, big_grid * 4, 0);
       FX_HIP(mark(11));
       fxk_desc_wg(s, P, B, batch, P.list_cap, big_grid, 0, 2);
       FX_HIP(mark(12));
@@ -214,7 +214,7 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof) {
       // second pass: only keypoints whose RNG ordinal moved (an earlier keypoint had no neighbours)
       fxk_desc_group(s, P, B, batch, desc_grid, 1);
       fxk_desc_fast(s, P, B, batch, big_grid * 4, 1);
-      fxk_desc_wg_fast(s, P, B, batch, P.list_cap, big_grid * 8, 1);
+      fxk_desc_wg_fast(s, P, B, batch, P.list_cap, big_grid * 4, 1);
       fxk_desc_wg(s, P, B, batch, P.list_cap, big_grid, 1, 2);
       fxk_desc_wg(s, P, B, batch, L.max_neighbors, big_grid, 1, 0);
       fxk_desc_spill(s, P, B, batch, c->spill_grid, 1, c->spill_slab);

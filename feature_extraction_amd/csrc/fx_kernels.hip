@@ -1834,6 +1834,7 @@ struct DescLds {
   uint32_t *sidx, *s_w;
 };
 #define FX_DESC_WORDS_PER_POINT 8
+#define FX_DGRID 13  // density grid cells per axis: 2 (R + R/5) / (R/5) = 12, + 1
 __device__ __forceinline__ DescLds desc_carve(uint32_t *smem, uint32_t cap) {
   DescLds L;
   L.s_w = smem;  // 16 words
@@ -1862,12 +1863,81 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
   if (tid < 4) L.s_w[tid] = 0;  // 0: support count, 1: binned neighbours, 2: all neighbours
   __syncthreads();
   uint32_t nS;
+  // Density grid: a list-fed support set is stored sorted by xy cell (cell width >= R/5, FX_DGRID cells
+  // per axis cover the support radius), so the density query of a neighbour only scans the three
+  // cell rows around it instead of the whole set.  The cell table borrows the (still unused) image.
+  constexpr uint32_t G = FX_DGRID, kCells = G * G;
+  constexpr int EPT = (1024 + NT - 1) / NT;  // list entries per thread (list_cap <= 1024)
+  uint32_t *cell_start = reinterpret_cast<uint32_t *>(L.img);  // [kCells + 1]
+  uint32_t *cell_fill = cell_start + kCells + 1;                // [kCells] counts, then fill cursors
+  const float r_sup = sqrtf(P.r2_support);
+  const float cell_w = fmaxf(sqrtf(P.r2_density) * 1.001f, 2.0f * r_sup / (float)(G - 1) * 1.0001f);
+  const float inv_cw = 1.0f / cell_w, gx0 = kp.x - r_sup, gy0 = kp.y - r_sup;
+  auto cell_x = [&](float x) { return (uint32_t)min(max((int)floorf((x - gx0) * inv_cw), 0), (int)G - 1); };
+  auto cell_y = [&](float y) { return (uint32_t)min(max((int)floorf((y - gy0) * inv_cw), 0), (int)G - 1); };
+  bool grid = false;
   if (from_list) {
     nS = B.s_cnt[row];
-    for (uint32_t e = tid; e < nS; e += NT) {
-      const float4 v = B.s_pts[(size_t)row * P.list_cap + e];
-      L.sp[e] = make_float4(v.x, v.y, v.z, dist2(kp.x, kp.y, kp.z, v.x, v.y, v.z));
-      L.sidx[e] = __float_as_uint(v.w);
+    grid = nS <= (uint32_t)EPT * NT;
+    if (grid) {
+      for (uint32_t t = tid; t < 2 * kCells + 1; t += NT) cell_start[t] = 0;
+      __syncthreads();
+      float4 mine[EPT];
+      uint32_t mcell[EPT];
+#pragma unroll
+      for (int u = 0; u < EPT; ++u) {
+        const uint32_t e = tid + u * NT;
+        if (e < nS) {
+          mine[u] = B.s_pts[(size_t)row * P.list_cap + e];
+          mcell[u] = cell_y(mine[u].y) * G + cell_x(mine[u].x);
+          atomicAdd(&cell_fill[mcell[u]], 1u);
+        }
+      }
+      __syncthreads();
+      if (tid < 64) {  // exclusive prefix over the cells by one wavefront
+        constexpr uint32_t per = (kCells + 63) / 64;
+        uint32_t c[per], sum = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < per; ++u) {
+          const uint32_t ci = tid * per + u;
+          c[u] = ci < kCells ? cell_fill[ci] : 0u;
+          sum += c[u];
+        }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+          if ((int)tid >= d) incl += o;
+        }
+        uint32_t run = incl - sum;
+#pragma unroll
+        for (uint32_t u = 0; u < per; ++u) {
+          const uint32_t ci = tid * per + u;
+          if (ci < kCells) {
+            cell_start[ci] = run;
+            cell_fill[ci] = 0;
+          }
+          run += c[u];
+        }
+        if (tid == 63) cell_start[kCells] = incl;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < EPT; ++u) {
+        const uint32_t e = tid + u * NT;
+        if (e < nS) {
+          const float4 v = mine[u];
+          const uint32_t slot = cell_start[mcell[u]] + atomicAdd(&cell_fill[mcell[u]], 1u);
+          L.sp[slot] = make_float4(v.x, v.y, v.z, dist2(kp.x, kp.y, kp.z, v.x, v.y, v.z));
+          L.sidx[slot] = __float_as_uint(v.w);
+        }
+      }
+    } else {
+      for (uint32_t e = tid; e < nS; e += NT) {
+        const float4 v = B.s_pts[(size_t)row * P.list_cap + e];
+        L.sp[e] = make_float4(v.x, v.y, v.z, dist2(kp.x, kp.y, kp.z, v.x, v.y, v.z));
+        L.sidx[e] = __float_as_uint(v.w);
+      }
     }
     __syncthreads();
   } else {
@@ -1900,7 +1970,6 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
     if (nS > cap) return false;  // the caller hands the keypoint to the spill tier
   }
   FX_STAMP(1);
-  for (uint32_t t = tid; t < FX_DESC_BINS; t += NT) L.img[t] = 0.0f;
 
   const FxScTables *T = B.tables;
   const float2 xa = B.xaxis[ord];
@@ -1919,26 +1988,44 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
     dens[2 * m] = 0u;
   }
   __syncthreads();
+  FX_STAMP(6);
   {
     // ---- local point density = support points within R/5 of the neighbour (itself included): every
     //      neighbour's count is split over `parts` lanes so that the whole workgroup is busy
     const uint32_t nMq = L.s_w[1];
     uint32_t parts = 1;
-    while (parts < 32 && nMq * parts * 2 <= (uint32_t)NT) parts <<= 1;
+    while (parts < (grid ? 4u : 32u) && nMq * parts * 2 <= (uint32_t)NT) parts <<= 1;
     const uint32_t chunk = (nS + parts - 1) / parts;
     for (uint32_t t = tid; t < nMq * parts; t += NT) {
       const uint32_t m = t / parts, part = t % parts;
       const float4 bq = L.sp[nlist[m]];
-      const uint32_t q0 = part * chunk, q1 = min(q0 + chunk, nS);
       uint32_t c = 0;
+      if (grid) {
+        const uint32_t cx = cell_x(bq.x), cy = cell_y(bq.y);
+        const uint32_t xa0 = cx > 0 ? cx - 1 : 0, xa1 = min(cx + 1, G - 1);
+        for (uint32_t rowi = part; rowi < 3; rowi += parts) {  // the cells of a row are stored back to back
+          const uint32_t yy = cy + rowi - 1u;
+          if (yy >= G) continue;  // (also the wrapped -1)
+          const uint32_t q0 = cell_start[yy * G + xa0], q1 = cell_start[yy * G + xa1 + 1];
 #pragma unroll 8
-      for (uint32_t q = q0; q < q1; ++q) {
-        const float4 sq = L.sp[q];
-        c += (dist2(bq.x, bq.y, bq.z, sq.x, sq.y, sq.z) < P.r2_density) ? 1u : 0u;
+          for (uint32_t q = q0; q < q1; ++q) {
+            const float4 sq = L.sp[q];
+            c += (dist2(bq.x, bq.y, bq.z, sq.x, sq.y, sq.z) < P.r2_density) ? 1u : 0u;
+          }
+        }
+      } else {
+        const uint32_t q0 = part * chunk, q1 = min(q0 + chunk, nS);
+#pragma unroll 8
+        for (uint32_t q = q0; q < q1; ++q) {
+          const float4 sq = L.sp[q];
+          c += (dist2(bq.x, bq.y, bq.z, sq.x, sq.y, sq.z) < P.r2_density) ? 1u : 0u;
+        }
       }
       if (c) atomicAdd(&dens[2 * m], c);
     }
     __syncthreads();
+    for (uint32_t t = tid; t < FX_DESC_BINS; t += NT) L.img[t] = 0.0f;  // (the cell table is done with)
+    FX_STAMP(7);
     // ---- bins and weights, one neighbour per lane
     for (uint32_t m = tid; m < nMq; m += NT) {
       const uint32_t e = nlist[m];
@@ -2080,7 +2167,9 @@ __device__ __forceinline__ void desc_wg_loop(const FxDevParams &P, const FxBuffe
 }
 // A long-list keypoint is a chain of dependent phases (density counts, bitonic sort, ...); wide
 // workgroups shorten the chain: 1024 threads for the fp32 pass, 512 for the register-heavier exact one.
-#define FX_DESC_WG_FAST_T 1024
+#ifndef FX_DESC_WG_FAST_T
+#define FX_DESC_WG_FAST_T 256
+#endif
 #define FX_DESC_WG_EXACT_T 512
 extern "C" __global__ __launch_bounds__(FX_DESC_WG_EXACT_T) void k_desc_wg(FxDevParams P, FxBuffers B, uint32_t batch,
                                                                             uint32_t cap, uint32_t mode, uint32_t src) {

@@ -41,5 +41,5 @@ tot = v[base:base + 12].sum()
 rows = max(v[base + 12], 1)
 print(f"-- long-list descriptor tier (fp32 pass): {rows / 3:.0f} rows/batch, support {v[base + 13] / rows:.0f}, neighbours {v[base + 14] / rows:.0f}, "
       f"{tot / rows:.0f} cycles per row")
-for k, nm in {1: "load list", 2: "bins + density", 3: "bitonic sort", 4: "bin sums", 5: "row write"}.items():
+for k, nm in {1: "load list", 6: "neighbour filter", 7: "density", 2: "bins + weights", 3: "sort", 4: "bin sums", 5: "row write"}.items():
     print(f"   {nm:24s} {v[base + k] / max(tot, 1) * 100:6.2f} %   {v[base + k] / rows:10.0f}")
