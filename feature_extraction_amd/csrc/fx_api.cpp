@@ -178,7 +178,16 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof) {
       // (LDS appears to be handed out in 2 KiB granules: a workgroup too many per CU queues behind the others)
       uint32_t per_cu = (uint32_t)(160 * 1024 / ((fxk_ring_wave_lds_bytes(ring_small, ring_small / 4) + 2047) / 2048 * 2048));
       if (per_cu > c->ring_waves_per_cu) per_cu = c->ring_waves_per_cu;
-      fxk_rings_small(s, P, B, batch, ring_small, ring_small / 4, ring_mid, (uint32_t)c->n_cu * per_cu);
+      // The items are (scan, ring) in scan-major order and a workgroup strides over them by the grid
+      // size: a grid that is a multiple of n_rings would hand it the same ring index of every scan (rings
+      // differ a lot in cost).  Make the stride step the ring index by about 0.38 n_rings instead.
+      uint32_t grid = (uint32_t)c->n_cu * per_cu;
+      const uint32_t R = (uint32_t)c->params.n_rings;
+      if (R > 1 && grid > 2 * R) {
+        const uint32_t want = ((uint32_t)(0.381966 * R) | 1u) % R;
+        grid -= (grid % R + R - want) % R;
+      }
+      fxk_rings_small(s, P, B, batch, ring_small, ring_small / 4, ring_mid, grid);
     }
     FX_HIP(mark(3));
     {
@@ -198,7 +207,6 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof) {
       FX_HIP(mark(6));
       fxk_gather(s, P, B, batch, c->box_margin);
       FX_HIP(mark(7));
-      fxk_desc_zero(s, P, B, batch, (uint32_t)c->n_cu * 8u);
       FX_HIP(mark(8));
       fxk_desc_group(s, P, B, batch, desc_grid, 0);
       FX_HIP(mark(9));

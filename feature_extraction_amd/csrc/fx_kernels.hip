@@ -1447,6 +1447,22 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
   }
   __syncthreads();
 
+  float4 *z4;   // 16-byte body of the share, cleared a slab per tile of the stream
+  uint32_t zn;
+  {
+    // this workgroup's share of the scan's descriptor rows is cleared here, in the shadow of the point
+    // stream below (descriptors are sparse: the keypoint kernels only write non-empty bins)
+    const size_t f0 = (size_t)row0 * FX_DESC_FLOATS, len = (size_t)K * FX_DESC_FLOATS;
+    size_t a = f0 + (len * slice / FX_GATHER_SLICES), b = f0 + (len * (slice + 1) / FX_GATHER_SLICES);
+    if (slice != 0) a &= ~(size_t)3;  // interior cuts on 16-byte boundaries
+    if (slice != FX_GATHER_SLICES - 1) b &= ~(size_t)3;
+    const size_t a4 = min((a + 3) & ~(size_t)3, b), b4 = max(b & ~(size_t)3, a4);
+    float *d = B.desc;
+    if (tid < a4 - a) d[a + tid] = 0.0f;
+    if (tid < b - b4) d[b4 + tid] = 0.0f;
+    z4 = reinterpret_cast<float4 *>(d + a4);
+    zn = (uint32_t)((b4 - a4) / 4);
+  }
   const uint32_t n = M.n;
   uint32_t chunk = (n + FX_GATHER_SLICES - 1) / FX_GATHER_SLICES;
   chunk = (chunk + FX_WG * 4 - 1) / (FX_WG * 4) * (FX_WG * 4);
@@ -1469,12 +1485,22 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
     if (tid == 0) s_w[8] = 0;
     __syncthreads();
   };
+  const uint32_t n_tiles = (hi > lo) ? (hi - lo + FX_WG * 4 - 1) / (FX_WG * 4) : 0u;
+  const uint32_t zslab = n_tiles ? (zn + n_tiles - 1) / n_tiles : 0u;
+  if (n_tiles == 0)
+    for (uint32_t t = tid; t < zn; t += FX_WG) z4[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  uint32_t zdone = 0;
   for (uint32_t i0 = lo; i0 < hi; i0 += FX_WG * 4) {
     float4 v[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const uint32_t i = i0 + u * FX_WG + tid;
       v[u] = i < hi ? *reinterpret_cast<const float4 *>(M.pts + (size_t)i * M.stride_f) : make_float4(NAN, NAN, NAN, 0);
+    }
+    {
+      const uint32_t zend = min(zdone + zslab, zn);
+      for (uint32_t t = zdone + tid; t < zend; t += FX_WG) z4[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+      zdone = zend;
     }
     if (i0 != lo) {  // flush when the next tile might not fit any more (workgroup-uniform decision)
       __syncthreads();
