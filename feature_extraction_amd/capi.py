@@ -20,9 +20,9 @@ FX_ERR_NO_DEVICE = 2
 FX_IN_DEVICE, FX_OUT_HOST, FX_OUT_DEBUG, FX_OUT_CLOUDS = 1, 2, 4, 8
 FX_FLAG_NAMES = {0x1: "RING_OVERFLOW", 0x2: "CAND_OVERFLOW", 0x4: "KP_OVERFLOW", 0x8: "NBR_OVERFLOW",
                  0x10: "TOTAL_KP_OVERFLOW", 0x20: "KPC_OVERFLOW"}
-FX_N_STAGES = 13
+FX_N_STAGES = 12
 STAGE_NAMES = ("k_prep", "k_bucket", "k_rings_small", "k_rings_big", "k_rings_big(large)+k_merge_small",
-               "k_merge_big+k_offsets", "k_gather", "k_desc_zero", "k_desc_group", "k_desc_fast", "k_desc_wg_fast",
+               "k_merge_big+k_offsets", "k_gather", "k_desc_group", "k_desc_fast", "k_desc_wg_fast",
                "k_desc_wg(exact)", "desc_tail")
 
 

@@ -34,13 +34,11 @@ void fxk_merge_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, ui
 void fxk_merge_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t grid);
 void fxk_offsets(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
 void fxk_gather(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float box_margin);
-void fxk_desc_zero(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid);
-void fxk_desc_group(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t mode);
-void fxk_desc_fast(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t mode);
+void fxk_desc_group(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid);
+void fxk_desc_fast(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid);
 void fxk_desc_wg(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t grid,
                  uint32_t mode, uint32_t src);
-void fxk_desc_wg_fast(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t grid,
-                      uint32_t mode);
+void fxk_desc_wg_fast(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t grid);
 void fxk_desc_spill(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t mode,
                     uint32_t slab_pts);
 void fxk_pack_kp_records(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, void *dst,
@@ -207,29 +205,24 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof) {
       FX_HIP(mark(6));
       fxk_gather(s, P, B, batch, c->box_margin);
       FX_HIP(mark(7));
+      fxk_desc_group(s, P, B, batch, desc_grid);
       FX_HIP(mark(8));
-      fxk_desc_group(s, P, B, batch, desc_grid, 0);
+      fxk_desc_fast(s, P, B, batch, big_grid * 4);
       FX_HIP(mark(9));
-      fxk_desc_fast(s, P, B, batch, big_grid * 4, 0);
+      fxk_desc_wg_fast(s, P, B, batch, P.list_cap, big_grid * 4);
       FX_HIP(mark(10));
-      fxk_desc_wg_fast(s, P, B, batch, P.list_cap, big_grid * 4, 0);
-      FX_HIP(mark(11));
       fxk_desc_wg(s, P, B, batch, P.list_cap, big_grid, 0, 2);
-      FX_HIP(mark(12));
+      FX_HIP(mark(11));
       fxk_desc_wg(s, P, B, batch, L.max_neighbors, big_grid, 0, 0);
       fxk_desc_spill(s, P, B, batch, c->spill_grid, 0, c->spill_slab);
       fxk_rng_ord(s, P, B, batch);
       // second pass: only keypoints whose RNG ordinal moved (an earlier keypoint had no neighbours)
-      fxk_desc_group(s, P, B, batch, desc_grid, 1);
-      fxk_desc_fast(s, P, B, batch, big_grid * 4, 1);
-      fxk_desc_wg_fast(s, P, B, batch, P.list_cap, big_grid * 4, 1);
-      fxk_desc_wg(s, P, B, batch, P.list_cap, big_grid, 1, 2);
       fxk_desc_wg(s, P, B, batch, L.max_neighbors, big_grid, 1, 0);
       fxk_desc_spill(s, P, B, batch, c->spill_grid, 1, c->spill_slab);
     } else {
-      for (int i = 6; i <= 12; ++i) FX_HIP(mark(i));
+      for (int i = 6; i <= 11; ++i) FX_HIP(mark(i));
     }
-    FX_HIP(mark(13));
+    FX_HIP(mark(12));
     FX_HIP(hipGetLastError());
   } else {
     for (int i = 1; i <= FX_N_STAGES; ++i) FX_HIP(mark(i));

@@ -1258,8 +1258,8 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_offsets(FxDevParams P, FxB
 // pcl::ShapeContext3DEstimation (ref: node.cpp:329-355):
 //   k_gather        one pass over each scan tests every (rotated) point against the keypoints of the
 //                   scan (binned along x) and appends the points within R + R/5 of a keypoint to that
-//                   keypoint's support list (a superset of the neighbour query and of every density query)
-//   k_desc_zero     clears the descriptor rows of the batch in one streaming pass
+//                   keypoint's support list (a superset of the neighbour query and of every density query);
+//                   it also clears the scan's descriptor rows (the keypoint kernels write non-empty bins only)
 //   k_desc_group    4 keypoints per wavefront: support sets of <= 64 points (the bulk)
 //   k_desc_fast     one wavefront per keypoint: 65..256 support points
 //   k_desc_wg_fast  one 1024-thread workgroup per keypoint: up to list_cap support points
@@ -1543,18 +1543,6 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
   flush(s_w[8]);
 }
 
-// ---------------------------------------------------------------- k_desc_zero
-// Descriptors are sparse (a few dozen of 1980 bins): the rows of the batch are zeroed in one
-// streaming pass (16 B per lane, coalesced) and the keypoint kernels only write non-empty bins.
-extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_zero(FxDevParams P, FxBuffers B, uint32_t batch) {
-  uint32_t total = B.kp_offset[batch];
-  if (total > P.max_total_kp) total = P.max_total_kp;
-  const size_t n4 = ((size_t)total * FX_DESC_FLOATS + 3) / 4;  // B.desc is 256-byte aligned; capacity is padded
-  float4 *d = reinterpret_cast<float4 *>(B.desc);
-  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (size_t i = (size_t)blockIdx.x * FX_WG + threadIdx.x; i < n4; i += (size_t)gridDim.x * FX_WG) d[i] = z;
-}
-
 // ---------------------------------------------------------------- k_desc_fast
 #define FX_WAVE_CAP 256
 #define FX_WAVE_WORDS (FX_WAVE_CAP * 8)
@@ -1567,9 +1555,8 @@ __device__ __forceinline__ void desc_fill_nan(float *out, uint32_t lane, uint32_
 // edge is not finished here but handed to the exact workgroup kernel (k_desc_wg, fp64 angles), so
 // the result is the exact one either way.
 template <bool FAST>
-__device__ __forceinline__ void desc_wave_body(const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t mode,
+__device__ __forceinline__ void desc_wave_body(const FxDevParams &P, const FxBuffers &B, uint32_t batch,
                                                uint32_t *smem) {
-  if (mode == 1 && B.counters[3] == 0) return;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t *base = smem + wave * FX_WAVE_WORDS;
   // per-wave LDS: support set as float4 (x, y, z, d2) + point index, unsorted (key, weight); the
@@ -1589,11 +1576,7 @@ __device__ __forceinline__ void desc_wave_body(const FxDevParams &P, const FxBuf
     const uint32_t row = FAST ? B.wave_desc[it] : B.exact_desc[it];
     const uint2 rm = B.row_map[row];
     const uint32_t scan = rm.x, k = rm.y;
-    uint32_t ord = k;
-    if (mode == 1) {
-      ord = B.rng_ord[(size_t)scan * P.max_keypoints + k];
-      if (ord == k) continue;
-    }
+    const uint32_t ord = k;
     const uint32_t nS = B.s_cnt[row];
     if (nS > FX_WAVE_CAP || nS > P.list_cap) {  // long (or truncated) list: workgroup tiers
       if (FAST && lane == 0) {
@@ -1655,12 +1638,7 @@ __device__ __forceinline__ void desc_wave_body(const FxDevParams &P, const FxBuf
       desc_fill_nan(out, lane, 64);
       continue;
     }
-    // the output rows were zeroed in bulk by k_desc_zero; only the non-empty bins are written here.
-    // (second pass: the row holds the first pass's bins, so it is cleared again first)
-    if (mode == 1) {
-      for (uint32_t t = lane; t < FX_DESC_FLOATS; t += 64) out[t] = 0.0f;
-      __builtin_amdgcn_s_waitcnt(0);
-    }
+    // the output rows were zeroed in bulk by k_gather; only the non-empty bins are written here.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1695,9 +1673,9 @@ __device__ __forceinline__ void desc_wave_body(const FxDevParams &P, const FxBuf
     __builtin_amdgcn_wave_barrier();
   }
 }
-extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_fast(FxDevParams P, FxBuffers B, uint32_t batch, uint32_t mode) {
+extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_fast(FxDevParams P, FxBuffers B, uint32_t batch) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  desc_wave_body<true>(P, B, batch, mode, smem);
+  desc_wave_body<true>(P, B, batch, smem);
 }
 
 // ---------------------------------------------------------------- k_desc_group
@@ -1710,9 +1688,8 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_fast(FxDevParams P, F
 #define FX_GROUPS (64 / FX_GLANES)
 #define FX_GROUP_CAP 64
 #define FX_GROUP_WORDS (FX_GROUP_CAP * 8 + 8)  // per group: support float4, keys, weights, indices + 8 counters
-extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_group(FxDevParams P, FxBuffers B, uint32_t batch, uint32_t mode) {
+extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_group(FxDevParams P, FxBuffers B, uint32_t batch) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  if (mode == 1 && B.counters[3] == 0) return;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t gl = lane % FX_GLANES, g = lane / FX_GLANES;
   uint32_t *base = smem + (wave * FX_GROUPS + g) * FX_GROUP_WORDS;
@@ -1736,10 +1713,6 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_group(FxDevParams P, 
     if (live) {
       const uint2 rm = B.row_map[row];
       scan = rm.x, k = rm.y, ord = k;
-      if (mode == 1) {
-        ord = B.rng_ord[(size_t)scan * P.max_keypoints + k];
-        live = ord != k;
-      }
     }
     if (live) {
       nS = B.s_cnt[row];
@@ -1801,11 +1774,8 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_group(FxDevParams P, 
       if (nAll == 0) {  // no neighbours: NaN descriptor, no RNG draw (A.8-3)
         desc_fill_nan(out, gl, FX_GLANES);
         nM = 0;
-      } else if (mode == 1) {  // second pass: clear the first pass's bins
-        for (uint32_t t = gl; t < FX_DESC_FLOATS; t += FX_GLANES) out[t] = 0.0f;
       }
     }
-    if (mode == 1) __builtin_amdgcn_s_waitcnt(0);
     // rank sort (keys are unique: they end in the point index); the sorted arrays reuse the support storage
     unsigned long long my_key[FX_GROUP_CAP / FX_GLANES];
     float my_w[FX_GROUP_CAP / FX_GLANES];
@@ -1835,7 +1805,7 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_group(FxDevParams P, 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // one lane per bin run adds its weights in sorted order (the rows were zeroed by k_desc_zero)
+    // one lane per bin run adds its weights in sorted order (the rows were zeroed by k_gather)
     for (uint32_t e = gl; e < nM; e += FX_GLANES) {
       const uint32_t bin = (uint32_t)(skey[e] >> 52);
       if (e > 0 && (uint32_t)(skey[e - 1] >> 52) == bin) continue;
@@ -2167,35 +2137,49 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
 template <bool FAST, int NT>
 __device__ __forceinline__ void desc_wg_loop(const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap,
                                              uint32_t mode, uint32_t src, uint32_t *smem) {
-  if (mode == 1 && B.counters[3] == 0) return;
+  // a support set that does not fit `cap` goes to the spill tier
+  auto spill = [&](uint32_t row, uint32_t scan, uint32_t k) {
+    if (threadIdx.x == 0) {
+      if (B.spill_pts) {
+        const uint32_t pos = atomicAdd(&B.counters[6], 1u);
+        B.spill_desc[pos] = row;
+      } else {  // context created without a spill slab (limits.max_neighbors is then a hard cap)
+        atomicOr(&B.flags[scan], FX_FLAG_NBR_OVERFLOW);
+        B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = FX_NONE;
+      }
+    }
+    if (!B.spill_pts) desc_fill_nan(B.desc + (size_t)row * FX_DESC_FLOATS, threadIdx.x, NT);
+  };
+  if (mode == 1) {
+    // second pass (rare): every keypoint whose RNG ordinal moved is redone here, whatever tier computed
+    // it first — from its list when that holds the whole support set, else re-gathered
+    if (B.counters[3] == 0) return;
+    uint32_t total = B.kp_offset[batch];
+    if (total > P.max_total_kp) total = P.max_total_kp;
+    for (uint32_t row = blockIdx.x; row < total; row += gridDim.x) {
+      const uint2 rm = B.row_map[row];
+      const uint32_t scan = rm.x, k = rm.y;
+      const uint32_t ord = B.rng_ord[(size_t)scan * P.max_keypoints + k];
+      if (ord == k) continue;
+      if (!desc_body<FAST, NT>(P, B, row, scan, k, ord, cap, smem, B.s_cnt[row] <= P.list_cap)) spill(row, scan, k);
+      __syncthreads();
+    }
+    return;
+  }
   const uint32_t n_items = B.counters[src == 0 ? 2 : (src == 1 ? 4 : 7)];
   const uint32_t *items = src == 0 ? B.big_desc : (src == 1 ? B.list_desc : B.exact_desc);
   for (uint32_t i = blockIdx.x; i < n_items; i += gridDim.x) {
     const uint32_t row = items[i];
     const uint2 rm = B.row_map[row];
     const uint32_t scan = rm.x, k = rm.y;
-    const uint32_t ord = mode == 1 ? B.rng_ord[(size_t)scan * P.max_keypoints + k] : k;
     if (B.s_cnt[row] > P.list_cap && src != 0) continue;  // (exact_desc rows always fit; list rows too)
-    if (!desc_body<FAST, NT>(P, B, row, scan, k, ord, cap, smem, src != 0)) {
-      if (threadIdx.x == 0) {
-        if (B.spill_pts) {
-          const uint32_t pos = atomicAdd(&B.counters[6], 1u);
-          B.spill_desc[pos] = row;
-        } else {  // context created without a spill slab (limits.max_neighbors is then a hard cap)
-          atomicOr(&B.flags[scan], FX_FLAG_NBR_OVERFLOW);
-          B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = FX_NONE;
-        }
-      }
-      if (!B.spill_pts) desc_fill_nan(B.desc + (size_t)row * FX_DESC_FLOATS, threadIdx.x, NT);
-    }
+    if (!desc_body<FAST, NT>(P, B, row, scan, k, k, cap, smem, src != 0)) spill(row, scan, k);
     __syncthreads();
   }
 }
-// A long-list keypoint is a chain of dependent phases (density counts, bitonic sort, ...); wide
-// workgroups shorten the chain: 1024 threads for the fp32 pass, 512 for the register-heavier exact one.
-#ifndef FX_DESC_WG_FAST_T
+// The fp32 pass runs 256-thread workgroups, four keypoints per CU at a time (most phases of a keypoint are
+// latency chains that leave lanes idle, so concurrency beats width); the register-heavier exact one 512.
 #define FX_DESC_WG_FAST_T 256
-#endif
 #define FX_DESC_WG_EXACT_T 512
 extern "C" __global__ __launch_bounds__(FX_DESC_WG_EXACT_T) void k_desc_wg(FxDevParams P, FxBuffers B, uint32_t batch,
                                                                             uint32_t cap, uint32_t mode, uint32_t src) {
@@ -2203,9 +2187,9 @@ extern "C" __global__ __launch_bounds__(FX_DESC_WG_EXACT_T) void k_desc_wg(FxDev
   desc_wg_loop<false, FX_DESC_WG_EXACT_T>(P, B, batch, cap, mode, src, smem);
 }
 extern "C" __global__ __launch_bounds__(FX_DESC_WG_FAST_T) void k_desc_wg_fast(FxDevParams P, FxBuffers B, uint32_t batch,
-                                                                                uint32_t cap, uint32_t mode) {
+                                                                                uint32_t cap) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  desc_wg_loop<true, FX_DESC_WG_FAST_T>(P, B, batch, cap, mode, 1u, smem);
+  desc_wg_loop<true, FX_DESC_WG_FAST_T>(P, B, batch, cap, 0u, 1u, smem);
 }
 
 // ---------------------------------------------------------------- spill tier
@@ -2493,23 +2477,18 @@ void fxk_gather(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_
   hipLaunchKernelGGL(k_gather, dim3(FX_GATHER_SLICES, batch), dim3(FX_WG),
                      fxk_gather_lds_bytes(P.max_keypoints), s, P, B, box_margin);
 }
-void fxk_desc_zero(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid) {
-  hipLaunchKernelGGL(k_desc_zero, dim3(grid), dim3(FX_WG), 0, s, P, B, batch);
+void fxk_desc_group(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid) {
+  hipLaunchKernelGGL(k_desc_group, dim3(grid), dim3(FX_WG), (size_t)FX_NWAVE * FX_GROUPS * FX_GROUP_WORDS * 4, s, P, B, batch);
 }
-void fxk_desc_group(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t mode) {
-  hipLaunchKernelGGL(k_desc_group, dim3(grid), dim3(FX_WG), (size_t)FX_NWAVE * FX_GROUPS * FX_GROUP_WORDS * 4, s, P, B, batch,
-                     mode);
-}
-void fxk_desc_fast(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t mode) {
-  hipLaunchKernelGGL(k_desc_fast, dim3(grid), dim3(FX_WG), (size_t)FX_NWAVE * FX_WAVE_WORDS * 4, s, P, B, batch, mode);
+void fxk_desc_fast(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid) {
+  hipLaunchKernelGGL(k_desc_fast, dim3(grid), dim3(FX_WG), (size_t)FX_NWAVE * FX_WAVE_WORDS * 4, s, P, B, batch);
 }
 void fxk_desc_wg(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t grid,
                  uint32_t mode, uint32_t src) {
   hipLaunchKernelGGL(k_desc_wg, dim3(grid), dim3(FX_DESC_WG_EXACT_T), fxk_desc_lds_bytes(cap), s, P, B, batch, cap, mode, src);
 }
-void fxk_desc_wg_fast(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t grid,
-                      uint32_t mode) {
-  hipLaunchKernelGGL(k_desc_wg_fast, dim3(grid), dim3(FX_DESC_WG_FAST_T), fxk_desc_lds_bytes(cap), s, P, B, batch, cap, mode);
+void fxk_desc_wg_fast(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t grid) {
+  hipLaunchKernelGGL(k_desc_wg_fast, dim3(grid), dim3(FX_DESC_WG_FAST_T), fxk_desc_lds_bytes(cap), s, P, B, batch, cap);
 }
 void fxk_desc_spill(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t mode,
                     uint32_t slab_pts) {

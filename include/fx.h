@@ -149,10 +149,10 @@ typedef struct fx_batch_view {
 } fx_batch_view;
 
 /* Per-stage device time of the last batch (HIP events on the context's stream). */
-#define FX_N_STAGES 13
+#define FX_N_STAGES 12
 typedef struct fx_timings {
   /* k_prep, k_bucket, k_rings_small, k_rings_big (mid tier), large ring tier + k_merge_small,
-   * k_merge_big + k_offsets, k_gather, k_desc_zero, k_desc_group, k_desc_fast, k_desc_wg_fast,
+   * k_merge_big + k_offsets, k_gather, k_desc_group, k_desc_fast, k_desc_wg_fast,
    * k_desc_wg (exact redo of near-edge keypoints), tail (re-gather / spill tiers, k_rng_ord, second pass) */
   float ms[FX_N_STAGES];
   float total_ms;

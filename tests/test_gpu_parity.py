@@ -88,3 +88,18 @@ def test_other_radii_and_tolerances(fxlib, oracle):
                  dict(cluster_min_count=3, cluster_max_count=20, cluster_radius_threshold=0.3, number_detection_channels=3),
                  dict(x_min=-75.0, y_min=-75.0, y_max=75.0, z_min=-1.0)):
         _run_and_compare(oracle, capi.params("default", **over), capi.limits(3, 28800), scans, 0.02, -0.015, str(over))
+
+
+def test_keypoints_without_neighbours_shift_the_rng_stream(fxlib, oracle):
+    """A keypoint with no neighbour inside R gets a NaN descriptor and draws no x-axis, so every later
+    keypoint's RNG ordinal moves: the second pass redoes those rows."""
+    scans = [util.vlp16_scan(1000 + b) for b in range(3)]
+    for radius in (0.04, 0.1):
+        p = capi.params("launch", descriptor_radius=radius)
+        ora = [oracle.run(p, s, roll=0.02, pitch=-0.015) for s in scans]
+        assert any((o["kp_neighbors"] == 0).any() and (o["kp_neighbors"] > 0).any() for o in ora)
+        ctx = capi.Context(p, capi.limits(3, 28800))
+        got = ctx.process_host(scans, roll=0.02, pitch=-0.015)
+        for b in range(3):
+            util.compare_scan(got[b], ora[b], tag=f"rng shift R={radius} scan {b}")
+        ctx.close()
