@@ -161,7 +161,7 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof) {
     return prof ? hipEventRecord(c->ev[i], s) : hipSuccess;
   };
   FX_HIP(mark(0));
-  FX_HIP(hipMemsetAsync(B.counters, 0, 16 * sizeof(uint32_t), s));
+  if (!batch) FX_HIP(hipMemsetAsync(B.counters, 0, 16 * sizeof(uint32_t), s));  // (k_prep clears them otherwise)
   if (batch) {
     const uint32_t ring_small = L.max_ring_points < kRingCapSmall ? L.max_ring_points : kRingCapSmall;
     const uint32_t merge_small = L.max_candidates < kMergeCapSmall ? L.max_candidates : kMergeCapSmall;
@@ -201,7 +201,6 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof) {
     fxk_merge_big(s, P, B, L.max_candidates, big_grid);
     fxk_offsets(s, P, B, batch);
     if (P.estimate_descriptors) {
-      FX_HIP(hipMemsetAsync(B.s_cnt, 0, (size_t)L.max_total_keypoints * sizeof(uint32_t), s));
       FX_HIP(mark(6));
       fxk_gather(s, P, B, batch, c->box_margin);
       FX_HIP(mark(7));

@@ -676,6 +676,7 @@ __global__ __launch_bounds__(FX_PREP_T) void k_prep(FxDevParams P, FxBuffers B) 
     B.n_filt[scan] = base;
     B.flags[scan] = 0u;
   }
+  if (scan == 0 && tid < 16) B.counters[tid] = 0u;  // work-list counters of the batch (used from k_rings_small on)
 }
 
 // ====================================================================== stage 2a: ring buckets
@@ -1219,6 +1220,11 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
 
 extern "C" __global__ __launch_bounds__(FX_WG) void k_merge_small(FxDevParams P, FxBuffers B, uint32_t cap) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  {  // the support-list counters of the batch are cleared here, a slice per scan (k_gather fills them)
+    const uint32_t per = (P.max_total_kp + gridDim.x - 1) / gridDim.x;
+    const uint32_t z0 = blockIdx.x * per, z1 = min(z0 + per, P.max_total_kp);
+    for (uint32_t t = z0 + threadIdx.x; t < z1; t += FX_WG) B.s_cnt[t] = 0u;
+  }
   if (!merge_body(P, B, blockIdx.x, cap, smem, false)) {
     if (threadIdx.x == 0) {
       const uint32_t pos = atomicAdd(&B.counters[1], 1u);
@@ -2336,18 +2342,24 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_spill(FxDevParams P, 
 
 // RNG ordinals: 3DSC draws its three numbers only for keypoints that have neighbours.
 extern "C" __global__ __launch_bounds__(FX_WG) void k_rng_ord(FxDevParams P, FxBuffers B, uint32_t batch) {
-  const uint32_t b = blockIdx.x * FX_WG + threadIdx.x;
+  // one wavefront per scan: ordinal of keypoint k = number of earlier keypoints that have neighbours
+  const uint32_t b = (blockIdx.x * FX_WG + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (b >= batch) return;
   const uint32_t K = B.n_kp[b];
-  uint32_t ord = 0;
+  uint32_t base = 0;
   bool fix = false;
-  for (uint32_t k = 0; k < K; ++k) {
-    B.rng_ord[(size_t)b * P.max_keypoints + k] = ord;
-    fix = fix || (ord != k);
-    const uint32_t nb = B.kp_nbrs[(size_t)b * P.max_keypoints + k];
-    if (nb != 0u) ++ord;
+  for (uint32_t k0 = 0; k0 < K; k0 += 64) {
+    const uint32_t k = k0 + lane;
+    const bool draws = k < K && B.kp_nbrs[(size_t)b * P.max_keypoints + k] != 0u;
+    const unsigned long long m = __ballot(draws);
+    const uint32_t ord = base + lanes_below(m);
+    if (k < K) {
+      B.rng_ord[(size_t)b * P.max_keypoints + k] = ord;
+      fix = fix || (ord != k);
+    }
+    base += (uint32_t)__popcll(m);
   }
-  if (fix) atomicAdd(&B.counters[3], 1u);
+  if (__ballot(fix) && lane == 0) atomicAdd(&B.counters[3], 1u);
 }
 
 // pcl::concatenateFields(keypoints, descriptors) -> pcl::PointDescriptor records (ref: node.cpp:119).
@@ -2495,7 +2507,7 @@ void fxk_desc_spill(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uin
   hipLaunchKernelGGL(k_desc_spill, dim3(grid), dim3(FX_WG), 0, s, P, B, batch, mode, slab_pts);
 }
 void fxk_rng_ord(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch) {
-  hipLaunchKernelGGL(k_rng_ord, dim3((batch + FX_WG - 1) / FX_WG), dim3(FX_WG), 0, s, P, B, batch);
+  hipLaunchKernelGGL(k_rng_ord, dim3((batch + FX_NWAVE - 1) / FX_NWAVE), dim3(FX_WG), 0, s, P, B, batch);
 }
 void fxk_pack_kp_records(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, void *dst,
                          uint32_t rec_kp) {
