@@ -44,6 +44,7 @@ void fxk_desc_spill(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uin
 void fxk_pack_kp_records(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, void *dst,
                          uint32_t rec_kp);
 void fxk_rng_ord(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
+void fxk_test_sort_replay(hipStream_t s, const uint32_t *sizes, uint32_t n_seq, uint32_t n, uint32_t *perm);
 void fxk_unpack_pc2(hipStream_t s, const void *src, uint32_t n, uint32_t point_step, uint32_t ox, uint32_t oy, uint32_t oz,
                     uint32_t oi, uint32_t big_endian, void *dst, uint32_t grid);
 void fxk_pack_xyzi32(hipStream_t s, const void *src, uint32_t n, void *dst, uint32_t grid);
@@ -699,6 +700,28 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
   out->h_flags = c->h_flags;
   out->h_n_filtered = c->h_n_filt;
   out->h_n_kpc = c->h_n_kpc;
+  return FX_OK;
+}
+
+// Test hook: the device build of the cluster-order replay on caller-supplied size sequences.
+fx_status fx_test_sort_replay_device(int device, const uint32_t *sizes, uint32_t n_seq, uint32_t n, uint32_t *perm_out) {
+  if (!sizes || !perm_out) return fail(FX_ERR_INVALID_ARG, "null argument");
+  if (n > 192) return fail(FX_ERR_TOO_LARGE, "n > 192");
+  if (!n_seq || !n) return FX_OK;
+  FX_HIP(hipSetDevice(device));
+  const size_t bytes = (size_t)n_seq * n * sizeof(uint32_t);
+  uint32_t *d_in = nullptr, *d_out = nullptr;
+  FX_HIP(hipMalloc((void **)&d_in, bytes));
+  hipError_t e = hipMalloc((void **)&d_out, bytes);
+  if (e == hipSuccess) e = hipMemcpy(d_in, sizes, bytes, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    fxk_test_sort_replay(nullptr, d_in, n_seq, n, d_out);
+    e = hipDeviceSynchronize();
+  }
+  if (e == hipSuccess) e = hipMemcpy(perm_out, d_out, bytes, hipMemcpyDeviceToHost);
+  (void)hipFree(d_in);
+  if (d_out) (void)hipFree(d_out);
+  FX_HIP(e);
   return FX_OK;
 }
 

@@ -247,5 +247,31 @@ void fx_test_sort_replay_ranked(const uint32_t *sizes, uint32_t n, uint32_t *per
   for (uint32_t i = 0; i < n; ++i) perm_out[i] = rec[i] & 0xffffu;
   delete[] rec;
 }
+// Phase 1 through the position-list statement of the partition step (the rule the wavefront version
+// in fx_kernels.hip implements with ballots), then the stable ranking.
+void fx_test_sort_replay_lists(const uint32_t *sizes, uint32_t n, uint32_t *perm_out) {
+  uint32_t *rec = new uint32_t[2 * (n ? n : 1)];
+  uint16_t *pos = new uint16_t[2 * (n ? n : 1)];
+  for (uint32_t i = 0; i < n; ++i) rec[i] = (sizes[i] << 16) | i;
+  int stk[FX_SORT_STACK_WORDS];
+  if (n >= 2) {
+    fx_sort_detail::RevView v{rec, (int)n};
+    fx_sort_partition_phase_lists(v, (int)n, stk, pos, pos + n);
+    uint32_t *tmp = rec + n;
+    for (uint32_t c = 0; c < n; ++c) {
+      const uint32_t sz = rec[c] >> 16;
+      uint32_t at = 0;
+      for (uint32_t d = 0; d < n; ++d) {
+        const uint32_t sd = rec[d] >> 16;
+        at += (sd > sz || (sd == sz && d < c)) ? 1u : 0u;
+      }
+      tmp[at] = rec[c];
+    }
+    for (uint32_t c = 0; c < n; ++c) rec[c] = tmp[c];
+  }
+  for (uint32_t i = 0; i < n; ++i) perm_out[i] = rec[i] & 0xffffu;
+  delete[] rec;
+  delete[] pos;
+}
 
 }  // extern "C"

@@ -241,7 +241,10 @@ __device__ __forceinline__ uint32_t cc_label(const float4 *pt, uint32_t n, float
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   FX_STAMP_INIT(stamps);
   const SegTable<NT> ST(s_w);
-  const uint32_t seg_len = max(8u, (n + 95u) / 96u);
+#ifndef FX_SEG_MIN
+#define FX_SEG_MIN 8u
+#endif
+  const uint32_t seg_len = max(FX_SEG_MIN, (n + 95u) / 96u);
   for (uint32_t t = threadIdx.x; t < kSegMax; t += NT) {
     ST.set_box(FX_MINX, t, __uint_as_float(f2ord(INFINITY)));
     ST.set_box(FX_MAXX, t, __uint_as_float(f2ord(-INFINITY)));
@@ -522,9 +525,118 @@ __device__ __forceinline__ uint32_t cc_label(const float4 *pt, uint32_t n, float
   return n_segs;
 }
 
+// Phase 1 of the cluster-order replay (std::__introsort_loop, csrc/fx_sort_replay.h) by ONE WAVEFRONT:
+// every partition step costs a fixed handful of LDS round trips instead of one per element visited.
+// The step follows the position-list rule proved in fx_sort_replay.h (partition_pivot_lists): with
+// L = positions holding an element not smaller than the pivot (ascending) and R = positions holding one
+// not larger (descending), the sequential loop swaps exactly the pairs (L_k, R_k) with L_k < R_k and cuts
+// at min(L_s, R_{s-1}).  Ballots give every lane the rank of its positions in L and R; two small position
+// tables pair them up.  Lane p + 64 w owns view position p + 64 w (n <= 64 W).  All 64 lanes must be here.
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <int W>
+__device__ __noinline__ void sort_partition_wave(uint32_t *crec, int n, int *stk, uint16_t *Lpos, uint16_t *Rpos) {
+  using namespace fx_sort_detail;
+  if (n <= FX_SORT_THRESHOLD) return;
+  const int lane = (int)(threadIdx.x & 63);
+  RevView v{crec, n};
+  const unsigned long long below = lane == 63 ? ~0ull >> 1 : ((1ull << lane) - 1ull);  // lanes strictly below
+  const unsigned long long above = lane == 63 ? 0ull : ~((2ull << lane) - 1ull);       // lanes strictly above
+  int lg = 0;
+  for (int t = n; t > 1; t >>= 1) ++lg;
+  int *stk_first = stk, *stk_last = stk + 40, *stk_depth = stk + 80;
+  if (lane == 0) {
+    stk_first[0] = 0;
+    stk_last[0] = n;
+    stk_depth[0] = 2 * lg;
+  }
+  wave_sync_lds();
+  int sp = 1;
+  while (sp > 0) {
+    --sp;
+    int first = stk_first[sp], last = stk_last[sp], depth = stk_depth[sp];
+    while (last - first > FX_SORT_THRESHOLD) {
+      if (depth == 0) {  // depth budget spent (adversarial input): heap sort, sequential
+        if (lane == 0) heap_sort(v, first, last);
+        wave_sync_lds();
+        break;
+      }
+      --depth;
+      if (lane == 0) median_to_first(v, first, first + 1, first + (last - first) / 2, last - 1);
+      wave_sync_lds();
+      const uint32_t pivot = v.get(first);
+      unsigned long long mL[W], mR[W];
+      bool isL[W], isR[W];
+      int nL = 0, nR = 0;
+#pragma unroll
+      for (int w = 0; w < W; ++w) {
+        const int p = w * 64 + lane;
+        const uint32_t a = p < n ? v.get(p) : 0u;
+        isL[w] = p > first && p < last && !less_size(a, pivot);
+        isR[w] = p >= first && p < last && !less_size(pivot, a);
+        mL[w] = __ballot(isL[w]);
+        mR[w] = __ballot(isR[w]);
+        nL += __popcll(mL[w]);
+        nR += __popcll(mR[w]);
+      }
+      int rankL[W], rankR[W];
+#pragma unroll
+      for (int w = 0; w < W; ++w) {
+        int bl = 0, ar = 0;
+#pragma unroll
+        for (int x = 0; x < W; ++x) {
+          if (x < w) bl += __popcll(mL[x]);
+          if (x > w) ar += __popcll(mR[x]);
+        }
+        rankL[w] = bl + __popcll(mL[w] & below);
+        rankR[w] = ar + __popcll(mR[w] & above);
+        if (isL[w]) Lpos[rankL[w]] = (uint16_t)(w * 64 + lane);
+        if (isR[w]) Rpos[rankR[w]] = (uint16_t)(w * 64 + lane);
+      }
+      wave_sync_lds();
+      int partner[W], s = 0;
+      uint32_t incoming[W];
+#pragma unroll
+      for (int w = 0; w < W; ++w) {
+        const int p = w * 64 + lane;
+        partner[w] = -1;
+        bool as_left = false;
+        if (isL[w] && rankL[w] < nR) {
+          const int r = Rpos[rankL[w]];
+          if (p < r) partner[w] = r, as_left = true;
+        }
+        if (isR[w] && rankR[w] < nL) {
+          const int l = Lpos[rankR[w]];
+          if (l < p) partner[w] = l;  // (a position never swaps in both roles)
+        }
+        incoming[w] = partner[w] >= 0 ? v.get(partner[w]) : 0u;
+        s += __popcll(__ballot(as_left));
+      }
+      wave_sync_lds();
+#pragma unroll
+      for (int w = 0; w < W; ++w)
+        if (partner[w] >= 0) v.set(w * 64 + lane, incoming[w]);
+      int cut = 0x7fffffff;
+      if (s < nL) cut = Lpos[s];
+      if (s >= 1) cut = min(cut, (int)Rpos[s - 1]);
+      if (lane == 0) {
+        stk_first[sp] = cut;
+        stk_last[sp] = last;
+        stk_depth[sp] = depth;
+      }
+      wave_sync_lds();
+      ++sp;
+      last = cut;
+    }
+  }
+}
+
 // Size-admissible components in discovery order (ascending smallest index), then PCL's final
-// std::sort(rbegin, rend, bySize): its partition phase is replayed sequentially by one lane
-// (only needed above 16 clusters), its insertion phase — a stable sort — as a parallel ranking
+// std::sort(rbegin, rend, bySize): its partition phase is replayed by one wavefront (only needed
+// above 16 clusters; one lane, sequentially, beyond 192), its insertion phase — a stable sort — as a parallel ranking
 // (csrc/fx_sort_replay.h).  crec[s] = (size << 16) | discovery ordinal, in the order PCL returns
 // the clusters; croot[ordinal] = root index; tmp: scratch.  croot / crec / tmp hold ccap entries;
 // returns the cluster count, which the caller must check against ccap (nothing is written past it,
@@ -558,9 +670,18 @@ __device__ __forceinline__ uint32_t cc_order(uint32_t n, const uint32_t *parent,
   FX_STAMP(5);
   if (n_c > ccap) return n_c;
   if (n_c > FX_SORT_THRESHOLD) {
-    if (threadIdx.x == 0) {
-      fx_sort_detail::RevView v{crec, (int)n_c};
-      fx_sort_partition_phase(v, (int)n_c, (int *)(s_w + 32));
+    if (threadIdx.x < 64) {  // one wavefront; tmp doubles as the two position tables
+      uint16_t *pos = reinterpret_cast<uint16_t *>(tmp);
+      if (n_c <= 64) {
+        sort_partition_wave<1>(crec, (int)n_c, (int *)(s_w + 32), pos, pos + n_c);
+      } else if (NT > 64 && n_c <= 128) {
+        sort_partition_wave<2>(crec, (int)n_c, (int *)(s_w + 32), pos, pos + n_c);
+      } else if (NT > 64 && n_c <= 192) {
+        sort_partition_wave<3>(crec, (int)n_c, (int *)(s_w + 32), pos, pos + n_c);
+      } else if (threadIdx.x == 0) {  // more clusters than three words of lanes: one lane, sequentially
+        fx_sort_detail::RevView v{crec, (int)n_c};
+        fx_sort_partition_phase(v, (int)n_c, (int *)(s_w + 32));
+      }
     }
     __syncthreads();
   }
@@ -1030,7 +1151,7 @@ extern "C" __global__ __launch_bounds__(FX_RING_SMALL_T) void k_rings_small(FxDe
     __syncthreads();
   }
 }
-extern "C" __global__ __launch_bounds__(FX_WG) void k_rings_big(FxDevParams P, FxBuffers B, uint32_t cap, uint32_t ccap,
+extern "C" __global__ __launch_bounds__(FX_WG, 5) void k_rings_big(FxDevParams P, FxBuffers B, uint32_t cap, uint32_t ccap,
                                                                  uint32_t huge) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const uint32_t n_big = B.counters[huge ? 5 : 0];
@@ -2432,6 +2553,34 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_pack_xyzi32(const float4 *
 }
 
 // ====================================================================== launchers
+// Test hook (fx_test_sort_replay_device): the cluster-order replay exactly as cc_order runs it, on
+// arbitrary size sequences; one 64-thread workgroup per sequence, n <= 192.
+extern "C" __global__ __launch_bounds__(64) void k_test_sort_replay(const uint32_t *sizes, uint32_t n, uint32_t *perm) {
+  __shared__ uint32_t crec[192], tmp[192], stk[FX_SORT_STACK_WORDS];
+  const uint32_t *src = sizes + (size_t)blockIdx.x * n;
+  for (uint32_t c = threadIdx.x; c < n; c += 64) crec[c] = (src[c] << 16) | c;
+  __syncthreads();
+  uint16_t *pos = reinterpret_cast<uint16_t *>(tmp);
+  if (n <= 64)
+    sort_partition_wave<1>(crec, (int)n, (int *)stk, pos, pos + n);
+  else if (n <= 128)
+    sort_partition_wave<2>(crec, (int)n, (int *)stk, pos, pos + n);
+  else
+    sort_partition_wave<3>(crec, (int)n, (int *)stk, pos, pos + n);
+  __syncthreads();
+  for (uint32_t c = threadIdx.x; c < n; c += 64) {
+    const uint32_t rec = crec[c], sz = rec >> 16;
+    uint32_t at = 0;
+    for (uint32_t d = 0; d < n; ++d) {
+      const uint32_t sd = crec[d] >> 16;
+      at += (sd > sz || (sd == sz && d < c)) ? 1u : 0u;
+    }
+    tmp[at] = rec;
+  }
+  __syncthreads();
+  for (uint32_t c = threadIdx.x; c < n; c += 64) perm[(size_t)blockIdx.x * n + c] = tmp[c] & 0xffffu;
+}
+
 extern "C" {
 
 size_t fxk_ring_lds_bytes(uint32_t cap, uint32_t ccap) {
@@ -2505,6 +2654,9 @@ void fxk_desc_wg_fast(hipStream_t s, const FxDevParams &P, const FxBuffers &B, u
 void fxk_desc_spill(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t mode,
                     uint32_t slab_pts) {
   hipLaunchKernelGGL(k_desc_spill, dim3(grid), dim3(FX_WG), 0, s, P, B, batch, mode, slab_pts);
+}
+void fxk_test_sort_replay(hipStream_t s, const uint32_t *sizes, uint32_t n_seq, uint32_t n, uint32_t *perm) {
+  hipLaunchKernelGGL(k_test_sort_replay, dim3(n_seq), dim3(64), 0, s, sizes, n, perm);
 }
 void fxk_rng_ord(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch) {
   hipLaunchKernelGGL(k_rng_ord, dim3((batch + FX_NWAVE - 1) / FX_NWAVE), dim3(FX_WG), 0, s, P, B, batch);

@@ -184,6 +184,66 @@ FX_HD inline void fx_sort_partition_phase(V &v, int n, int *stk) {
   }
 }
 
+// The same partition step stated without the two walking pointers, which is what lets a wavefront do
+// it in a handful of steps (fx_kernels.hip: sort_partition_wave).  After the median has moved to
+// `first`, let L_0 < L_1 < ... be the positions in (first, last) holding an element that is NOT
+// smaller than the pivot, and R_0 > R_1 > ... the positions in [first, last) holding one that is NOT
+// larger (R ends with `first` itself).  The k-th stop of the left pointer is L_k and of the right one
+// R_k as long as L_k < R_k — positions between the pointers are untouched by earlier swaps — so the
+// loop swaps exactly the pairs (L_k, R_k), k < s, where s is the first k with L_k >= R_k, and returns
+// min(L_s, R_{s-1}): the left pointer stops at L_s unless it first meets the element just swapped to
+// R_{s-1}.  This routine is the sequential statement of that rule (tests check it against std::sort);
+// Lpos / Rpos: scratch for the two position lists.
+template <class V>
+FX_HD inline int partition_pivot_lists(V &v, int first, int last, uint16_t *Lpos, uint16_t *Rpos) {
+  using namespace fx_sort_detail;
+  const int mid = first + (last - first) / 2;
+  median_to_first(v, first, first + 1, mid, last - 1);
+  const uint32_t pivot = v.get(first);
+  int nL = 0, nR = 0;
+  for (int p = first + 1; p < last; ++p)
+    if (!less_size(v.get(p), pivot)) Lpos[nL++] = (uint16_t)p;
+  for (int p = last - 1; p >= first; --p)
+    if (!less_size(pivot, v.get(p))) Rpos[nR++] = (uint16_t)p;
+  int s = 0;
+  while (s < nL && s < nR && Lpos[s] < Rpos[s]) ++s;
+  for (int k = 0; k < s; ++k) v.swap(Lpos[k], Rpos[k]);
+  int cut = 0x7fffffff;
+  if (s < nL) cut = Lpos[s];
+  if (s >= 1 && Rpos[s - 1] < cut) cut = Rpos[s - 1];
+  return cut;
+}
+// Phase 1 with the list form of the partition step (host test of the rule; n < 65536).
+template <class V>
+FX_HD inline void fx_sort_partition_phase_lists(V &v, int n, int *stk, uint16_t *Lpos, uint16_t *Rpos) {
+  using namespace fx_sort_detail;
+  if (n <= FX_SORT_THRESHOLD) return;
+  int lg = 0;
+  for (int t = n; t > 1; t >>= 1) ++lg;
+  int *stk_first = stk, *stk_last = stk + 40, *stk_depth = stk + 80;
+  int sp = 1;
+  stk_first[0] = 0;
+  stk_last[0] = n;
+  stk_depth[0] = 2 * lg;
+  while (sp > 0) {
+    --sp;
+    int first = stk_first[sp], last = stk_last[sp], depth = stk_depth[sp];
+    while (last - first > FX_SORT_THRESHOLD) {
+      if (depth == 0) {
+        heap_sort(v, first, last);
+        break;
+      }
+      --depth;
+      const int cut = partition_pivot_lists(v, first, last, Lpos, Rpos);
+      stk_first[sp] = cut;
+      stk_last[sp] = last;
+      stk_depth[sp] = depth;
+      ++sp;
+      last = cut;
+    }
+  }
+}
+
 // Phase 2 of std::sort (std::__final_insertion_sort): a guarded insertion sort of the first 16
 // elements and an unguarded one of the rest.  Both move an element left only past strictly
 // greater ones, i.e. together they are a STABLE sort of whatever phase 1 left behind — which is

@@ -260,6 +260,11 @@ uint32_t fx_synth_scan(const fx_synth_cfg *c, float *xyzi_out, uint32_t capacity
 void fx_test_sort_replay(const uint32_t *sizes, uint32_t n, uint32_t *perm_out);
 /* same, with the final insertion phase replaced by the stable ranking the kernels use */
 void fx_test_sort_replay_ranked(const uint32_t *sizes, uint32_t n, uint32_t *perm_out);
+/* same, with the partition step stated through position lists (the rule the wavefront version follows) */
+void fx_test_sort_replay_lists(const uint32_t *sizes, uint32_t n, uint32_t *perm_out);
+/* Test hook: the replay as the kernels run it (wavefront partition phase + ranking) on device `device`,
+ * one workgroup per sequence; n <= 192 per sequence.  sizes / perm_out: host arrays [n_seq][n]. */
+fx_status fx_test_sort_replay_device(int device, const uint32_t *sizes, uint32_t n_seq, uint32_t n, uint32_t *perm_out);
 
 #ifdef __cplusplus
 }
