@@ -414,6 +414,8 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   FX_A(dev_alloc(c, &b.s_pts, (size_t)L.max_total_keypoints * P.list_cap));
   FX_A(dev_alloc(c, &b.s_cnt, L.max_total_keypoints));
   FX_A(dev_alloc(c, &b.row_map, L.max_total_keypoints));
+  FX_A(dev_alloc(c, &b.row_kp, L.max_total_keypoints));
+  FX_A(dev_alloc(c, &b.row_xa, L.max_total_keypoints));
   FX_A(dev_alloc(c, &b.spill_desc, L.max_total_keypoints));
   FX_A(dev_alloc(c, &b.exact_desc, L.max_total_keypoints));
   FX_A(dev_alloc(c, &b.wave_desc, L.max_total_keypoints));

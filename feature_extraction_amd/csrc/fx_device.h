@@ -97,6 +97,8 @@ struct FxBuffers {
   float4 *s_pts;          // [max_total_kp][list_cap]  (x, y, z rotated, point index as bits)
   uint32_t *s_cnt;        // [max_total_kp]
   uint2 *row_map;         // [max_total_kp]  (scan, keypoint ordinal) of each descriptor row
+  float4 *row_kp;         // [max_total_kp]  the row's keypoint and its 3DSC x-axis (first-pass ordinal), so that the
+  float2 *row_xa;         //                 per-keypoint kernels fetch everything a row needs in one round trip
   unsigned long long *stamps;  // [32] diagnostic build only (-DFX_STAMPS)
   uint32_t *counters;     // [16]: 0 big_rings, 1 big_merge, 2 big_desc, 3 need_rng_fix, 4 list_desc, 5 huge_rings, 6 spill_desc, 7 exact_desc, 8 wave_desc
 };

@@ -1533,6 +1533,10 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
   for (uint32_t k = tid; k < K; k += FX_WG) {
     const float4 kp = B.keypoints[(size_t)scan * P.max_keypoints + k];
     s_kp[k] = kp;
+    if (slice == 0) {
+      B.row_kp[row0 + k] = kp;
+      B.row_xa[row0 + k] = B.xaxis[k];
+    }
     atomicMin(&s_w[0], f2ord(kp.x));
     atomicMax(&s_w[1], f2ord(kp.x));
     atomicMin(&s_w[2], f2ord(kp.y));
@@ -1704,7 +1708,15 @@ __device__ __forceinline__ void desc_wave_body(const FxDevParams &P, const FxBuf
     const uint2 rm = B.row_map[row];
     const uint32_t scan = rm.x, k = rm.y;
     const uint32_t ord = k;
+    // everything the row needs is fetched in one round trip: the list entries are loaded before the
+    // list length is known (slots past the length hold stale data and are ignored)
     const uint32_t nS = B.s_cnt[row];
+    const float4 kp = B.row_kp[row];
+    const float2 xa = B.row_xa[row];
+    float4 lv[FX_WAVE_CAP / 64];
+#pragma unroll
+    for (uint32_t u = 0; u < FX_WAVE_CAP / 64; ++u)
+      if (lane + u * 64 < P.list_cap) lv[u] = B.s_pts[(size_t)row * P.list_cap + lane + u * 64];
     if (nS > FX_WAVE_CAP || nS > P.list_cap) {  // long (or truncated) list: workgroup tiers
       if (FAST && lane == 0) {
         const uint32_t pos = atomicAdd(&B.counters[nS > P.list_cap ? 2 : 4], 1u);
@@ -1712,14 +1724,16 @@ __device__ __forceinline__ void desc_wave_body(const FxDevParams &P, const FxBuf
       }
       continue;
     }
-    const float4 kp = B.keypoints[(size_t)scan * P.max_keypoints + k];
-    const float2 xa = B.xaxis[ord];
     float *out = B.desc + (size_t)row * FX_DESC_FLOATS;
     __builtin_amdgcn_wave_barrier();
-    for (uint32_t e = lane; e < nS; e += 64) {
-      const float4 v = B.s_pts[(size_t)row * P.list_cap + e];
-      sp[e] = make_float4(v.x, v.y, v.z, dist2(kp.x, kp.y, kp.z, v.x, v.y, v.z));
-      sidx[e] = __float_as_uint(v.w);
+#pragma unroll
+    for (uint32_t u = 0; u < FX_WAVE_CAP / 64; ++u) {
+      const uint32_t e = lane + u * 64;
+      if (e < nS) {
+        const float4 v = lv[u];
+        sp[e] = make_float4(v.x, v.y, v.z, dist2(kp.x, kp.y, kp.z, v.x, v.y, v.z));
+        sidx[e] = __float_as_uint(v.w);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1836,13 +1850,23 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_group(FxDevParams P, 
   for (uint32_t r0 = (blockIdx.x * FX_NWAVE + wave) * FX_GROUPS; r0 < total; r0 += stride) {
     const uint32_t row = r0 + g;
     bool live = row < total;
-    uint32_t scan = 0, k = 0, ord = 0, nS = 0;
+    uint32_t scan = 0, k = 0, nS = 0;
+    // everything the row needs is fetched in one round trip: keypoint, x-axis, and the list entries
+    // before the list length is known (slots past the length hold stale data and are ignored)
+    float4 kp = make_float4(0, 0, 0, 0);
+    float2 xa = make_float2(1.f, 0.f);
+    float4 lv[FX_GROUP_CAP / FX_GLANES];
     if (live) {
       const uint2 rm = B.row_map[row];
-      scan = rm.x, k = rm.y, ord = k;
+      nS = B.s_cnt[row];
+      kp = B.row_kp[row];
+      xa = B.row_xa[row];
+#pragma unroll
+      for (uint32_t u = 0; u < FX_GROUP_CAP / FX_GLANES; ++u)
+        if (gl + u * FX_GLANES < P.list_cap) lv[u] = B.s_pts[(size_t)row * P.list_cap + gl + u * FX_GLANES];
+      scan = rm.x, k = rm.y;
     }
     if (live) {
-      nS = B.s_cnt[row];
       if (nS > FX_GROUP_CAP || nS > P.list_cap) {  // too long for a group (or truncated): wavefront / workgroup / re-gather tiers
         if (gl == 0) {
           const uint32_t c = nS > P.list_cap ? 2u : (nS > FX_WAVE_CAP ? 4u : 8u);
@@ -1852,15 +1876,17 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_group(FxDevParams P, 
         live = false;
       }
     }
-    const float4 kp = live ? B.keypoints[(size_t)scan * P.max_keypoints + k] : make_float4(0, 0, 0, 0);
-    const float2 xa = live ? B.xaxis[ord] : make_float2(1.f, 0.f);
     float *out = B.desc + (size_t)row * FX_DESC_FLOATS;
     if (!live) nS = 0;
     __builtin_amdgcn_wave_barrier();
-    for (uint32_t e = gl; e < nS; e += FX_GLANES) {
-      const float4 v = B.s_pts[(size_t)row * P.list_cap + e];
-      sp[e] = make_float4(v.x, v.y, v.z, dist2(kp.x, kp.y, kp.z, v.x, v.y, v.z));
-      sidx[e] = __float_as_uint(v.w);
+#pragma unroll
+    for (uint32_t u = 0; u < FX_GROUP_CAP / FX_GLANES; ++u) {
+      const uint32_t e = gl + u * FX_GLANES;
+      if (e < nS) {
+        const float4 v = lv[u];
+        sp[e] = make_float4(v.x, v.y, v.z, dist2(kp.x, kp.y, kp.z, v.x, v.y, v.z));
+        sidx[e] = __float_as_uint(v.w);
+      }
     }
     if (gl < 3) cnt[gl] = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
