@@ -1472,22 +1472,19 @@ __device__ __forceinline__ uint32_t sc3d_bin(const float4 kp, float bx, float by
           near_multiple(theta, 180.0f / 11.0f, 11.0f / 180.0f);
   }
 
+  // PCL scans each edge table for the first edge >= the value and falls back to bin 0 when there is
+  // none (A.8-9).  The edges ascend, so "first edge >= v" is the number of edges below v: counted
+  // without branches; a count that runs off the table (or a NaN, which counts nothing) is the fallback.
   uint32_t j = 0, kk = 0, l = 0;
-  for (uint32_t rad = 1; rad < 16; ++rad)
-    if (r <= T->radii[rad]) {
-      j = rad - 1;
-      break;
-    }
-  for (uint32_t ang = 1; ang < 12; ++ang)
-    if (theta <= T->theta[ang]) {
-      kk = ang - 1;
-      break;
-    }
-  for (uint32_t ang = 1; ang < 13; ++ang)
-    if (phi <= T->phi[ang]) {
-      l = ang - 1;
-      break;
-    }
+#pragma unroll
+  for (uint32_t rad = 1; rad < 16; ++rad) j += (r > T->radii[rad]) ? 1u : 0u;
+#pragma unroll
+  for (uint32_t ang = 1; ang < 12; ++ang) kk += (theta > T->theta[ang]) ? 1u : 0u;
+#pragma unroll
+  for (uint32_t ang = 1; ang < 13; ++ang) l += (phi > T->phi[ang]) ? 1u : 0u;
+  j = j == 15u ? 0u : j;
+  kk = kk == 11u ? 0u : kk;
+  l = l == 12u ? 0u : l;
   lut = T->lut[kk * 15 + j];
   return (l * 11 + kk) * 15 + j;
 }
@@ -1681,6 +1678,16 @@ __device__ __forceinline__ void desc_fill_nan(float *out, uint32_t lane, uint32_
   for (uint32_t t = lane; t < FX_DESC_FLOATS; t += stride) out[t] = t < FX_DESC_BINS ? NAN : 0.0f;
 }
 
+// The 3DSC edge tables and weight table (206 floats) are copied to LDS once per workgroup: the bin
+// search and the weight lookup of every neighbour then stay on chip.  Contains a barrier.
+#define FX_TABLE_WORDS 208
+__device__ __forceinline__ const FxScTables *tables_to_lds(const FxBuffers &B, uint32_t *dst) {
+  const float *src = reinterpret_cast<const float *>(B.tables);
+  for (uint32_t t = threadIdx.x; t < sizeof(FxScTables) / 4; t += blockDim.x) dst[t] = __float_as_uint(src[t]);
+  __syncthreads();
+  return reinterpret_cast<const FxScTables *>(dst);
+}
+
 // One wavefront per keypoint, for the rows in B.wave_desc (support sets of 65..256 points).
 // Angles in fp32; a keypoint with any neighbour whose angle lies within FX_FAST_EPS_DEG of a bin
 // edge is not finished here but handed to the exact workgroup kernel (k_desc_wg, fp64 angles), so
@@ -1698,7 +1705,7 @@ __device__ __forceinline__ void desc_wave_body(const FxDevParams &P, const FxBuf
   uint32_t *sidx = base + 7 * FX_WAVE_CAP;
   unsigned long long *skey = reinterpret_cast<unsigned long long *>(base);  // aliases sp
   float *sw = reinterpret_cast<float *>(base + 2 * FX_WAVE_CAP);            // aliases sp
-  const FxScTables *T = B.tables;
+  const FxScTables *T = tables_to_lds(B, smem + FX_NWAVE * FX_WAVE_WORDS);
 
   uint32_t total = B.kp_offset[batch];
   if (total > P.max_total_kp) total = P.max_total_kp;
@@ -1841,7 +1848,7 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_group(FxDevParams P, 
   uint32_t *cnt = base + 8 * FX_GROUP_CAP;  // [0] neighbours, [1] binned neighbours, [2] ambiguous
   unsigned long long *skey = reinterpret_cast<unsigned long long *>(base);  // aliases sp
   float *sw = reinterpret_cast<float *>(base + 2 * FX_GROUP_CAP);           // aliases sp
-  const FxScTables *T = B.tables;
+  const FxScTables *T = tables_to_lds(B, smem + FX_NWAVE * FX_GROUPS * FX_GROUP_WORDS);
 
   uint32_t total = B.kp_offset[batch];
   if (total > P.max_total_kp) total = P.max_total_kp;
@@ -2010,6 +2017,9 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
   float *out = B.desc + (size_t)row * FX_DESC_FLOATS;
 
   if (tid < 4) L.s_w[tid] = 0;  // 0: support count, 1: binned neighbours, 2: all neighbours
+  // the 3DSC tables ride in the image until the bins are known (the image is cleared after that)
+  uint32_t *tl = reinterpret_cast<uint32_t *>(L.img) + 512;
+  for (uint32_t t = tid; t < sizeof(FxScTables) / 4; t += NT) tl[t] = __float_as_uint(reinterpret_cast<const float *>(B.tables)[t]);
   __syncthreads();
   uint32_t nS;
   // Density grid: a list-fed support set is stored sorted by xy cell (cell width >= R/5, FX_DGRID cells
@@ -2120,7 +2130,7 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
   }
   FX_STAMP(1);
 
-  const FxScTables *T = B.tables;
+  const FxScTables *T = reinterpret_cast<const FxScTables *>(tl);
   const float2 xa = B.xaxis[ord];
   // ---- neighbours (d2 < R^2, not the keypoint itself) packed densely: nlist[m] = support position.
   //      The list lives in the weight array and the density counters in the key array until the
@@ -2173,7 +2183,6 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
       if (c) atomicAdd(&dens[2 * m], c);
     }
     __syncthreads();
-    for (uint32_t t = tid; t < FX_DESC_BINS; t += NT) L.img[t] = 0.0f;  // (the cell table is done with)
     FX_STAMP(7);
     // ---- bins and weights, one neighbour per lane
     for (uint32_t m = tid; m < nMq; m += NT) {
@@ -2190,6 +2199,7 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
   }
   __syncthreads();
   FX_STAMP(2);
+  for (uint32_t t = tid; t < FX_DESC_BINS; t += NT) L.img[t] = 0.0f;  // (cell table and 3DSC tables are done with)
   const uint32_t nM = L.s_w[1], nAll = L.s_w[2];
   if (tid == 0) {
     FX_COUNT(12, 1);
@@ -2665,10 +2675,10 @@ void fxk_gather(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_
                      fxk_gather_lds_bytes(P.max_keypoints), s, P, B, box_margin);
 }
 void fxk_desc_group(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid) {
-  hipLaunchKernelGGL(k_desc_group, dim3(grid), dim3(FX_WG), (size_t)FX_NWAVE * FX_GROUPS * FX_GROUP_WORDS * 4, s, P, B, batch);
+  hipLaunchKernelGGL(k_desc_group, dim3(grid), dim3(FX_WG), (size_t)(FX_NWAVE * FX_GROUPS * FX_GROUP_WORDS + FX_TABLE_WORDS) * 4, s, P, B, batch);
 }
 void fxk_desc_fast(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid) {
-  hipLaunchKernelGGL(k_desc_fast, dim3(grid), dim3(FX_WG), (size_t)FX_NWAVE * FX_WAVE_WORDS * 4, s, P, B, batch);
+  hipLaunchKernelGGL(k_desc_fast, dim3(grid), dim3(FX_WG), (size_t)(FX_NWAVE * FX_WAVE_WORDS + FX_TABLE_WORDS) * 4, s, P, B, batch);
 }
 void fxk_desc_wg(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t grid,
                  uint32_t mode, uint32_t src) {
