@@ -241,10 +241,7 @@ __device__ __forceinline__ uint32_t cc_label(const float4 *pt, uint32_t n, float
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   FX_STAMP_INIT(stamps);
   const SegTable<NT> ST(s_w);
-#ifndef FX_SEG_MIN
-#define FX_SEG_MIN 8u
-#endif
-  const uint32_t seg_len = max(FX_SEG_MIN, (n + 95u) / 96u);
+  const uint32_t seg_len = max(8u, (n + 95u) / 96u);
   for (uint32_t t = threadIdx.x; t < kSegMax; t += NT) {
     ST.set_box(FX_MINX, t, __uint_as_float(f2ord(INFINITY)));
     ST.set_box(FX_MAXX, t, __uint_as_float(f2ord(-INFINITY)));
