@@ -39,6 +39,8 @@ void fxk_desc_fast(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint
 void fxk_desc_wg(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t grid,
                  uint32_t mode, uint32_t src);
 void fxk_desc_wg_fast(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t grid);
+void fxk_desc_wg_xl(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t ns_lo,
+                    uint32_t grid);
 void fxk_desc_spill(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t mode,
                     uint32_t slab_pts);
 void fxk_pack_kp_records(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, void *dst,
@@ -68,7 +70,7 @@ fx_status fail(fx_status s, const std::string &msg) {
   } while (0)
 
 constexpr int kMetaSlots = 8;
-constexpr uint32_t kRingCapSmall = 256, kRingCapMid = 640, kMergeCapSmall = 512, kListCap = 1024;
+constexpr uint32_t kRingCapSmall = 256, kRingCapMid = 640, kMergeCapSmall = 512, kListCap = 4096, kListSplit = 1024;
 }  // namespace
 
 struct fx_ctx {
@@ -209,7 +211,12 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof) {
       FX_HIP(mark(8));
       fxk_desc_fast(s, P, B, batch, big_grid * 4);
       FX_HIP(mark(9));
-      fxk_desc_wg_fast(s, P, B, batch, P.list_cap, big_grid * 4);
+      {
+        // lists of up to kListSplit entries: four keypoints per CU in flight; longer ones: one per CU
+        const uint32_t split = P.list_cap < kListSplit ? P.list_cap : kListSplit;
+        fxk_desc_wg_fast(s, P, B, batch, split, big_grid * 4);
+        if (P.list_cap > split) fxk_desc_wg_xl(s, P, B, batch, P.list_cap, split, big_grid);
+      }
       FX_HIP(mark(10));
       fxk_desc_wg(s, P, B, batch, P.list_cap, big_grid, 0, 2);
       FX_HIP(mark(11));
@@ -424,7 +431,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
     uint32_t slab = 1;
     while (slab < L.max_points) slab <<= 1;
     c->spill_slab = slab;
-    c->spill_grid = 32;
+    c->spill_grid = (uint32_t)c->n_cu;
     const size_t n = (size_t)c->spill_grid * slab;
     FX_A(dev_alloc(c, &b.spill_pts, n));
     FX_A(dev_alloc(c, &b.spill_d2, n));

@@ -2023,7 +2023,6 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
   // per axis cover the support radius), so the density query of a neighbour only scans the three
   // cell rows around it instead of the whole set.  The cell table borrows the (still unused) image.
   constexpr uint32_t G = FX_DGRID, kCells = G * G;
-  constexpr int EPT = (1024 + NT - 1) / NT;  // list entries per thread (list_cap <= 1024)
   uint32_t *cell_start = reinterpret_cast<uint32_t *>(L.img);  // [kCells + 1]
   uint32_t *cell_fill = cell_start + kCells + 1;                // [kCells] counts, then fill cursors
   const float r_sup = sqrtf(P.r2_support);
@@ -2034,20 +2033,14 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
   bool grid = false;
   if (from_list) {
     nS = B.s_cnt[row];
-    grid = nS <= (uint32_t)EPT * NT;
+    grid = nS <= cap;
     if (grid) {
+      const float4 *lst = B.s_pts + (size_t)row * P.list_cap;
       for (uint32_t t = tid; t < 2 * kCells + 1; t += NT) cell_start[t] = 0;
       __syncthreads();
-      float4 mine[EPT];
-      uint32_t mcell[EPT];
-#pragma unroll
-      for (int u = 0; u < EPT; ++u) {
-        const uint32_t e = tid + u * NT;
-        if (e < nS) {
-          mine[u] = B.s_pts[(size_t)row * P.list_cap + e];
-          mcell[u] = cell_y(mine[u].y) * G + cell_x(mine[u].x);
-          atomicAdd(&cell_fill[mcell[u]], 1u);
-        }
+      for (uint32_t e = tid; e < nS; e += NT) {
+        const float4 v = lst[e];
+        atomicAdd(&cell_fill[cell_y(v.y) * G + cell_x(v.x)], 1u);
       }
       __syncthreads();
       if (tid < 64) {  // exclusive prefix over the cells by one wavefront
@@ -2078,15 +2071,12 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
         if (tid == 63) cell_start[kCells] = incl;
       }
       __syncthreads();
-#pragma unroll
-      for (int u = 0; u < EPT; ++u) {
-        const uint32_t e = tid + u * NT;
-        if (e < nS) {
-          const float4 v = mine[u];
-          const uint32_t slot = cell_start[mcell[u]] + atomicAdd(&cell_fill[mcell[u]], 1u);
-          L.sp[slot] = make_float4(v.x, v.y, v.z, dist2(kp.x, kp.y, kp.z, v.x, v.y, v.z));
-          L.sidx[slot] = __float_as_uint(v.w);
-        }
+      for (uint32_t e = tid; e < nS; e += NT) {  // second read of the list (cache-resident): each entry to its cell
+        const float4 v = lst[e];
+        const uint32_t ce = cell_y(v.y) * G + cell_x(v.x);
+        const uint32_t slot = cell_start[ce] + atomicAdd(&cell_fill[ce], 1u);
+        L.sp[slot] = make_float4(v.x, v.y, v.z, dist2(kp.x, kp.y, kp.z, v.x, v.y, v.z));
+        L.sidx[slot] = __float_as_uint(v.w);
       }
     } else {
       for (uint32_t e = tid; e < nS; e += NT) {
@@ -2296,7 +2286,7 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
 // src 2: rows with an angle near a bin edge (exact_desc): from the list, exact angles
 template <bool FAST, int NT>
 __device__ __forceinline__ void desc_wg_loop(const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap,
-                                             uint32_t mode, uint32_t src, uint32_t *smem) {
+                                             uint32_t mode, uint32_t src, uint32_t *smem, uint32_t ns_lo = 0) {
   // a support set that does not fit `cap` goes to the spill tier
   auto spill = [&](uint32_t row, uint32_t scan, uint32_t k) {
     if (threadIdx.x == 0) {
@@ -2332,7 +2322,9 @@ __device__ __forceinline__ void desc_wg_loop(const FxDevParams &P, const FxBuffe
     const uint32_t row = items[i];
     const uint2 rm = B.row_map[row];
     const uint32_t scan = rm.x, k = rm.y;
-    if (B.s_cnt[row] > P.list_cap && src != 0) continue;  // (exact_desc rows always fit; list rows too)
+    const uint32_t nS = B.s_cnt[row];
+    if (nS > P.list_cap && src != 0) continue;     // (exact_desc rows always fit; list rows too)
+    if (src == 1 && (nS <= ns_lo || nS > cap)) continue;  // list rows are split by length over two launches
     if (!desc_body<FAST, NT>(P, B, row, scan, k, k, cap, smem, src != 0)) spill(row, scan, k);
     __syncthreads();
   }
@@ -2350,6 +2342,13 @@ extern "C" __global__ __launch_bounds__(FX_DESC_WG_FAST_T) void k_desc_wg_fast(F
                                                                                 uint32_t cap) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   desc_wg_loop<true, FX_DESC_WG_FAST_T>(P, B, batch, cap, 0u, 1u, smem);
+}
+// the longest lists (beyond FX_LIST_SPLIT entries, up to list_cap): one 1024-thread workgroup per CU
+#define FX_DESC_WG_XL_T 1024
+extern "C" __global__ __launch_bounds__(FX_DESC_WG_XL_T) void k_desc_wg_xl(FxDevParams P, FxBuffers B, uint32_t batch,
+                                                                            uint32_t cap, uint32_t ns_lo) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  desc_wg_loop<true, FX_DESC_WG_XL_T>(P, B, batch, cap, 0u, 1u, smem, ns_lo);
 }
 
 // ---------------------------------------------------------------- spill tier
@@ -2637,6 +2636,8 @@ hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t desc_big) {
   e = hipFuncSetAttribute((const void *)k_merge_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)merge_big);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void *)k_desc_wg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)desc_big);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void *)k_desc_wg_xl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)desc_big);
   return e;
 }
 
@@ -2680,6 +2681,10 @@ void fxk_desc_fast(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint
 void fxk_desc_wg(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t grid,
                  uint32_t mode, uint32_t src) {
   hipLaunchKernelGGL(k_desc_wg, dim3(grid), dim3(FX_DESC_WG_EXACT_T), fxk_desc_lds_bytes(cap), s, P, B, batch, cap, mode, src);
+}
+void fxk_desc_wg_xl(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t ns_lo,
+                    uint32_t grid) {
+  hipLaunchKernelGGL(k_desc_wg_xl, dim3(grid), dim3(FX_DESC_WG_XL_T), fxk_desc_lds_bytes(cap), s, P, B, batch, cap, ns_lo);
 }
 void fxk_desc_wg_fast(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t grid) {
   hipLaunchKernelGGL(k_desc_wg_fast, dim3(grid), dim3(FX_DESC_WG_FAST_T), fxk_desc_lds_bytes(cap), s, P, B, batch, cap);

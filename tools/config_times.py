@@ -1,0 +1,59 @@
+"""Diagnostic: stage times and capacity flags of the other BASELINE.json configurations
+(3: HDL-64-style 64 x 2048, batch 256; 5: 128 x 2048, R = 2 m, batch 64).  Usage on the GPU box:
+  python tools/config_times.py [3|5] [batch]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from feature_extraction_amd import capi
+
+import torch
+
+which = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+capi.load()
+if which == 3:
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+    cfg = dict(n_rings=64, n_az=2048, el0_deg=-24.8, el_step_deg=26.8 / 63, n_poles=256)
+    p = capi.params("launch", n_rings=64, el0_deg=-24.8, el_step_deg=26.8 / 63, secondary_max=64)
+    lim = capi.limits(B, 64 * 2048, max_candidates=3500, max_kpc_points=32768, max_keypoints=512, max_total_keypoints=B * 512)
+else:
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+    cfg = dict(n_rings=128, n_az=2048, el0_deg=-25.0, el_step_deg=40.0 / 127, n_poles=256)
+    p = capi.params("default", n_rings=128, el0_deg=-25.0, el_step_deg=40.0 / 127, secondary_max=128, descriptor_radius=2.0)
+    lim = capi.limits(B, 128 * 2048, max_candidates=3500, max_kpc_points=65536, max_keypoints=512, max_total_keypoints=B * 512)
+uniq = [capi.synth_scan(capi.synth_cfg(10 + b, **cfg)) for b in range(min(B, 16))]
+dev = [torch.from_numpy(s).cuda() for s in uniq]
+ctx = capi.Context(p, lim)
+descs = ctx.make_descs([dev[b % len(dev)].data_ptr() for b in range(B)], [len(uniq[b % len(uniq)]) for b in range(B)], 16, 0.02, -0.015)
+steps = 5
+ctx.set_profiling(steps)
+for _ in range(2):
+    v = ctx.process_raw(descs, B, capi.FX_IN_DEVICE | capi.FX_OUT_HOST | capi.FX_OUT_DEBUG)
+flags = np.ctypeslib.as_array(v.h_flags, shape=(B,)).copy()
+nk = np.ctypeslib.as_array(v.h_n_keypoints, shape=(B,)).copy()
+for _ in range(steps):
+    ctx.process_raw(descs, B, capi.FX_IN_DEVICE)
+ctx.synchronize()
+acc, tot = {}, 0.0
+for k in range(steps):
+    ms, total = ctx.timings(k)
+    tot += total
+    for n, x in ms.items():
+        acc[n] = acc.get(n, 0.0) + x
+print(f"config {which}: batch {B}, {len(uniq[0])} points/scan, keypoints/scan {nk.mean():.1f}, flags OR 0x{int(np.bitwise_or.reduce(flags)):x}")
+print(f"  total {tot / steps:.3f} ms/batch -> {B / (tot / steps) * 1e3:.0f} scans/s")
+print("  " + "  ".join(f"{n}={x / steps:.3f}" for n, x in acc.items()))
+import ctypes as C
+out = (C.c_uint32 * 16)()
+lib = capi.load()
+lib.fx_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
+capi.check(lib.fx_debug_counters(ctx.handle, out))
+names = ["rings -> mid tier", "scans -> big merge", "rows -> re-gather tier", "scans needing RNG fix", "rows -> list tier",
+         "rings -> large tier", "rows -> spill tier", "rows -> exact angle pass", "rows -> wavefront tier"]
+print("  " + ", ".join(f"{n}: {c}" for n, c in zip(names, out)) + f", rows total {int(nk.sum())}")
+nb = np.ctypeslib.as_array(v.h_kp_neighbors, shape=(B, lim.max_keypoints)) if v.h_kp_neighbors else None
+if nb is not None:
+    allnb = np.concatenate([nb[b, :nk[b]] for b in range(B)])
+    print("  neighbours per keypoint: median %d, p90 %d, p99 %d, max %d" % (np.median(allnb), np.percentile(allnb, 90), np.percentile(allnb, 99), allnb.max()))
