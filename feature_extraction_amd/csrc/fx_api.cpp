@@ -23,6 +23,7 @@ size_t fxk_ring_wave_lds_bytes(uint32_t cap, uint32_t ccap);
 size_t fxk_merge_lds_bytes(uint32_t cap, uint32_t n_rings);
 size_t fxk_desc_lds_bytes(uint32_t cap);
 size_t fxk_gather_lds_bytes(uint32_t max_keypoints);
+uint32_t fxk_huge_cap(void);
 hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t desc_big);
 void fxk_prep(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
 void fxk_bucket(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float el0, float inv_step);
@@ -43,6 +44,8 @@ void fxk_desc_wg_xl(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uin
                     uint32_t grid);
 void fxk_desc_spill(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t mode,
                     uint32_t slab_pts);
+void fxk_desc_huge(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t mode,
+                   uint32_t slab_pts);
 void fxk_pack_kp_records(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, void *dst,
                          uint32_t rec_kp);
 void fxk_rng_ord(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
@@ -221,10 +224,12 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof) {
       fxk_desc_wg(s, P, B, batch, P.list_cap, big_grid, 0, 2);
       FX_HIP(mark(11));
       fxk_desc_wg(s, P, B, batch, L.max_neighbors, big_grid, 0, 0);
+      fxk_desc_huge(s, P, B, batch, c->spill_grid, 0, c->spill_slab);
       fxk_desc_spill(s, P, B, batch, c->spill_grid, 0, c->spill_slab);
       fxk_rng_ord(s, P, B, batch);
       // second pass: only keypoints whose RNG ordinal moved (an earlier keypoint had no neighbours)
       fxk_desc_wg(s, P, B, batch, L.max_neighbors, big_grid, 1, 0);
+      fxk_desc_huge(s, P, B, batch, c->spill_grid, 1, c->spill_slab);
       fxk_desc_spill(s, P, B, batch, c->spill_grid, 1, c->spill_slab);
     } else {
       for (int i = 6; i <= 11; ++i) FX_HIP(mark(i));
@@ -362,6 +367,11 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   P.max_neighbors = L.max_neighbors;
   P.max_ring_points = L.max_ring_points;
   P.list_cap = L.max_neighbors < kListCap ? L.max_neighbors : kListCap;
+  P.huge_cap = fxk_huge_cap();
+  if (const char *e = getenv("FX_HUGE_CAP")) {  // test hook: push large support sets on to the slab tier
+    const uint32_t v = (uint32_t)atoi(e);
+    if (v < P.huge_cap) P.huge_cap = v;
+  }
   P.ring_slot_cap = 2 * L.max_points;  // worst case: every point on a window boundary, i.e. in two rings
 
   fx_status st = FX_OK;
@@ -424,6 +434,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   FX_A(dev_alloc(c, &b.row_kp, L.max_total_keypoints));
   FX_A(dev_alloc(c, &b.row_xa, L.max_total_keypoints));
   FX_A(dev_alloc(c, &b.spill_desc, L.max_total_keypoints));
+  FX_A(dev_alloc(c, &b.huge_desc, L.max_total_keypoints));
   FX_A(dev_alloc(c, &b.exact_desc, L.max_total_keypoints));
   FX_A(dev_alloc(c, &b.wave_desc, L.max_total_keypoints));
   {

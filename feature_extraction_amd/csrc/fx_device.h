@@ -31,6 +31,7 @@ struct FxDevParams {
   // capacities
   uint32_t max_points, max_ring_cands, max_candidates, max_keypoints, max_total_kp, max_kpc, max_neighbors,
       max_ring_points, list_cap, ring_slot_cap;
+  uint32_t huge_cap;  // support points k_desc_huge takes (<= its LDS capacity; tests lower it to reach the slab tier)
 };
 
 // 3DSC tables in device memory (built on the host by fx_sc3d_tables / fx_sc3d_xaxis).
@@ -88,6 +89,7 @@ struct FxBuffers {
   uint32_t *wave_desc;    // [max_total_kp]  rows with 65..256 support points (one wavefront each)
   uint32_t *exact_desc;   // [max_total_kp]  rows with an angle too close to a bin edge for the fp32 pass
   // spill tier slabs, one per workgroup of k_desc_spill (null when the context has none)
+  uint32_t *huge_desc;    // [max_total_kp]  rows k_desc_huge could not hold either (k_desc_spill takes them)
   float4 *spill_pts;
   float *spill_d2;
   uint32_t *spill_nlist;

@@ -2356,6 +2356,214 @@ extern "C" __global__ __launch_bounds__(FX_DESC_WG_XL_T) void k_desc_wg_xl(FxDev
 // R + R/5).  Same algorithm, with the support set, the neighbour list and the sort in a
 // per-workgroup slab of global memory; the density count streams the support set through LDS
 // tiles.  Slow but exact and without a capacity limit below max_points.
+// ---------------------------------------------------------------- k_desc_huge
+// Support sets beyond the lists (more than list_cap points; up to FX_HUGE_CAP): the whole LDS of a CU
+// goes to one keypoint.  The scan is streamed twice — a cell histogram, then a scatter — so that the
+// support set lands in LDS as xyz triples sorted by density cell (the same 13 x 13 xy cells as the list
+// tiers); indices, distances, keys and weights live in the workgroup's global slab.  The density count
+// of a neighbour then scans three cell rows in LDS instead of the whole set, and the (bin, d2, index)
+// keys are sorted in LDS once the support set is no longer needed.  Angles in fp64 (the exact policy).
+// Anything larger still goes to k_desc_spill.
+#define FX_HUGE_T 1024
+#define FX_HUGE_CAP 12288   // support points (3 floats each)
+#define FX_HUGE_WORDS (16 + 2 * FX_DGRID * FX_DGRID + 2 + FX_TABLE_WORDS + 3 * FX_HUGE_CAP + FX_DESC_BINS)
+extern "C" __global__ __launch_bounds__(FX_HUGE_T) void k_desc_huge(FxDevParams P, FxBuffers B, uint32_t batch, uint32_t mode,
+                                                                     uint32_t slab_pts) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  constexpr uint32_t G = FX_DGRID, kCells = G * G;
+  uint32_t *s_w = smem;                         // 0 support, 1 binned neighbours, 2 all neighbours
+  uint32_t *cell_start = smem + 16;             // [kCells + 1]
+  uint32_t *cell_fill = cell_start + kCells + 1;  // [kCells]
+  uint32_t *tl = smem + 16 + 2 * kCells + 2;      // (keeps what follows 16-byte aligned)
+  float *xyz = reinterpret_cast<float *>(tl + FX_TABLE_WORDS);  // [3 * FX_HUGE_CAP]; later the sort arrays
+  float *img = xyz + 3 * FX_HUGE_CAP;
+  if (mode == 1 && B.counters[3] == 0) return;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t n_items = B.counters[6];
+  float *sd2 = B.spill_d2 + (size_t)blockIdx.x * slab_pts;                 // squared distance to the keypoint
+  uint32_t *sidx = reinterpret_cast<uint32_t *>(B.spill_w) + (size_t)blockIdx.x * slab_pts;  // point index (weights come later)
+  uint32_t *nlist = B.spill_nlist + (size_t)blockIdx.x * slab_pts;         // support positions of the binned neighbours
+  unsigned long long *nkey = B.spill_key + (size_t)blockIdx.x * slab_pts;
+  float *w_by_idx = reinterpret_cast<float *>(B.spill_pts) + (size_t)blockIdx.x * slab_pts * 4;  // weight of point i (the float4 slab is free here)
+  const FxScTables *T = tables_to_lds(B, tl);
+  const float r_sup = sqrtf(P.r2_support);
+  const float cell_w = fmaxf(sqrtf(P.r2_density) * 1.001f, 2.0f * r_sup / (float)(G - 1) * 1.0001f);
+  const float inv_cw = 1.0f / cell_w;
+  for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+    const uint32_t row = B.spill_desc[it];
+    const uint2 rm = B.row_map[row];
+    const uint32_t scan = rm.x, k = rm.y;
+    const uint32_t ord = mode == 1 ? B.rng_ord[(size_t)scan * P.max_keypoints + k] : k;
+    if (mode == 1 && ord == k) continue;
+    const FxScanMeta M = B.meta[scan];
+    const float4 kp = B.keypoints[(size_t)scan * P.max_keypoints + k];
+    const float2 xa = B.xaxis[ord];
+    float *out = B.desc + (size_t)row * FX_DESC_FLOATS;
+    const float gx0 = kp.x - r_sup, gy0 = kp.y - r_sup;
+    auto cell_of = [&](float x, float y) {
+      const uint32_t cx = (uint32_t)min(max((int)floorf((x - gx0) * inv_cw), 0), (int)G - 1);
+      const uint32_t cy = (uint32_t)min(max((int)floorf((y - gy0) * inv_cw), 0), (int)G - 1);
+      return cy * G + cx;
+    };
+    __syncthreads();
+    if (tid < 4) s_w[tid] = 0;
+    for (uint32_t t = tid; t < 2 * kCells + 1; t += FX_HUGE_T) cell_start[t] = 0;
+    __syncthreads();
+    // ---- the scan twice: pass 0 counts the support points per cell, pass 1 places them
+    const uint32_t n = M.n;
+    for (int pass = 0; pass < 2; ++pass) {
+      for (uint32_t i0 = 0; i0 < n; i0 += FX_HUGE_T * 4) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t i = i0 + u * FX_HUGE_T + tid;
+          v[u] = i < n ? *reinterpret_cast<const float4 *>(M.pts + (size_t)i * M.stride_f) : make_float4(NAN, NAN, NAN, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float x = v[u].x, y = v[u].y, z = v[u].z;
+          const float rx = ((M.R[0] * x + M.R[1] * y) + M.R[2] * z) + 0.0f;
+          const float ry = ((M.R[3] * x + M.R[4] * y) + M.R[5] * z) + 0.0f;
+          const float rz = ((M.R[6] * x + M.R[7] * y) + M.R[8] * z) + 0.0f;
+          const float d = dist2(kp.x, kp.y, kp.z, rx, ry, rz);
+          if (!(d < P.r2_support && isfinite(rx) && isfinite(ry) && isfinite(rz))) continue;
+          const uint32_t ce = cell_of(rx, ry);
+          if (pass == 0) {
+            atomicAdd(&cell_fill[ce], 1u);
+            atomicAdd(&s_w[0], 1u);
+          } else {
+            const uint32_t slot = cell_start[ce] + atomicAdd(&cell_fill[ce], 1u);
+            xyz[3 * slot + 0] = rx;
+            xyz[3 * slot + 1] = ry;
+            xyz[3 * slot + 2] = rz;
+            sd2[slot] = d;
+            sidx[slot] = i0 + u * FX_HUGE_T + tid;
+            if (d < P.r2_search) {
+              atomicAdd(&s_w[2], 1u);
+              if (!(fabsf(d - 0.0f) < FLT_EPSILON)) nlist[atomicAdd(&s_w[1], 1u)] = slot;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      if (pass == 0) {
+        if (s_w[0] > P.huge_cap) break;  // (workgroup-uniform)
+        if (tid < 64) {  // exclusive prefix over the cells by one wavefront
+          constexpr uint32_t per = (kCells + 63) / 64;
+          uint32_t c[per], sum = 0;
+#pragma unroll
+          for (uint32_t u = 0; u < per; ++u) {
+            const uint32_t ci = tid * per + u;
+            c[u] = ci < kCells ? cell_fill[ci] : 0u;
+            sum += c[u];
+          }
+          uint32_t incl = sum;
+#pragma unroll
+          for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+            if ((int)tid >= d) incl += o;
+          }
+          uint32_t run = incl - sum;
+#pragma unroll
+          for (uint32_t u = 0; u < per; ++u) {
+            const uint32_t ci = tid * per + u;
+            if (ci < kCells) {
+              cell_start[ci] = run;
+              cell_fill[ci] = 0;
+            }
+            run += c[u];
+          }
+          if (tid == 63) cell_start[kCells] = incl;
+        }
+        __syncthreads();
+      }
+    }
+    const uint32_t nS = s_w[0];
+    if (nS > P.huge_cap) {  // does not fit even here: the slab tier
+      if (tid == 0) B.huge_desc[atomicAdd(&B.counters[12], 1u)] = row;
+      continue;
+    }
+    __threadfence();  // the slab arrays are re-read by other waves of this workgroup
+    __syncthreads();
+    const uint32_t nM = s_w[1], nAll = s_w[2];
+    if (tid == 0) B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = nAll;
+    if (nAll == 0) {
+      desc_fill_nan(out, tid, FX_HUGE_T);
+      continue;
+    }
+    // ---- one neighbour per lane at a time: density from three cell rows of the LDS copy, bin, weight
+    for (uint32_t m = tid; m < nM; m += FX_HUGE_T) {
+      const uint32_t e = nlist[m];
+      const float bx = xyz[3 * e], by = xyz[3 * e + 1], bz = xyz[3 * e + 2];
+      const float d2 = sd2[e];
+      const uint32_t cx = (uint32_t)min(max((int)floorf((bx - gx0) * inv_cw), 0), (int)G - 1);
+      const uint32_t cy = (uint32_t)min(max((int)floorf((by - gy0) * inv_cw), 0), (int)G - 1);
+      const uint32_t xa0 = cx > 0 ? cx - 1 : 0, xa1 = min(cx + 1, G - 1);
+      uint32_t dens = 0;
+      for (uint32_t rowi = 0; rowi < 3; ++rowi) {
+        const uint32_t yy = cy + rowi - 1u;
+        if (yy >= G) continue;
+        const uint32_t q0 = cell_start[yy * G + xa0], q1 = cell_start[yy * G + xa1 + 1];
+#pragma unroll 8
+        for (uint32_t q = q0; q < q1; ++q)
+          dens += (dist2(bx, by, bz, xyz[3 * q], xyz[3 * q + 1], xyz[3 * q + 2]) < P.r2_density) ? 1u : 0u;
+      }
+      float lut;
+      bool amb_unused = false;
+      const uint32_t bin = sc3d_bin<false>(kp, bx, by, bz, d2, xa, T, lut, amb_unused);
+      const uint32_t idx = sidx[e];
+      nkey[m] = sc3d_key(bin, d2, idx);
+      w_by_idx[idx] = (1.0f / (float)dens) * lut;
+    }
+    __threadfence();
+    __syncthreads();
+    // ---- sort the keys (bin, d2, index) in LDS: the support copy is done with, and 2^14 keys fit where it
+    //      was; the weights stay in the slab, addressed by point index (the low bits of a key)
+    uint32_t p2 = 1;
+    while (p2 < nM) p2 <<= 1;
+    unsigned long long *sk = reinterpret_cast<unsigned long long *>(xyz);
+    for (uint32_t t = tid; t < p2; t += FX_HUGE_T) sk[t] = t < nM ? nkey[t] : ~0ull;
+    __syncthreads();
+    for (uint32_t kb = 2; kb <= p2; kb <<= 1) {
+      for (uint32_t jb = kb >> 1; jb > 0; jb >>= 1) {
+        for (uint32_t t = tid; t < p2; t += FX_HUGE_T) {
+          const uint32_t x = t ^ jb;
+          if (x > t) {
+            const unsigned long long a = sk[t], c = sk[x];
+            const bool up = (t & kb) == 0;
+            if ((a > c) == up) {
+              sk[t] = c;
+              sk[x] = a;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    // ---- every sorted key fetches its weight (in parallel) and becomes (bin, weight) in place
+    for (uint32_t t = tid; t < nM; t += FX_HUGE_T) {
+      const unsigned long long key = sk[t];
+      sk[t] = ((key >> 52) << 32) | (unsigned long long)__float_as_uint(w_by_idx[(uint32_t)(key & 0xfffffull)]);
+    }
+    // ---- the image: one lane per bin run adds its weights in sorted order; then the row
+    for (uint32_t t = tid; t < FX_DESC_BINS; t += FX_HUGE_T) img[t] = 0.0f;
+    __syncthreads();
+    for (uint32_t t = tid; t < nM; t += FX_HUGE_T) {
+      const uint32_t bin = (uint32_t)(sk[t] >> 32);
+      if (t > 0 && (uint32_t)(sk[t - 1] >> 32) == bin) continue;
+      float acc = 0.0f;
+      uint32_t e = t;
+      do {
+        acc += __uint_as_float((uint32_t)sk[e]);
+        ++e;
+      } while (e < nM && (uint32_t)(sk[e] >> 32) == bin);
+      img[bin] = acc;
+    }
+    __syncthreads();
+    for (uint32_t t = tid; t < FX_DESC_FLOATS; t += FX_HUGE_T) out[t] = t < FX_DESC_BINS ? img[t] : 0.0f;  // rf = 0
+  }
+}
+
 #define FX_SPILL_TILE 1024
 extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_spill(FxDevParams P, FxBuffers B, uint32_t batch, uint32_t mode,
                                                                   uint32_t slab_pts) {
@@ -2363,7 +2571,7 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_spill(FxDevParams P, 
   __shared__ uint32_t s_cnt[4];
   if (mode == 1 && B.counters[3] == 0) return;
   const uint32_t tid = threadIdx.x;
-  const uint32_t n_items = B.counters[6];
+  const uint32_t n_items = B.counters[12];  // what k_desc_huge could not hold
   float4 *sp = B.spill_pts + (size_t)blockIdx.x * slab_pts;              // support set (x, y, z, index bits)
   float *sd2 = B.spill_d2 + (size_t)blockIdx.x * slab_pts;               // its squared distances
   uint32_t *nlist = B.spill_nlist + (size_t)blockIdx.x * slab_pts;       // support positions of the binned neighbours
@@ -2371,10 +2579,11 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_spill(FxDevParams P, 
   float *nw = B.spill_w + (size_t)blockIdx.x * slab_pts;
   const FxScTables *T = B.tables;
   for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
-    const uint32_t row = B.spill_desc[it];
+    const uint32_t row = B.huge_desc[it];
     const uint2 rm = B.row_map[row];
     const uint32_t scan = rm.x, k = rm.y;
     const uint32_t ord = mode == 1 ? B.rng_ord[(size_t)scan * P.max_keypoints + k] : k;
+    if (mode == 1 && ord == k) continue;
     const FxScanMeta M = B.meta[scan];
     const float4 kp = B.keypoints[(size_t)scan * P.max_keypoints + k];
     const float2 xa = B.xaxis[ord];
@@ -2624,6 +2833,7 @@ size_t fxk_ring_wave_lds_bytes(uint32_t cap, uint32_t ccap) {
 size_t fxk_merge_lds_bytes(uint32_t cap, uint32_t n_rings) {
   return (size_t)(SegCfg<FX_WG>::kWords + FX_MERGE_WORDS_PER_CAND * cap + 2 * (n_rings + 1)) * 4;
 }
+uint32_t fxk_huge_cap(void) { return FX_HUGE_CAP; }
 size_t fxk_gather_lds_bytes(uint32_t max_keypoints) {
   return (16 + 80 + 7 * (size_t)max_keypoints + FX_GATHER_BINS + FX_GATHER_STAGE + 4 + 4 * FX_GATHER_STAGE) * 4;
 }
@@ -2638,6 +2848,8 @@ hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t desc_big) {
   e = hipFuncSetAttribute((const void *)k_desc_wg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)desc_big);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void *)k_desc_wg_xl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)desc_big);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void *)k_desc_huge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FX_HUGE_WORDS * 4));
   return e;
 }
 
@@ -2688,6 +2900,10 @@ void fxk_desc_wg_xl(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uin
 }
 void fxk_desc_wg_fast(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t grid) {
   hipLaunchKernelGGL(k_desc_wg_fast, dim3(grid), dim3(FX_DESC_WG_FAST_T), fxk_desc_lds_bytes(cap), s, P, B, batch, cap);
+}
+void fxk_desc_huge(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t mode,
+                   uint32_t slab_pts) {
+  hipLaunchKernelGGL(k_desc_huge, dim3(grid), dim3(FX_HUGE_T), (size_t)FX_HUGE_WORDS * 4, s, P, B, batch, mode, slab_pts);
 }
 void fxk_desc_spill(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t mode,
                     uint32_t slab_pts) {

@@ -175,6 +175,14 @@ def test_support_sets_beyond_lds_use_the_spill_tier(fxlib, oracle):
     _cmp(oracle, capi.params("default"), capi.limits(1, 28800, max_neighbors=128), [s], 0.02, -0.015, "spill tier default")
 
 
+def test_support_sets_beyond_the_whole_cu_tier_use_global_slabs(fxlib, oracle, monkeypatch):
+    """k_desc_huge keeps up to 12288 support points in LDS; the slab tier behind it is reached here by
+    lowering that capacity (FX_HUGE_CAP is read at fx_create)."""
+    s = util.vlp16_scan(1000)
+    monkeypatch.setenv("FX_HUGE_CAP", "100")
+    _cmp(oracle, capi.params("launch"), capi.limits(1, 28800, max_neighbors=64), [s], 0.02, -0.015, "slab tier")
+
+
 def test_long_support_lists_use_the_workgroup_tiers(fxlib, oracle):
     """Keypoints with > 256 and > 1024 support points (list tier and re-gather tier)."""
     s = util.vlp16_scan(1000, n_poles=8, x_lo=3.0, x_hi=8.0, y_lo=-4.0, y_hi=4.0)
