@@ -87,7 +87,7 @@ class FxSynthCfg(C.Structure):
 
 # every symbol include/fx.h declares (tests/test_capi_symbols.py checks the list against the header)
 EXPORTS = ("fx_version", "fx_status_str", "fx_last_error", "fx_params_default", "fx_params_launch",
-           "fx_limits_default", "fx_create", "fx_destroy", "fx_set_stream", "fx_set_graph_batch", "fx_set_profiling", "fx_get_timings",
+           "fx_limits_default", "fx_create", "fx_destroy", "fx_set_stream", "fx_set_graph_batch", "fx_set_profiling", "fx_set_profiling_stages", "fx_get_timings",
            "fx_get_limits", "fx_process_batch", "fx_synchronize", "fx_pack_features", "fx_pack_keypoint_records",
            "fx_rotation_from_roll_pitch", "fx_sc3d_tables", "fx_sc3d_xaxis", "fx_synth_cfg_vlp16",
            "fx_synth_scan", "fx_test_sort_replay", "fx_test_sort_replay_ranked", "fx_test_sort_replay_lists", "fx_test_sort_replay_device", "fx_unpack_pointcloud2",
@@ -126,6 +126,7 @@ def load():
     lib.fx_destroy.restype = None
     lib.fx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     lib.fx_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    lib.fx_set_profiling_stages.argtypes = [C.c_void_p, C.c_uint32]
     lib.fx_set_graph_batch.argtypes = [C.c_void_p, C.c_uint32]
     lib.fx_get_timings.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(FxTimings)]
     lib.fx_get_limits.argtypes = [C.c_void_p, C.POINTER(FxLimits)]
@@ -249,8 +250,11 @@ class Context:
     def set_graph_batch(self, max_batch):
         check(self.lib.fx_set_graph_batch(self.handle, int(max_batch)))
 
-    def set_profiling(self, depth):
+    def set_profiling(self, depth, stages=None):
+        """depth > 0: keep HIP-event timings of the last `depth` batches; stages: names to time (default all)."""
         check(self.lib.fx_set_profiling(self.handle, int(depth)))
+        mask = 0xffffffff if stages is None else sum(1 << STAGE_NAMES.index(n) for n in stages)
+        check(self.lib.fx_set_profiling_stages(self.handle, mask))
 
     def timings(self, back=0):
         """Per-kernel device ms (HIP events on the launch stream) of the batch `back` calls ago."""

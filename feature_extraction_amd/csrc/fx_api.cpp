@@ -110,6 +110,8 @@ struct fx_ctx {
   bool profiling = false;
   std::vector<hipEvent_t> ev_ring;  // depth * (FX_N_STAGES + 1)
   uint32_t ev_depth = 0, ev_count = 0;
+  uint32_t prof_mask = ~0u;        // stages that get events (bit i = stage i); fx_set_profiling_stages
+  std::vector<uint32_t> ev_mask;   // the mask each ring slot was recorded with
   hipEvent_t *ev = nullptr;  // set of the batch being enqueued
   uint32_t last_batch = 0;
   // HIP graphs of the stage sequence, one per batch size (batches up to graph_max_batch)
@@ -157,14 +159,20 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof) {
   const FxDevParams &P = c->dp;
   const FxBuffers &B = c->buf;
   const uint32_t big_grid = (uint32_t)c->n_cu;
-  if (prof) c->ev = &c->ev_ring[(size_t)(c->ev_count % c->ev_depth) * (FX_N_STAGES + 1)];
+  if (prof) {
+    c->ev = &c->ev_ring[(size_t)(c->ev_count % c->ev_depth) * (FX_N_STAGES + 1)];
+    c->ev_mask[c->ev_count % c->ev_depth] = c->prof_mask;
+  }
+  const uint32_t pmask = c->prof_mask;
   auto mark = [&](int i) -> hipError_t {
     if (c->debug_sync) {  // FX_DEBUG_SYNC=1: name the stage a device fault belongs to
       fprintf(stderr, "[fx] stage %d enqueued\n", i);
       hipError_t e = hipStreamSynchronize(s);
       if (e != hipSuccess) return e;
     }
-    return prof ? hipEventRecord(c->ev[i], s) : hipSuccess;
+    // event i closes stage i - 1 and opens stage i; the first and last always bracket the batch
+    const bool wanted = i == 0 || i == FX_N_STAGES || ((pmask >> i) & 1u) || ((pmask >> (i - 1)) & 1u);
+    return (prof && wanted) ? hipEventRecord(c->ev[i], s) : hipSuccess;
   };
   FX_HIP(mark(0));
   if (!batch) FX_HIP(hipMemsetAsync(B.counters, 0, 16 * sizeof(uint32_t), s));  // (k_prep clears them otherwise)
@@ -541,12 +549,18 @@ fx_status fx_set_profiling(fx_ctx *c, int depth) {
   c->ev_count = 0;
   c->profiling = depth > 0;
   c->ev_ring.resize((size_t)depth * (FX_N_STAGES + 1), nullptr);
+  c->ev_mask.assign((size_t)depth, ~0u);
   for (hipEvent_t &e : c->ev_ring) FX_HIP(hipEventCreate(&e));
   return FX_OK;
 }
 fx_status fx_get_limits(const fx_ctx *c, fx_limits *l) {
   if (!c || !l) return fail(FX_ERR_INVALID_ARG, "null argument");
   *l = c->lim;
+  return FX_OK;
+}
+fx_status fx_set_profiling_stages(fx_ctx *c, uint32_t stage_mask) {
+  if (!c) return fail(FX_ERR_INVALID_ARG, "null ctx");
+  c->prof_mask = stage_mask;
   return FX_OK;
 }
 fx_status fx_get_timings(fx_ctx *c, uint32_t back, fx_timings *t) {
@@ -556,7 +570,9 @@ fx_status fx_get_timings(fx_ctx *c, uint32_t back, fx_timings *t) {
     return fail(FX_ERR_INVALID_ARG, "no profiled batch that far back (fx_set_profiling(depth) first)");
   hipEvent_t *ev = &c->ev_ring[(size_t)((c->ev_count - 1 - back) % c->ev_depth) * (FX_N_STAGES + 1)];
   FX_HIP(hipEventSynchronize(ev[FX_N_STAGES]));
-  for (int i = 0; i < FX_N_STAGES; ++i) FX_HIP(hipEventElapsedTime(&t->ms[i], ev[i], ev[i + 1]));
+  const uint32_t mask = c->ev_mask[(c->ev_count - 1 - back) % c->ev_depth];
+  for (int i = 0; i < FX_N_STAGES; ++i)
+    if ((mask >> i) & 1u) FX_HIP(hipEventElapsedTime(&t->ms[i], ev[i], ev[i + 1]));  // (stages without events stay 0)
   FX_HIP(hipEventElapsedTime(&t->total_ms, ev[0], ev[FX_N_STAGES]));
   return FX_OK;
 }

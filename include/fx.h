@@ -185,6 +185,10 @@ fx_status fx_set_graph_batch(fx_ctx *ctx, uint32_t max_batch);
  * last `depth` batches; 0 disables.  fx_get_timings reads the batch `back` calls ago
  * (0 = most recent) and waits for it to finish. */
 fx_status fx_set_profiling(fx_ctx *ctx, int depth);
+/* Restrict the events to some stages (bit i = stage i of fx_timings; default all): every event costs a
+ * few microseconds of stream time, so a throughput measurement times only the kernel it needs.  The
+ * first and last event of a batch are always recorded (total_ms); untimed stages read 0. */
+fx_status fx_set_profiling_stages(fx_ctx *ctx, uint32_t stage_mask);
 fx_status fx_get_timings(fx_ctx *ctx, uint32_t back, fx_timings *t);
 fx_status fx_get_limits(const fx_ctx *ctx, fx_limits *l);
 
