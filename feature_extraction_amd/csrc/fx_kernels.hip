@@ -820,19 +820,21 @@ __device__ __forceinline__ uint32_t ring_membership(float el, const float2 *win,
   return mask;
 }
 
-extern "C" __global__ __launch_bounds__(FX_WG) void k_bucket(FxDevParams P, FxBuffers B, float el0, float inv_step) {
+#define FX_BUCKET_T 512
+#define FX_BUCKET_NW (FX_BUCKET_T / 64)
+extern "C" __global__ __launch_bounds__(FX_BUCKET_T) void k_bucket(FxDevParams P, FxBuffers B, float el0, float inv_step) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const uint32_t R = (uint32_t)P.n_rings;
-  uint32_t *s_w = smem;            // 16
-  uint32_t *cnt = smem + 16;       // [R] total per ring, then running fill
+  uint32_t *s_w = smem;            // 48: block helpers, per-wave ring ranges
+  uint32_t *cnt = smem + 48;       // [R] total per ring, then running fill
   uint32_t *off = cnt + R;         // [R + 1]
-  uint32_t *cw = off + R + 1;      // [FX_NWAVE][R] per-wave counts of the current chunk
+  uint32_t *cw = off + R + 1;      // [FX_BUCKET_NW][R] per-wave counts of the current chunk
   const uint32_t scan = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t nf = B.n_filt[scan];
   const float4 *f = B.filt + (size_t)scan * P.max_points;
-  for (uint32_t r = tid; r < R; r += FX_WG) cnt[r] = 0;
+  for (uint32_t r = tid; r < R; r += FX_BUCKET_T) cnt[r] = 0;
   __syncthreads();
-  for (uint32_t i = tid; i < nf; i += FX_WG) {
+  for (uint32_t i = tid; i < nf; i += FX_BUCKET_T) {
     const float el = f[i].w;
     int r_first;
     uint32_t mask = isfinite(el) ? ring_membership(el, B.ring_win, P.n_rings, el0, inv_step, r_first) : 0u;
@@ -842,18 +844,18 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_bucket(FxDevParams P, FxBu
   }
   __syncthreads();
   uint32_t total = 0;
-  for (uint32_t b0 = 0; b0 < R; b0 += FX_WG) {
+  for (uint32_t b0 = 0; b0 < R; b0 += FX_BUCKET_T) {
     const uint32_t r = b0 + tid;
     const uint32_t c = r < R ? cnt[r] : 0u;
     uint32_t tot;
-    const uint32_t ex = block_excl_scan<FX_WG>(c, s_w, tot);
+    const uint32_t ex = block_excl_scan<FX_BUCKET_T>(c, s_w, tot);
     if (r < R) off[r] = total + ex;
     total += tot;
   }
   __syncthreads();
   const bool overflow = total > P.ring_slot_cap;
   uint32_t *g_off = B.ring_off + (size_t)scan * R, *g_cnt = B.ring_cnt + (size_t)scan * R;
-  for (uint32_t r = tid; r < R; r += FX_WG) {
+  for (uint32_t r = tid; r < R; r += FX_BUCKET_T) {
     g_off[r] = overflow ? 0u : off[r];
     g_cnt[r] = overflow ? 0u : cnt[r];
     cnt[r] = 0;  // becomes the running fill
@@ -864,7 +866,7 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_bucket(FxDevParams P, FxBu
   }
   __syncthreads();
   float4 *dst = B.ring_pts + (size_t)scan * P.ring_slot_cap;
-  for (uint32_t b0 = 0; b0 < nf; b0 += FX_WG) {
+  for (uint32_t b0 = 0; b0 < nf; b0 += FX_BUCKET_T) {
     const uint32_t i = b0 + tid;
     float4 v = make_float4(0, 0, 0, 0);
     int r_first = 0;
@@ -882,14 +884,14 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_bucket(FxDevParams P, FxBu
     }
     if (lane == 0) {
       s_w[wave] = (uint32_t)lo;
-      s_w[4 + wave] = (uint32_t)hi;
+      s_w[FX_BUCKET_NW + wave] = (uint32_t)hi;
     }
     __syncthreads();
     lo = 0x7fffffff, hi = -1;
 #pragma unroll
-    for (int w = 0; w < FX_NWAVE; ++w) {
+    for (int w = 0; w < FX_BUCKET_NW; ++w) {
       lo = min(lo, (int)s_w[w]);
-      hi = max(hi, (int)s_w[4 + w]);
+      hi = max(hi, (int)s_w[FX_BUCKET_NW + w]);
     }
     lo = max(lo, 0);
     hi = min(hi, (int)R);
@@ -908,15 +910,15 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_bucket(FxDevParams P, FxBu
         const uint32_t r = (uint32_t)(r_first + d);
         uint32_t before = 0;
 #pragma unroll
-        for (int w = 0; w < FX_NWAVE; ++w) before += (w < (int)wave) ? cw[w * R + r] : 0u;
+        for (int w = 0; w < FX_BUCKET_NW; ++w) before += (w < (int)wave) ? cw[w * R + r] : 0u;
         dst[off[r] + cnt[r] + before + my_rank[d]] = v;
       }
     }
     __syncthreads();
-    for (int r = lo + (int)tid; r < hi; r += FX_WG) {
+    for (int r = lo + (int)tid; r < hi; r += FX_BUCKET_T) {
       uint32_t c = 0;
 #pragma unroll
-      for (int w = 0; w < FX_NWAVE; ++w) c += cw[w * R + r];
+      for (int w = 0; w < FX_BUCKET_NW; ++w) c += cw[w * R + r];
       cnt[r] += c;
     }
     __syncthreads();
@@ -2857,8 +2859,8 @@ void fxk_prep(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t 
   hipLaunchKernelGGL(k_prep, dim3(batch), dim3(FX_PREP_T), 0, s, P, B);
 }
 void fxk_bucket(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float el0, float inv_step) {
-  const size_t lds = (16 + (size_t)P.n_rings * (2 + FX_NWAVE) + 1) * 4;
-  hipLaunchKernelGGL(k_bucket, dim3(batch), dim3(FX_WG), lds, s, P, B, el0, inv_step);
+  const size_t lds = (48 + (size_t)P.n_rings * (2 + FX_BUCKET_NW) + 1) * 4;
+  hipLaunchKernelGGL(k_bucket, dim3(batch), dim3(FX_BUCKET_T), lds, s, P, B, el0, inv_step);
 }
 void fxk_rings_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t ccap,
                      uint32_t mid_cap, uint32_t grid) {
