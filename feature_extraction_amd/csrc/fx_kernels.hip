@@ -1989,7 +1989,8 @@ struct DescLds {
   uint32_t *sidx, *s_w;
 };
 #define FX_DESC_WORDS_PER_POINT 8
-#define FX_DGRID 13  // density grid cells per axis: 2 (R + R/5) / (R/5) = 12, + 1
+#define FX_DGRID 13  // k_desc_huge's xy density grid, cells per axis: 2 (R + R/5) / (R/5) = 12, + 1
+#define FX_DGRID3 12  // the list tiers' xyz density grid (12^3 cell words + the 3DSC tables fit the image)
 __device__ __forceinline__ DescLds desc_carve(uint32_t *smem, uint32_t cap) {
   DescLds L;
   L.s_w = smem;  // 16 words
@@ -2017,42 +2018,40 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
 
   if (tid < 4) L.s_w[tid] = 0;  // 0: support count, 1: binned neighbours, 2: all neighbours
   // the 3DSC tables ride in the image until the bins are known (the image is cleared after that)
-  uint32_t *tl = reinterpret_cast<uint32_t *>(L.img) + 512;
+  uint32_t *tl = reinterpret_cast<uint32_t *>(L.img) + FX_DGRID3 * FX_DGRID3 * FX_DGRID3;  // behind the cell table
   for (uint32_t t = tid; t < sizeof(FxScTables) / 4; t += NT) tl[t] = __float_as_uint(reinterpret_cast<const float *>(B.tables)[t]);
   __syncthreads();
   uint32_t nS;
-  // Density grid: a list-fed support set is stored sorted by xy cell (cell width >= R/5, FX_DGRID cells
-  // per axis cover the support radius), so the density query of a neighbour only scans the three
-  // cell rows around it instead of the whole set.  The cell table borrows the (still unused) image.
-  constexpr uint32_t G = FX_DGRID, kCells = G * G;
-  uint32_t *cell_start = reinterpret_cast<uint32_t *>(L.img);  // [kCells + 1]
-  uint32_t *cell_fill = cell_start + kCells + 1;                // [kCells] counts, then fill cursors
+  // Density grid: a list-fed support set is stored sorted by cell (12 x 12 x 12 cells of width >= R/5
+  // over the support sphere's box), so the density query of a neighbour only scans the nine rows of
+  // three x-cells around it instead of the whole set.  One word per cell — first its count, then its
+  // start, then (after the fill) its end, which is the next cell's start — borrows the image.
+  constexpr uint32_t G = FX_DGRID3, kCells = G * G * G;
+  uint32_t *cell_end = reinterpret_cast<uint32_t *>(L.img);  // [kCells]
   const float r_sup = sqrtf(P.r2_support);
   const float cell_w = fmaxf(sqrtf(P.r2_density) * 1.001f, 2.0f * r_sup / (float)(G - 1) * 1.0001f);
-  const float inv_cw = 1.0f / cell_w, gx0 = kp.x - r_sup, gy0 = kp.y - r_sup;
-  auto cell_x = [&](float x) { return (uint32_t)min(max((int)floorf((x - gx0) * inv_cw), 0), (int)G - 1); };
-  auto cell_y = [&](float y) { return (uint32_t)min(max((int)floorf((y - gy0) * inv_cw), 0), (int)G - 1); };
+  const float inv_cw = 1.0f / cell_w, gx0 = kp.x - r_sup, gy0 = kp.y - r_sup, gz0 = kp.z - r_sup;
+  auto cell_1d = [&](float v, float v0) { return (uint32_t)min(max((int)floorf((v - v0) * inv_cw), 0), (int)G - 1); };
+  auto cell_of = [&](float x, float y, float z) { return (cell_1d(z, gz0) * G + cell_1d(y, gy0)) * G + cell_1d(x, gx0); };
   bool grid = false;
   if (from_list) {
     nS = B.s_cnt[row];
     grid = nS <= cap;
     if (grid) {
       const float4 *lst = B.s_pts + (size_t)row * P.list_cap;
-      for (uint32_t t = tid; t < 2 * kCells + 1; t += NT) cell_start[t] = 0;
+      for (uint32_t t = tid; t < kCells; t += NT) cell_end[t] = 0;
       __syncthreads();
       for (uint32_t e = tid; e < nS; e += NT) {
         const float4 v = lst[e];
-        atomicAdd(&cell_fill[cell_y(v.y) * G + cell_x(v.x)], 1u);
+        atomicAdd(&cell_end[cell_of(v.x, v.y, v.z)], 1u);
       }
       __syncthreads();
-      if (tid < 64) {  // exclusive prefix over the cells by one wavefront
+      if (tid < 64) {  // counts -> exclusive starts, in place, by one wavefront
         constexpr uint32_t per = (kCells + 63) / 64;
-        uint32_t c[per], sum = 0;
-#pragma unroll
+        uint32_t sum = 0;
         for (uint32_t u = 0; u < per; ++u) {
           const uint32_t ci = tid * per + u;
-          c[u] = ci < kCells ? cell_fill[ci] : 0u;
-          sum += c[u];
+          sum += ci < kCells ? cell_end[ci] : 0u;
         }
         uint32_t incl = sum;
 #pragma unroll
@@ -2061,22 +2060,19 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
           if ((int)tid >= d) incl += o;
         }
         uint32_t run = incl - sum;
-#pragma unroll
         for (uint32_t u = 0; u < per; ++u) {
           const uint32_t ci = tid * per + u;
           if (ci < kCells) {
-            cell_start[ci] = run;
-            cell_fill[ci] = 0;
+            const uint32_t c = cell_end[ci];
+            cell_end[ci] = run;
+            run += c;
           }
-          run += c[u];
         }
-        if (tid == 63) cell_start[kCells] = incl;
       }
       __syncthreads();
       for (uint32_t e = tid; e < nS; e += NT) {  // second read of the list (cache-resident): each entry to its cell
         const float4 v = lst[e];
-        const uint32_t ce = cell_y(v.y) * G + cell_x(v.x);
-        const uint32_t slot = cell_start[ce] + atomicAdd(&cell_fill[ce], 1u);
+        const uint32_t slot = atomicAdd(&cell_end[cell_of(v.x, v.y, v.z)], 1u);
         L.sp[slot] = make_float4(v.x, v.y, v.z, dist2(kp.x, kp.y, kp.z, v.x, v.y, v.z));
         L.sidx[slot] = __float_as_uint(v.w);
       }
@@ -2142,19 +2138,20 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
     //      neighbour's count is split over `parts` lanes so that the whole workgroup is busy
     const uint32_t nMq = L.s_w[1];
     uint32_t parts = 1;
-    while (parts < (grid ? 4u : 32u) && nMq * parts * 2 <= (uint32_t)NT) parts <<= 1;
+    while (parts < (grid ? 8u : 32u) && nMq * parts * 2 <= (uint32_t)NT) parts <<= 1;
     const uint32_t chunk = (nS + parts - 1) / parts;
     for (uint32_t t = tid; t < nMq * parts; t += NT) {
       const uint32_t m = t / parts, part = t % parts;
       const float4 bq = L.sp[nlist[m]];
       uint32_t c = 0;
       if (grid) {
-        const uint32_t cx = cell_x(bq.x), cy = cell_y(bq.y);
+        const uint32_t cx = cell_1d(bq.x, gx0), cy = cell_1d(bq.y, gy0), cz = cell_1d(bq.z, gz0);
         const uint32_t xa0 = cx > 0 ? cx - 1 : 0, xa1 = min(cx + 1, G - 1);
-        for (uint32_t rowi = part; rowi < 3; rowi += parts) {  // the cells of a row are stored back to back
-          const uint32_t yy = cy + rowi - 1u;
-          if (yy >= G) continue;  // (also the wrapped -1)
-          const uint32_t q0 = cell_start[yy * G + xa0], q1 = cell_start[yy * G + xa1 + 1];
+        for (uint32_t rowi = part; rowi < 9; rowi += parts) {  // the cells of an x-row are stored back to back
+          const uint32_t yy = cy + rowi % 3u - 1u, zz = cz + rowi / 3u - 1u;
+          if (yy >= G || zz >= G) continue;  // (also the wrapped -1)
+          const uint32_t c0 = (zz * G + yy) * G + xa0, c1 = (zz * G + yy) * G + xa1;
+          const uint32_t q0 = c0 ? cell_end[c0 - 1] : 0u, q1 = cell_end[c1];
 #pragma unroll 8
           for (uint32_t q = q0; q < q1; ++q) {
             const float4 sq = L.sp[q];
