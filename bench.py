@@ -145,7 +145,7 @@ def main():
     torch.cuda.synchronize(dev)
     warm, _tot = ctx.timings(0)  # the last warm-up step
     dom = max(warm, key=warm.get)
-    if world > 1:  # every rank times the same kernel
+    if use_dist:  # every rank times the same kernel
         names = list(capi.STAGE_NAMES)
         t = torch.tensor([names.index(dom)], dtype=torch.int64, device=dev)
         dist.broadcast(t, 0)
