@@ -706,23 +706,25 @@ __device__ __forceinline__ uint32_t cc_order(uint32_t n, const uint32_t *parent,
 // ====================================================================== stage 1: prep
 // One workgroup per scan streams the scan once: rotate (fp32, PCL's scalar order), apply
 // the three PassThrough predicates at once and compact the survivors of a tile, in input
-// order (wave ballot + prefix), into LDS.  The elevation angle (fp64 atan2) is then computed
-// by a dense sweep over the compacted survivors only — about one point in ten survives, and
-// in firing order the survivors are spread over every wavefront.
+// order (wave ballot + prefix), into an LDS buffer.  The elevation angle (fp64 atan2) is computed
+// by dense sweeps over the buffered survivors only — about one point in ten survives, and in
+// firing order the survivors are spread over every wavefront.
 #define FX_PREP_T 512
 #define FX_PREP_U 4
 typedef float __attribute__((address_space(1))) gfloat;
 __global__ __launch_bounds__(FX_PREP_T) void k_prep(FxDevParams P, FxBuffers B) {
+  constexpr int NW = FX_PREP_T / 64;
+  constexpr uint32_t kTile = FX_PREP_T * FX_PREP_U;  // points per tile
+  constexpr uint32_t kKeep = 2 * kTile;              // survivors buffered between sweeps
   const uint32_t scan = blockIdx.x;
   const FxScanMeta M = B.meta[scan];
-  __shared__ uint32_t s_cnt[FX_PREP_U * (FX_PREP_T / 64)];
-  __shared__ float4 s_keep[FX_PREP_T * FX_PREP_U];  // un-rotated survivors of the tile
+  __shared__ uint32_t s_cnt[2][FX_PREP_U * NW];  // per-wave survivor counts, double-buffered by tile parity
+  __shared__ float4 s_keep[kKeep];               // un-rotated survivors waiting for the elevation sweep
   float4 *out = B.filt + (size_t)scan * P.max_points;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr int NW = FX_PREP_T / 64;
-  uint32_t base = 0;
+  uint32_t base = 0, buffered = 0, parity = 0;
   const uint32_t n = M.n;
-  // the loads of the next tile are issued before this tile's barriers, so the memory pipe stays full
+  // the loads of the next tile are issued before this tile's barrier, so the memory pipe stays full
   // while the tile is compacted
   // (global address space stated: a generic-pointer load would be a flat load, which also counts as an
   //  LDS access and gets waited for at the next LDS instruction)
@@ -736,10 +738,29 @@ __global__ __launch_bounds__(FX_PREP_T) void k_prep(FxDevParams P, FxBuffers B) 
       v[u] = i < n ? w : make_float4(NAN, NAN, NAN, 0.f);
     }
   };
+  // The fp64 elevation (getElevationAngles, ref: node.cpp:147-156) is a long dependent chain: it runs
+  // over the buffered survivors only when the buffer could overflow on the next tile (about every tenth
+  // tile at the usual one-in-ten survival), with every lane busy, instead of after each tile with a few.
+  // Called by the whole workgroup after a barrier.
+  auto sweep = [&]() {
+    for (uint32_t j = tid; j < buffered; j += FX_PREP_T) {
+      const float4 q = s_keep[j];
+      const float rx = ((M.R[0] * q.x + M.R[1] * q.y) + M.R[2] * q.z) + 0.0f;
+      const float ry = ((M.R[3] * q.x + M.R[4] * q.y) + M.R[5] * q.z) + 0.0f;
+      const float rz = ((M.R[6] * q.x + M.R[7] * q.y) + M.R[8] * q.z) + 0.0f;
+      // atan2(z, |xy|) of the un-rotated point in degrees, fp64 -> fp32.
+      // (cos(az) x + sin(az) y equals |xy| to within fp64 rounding; SURVEY.md B-5.)
+      const double x = q.x, y = q.y, z = q.z;
+      const double el = atan2(z, sqrt(x * x + y * y)) * 180 / M_PI;
+      out[base + j] = make_float4(rx, ry, rz, (float)el);
+    }
+    base += buffered;
+    buffered = 0;
+  };
   float4 v[FX_PREP_U], nv[FX_PREP_U];
   load_tile(0, v);
-  for (uint32_t t0 = 0; t0 < n; t0 += FX_PREP_T * FX_PREP_U) {
-    load_tile(t0 + FX_PREP_T * FX_PREP_U, nv);
+  for (uint32_t t0 = 0; t0 < n; t0 += kTile) {
+    load_tile(t0 + kTile, nv);
     bool keep[FX_PREP_U];
     unsigned long long mask[FX_PREP_U];
 #pragma unroll
@@ -755,41 +776,38 @@ __global__ __launch_bounds__(FX_PREP_T) void k_prep(FxDevParams P, FxBuffers B) 
       k = k && !(rx < P.x_min || rx > P.x_max);
       keep[u] = k;
       mask[u] = __ballot(k);
-      if (lane == 0) s_cnt[u * NW + wave] = (uint32_t)__popcll(mask[u]);
+      if (lane == 0) s_cnt[parity][u * NW + wave] = (uint32_t)__popcll(mask[u]);
     }
+    // One barrier per tile: it orders this tile's counts before their readers, the previous sweep's
+    // reads of s_keep before this tile's writes, and (a wave cannot be two tiles ahead of another) the
+    // readers of the other parity's counts before they are overwritten next tile.
     __syncthreads();
-    // tile slot = survivors of earlier slices of the tile + survivors of earlier waves in my
-    //             slice + earlier lanes of my wave
+    // buffer slot = survivors already buffered + those of earlier slices of the tile + of earlier
+    //               waves in my slice + of earlier lanes of my wave: input order is kept
     uint32_t tile_total = 0;
 #pragma unroll
     for (int u = 0; u < FX_PREP_U; ++u) {
       uint32_t before = 0, slice = 0;
 #pragma unroll
       for (int w = 0; w < NW; ++w) {
-        const uint32_t c = s_cnt[u * NW + w];
+        const uint32_t c = s_cnt[parity][u * NW + w];
         before += (w < (int)wave) ? c : 0u;
         slice += c;
       }
-      if (keep[u]) s_keep[tile_total + before + lanes_below(mask[u])] = v[u];
+      if (keep[u]) s_keep[buffered + tile_total + before + lanes_below(mask[u])] = v[u];
       tile_total += slice;
     }
-    __syncthreads();
-    for (uint32_t j = tid; j < tile_total; j += FX_PREP_T) {
-      const float4 q = s_keep[j];
-      const float rx = ((M.R[0] * q.x + M.R[1] * q.y) + M.R[2] * q.z) + 0.0f;
-      const float ry = ((M.R[3] * q.x + M.R[4] * q.y) + M.R[5] * q.z) + 0.0f;
-      const float rz = ((M.R[6] * q.x + M.R[7] * q.y) + M.R[8] * q.z) + 0.0f;
-      // getElevationAngles on the un-rotated point: atan2(z, |xy|) in degrees, fp64 -> fp32.
-      // (cos(az) x + sin(az) y equals |xy| to within fp64 rounding; SURVEY.md B-5.)
-      const double x = q.x, y = q.y, z = q.z;
-      const double el = atan2(z, sqrt(x * x + y * y)) * 180 / M_PI;
-      out[base + j] = make_float4(rx, ry, rz, (float)el);
+    buffered += tile_total;
+    parity ^= 1u;
+    if (buffered > kKeep - kTile) {  // the next tile might not fit (workgroup-uniform)
+      __syncthreads();
+      sweep();
     }
-    base += tile_total;
-    // (the next tile's s_keep writes come after its first barrier, i.e. after every lane left this sweep)
 #pragma unroll
     for (int u = 0; u < FX_PREP_U; ++u) v[u] = nv[u];
   }
+  __syncthreads();
+  sweep();
   if (tid == 0) {
     B.n_filt[scan] = base;
     B.flags[scan] = 0u;
