@@ -623,7 +623,19 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
       hm[i].stride_f = 4;
       if (!d.n_points) continue;
       if (d.stride_bytes == 16) {
-        FX_HIP(hipMemcpyAsync(dst, d.points, (size_t)d.n_points * 16, hipMemcpyHostToDevice, s));
+        // full-size scans that follow one another in host memory (a stacked batch) go over in one copy
+        uint32_t j = i;
+        size_t bytes = (size_t)d.n_points * 16;
+        while (d.n_points == L.max_points && j + 1 < batch && scans[j + 1].stride_bytes == 16 &&
+               scans[j + 1].n_points == L.max_points &&
+               (const uint8_t *)scans[j + 1].points == (const uint8_t *)scans[j].points + (size_t)L.max_points * 16) {
+          ++j;
+          bytes += (size_t)L.max_points * 16;
+          hm[j].pts = c->d_stage + (size_t)j * L.max_points * 4;
+          hm[j].stride_f = 4;
+        }
+        FX_HIP(hipMemcpyAsync(dst, d.points, bytes, hipMemcpyHostToDevice, s));
+        i = j;
       } else {
         c->repack.resize((size_t)d.n_points * 4);
         const uint8_t *src = (const uint8_t *)d.points;
