@@ -1510,9 +1510,6 @@ __device__ __forceinline__ unsigned long long sc3d_key(uint32_t bin, float d2, u
 }
 
 // ---------------------------------------------------------------- k_gather
-#ifndef FX_GATHER_SLICES
-#define FX_GATHER_SLICES 2
-#endif
 #define FX_GATHER_BINS 64
 #ifndef FX_GATHER_STAGE
 #define FX_GATHER_STAGE 512  // hits one workgroup stages between flushes (a larger stage costs more in occupancy than it saves in flushes)
@@ -1598,9 +1595,10 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
     // this workgroup's share of the scan's descriptor rows is cleared here, in the shadow of the point
     // stream below (descriptors are sparse: the keypoint kernels only write non-empty bins)
     const size_t f0 = (size_t)row0 * FX_DESC_FLOATS, len = (size_t)K * FX_DESC_FLOATS;
-    size_t a = f0 + (len * slice / FX_GATHER_SLICES), b = f0 + (len * (slice + 1) / FX_GATHER_SLICES);
+    const uint32_t n_slices = gridDim.x;  // workgroups per scan: 2 in throughput batches, more when few scans are in flight
+    size_t a = f0 + (len * slice / n_slices), b = f0 + (len * (slice + 1) / n_slices);
     if (slice != 0) a &= ~(size_t)3;  // interior cuts on 16-byte boundaries
-    if (slice != FX_GATHER_SLICES - 1) b &= ~(size_t)3;
+    if (slice != n_slices - 1) b &= ~(size_t)3;
     const size_t a4 = min((a + 3) & ~(size_t)3, b), b4 = max(b & ~(size_t)3, a4);
     float *d = B.desc;
     if (tid < a4 - a) d[a + tid] = 0.0f;
@@ -1609,7 +1607,7 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
     zn = (uint32_t)((b4 - a4) / 4);
   }
   const uint32_t n = M.n;
-  uint32_t chunk = (n + FX_GATHER_SLICES - 1) / FX_GATHER_SLICES;
+  uint32_t chunk = (n + gridDim.x - 1) / gridDim.x;
   chunk = (chunk + FX_WG * 4 - 1) / (FX_WG * 4) * (FX_WG * 4);
   const uint32_t lo = slice * chunk;
   const uint32_t hi = lo + chunk < n ? lo + chunk : n;
@@ -2898,7 +2896,9 @@ void fxk_offsets(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32
   hipLaunchKernelGGL(k_offsets, dim3(1), dim3(FX_WG), 0, s, P, B, batch);
 }
 void fxk_gather(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float box_margin) {
-  hipLaunchKernelGGL(k_gather, dim3(FX_GATHER_SLICES, batch), dim3(FX_WG),
+  // a scan is split over 2 workgroups when the batch fills the GPU anyway, over more when it does not (streaming)
+  const uint32_t slices = batch >= 128 ? 2u : (batch >= 16 ? 4u : 16u);
+  hipLaunchKernelGGL(k_gather, dim3(slices, batch), dim3(FX_WG),
                      fxk_gather_lds_bytes(P.max_keypoints), s, P, B, box_margin);
 }
 void fxk_desc_group(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid) {
