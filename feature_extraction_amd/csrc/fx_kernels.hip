@@ -1628,9 +1628,6 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
     if (tid == 0) s_w[8] = 0;
     __syncthreads();
   };
-  typedef float v4f __attribute__((ext_vector_type(4)));
-  v4f *zv = reinterpret_cast<v4f *>(z4);
-  const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
   const uint32_t n_tiles = (hi > lo) ? (hi - lo + FX_WG * 4 - 1) / (FX_WG * 4) : 0u;
   const uint32_t zslab = n_tiles ? (zn + n_tiles - 1) / n_tiles : 0u;
   if (n_tiles == 0)
@@ -1645,7 +1642,7 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
     }
     {
       const uint32_t zend = min(zdone + zslab, zn);
-      for (uint32_t t = zdone + tid; t < zend; t += FX_WG) __builtin_nontemporal_store(zero4, zv + t);  // streamed past the caches: nothing reads these lines soon
+      for (uint32_t t = zdone + tid; t < zend; t += FX_WG) z4[t] = make_float4(0.f, 0.f, 0.f, 0.f);
       zdone = zend;
     }
     if (i0 != lo) {  // flush when the next tile might not fit any more (workgroup-uniform decision)
