@@ -305,6 +305,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   if (!L.max_total_keypoints) L.max_total_keypoints = D.max_total_keypoints;
   if (!L.max_kpc_points) L.max_kpc_points = D.max_kpc_points;
   if (L.max_batch == 0 || L.max_points == 0) return fail(FX_ERR_INVALID_ARG, "max_batch and max_points must be > 0");
+  if (L.max_batch > 65535) return fail(FX_ERR_INVALID_ARG, "max_batch > 65535 (one grid row per scan in the support gather)");
   if (L.max_points > (1u << 20)) return fail(FX_ERR_INVALID_ARG, "max_points > 2^20 (descriptor sort key packs the point index in 20 bits)");
   if (params->n_rings < 1 || params->n_rings > 1024) return fail(FX_ERR_INVALID_ARG, "n_rings must be in [1, 1024]");
   if (!(params->descriptor_radius > 0.0) || !(params->el_step_deg > 0.0))
