@@ -175,7 +175,7 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof) {
     return (prof && wanted) ? hipEventRecord(c->ev[i], s) : hipSuccess;
   };
   FX_HIP(mark(0));
-  if (!batch) FX_HIP(hipMemsetAsync(B.counters, 0, 16 * sizeof(uint32_t), s));  // (k_prep clears them otherwise)
+  if (!batch) FX_HIP(hipMemsetAsync(B.counters, 0, FX_N_COUNTERS * sizeof(uint32_t), s));  // (k_prep clears them otherwise)
   if (batch) {
     const uint32_t ring_small = L.max_ring_points < kRingCapSmall ? L.max_ring_points : kRingCapSmall;
     const uint32_t merge_small = L.max_candidates < kMergeCapSmall ? L.max_candidates : kMergeCapSmall;
@@ -195,10 +195,12 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof) {
       // differ a lot in cost).  Make the stride step the ring index by about 0.38 n_rings instead.
       uint32_t grid = (uint32_t)c->n_cu * per_cu;
       const uint32_t R = (uint32_t)c->params.n_rings;
-      if (R > 1 && grid > 2 * R) {
+      uint32_t per_cls = grid / 8;  // blocks per XCD class (k_rings_small deals the scans by class)
+      if (R > 1 && per_cls > 2 * R) {
         const uint32_t want = ((uint32_t)(0.381966 * R) | 1u) % R;
-        grid -= (grid % R + R - want) % R;
+        per_cls -= (per_cls % R + R - want) % R;
       }
+      grid = per_cls ? per_cls * 8 : 8;
       fxk_rings_small(s, P, B, batch, ring_small, ring_small / 4, ring_mid, grid);
     }
     FX_HIP(mark(3));
@@ -206,10 +208,10 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof) {
       uint32_t per_cu = (uint32_t)(160 * 1024 / ((fxk_ring_lds_bytes(ring_mid, ring_mid / 4) + 2047) / 2048 * 2048));
       if (per_cu > 8) per_cu = 8;
       if (per_cu < 1) per_cu = 1;
-      fxk_rings_big(s, P, B, ring_mid, ring_mid / 4, big_grid * per_cu, 0);
+      fxk_rings_big(s, P, B, ring_mid, ring_mid / 4, (big_grid * per_cu + 7) / 8 * 8, 0);
     }
     FX_HIP(mark(4));
-    fxk_rings_big(s, P, B, L.max_ring_points, L.max_ring_points, big_grid, 1);
+    fxk_rings_big(s, P, B, L.max_ring_points, L.max_ring_points, (big_grid + 7) / 8 * 8, 1);
     fxk_merge_small(s, P, B, batch, merge_small);
     FX_HIP(mark(5));
     fxk_merge_big(s, P, B, L.max_candidates, big_grid);
@@ -382,6 +384,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
     if (v < P.huge_cap) P.huge_cap = v;
   }
   P.ring_slot_cap = 2 * L.max_points;  // worst case: every point on a window boundary, i.e. in two rings
+  P.ring_list_cap = ((L.max_batch + 7) / 8) * (uint32_t)params->n_rings;  // rings of the scans of one XCD class
 
   fx_status st = FX_OK;
   auto bail = [&](fx_status s) {
@@ -432,8 +435,8 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   FX_A(dev_alloc(c, &b.n_kpc, B));
   FX_A(dev_alloc(c, &b.desc, (size_t)L.max_total_keypoints * FX_DESC_FLOATS + 4));
   FX_A(dev_alloc(c, &b.flags, B));
-  FX_A(dev_alloc(c, &b.big_rings, B * R));
-  FX_A(dev_alloc(c, &b.huge_rings, B * R));
+  FX_A(dev_alloc(c, &b.big_rings, (size_t)8 * P.ring_list_cap));
+  FX_A(dev_alloc(c, &b.huge_rings, (size_t)8 * P.ring_list_cap));
   FX_A(dev_alloc(c, &b.big_merge, B));
   FX_A(dev_alloc(c, &b.big_desc, L.max_total_keypoints));
   FX_A(dev_alloc(c, &b.list_desc, L.max_total_keypoints));
@@ -459,7 +462,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
     FX_A(dev_alloc(c, &b.spill_key, n));
     FX_A(dev_alloc(c, &b.spill_w, n));
   }
-  FX_A(dev_alloc(c, &b.counters, 16));
+  FX_A(dev_alloc(c, &b.counters, FX_N_COUNTERS));
   FX_A(dev_alloc(c, &b.stamps, 64 * 64));
   if (hipMemset(b.stamps, 0, 64 * 64 * 8) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
 
@@ -505,7 +508,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
                                   fxk_desc_lds_bytes(L.max_neighbors));
     if (ce != hipSuccess) return bail(fail(FX_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(ce)));
   }
-  if (hipMemset(b.counters, 0, 16 * sizeof(uint32_t)) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
+  if (hipMemset(b.counters, 0, FX_N_COUNTERS * sizeof(uint32_t)) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
   if (hipMemset(b.kp_offset, 0, (B + 1) * sizeof(uint32_t)) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
   if (hipMemset(b.n_kp, 0, B * sizeof(uint32_t)) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
 #undef FX_A
@@ -779,7 +782,14 @@ fx_status fx_debug_counters(fx_ctx *c, uint32_t *out8 /* 16 words */) {
   if (!c || !out8) return fail(FX_ERR_INVALID_ARG, "null argument");
   FX_HIP(hipSetDevice(c->device));
   FX_HIP(hipStreamSynchronize(c->stream));
-  FX_HIP(hipMemcpy(out8, c->buf.counters, 16 * 4, hipMemcpyDeviceToHost));
+  uint32_t all[FX_N_COUNTERS];
+  FX_HIP(hipMemcpy(all, c->buf.counters, sizeof(all), hipMemcpyDeviceToHost));
+  std::memcpy(out8, all, 16 * 4);
+  out8[0] = out8[5] = 0;  // the deferred rings are counted per XCD class
+  for (int k = 0; k < 8; ++k) {
+    out8[0] += all[FX_CNT_MID + k];
+    out8[5] += all[FX_CNT_LARGE + k];
+  }
   return FX_OK;
 }
 

@@ -31,6 +31,7 @@ struct FxDevParams {
   // capacities
   uint32_t max_points, max_ring_cands, max_candidates, max_keypoints, max_total_kp, max_kpc, max_neighbors,
       max_ring_points, list_cap, ring_slot_cap;
+  uint32_t ring_list_cap;  // entries per XCD class of the deferred-ring lists
   uint32_t huge_cap;  // support points k_desc_huge takes (<= its LDS capacity; tests lower it to reach the slab tier)
 };
 
@@ -43,6 +44,9 @@ struct FxScTables {
 };
 
 // Every device buffer of a context.
+#define FX_N_COUNTERS 32
+#define FX_CNT_MID 16    // counters[16 + c]: rings of XCD class c deferred to the mid tier
+#define FX_CNT_LARGE 24  // counters[24 + c]: ... to the large tier
 struct FxBuffers {
   const FxScanMeta *meta;
   const float2 *ring_win;  // [n_rings] (lo, hi) as float, inclusive
@@ -102,7 +106,7 @@ struct FxBuffers {
   float4 *row_kp;         // [max_total_kp]  the row's keypoint and its 3DSC x-axis (first-pass ordinal), so that the
   float2 *row_xa;         //                 per-keypoint kernels fetch everything a row needs in one round trip
   unsigned long long *stamps;  // [32] diagnostic build only (-DFX_STAMPS)
-  uint32_t *counters;     // [16]: 0 big_rings, 1 big_merge, 2 big_desc, 3 need_rng_fix, 4 list_desc, 5 huge_rings, 6 spill_desc, 7 exact_desc, 8 wave_desc
+  uint32_t *counters;     // [FX_N_COUNTERS]: 16.. deferred rings per XCD class (8 mid, 8 large); 0 big_rings, 1 big_merge, 2 big_desc, 3 need_rng_fix, 4 list_desc, 5 huge_rings, 6 spill_desc, 7 exact_desc, 8 wave_desc
 };
 
 #endif

@@ -812,7 +812,7 @@ __global__ __launch_bounds__(FX_PREP_T) void k_prep(FxDevParams P, FxBuffers B) 
     B.n_filt[scan] = base;
     B.flags[scan] = 0u;
   }
-  if (scan == 0 && tid < 16) B.counters[tid] = 0u;  // work-list counters of the batch (used from k_rings_small on)
+  if (scan == 0 && tid < FX_N_COUNTERS) B.counters[tid] = 0u;  // work-list counters of the batch (used from k_rings_small on)
 }
 
 // ====================================================================== stage 2a: ring buckets
@@ -1154,15 +1154,22 @@ __device__ __forceinline__ bool ring_body(const FxDevParams &P, const FxBuffers 
 extern "C" __global__ __launch_bounds__(FX_RING_SMALL_T) void k_rings_small(FxDevParams P, FxBuffers B, uint32_t cap,
                                                                             uint32_t ccap, uint32_t mid_cap, uint32_t n_items) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  // persistent wavefronts: each strides over the (scan, ring) items
-  for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
-    const uint32_t scan = item / P.n_rings, ring = item % P.n_rings;
+  // Persistent wavefronts over the (scan, ring) items.  Blocks are dealt round-robin over the 8 XCDs
+  // (observed, for speed only): block b works on scans s = b (mod 8), whose ring-major points the
+  // k_bucket block s wrote into that same XCD's L2.  Within its class a block strides over (scan, ring).
+  const uint32_t R = (uint32_t)P.n_rings, n_scans = n_items / R;
+  const uint32_t cls = blockIdx.x & 7u, slot = blockIdx.x >> 3, per_cls = gridDim.x >> 3;  // (grid is a multiple of 8)
+  const uint32_t cls_items = ((n_scans + 7u - cls) / 8u) * R;
+  for (uint32_t q = slot; q < cls_items; q += per_cls) {
+    const uint32_t scan = cls + 8u * (q / R), ring = q % R;
+    const uint32_t item = scan * R + ring;
     if (!ring_body<FX_RING_SMALL_T>(P, B, scan, ring, cap, ccap, smem, false)) {
       if (threadIdx.x == 0) {
         // too big for one wavefront: workgroup tiers (mid: fits mid_cap points, else the large one)
+        // (one list per XCD class, so that the larger tier too finds the ring's points in its own L2)
         const bool mid = B.ring_cnt[item] <= mid_cap;
-        const uint32_t pos = atomicAdd(&B.counters[mid ? 0 : 5], 1u);
-        (mid ? B.big_rings : B.huge_rings)[pos] = item;
+        const uint32_t pos = atomicAdd(&B.counters[(mid ? FX_CNT_MID : FX_CNT_LARGE) + cls], 1u);
+        (mid ? B.big_rings : B.huge_rings)[(size_t)cls * P.ring_list_cap + pos] = item;
       }
     }
     __syncthreads();
@@ -1171,14 +1178,16 @@ extern "C" __global__ __launch_bounds__(FX_RING_SMALL_T) void k_rings_small(FxDe
 extern "C" __global__ __launch_bounds__(FX_WG, 5) void k_rings_big(FxDevParams P, FxBuffers B, uint32_t cap, uint32_t ccap,
                                                                  uint32_t huge) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  const uint32_t n_big = B.counters[huge ? 5 : 0];
-  const uint32_t *items = huge ? B.huge_rings : B.big_rings;
-  for (uint32_t w = blockIdx.x; w < n_big; w += gridDim.x) {
+  // block b takes the list of XCD class b mod 8 (the grid is a multiple of 8): see k_rings_small
+  const uint32_t cls = blockIdx.x & 7u;
+  const uint32_t n_big = B.counters[(huge ? FX_CNT_LARGE : FX_CNT_MID) + cls];
+  const uint32_t *items = (huge ? B.huge_rings : B.big_rings) + (size_t)cls * P.ring_list_cap;
+  for (uint32_t w = blockIdx.x >> 3; w < n_big; w += gridDim.x >> 3) {
     const uint32_t item = items[w];
     if (!ring_body<FX_WG>(P, B, item / P.n_rings, item % P.n_rings, cap, ccap, smem, huge != 0)) {
       if (threadIdx.x == 0) {  // mid tier only: more clusters than it holds
-        const uint32_t pos = atomicAdd(&B.counters[5], 1u);
-        B.huge_rings[pos] = item;
+        const uint32_t pos = atomicAdd(&B.counters[FX_CNT_LARGE + cls], 1u);
+        B.huge_rings[(size_t)cls * P.ring_list_cap + pos] = item;
       }
     }
     __syncthreads();
