@@ -12,6 +12,8 @@ from feature_extraction_amd import capi
 import torch
 
 which = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+if len(sys.argv) > 3:
+    capi.LIB_PATH = os.path.join(os.path.dirname(capi.LIB_PATH), sys.argv[3])
 capi.load()
 if which == 3:
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
