@@ -53,3 +53,26 @@ def test_random_scenes_parameters_and_perturbations(fxlib, oracle, block):
         total_k += st["K"]
         ctx.close()
     assert total_k > 0, "a whole block of cases without a single keypoint tests nothing"
+
+
+def test_unstructured_clouds_are_flagged_or_exact_never_fatal(fxlib, oracle):
+    """Points with arbitrary elevations and no scan order (nothing like a spinning LiDAR): rings overflow
+    their capacity, candidates overflow theirs — the call must come back with flags, and whatever is not
+    flagged must still match the oracle."""
+    rng = np.random.default_rng(5)
+    for n, B in ((28800, 4), (6000, 16), (20000, 8)):
+        scans = []
+        for _ in range(B):
+            pts = np.zeros((n, 4), np.float32)
+            pts[:, 0] = rng.uniform(0, 100, n)
+            pts[:, 1] = rng.uniform(-50, 50, n)
+            pts[:, 2] = rng.uniform(-1.5, 4, n)
+            scans.append(pts)
+        for preset in ("launch", "default"):
+            p = capi.params(preset)
+            ctx = capi.Context(p, capi.limits(B, 28800))
+            got = ctx.process_host(scans)
+            for b in range(2):
+                if got[b]["flags"] == 0:
+                    util.compare_scan(got[b], oracle.run(p, scans[b]), tag=f"unstructured {n} {preset} {b}")
+            ctx.close()
