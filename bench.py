@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="scans per GPU per step")
     ap.add_argument("--preset", default="launch", choices=["default", "launch"])
+    ap.add_argument("--contexts", type=int, default=3,
+                    help="batches in flight per GPU: contexts (each on its own HIP stream) taking the steps in turn")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", type=int, default=4, help="scans of rank 0 checked against the oracle after timing")
     args = ap.parse_args()
@@ -104,53 +106,80 @@ def main():
     host = np.stack(scans)  # [B, N, 4]
     d_in = torch.from_numpy(host).to(dev)  # resident in HBM before the timed region
     params = capi.params(args.preset)
-    ctx = capi.Context(params, capi.limits(B, N), device=local_rank)
-    stream = torch.cuda.current_stream(dev)
-    ctx.set_stream(stream.cuda_stream)
+    # K contexts, each on its own HIP stream, take the steps in turn: the stage kernels of a batch are latency
+    # bound and leave issue slots, LDS and whole CUs idle (tails, the large tiers' thin launches), which the
+    # kernels of the other batches in flight fill.  One step is still one pass over one batch of B scans.
+    K = max(1, args.contexts)
+    ctxs = [capi.Context(params, capi.limits(B, N), device=local_rank) for _ in range(K)]
+    ctx = ctxs[0]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(K)]
+    for c, st in zip(ctxs, streams):
+        c.set_stream(st.cuda_stream)
     base = d_in.data_ptr()
     descs = ctx.make_descs([base + b * N * 16 for b in range(B)], [N] * B, 16, roll, pitch)
-    # keypoint records: double-buffered so that the gather of batch i (RCCL, its own stream) overlaps
-    # the kernels of batch i + 1; a buffer is reused only after its collective has completed
+    # keypoint records, one buffer per context: the gather of a batch (RCCL, its own stream) overlaps the
+    # kernels of the batches behind it; a buffer is reused only after its collective has completed
     use_dist = world > 1 or os.environ.get("FX_BENCH_FORCE_DIST") == "1"
-    recs = [torch.zeros((B, 1 + REC_KP, 4), dtype=torch.float32, device=dev) for _ in range(2)]
-    gathered = [torch.zeros((world * B, 1 + REC_KP, 4), dtype=torch.float32, device=dev) for _ in range(2)] if use_dist else None
-    pending = [None, None]
+    recs = [torch.zeros((B, 1 + REC_KP, 4), dtype=torch.float32, device=dev) for _ in range(K)]
+    gathered = [torch.zeros((world * B, 1 + REC_KP, 4), dtype=torch.float32, device=dev) for _ in range(K)] if use_dist else None
+    pending = [None] * K
     counter = [0]
+    torch.cuda.synchronize(dev)  # inputs and zeroed buffers are in place before any side stream starts
 
     def step():
-        j = counter[0] & 1
+        j = counter[0] % K
         counter[0] += 1
-        if pending[j] is not None:
-            pending[j].wait()  # stream-level wait: rec[j] / gathered[j] are free again
-            pending[j] = None
-        ctx.process_raw(descs, B, capi.FX_IN_DEVICE)
-        ctx.pack_keypoint_records(recs[j].data_ptr(), REC_KP)
-        if use_dist:
-            pending[j] = dist.all_gather_into_tensor(gathered[j].view(-1), recs[j].view(-1), async_op=True)
+        with torch.cuda.stream(streams[j]):
+            if pending[j] is not None:
+                pending[j].wait()  # stream-level wait: rec[j] / gathered[j] are free again
+                pending[j] = None
+            ctxs[j].process_raw(descs, B, capi.FX_IN_DEVICE)
+            ctxs[j].pack_keypoint_records(recs[j].data_ptr(), REC_KP)
+            if use_dist:
+                pending[j] = dist.all_gather_into_tensor(gathered[j].view(-1), recs[j].view(-1), async_op=True)
 
     def drain():
-        for j in range(2):
+        for j in range(K):
             if pending[j] is not None:
-                pending[j].wait()
+                with torch.cuda.stream(streams[j]):
+                    pending[j].wait()
                 pending[j] = None
+
+    def profile_all(depth, stages=None):
+        for c in ctxs:
+            c.set_profiling(depth, stages=stages)
+
+    def mean_timings(per_ctx):
+        acc, n = {}, 0
+        for c in ctxs:
+            for back in range(per_ctx):
+                try:
+                    ms, _tot = c.timings(back)
+                except capi.FxError:  # fewer timed steps than contexts: this one has nothing that far back
+                    break
+                n += 1
+                for k, v in ms.items():
+                    acc[k] = acc.get(k, 0.0) + v
+        return {k: v / n for k, v in acc.items()}
 
     # warm-up, with HIP events around every stage kernel: it names the dominant kernel.  Every event costs
     # a few microseconds of stream time (13 of them: ~4 % of a batch), so the timed region below keeps only
     # the events that bracket that kernel (and the batch); the other per-kernel durations are reported
     # from a short profiled pass after it.
-    ctx.set_profiling(1)
-    for _ in range(max(args.warmup, 2)):  # (at least two: the first step pays for code upload and cold caches)
+    profile_all(1)
+    for _ in range(max(args.warmup, 2) * K):  # (at least two per context: the first pays for code upload and cold caches)
         step()
     drain()
     torch.cuda.synchronize(dev)
-    warm, _tot = ctx.timings(0)  # the last warm-up step
+    warm = mean_timings(1)  # the last warm-up step of every context
     dom = max(warm, key=warm.get)
     if use_dist:  # every rank times the same kernel
         names = list(capi.STAGE_NAMES)
         t = torch.tensor([names.index(dom)], dtype=torch.int64, device=dev)
         dist.broadcast(t, 0)
         dom = names[int(t.item())]
-    ctx.set_profiling(max(args.steps, 1), stages=[dom])  # on the launch stream, inside the timed region
+    per_ctx_steps = max(1, args.steps // K)
+    profile_all(per_ctx_steps, stages=[dom])  # on the launch streams, inside the timed region
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -168,23 +197,16 @@ def main():
         elapsed = float(t.item())
 
     # ---- the dominant kernel's duration over the timed steps (HIP events recorded inside the timed region)
-    dom_ms = 0.0
-    for back in range(args.steps):
-        ms, _tot = ctx.timings(back)
-        dom_ms += ms[dom] / args.steps
+    dom_ms = mean_timings(per_ctx_steps)[dom]
     # ---- all per-kernel durations, from a few more steps with every event on (outside the timed region)
-    n_prof = 5
-    ctx.set_profiling(n_prof)
-    for _ in range(n_prof):
+    n_prof = 4
+    profile_all(n_prof)
+    for _ in range(n_prof * K):
         step()
     drain()
     torch.cuda.synchronize(dev)
-    stage_ms = {}
-    for back in range(n_prof):
-        ms, _tot = ctx.timings(back)
-        for k, v in ms.items():
-            stage_ms[k] = stage_ms.get(k, 0.0) + v / n_prof
-    ctx.set_profiling(0)
+    stage_ms = mean_timings(n_prof)
+    profile_all(0)
 
     # ---- what the batch produced (for the algorithmic byte count) + a parity spot check
     v = ctx.process_raw(descs, B, capi.FX_IN_DEVICE | capi.FX_OUT_HOST)
@@ -236,13 +258,13 @@ def main():
                                    f"device-resident, preset '{args.preset}', roll/pitch 0.02/-0.015",
                        "scans_per_gpu": B, "points_per_scan": N, "preset": args.preset,
                        "parallelism": f"frame-sharded x{world}" + (", all-gather of keypoint records (RCCL)" if world > 1 else ""),
-                       "keypoints_per_scan": k_all / (world * B), "flags_or": flags_or},
+                       "keypoints_per_scan": k_all / (world * B), "flags_or": flags_or, "batches_in_flight": K},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "alg_bytes_per_launch": alg_bytes, "kernel_ms": dom_ms,
                          "timed": "HIP events around this kernel on the launch stream, inside the timed region"},
             "kernel_ms": stage_ms,
-            "kernel_ms_source": f"all stages: {n_prof} extra profiled steps after the timed region",
+            "kernel_ms_source": f"all stages: {n_prof * K} extra profiled steps after the timed region, {K} batches in flight",
             "parity": parity,
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -251,9 +273,11 @@ def main():
         result_line = json.dumps(out)
     if use_dist and rank == 0:
         # the gathered table holds every rank's records in stream order: check this rank's block
-        g = gathered[(counter[0] - 1) & 1][rank * B:(rank + 1) * B]
-        assert torch.equal(g, recs[(counter[0] - 1) & 1]), "gathered keypoint records differ from the local ones"
-    ctx.close()
+        last = (counter[0] - 1) % K
+        g = gathered[last][rank * B:(rank + 1) * B]
+        assert torch.equal(g, recs[last]), "gathered keypoint records differ from the local ones"
+    for c in ctxs:
+        c.close()
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
