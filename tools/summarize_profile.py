@@ -18,7 +18,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-n_batches = int(sys.argv[2]) if len(sys.argv) > 2 else 18  # warm-up 2 + timed 10 + profiled 5 + the totals pass
+n_batches = int(sys.argv[2]) if len(sys.argv) > 2 else 29  # 3 contexts: warm-up 6 + timed 10 + profiled 12 + the totals pass
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
