@@ -641,10 +641,14 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
         FX_HIP(hipMemcpyAsync(dst, d.points, bytes, hipMemcpyHostToDevice, s));
         i = j;
       } else {
+        // wider records (pcl::PointXYZI in memory: 32 bytes) are repacked on the host.  The copy is ordered on the
+        // context's stream — an earlier batch issued without FX_OUT_HOST may still be reading d_stage — and
+        // waited for, because the repack buffer is reused by the next scan.
         c->repack.resize((size_t)d.n_points * 4);
         const uint8_t *src = (const uint8_t *)d.points;
         for (uint32_t p = 0; p < d.n_points; ++p) std::memcpy(&c->repack[(size_t)p * 4], src + (size_t)p * d.stride_bytes, 16);
-        FX_HIP(hipMemcpy(dst, c->repack.data(), (size_t)d.n_points * 16, hipMemcpyHostToDevice));
+        FX_HIP(hipMemcpyAsync(dst, c->repack.data(), (size_t)d.n_points * 16, hipMemcpyHostToDevice, s));
+        FX_HIP(hipStreamSynchronize(s));
       }
     }
   }

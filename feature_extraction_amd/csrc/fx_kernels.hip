@@ -729,6 +729,14 @@ __global__ __launch_bounds__(FX_PREP_T) void k_prep(FxDevParams P, FxBuffers B) 
   // (global address space stated: a generic-pointer load would be a flat load, which also counts as an
   //  LDS access and gets waited for at the next LDS instruction)
   const gfloat *gpts = (const gfloat *)M.pts;
+  if (n == 0) {  // empty scan (ref: node.cpp:209-210, 263-264): its pointer may be null — nothing is loaded
+    if (tid == 0) {
+      B.n_filt[scan] = 0u;
+      B.flags[scan] = 0u;
+    }
+    if (scan == 0 && tid < FX_N_COUNTERS) B.counters[tid] = 0u;
+    return;
+  }
   auto load_tile = [&](uint32_t t0, float4 (&v)[FX_PREP_U]) {
 #pragma unroll
     for (int u = 0; u < FX_PREP_U; ++u) {
@@ -748,10 +756,12 @@ __global__ __launch_bounds__(FX_PREP_T) void k_prep(FxDevParams P, FxBuffers B) 
       const float rx = ((M.R[0] * q.x + M.R[1] * q.y) + M.R[2] * q.z) + 0.0f;
       const float ry = ((M.R[3] * q.x + M.R[4] * q.y) + M.R[5] * q.z) + 0.0f;
       const float rz = ((M.R[6] * q.x + M.R[7] * q.y) + M.R[8] * q.z) + 0.0f;
-      // atan2(z, |xy|) of the un-rotated point in degrees, fp64 -> fp32.
-      // (cos(az) x + sin(az) y equals |xy| to within fp64 rounding)
+      // the reference's own expression on the un-rotated point, fp64 -> fp32 (ref: node.cpp:150-154):
+      //   az = atan2(y, x); xp = cos(az) x + sin(az) y; intensity = atan2(z, xp) * 180 / M_PI
       const double x = q.x, y = q.y, z = q.z;
-      const double el = atan2(z, sqrt(x * x + y * y)) * 180 / M_PI;
+      const double az = atan2(y, x);
+      const double xp = cos(az) * x + sin(az) * y;
+      const double el = atan2(z, xp) * 180 / M_PI;
       out[base + j] = make_float4(rx, ry, rz, (float)el);
     }
     base += buffered;
@@ -1514,6 +1524,10 @@ __device__ __forceinline__ uint32_t sc3d_bin(const float4 kp, float bx, float by
   lut = T->lut[kk * 15 + j];
   return (l * 11 + kk) * 15 + j;
 }
+// 3DSC skips a neighbour whose squared distance "equals" zero: pcl::utils::equal(nn_dists[ne], 0.0f) with its
+// default tolerance std::numeric_limits<float>::min() (pcl/common/utils.h), i.e. |d2 - 0| < FLT_MIN — the point
+// the keypoint sits on (or one a subnormal d2 away), nothing farther.
+__device__ __forceinline__ bool sc3d_is_origin(float d2) { return fabsf(d2 - 0.0f) < FLT_MIN; }
 __device__ __forceinline__ unsigned long long sc3d_key(uint32_t bin, float d2, uint32_t idx) {
   return ((unsigned long long)bin << 52) | ((unsigned long long)__float_as_uint(d2) << 20) | (unsigned long long)idx;
 }
@@ -1778,7 +1792,7 @@ __device__ __forceinline__ void desc_wave_body(const FxDevParams &P, const FxBuf
       const float d2 = b.w;
       const bool nb = d2 < P.r2_search;
       nAll += (uint32_t)__popcll(__ballot(nb));
-      const bool use = nb && !(fabsf(d2 - 0.0f) < FLT_EPSILON);  // pcl::utils::equal(nn_dists[ne], 0.0f)
+      const bool use = nb && !sc3d_is_origin(d2);
       unsigned long long key = 0;
       float w = 0.f;
       if (use) {
@@ -1928,7 +1942,7 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_group(FxDevParams P, 
       const float d2 = b.w;
       if (!(d2 < P.r2_search)) continue;
       atomicAdd(&cnt[0], 1u);
-      if (fabsf(d2 - 0.0f) < FLT_EPSILON) continue;  // pcl::utils::equal(nn_dists[ne], 0.0f)
+      if (sc3d_is_origin(d2)) continue;
       float lut;
       bool amb = false;
       const uint32_t bin = sc3d_bin<true>(kp, b.x, b.y, b.z, d2, xa, T, lut, amb);
@@ -2151,7 +2165,7 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
     const float d2 = L.sp[e].w;
     if (!(d2 < P.r2_search)) continue;
     atomicAdd(&L.s_w[2], 1u);
-    if (fabsf(d2 - 0.0f) < FLT_EPSILON) continue;  // pcl::utils::equal(nn_dists[ne], 0.0f)
+    if (sc3d_is_origin(d2)) continue;
     const uint32_t m = atomicAdd(&L.s_w[1], 1u);
     nlist[m] = e;
     dens[2 * m] = 0u;
@@ -2464,7 +2478,7 @@ extern "C" __global__ __launch_bounds__(FX_HUGE_T) void k_desc_huge(FxDevParams 
             sidx[slot] = i0 + u * FX_HUGE_T + tid;
             if (d < P.r2_search) {
               atomicAdd(&s_w[2], 1u);
-              if (!(fabsf(d - 0.0f) < FLT_EPSILON)) nlist[atomicAdd(&s_w[1], 1u)] = slot;
+              if (!sc3d_is_origin(d)) nlist[atomicAdd(&s_w[1], 1u)] = slot;
             }
           }
         }
@@ -2636,7 +2650,7 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_spill(FxDevParams P, 
           sd2[pos] = d;
           if (d < P.r2_search) {
             atomicAdd(&s_cnt[2], 1u);
-            if (!(fabsf(d - 0.0f) < FLT_EPSILON)) nlist[atomicAdd(&s_cnt[1], 1u)] = pos;
+            if (!sc3d_is_origin(d)) nlist[atomicAdd(&s_cnt[1], 1u)] = pos;
           }
         }
       }

@@ -510,7 +510,9 @@ static void estimate_descriptors(Result &R, int search_kind, int trig_kind) {
     normalize3(x_axis);
 
     for (size_t ne = 0; ne < neighb_cnt; ne++) {
-      if (std::fabs(nn[ne].d - 0.0f) < std::numeric_limits<float>::epsilon()) continue; /* pcl::utils::equal */
+      /* pcl::utils::equal(nn_dists[ne], 0.0f): default tolerance std::numeric_limits<float>::min()
+       * (pcl/common/utils.h) — only the point the keypoint sits on is skipped */
+      if (std::fabs(nn[ne].d - 0.0f) < std::numeric_limits<float>::min()) continue;
       const P4 &nbp = surface[nn[ne].idx];
       V3 neighbour = {{nbp.x, nbp.y, nbp.z}};
       float r = sqrtf(nn[ne].d);

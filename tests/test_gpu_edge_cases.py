@@ -190,3 +190,60 @@ def test_long_support_lists_use_the_workgroup_tiers(fxlib, oracle):
     ora = oracle.run(p, s)
     assert ora["kp_neighbors"].max() > 1100
     _cmp(oracle, p, capi.limits(1, 28800), [s], tag="dense neighbourhoods")
+
+
+@pytest.mark.parametrize("empty_at", ["first", "middle", "last", "all"])
+def test_device_resident_empty_scans_with_null_pointer(fxlib, oracle, empty_at):
+    """FX_IN_DEVICE + n_points = 0 + points = NULL is legal (fx_process_batch) and loads nothing."""
+    import torch
+    p = capi.params("launch")
+    full = [util.vlp16_scan(1000 + b) for b in range(2)]
+    layout = {"first": [None, 0, 1], "middle": [0, None, 1], "last": [0, 1, None], "all": [None, None, None]}[empty_at]
+    dev = [torch.from_numpy(s).cuda() for s in full]
+    ctx = capi.Context(p, capi.limits(len(layout), 28800))
+    ptrs = [0 if i is None else dev[i].data_ptr() for i in layout]
+    cnts = [0 if i is None else 28800 for i in layout]
+    descs = ctx.make_descs(ptrs, cnts, 16, 0.02, -0.015)
+    for _ in range(2):  # (twice: the second call sees the first one's counters and lists)
+        v = ctx.process_raw(descs, len(layout), capi.FX_IN_DEVICE | capi.FX_OUT_HOST | capi.FX_OUT_CLOUDS | capi.FX_OUT_DEBUG)
+        got = ctx.unpack(v)
+    for b, i in enumerate(layout):
+        if i is None:
+            assert got[b]["n_keypoints"] == 0 and got[b]["flags"] == 0 and len(got[b]["filtered"]) == 0
+        else:
+            util.compare_scan(got[b], oracle.run(p, full[i], roll=0.02, pitch=-0.015), tag=f"empty {empty_at}, scan {b}")
+    ctx.close()
+
+
+def test_small_max_points_with_an_empty_last_scan(fxlib, oracle):
+    """max_points below one k_prep tile (2048 points) and an empty scan in the last staging slot."""
+    s = util.vlp16_scan(1000)[:1500]
+    scans = [s, s[:700], np.zeros((0, 4), np.float32)]
+    got = _cmp(oracle, capi.params("launch"), capi.limits(3, 1500), scans, 0.02, -0.015, "small max_points")
+    assert got[2]["n_keypoints"] == 0
+
+
+def test_neighbour_a_tenth_of_a_millimetre_from_the_keypoint_counts(fxlib, oracle):
+    """3DSC only skips a neighbour whose squared distance is below FLT_MIN (pcl::utils::equal's default
+    tolerance is numeric_limits<float>::min(), not epsilon()): a surface point 0.1 mm from a keypoint
+    (d2 = 1e-8 < FLT_EPSILON) is binned like any other."""
+    p = capi.params("launch")
+    s = util.vlp16_scan(1000)
+    base = oracle.run(p, s)
+    kp = base["keypoints"][:4, :3].astype(np.float64)
+    extra = np.zeros((len(kp), 4), np.float32)
+    extra[:, :3] = (kp + np.array([1.0e-4, 0.0, 0.0])).astype(np.float32)
+    s2 = np.concatenate([s, extra])
+    ora = oracle.run(p, s2, want_rotated=True)
+    # at least one keypoint now has a neighbour with 0 < d2 < FLT_EPSILON in the oracle's own cloud
+    rot = ora["rotated"][:, :3].astype(np.float32)
+    near = 0
+    for k in ora["keypoints"][:, :3]:
+        d = rot - k.astype(np.float32)
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        near += int(((d2 > 0) & (d2 < np.finfo(np.float32).eps)).sum())
+    assert near > 0
+    ctx = capi.Context(p, capi.limits(1, len(s2)))
+    got = ctx.process_host([s2])[0]
+    util.compare_scan(got, ora, tag="near-origin neighbour")
+    ctx.close()
