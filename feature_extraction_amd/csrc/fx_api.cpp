@@ -24,7 +24,8 @@ size_t fxk_merge_lds_bytes(uint32_t cap, uint32_t n_rings);
 size_t fxk_desc_lds_bytes(uint32_t cap);
 size_t fxk_gather_lds_bytes(uint32_t max_keypoints);
 uint32_t fxk_huge_cap(void);
-hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t desc_big);
+size_t fxk_merge_huge_lds_bytes(uint32_t cap, uint32_t ccap, uint32_t n_rings);
+hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t merge_huge, size_t desc_big);
 void fxk_prep(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
 void fxk_bucket(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float el0, float inv_step);
 void fxk_rings_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t ccap,
@@ -32,7 +33,8 @@ void fxk_rings_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, ui
 void fxk_rings_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t ccap, uint32_t grid,
                    uint32_t huge);
 void fxk_merge_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap);
-void fxk_merge_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t grid);
+void fxk_merge_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t grid, uint32_t last);
+void fxk_merge_huge(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t ccap, uint32_t grid);
 void fxk_offsets(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
 void fxk_gather(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float box_margin);
 void fxk_desc_group(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid);
@@ -96,6 +98,8 @@ struct fx_ctx {
   uint32_t ring_waves_per_cu = 16;
   uint32_t desc_wgs_per_cu = 10;
   uint32_t spill_grid = 0, spill_slab = 0;
+  uint32_t merge_big_cap = 0;    // candidates the LDS merge tier holds as points (<= max_candidates)
+  uint32_t merge_huge_ccap = 0;  // clusters the large merge tier can order (>= max_keypoints)
   // host-input staging
   float *d_stage = nullptr;
   std::vector<float> repack;
@@ -214,7 +218,8 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof) {
     fxk_rings_big(s, P, B, L.max_ring_points, L.max_ring_points, (big_grid + 7) / 8 * 8, 1);
     fxk_merge_small(s, P, B, batch, merge_small);
     FX_HIP(mark(5));
-    fxk_merge_big(s, P, B, L.max_candidates, big_grid);
+    fxk_merge_big(s, P, B, c->merge_big_cap, big_grid, c->merge_big_cap >= L.max_candidates);
+    if (c->merge_big_cap < L.max_candidates) fxk_merge_huge(s, P, B, L.max_candidates, c->merge_huge_ccap, big_grid);
     fxk_offsets(s, P, B, batch);
     if (P.estimate_descriptors) {
       FX_HIP(mark(6));
@@ -317,8 +322,18 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   const size_t kLds = 160 * 1024;
   if (fxk_ring_lds_bytes(L.max_ring_points, L.max_ring_points) > kLds)
     return fail(FX_ERR_INVALID_ARG, "max_ring_points exceeds the LDS budget (<= 2600)");
-  if (fxk_merge_lds_bytes(L.max_candidates, params->n_rings) > kLds)
-    return fail(FX_ERR_INVALID_ARG, "max_candidates exceeds the LDS budget (<= ~3500)");
+  // merge tiers: up to merge_big_cap candidates a scan live in LDS as points; beyond that (dense many-ring scans)
+  // the large tier keeps only parents and a cell sort in LDS
+  uint32_t merge_big_cap = L.max_candidates;
+  while (fxk_merge_lds_bytes(merge_big_cap, params->n_rings) > kLds) merge_big_cap -= merge_big_cap > 64 ? 64 : 1;
+  if (const char *e = getenv("FX_MERGE_BIG_CAP")) {  // test hook: push scans on to the large merge tier
+    const uint32_t v = (uint32_t)atoi(e);
+    if (v >= 16 && v < merge_big_cap) merge_big_cap = v;
+  }
+  const uint32_t merge_huge_ccap = L.max_keypoints > 64 ? L.max_keypoints : 64;
+  if (merge_big_cap < L.max_candidates &&
+      (L.max_candidates > 65535 || fxk_merge_huge_lds_bytes(L.max_candidates, merge_huge_ccap, params->n_rings) > kLds))
+    return fail(FX_ERR_INVALID_ARG, "max_candidates (with max_keypoints) exceeds the LDS budget of the large merge tier (<= ~16000)");
   if (fxk_gather_lds_bytes(L.max_keypoints) > 64 * 1024)
     return fail(FX_ERR_INVALID_ARG, "max_keypoints exceeds the LDS budget of the support gather (<= ~1500)");
   if (fxk_desc_lds_bytes(L.max_neighbors) > kLds) return fail(FX_ERR_INVALID_ARG, "max_neighbors exceeds the LDS budget (<= ~4800)");
@@ -330,6 +345,8 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   c->params = *params;
   c->lim = L;
   c->device = device_id;
+  c->merge_big_cap = merge_big_cap;
+  c->merge_huge_ccap = merge_huge_ccap;
   if (const char *e = getenv("FX_RING_WAVES_PER_CU")) c->ring_waves_per_cu = (uint32_t)atoi(e);
   if (const char *e = getenv("FX_DESC_WGS_PER_CU")) c->desc_wgs_per_cu = (uint32_t)atoi(e);
   if (const char *e = getenv("FX_DEBUG_SYNC")) c->debug_sync = atoi(e) != 0;
@@ -438,6 +455,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   FX_A(dev_alloc(c, &b.big_rings, (size_t)8 * P.ring_list_cap));
   FX_A(dev_alloc(c, &b.huge_rings, (size_t)8 * P.ring_list_cap));
   FX_A(dev_alloc(c, &b.big_merge, B));
+  FX_A(dev_alloc(c, &b.huge_merge, B));
   FX_A(dev_alloc(c, &b.big_desc, L.max_total_keypoints));
   FX_A(dev_alloc(c, &b.list_desc, L.max_total_keypoints));
   FX_A(dev_alloc(c, &b.s_pts, (size_t)L.max_total_keypoints * P.list_cap));
@@ -504,7 +522,8 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
     return bail(fail(FX_ERR_HIP, "hipStreamCreate"));
   c->stream = c->own_stream;
   {
-    hipError_t ce = fxk_configure(fxk_ring_lds_bytes(L.max_ring_points, L.max_ring_points), fxk_merge_lds_bytes(L.max_candidates, params->n_rings),
+    hipError_t ce = fxk_configure(fxk_ring_lds_bytes(L.max_ring_points, L.max_ring_points), fxk_merge_lds_bytes(c->merge_big_cap, params->n_rings),
+                                  c->merge_big_cap < L.max_candidates ? fxk_merge_huge_lds_bytes(L.max_candidates, c->merge_huge_ccap, params->n_rings) : 0,
                                   fxk_desc_lds_bytes(L.max_neighbors));
     if (ce != hipSuccess) return bail(fail(FX_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(ce)));
   }

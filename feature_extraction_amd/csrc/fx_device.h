@@ -87,6 +87,7 @@ struct FxBuffers {
   uint32_t *big_rings;    // [B*n_rings]  rings for the mid workgroup tier
   uint32_t *huge_rings;   // [B*n_rings]  rings for the large workgroup tier
   uint32_t *big_merge;    // [B]
+  uint32_t *huge_merge;   // [B]  scans with more candidates than the LDS merge tiers hold
   uint32_t *big_desc;     // [max_total_kp]  rows whose support list overflowed list_cap
   uint32_t *list_desc;    // [max_total_kp]  rows whose list is too long for one wavefront
   uint32_t *spill_desc;   // [max_total_kp]  rows whose support set does not fit LDS
@@ -106,7 +107,7 @@ struct FxBuffers {
   float4 *row_kp;         // [max_total_kp]  the row's keypoint and its 3DSC x-axis (first-pass ordinal), so that the
   float2 *row_xa;         //                 per-keypoint kernels fetch everything a row needs in one round trip
   unsigned long long *stamps;  // [32] diagnostic build only (-DFX_STAMPS)
-  uint32_t *counters;     // [FX_N_COUNTERS]: 16.. deferred rings per XCD class (8 mid, 8 large); 0 big_rings, 1 big_merge, 2 big_desc, 3 need_rng_fix, 4 list_desc, 5 huge_rings, 6 spill_desc, 7 exact_desc, 8 wave_desc
+  uint32_t *counters;     // [FX_N_COUNTERS]: 16.. deferred rings per XCD class (8 mid, 8 large); 0 big_rings, 1 big_merge, 2 big_desc, 3 need_rng_fix, 4 list_desc, 5 huge_rings, 6 spill_desc, 7 exact_desc, 8 wave_desc, 9 huge_merge, 12 huge_desc
 };
 
 #endif

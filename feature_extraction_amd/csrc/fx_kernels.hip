@@ -1240,6 +1240,92 @@ __device__ __forceinline__ uint32_t prefix_owner(const uint32_t *base, uint32_t 
   return lo;
 }
 
+// Second half of the secondary merge, shared by the LDS tiers and the large tier: the clusters cc_order returned
+// (n_c of them, in PCL's order) become keypoints (fp64 centroid of the members' true xyz in ascending candidate
+// order, intensity of the first member: ref: node.cpp:238-257), every candidate learns its keypoint, and the
+// scan's keypoint_cloud chunks are laid out in ring order (ref: node.cpp:206).  point(i) = candidate i as
+// (x, y, true z, elevation).
+template <int NT, typename PointFn>
+__device__ __forceinline__ void merge_finish(const FxDevParams &P, const FxBuffers &B, uint32_t scan, uint32_t C, uint32_t n_c,
+                                             const uint32_t *parent, uint32_t *csize, const uint32_t *croot,
+                                             const uint32_t *crec, const uint32_t *rbase, uint32_t *kbase, uint32_t *s_w,
+                                             PointFn point) {
+  const uint32_t tid = threadIdx.x;
+  const uint32_t R = (uint32_t)P.n_rings;
+  int32_t *cand_kp = B.cand_kp + (size_t)scan * P.max_candidates;
+  uint32_t K = 0;
+  if (C > 0) {
+    K = n_c < P.max_keypoints ? n_c : P.max_keypoints;
+    if (n_c > P.max_keypoints && tid == 0) atomicOr(&B.flags[scan], FX_FLAG_KP_OVERFLOW);
+    float4 *kp = B.keypoints + (size_t)scan * P.max_keypoints;
+    uint32_t *kps = B.kp_size + (size_t)scan * P.max_keypoints;
+    for (uint32_t s = tid; s < n_c; s += NT) {
+      const uint32_t rec = crec[s];
+      const uint32_t sz = rec >> 16, root = croot[rec & 0xffffu];
+      csize[root] |= (s + 1u) << 16;  // position in PCL's order, next to the size
+      if (s >= K) continue;
+      double sumx = 0.0, sumy = 0.0, sumz = 0.0;
+      uint32_t cnt = 0;
+      // (members are scattered over the candidate list: eight labels per LDS round trip)
+      for (uint32_t i = root; i < C && cnt < sz; i += 8) {
+        uint32_t pr[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) pr[u] = parent[min(i + u, C - 1u)];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+          if (i + u >= C || pr[u] != root) continue;
+          const float4 q = point(i + u);
+          sumx += (double)q.x;
+          sumy += (double)q.y;
+          sumz += (double)q.z;
+          ++cnt;
+        }
+      }
+      kp[s] = make_float4((float)(sumx / (double)sz), (float)(sumy / (double)sz), (float)(sumz / (double)sz), point(root).w);
+      kps[s] = sz;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < C; i += NT) {
+      const uint32_t pos = csize[parent[i]] >> 16;
+      cand_kp[i] = (pos != 0 && pos - 1u < K) ? (int32_t)(pos - 1u) : -1;
+    }
+  }
+
+  // ---- keypoint_cloud: chunks into ring order, candidate slot -> ordinal in keypoints_full
+  const uint32_t *koff = B.ring_off + (size_t)scan * R;
+  const uint32_t *kcnt = B.kpc_ring_cnt + (size_t)scan * R;
+  const float4 *pool = B.kpc_pool + (size_t)scan * P.ring_slot_cap;
+  const uint32_t *pool_c = B.kpc_pool_cand + (size_t)scan * P.ring_slot_cap;
+  float4 *kpc = B.kpc + (size_t)scan * P.max_kpc;
+  uint32_t *kpc_c = B.kpc_cand + (size_t)scan * P.max_kpc;
+  uint32_t run = 0;
+  for (uint32_t b0 = 0; b0 < R; b0 += NT) {
+    const uint32_t r = b0 + tid;
+    const uint32_t c = r < R ? kcnt[r] : 0u;
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan<NT>(c, s_w, tot);
+    if (r < R) kbase[r] = run + ex;
+    run += tot;
+  }
+  if (tid == 0) kbase[R] = run;
+  __syncthreads();
+  if (run > P.max_kpc) {
+    if (tid == 0) atomicOr(&B.flags[scan], FX_FLAG_KPC_OVERFLOW);
+    run = 0;
+  }
+  for (uint32_t t = tid; t < run; t += NT) {
+    const uint32_t r = prefix_owner(kbase, R, t), j = t - kbase[r];
+    kpc[t] = pool[koff[r] + j];
+    kpc_c[t] = rbase[r] + pool_c[koff[r] + j];
+  }
+  if (tid == 0) {
+    B.n_cand[scan] = C;
+    B.n_kp[scan] = K;
+    B.n_kpc[scan] = run;
+  }
+  __syncthreads();
+}
+
 // One scan: keypoints_full = per-ring candidates in ring order (ref: node.cpp:205), pseudo-z,
 // second Euclidean clustering, centroids -> keypoints (ref: node.cpp:212-257); then the
 // scan's keypoint_cloud chunks are laid out in ring order (ref: node.cpp:206).
@@ -1278,7 +1364,6 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
 
   float4 *cand = B.cand + (size_t)scan * P.max_candidates;
   uint32_t *cand_size = B.cand_size + (size_t)scan * P.max_candidates;
-  int32_t *cand_kp = B.cand_kp + (size_t)scan * P.max_candidates;
   // all candidates in parallel (each finds its ring in the prefix table)
   for (uint32_t idx = tid; idx < C; idx += FX_WG) {
     const uint32_t r = prefix_owner(L.rbase, R, idx), j = idx - L.rbase[r];
@@ -1292,85 +1377,13 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
   __syncthreads();
 
   FX_STAMP(1);
-  uint32_t K = 0;
+  uint32_t n_c = 0;
   if (C > 0) {  // ref: node.cpp:209-210
     cc_label<FX_WG>(L.pt, C, P.r2_merge, L.parent, L.csize, L.rid, L.s_w, stamp_base);
-    const uint32_t n_c =
-        cc_order<FX_WG>(C, L.parent, L.csize, P.ndc, P.secondary_max, L.croot, L.crec, L.rid, cap, L.s_w, stamp_base);
-#ifdef FX_STAMPS
-    stamp_prev_ = __builtin_amdgcn_s_memtime();
-#endif
-    K = n_c < P.max_keypoints ? n_c : P.max_keypoints;
-    if (n_c > P.max_keypoints && tid == 0) atomicOr(&B.flags[scan], FX_FLAG_KP_OVERFLOW);
-    float4 *kp = B.keypoints + (size_t)scan * P.max_keypoints;
-    uint32_t *kps = B.kp_size + (size_t)scan * P.max_keypoints;
-    for (uint32_t s = tid; s < n_c; s += FX_WG) {
-      const uint32_t rec = L.crec[s];
-      const uint32_t sz = rec >> 16, root = L.croot[rec & 0xffffu];
-      L.csize[root] |= (s + 1u) << 16;  // position in PCL's order, next to the size
-      if (s >= K) continue;
-      double sumx = 0.0, sumy = 0.0, sumz = 0.0;
-      uint32_t cnt = 0;
-      // (members are scattered over the candidate list: eight labels per LDS round trip)
-      for (uint32_t i = root; i < C && cnt < sz; i += 8) {
-        uint32_t pr[8];
-#pragma unroll
-        for (uint32_t u = 0; u < 8; ++u) pr[u] = L.parent[min(i + u, C - 1u)];
-#pragma unroll
-        for (uint32_t u = 0; u < 8; ++u) {
-          if (i + u >= C || pr[u] != root) continue;
-          const float4 q = L.pt[i + u];
-          sumx += (double)q.x;
-          sumy += (double)q.y;
-          sumz += (double)L.cz[i + u];
-          ++cnt;
-        }
-      }
-      kp[s] = make_float4((float)(sumx / (double)sz), (float)(sumy / (double)sz), (float)(sumz / (double)sz),
-                          L.pt[root].w);
-      kps[s] = sz;
-    }
-    __syncthreads();
-    FX_STAMP(9);
-    for (uint32_t i = tid; i < C; i += FX_WG) {
-      const uint32_t pos = L.csize[L.parent[i]] >> 16;
-      cand_kp[i] = (pos != 0 && pos - 1u < K) ? (int32_t)(pos - 1u) : -1;
-    }
+    n_c = cc_order<FX_WG>(C, L.parent, L.csize, P.ndc, P.secondary_max, L.croot, L.crec, L.rid, cap, L.s_w, stamp_base);
   }
-
-  // ---- keypoint_cloud: chunks into ring order, candidate slot -> ordinal in keypoints_full
-  const uint32_t *koff = B.ring_off + (size_t)scan * R;
-  const uint32_t *kcnt = B.kpc_ring_cnt + (size_t)scan * R;
-  const float4 *pool = B.kpc_pool + (size_t)scan * P.ring_slot_cap;
-  const uint32_t *pool_c = B.kpc_pool_cand + (size_t)scan * P.ring_slot_cap;
-  float4 *kpc = B.kpc + (size_t)scan * P.max_kpc;
-  uint32_t *kpc_c = B.kpc_cand + (size_t)scan * P.max_kpc;
-  uint32_t run = 0;
-  for (uint32_t b0 = 0; b0 < R; b0 += FX_WG) {
-    const uint32_t r = b0 + tid;
-    const uint32_t c = r < R ? kcnt[r] : 0u;
-    uint32_t tot;
-    const uint32_t ex = block_excl_scan<FX_WG>(c, L.s_w, tot);
-    if (r < R) L.kbase[r] = run + ex;
-    run += tot;
-  }
-  if (tid == 0) L.kbase[R] = run;
-  __syncthreads();
-  if (run > P.max_kpc) {
-    if (tid == 0) atomicOr(&B.flags[scan], FX_FLAG_KPC_OVERFLOW);
-    run = 0;
-  }
-  for (uint32_t t = tid; t < run; t += FX_WG) {
-    const uint32_t r = prefix_owner(L.kbase, R, t), j = t - L.kbase[r];
-    kpc[t] = pool[koff[r] + j];
-    kpc_c[t] = L.rbase[r] + pool_c[koff[r] + j];
-  }
-  if (tid == 0) {
-    B.n_cand[scan] = C;
-    B.n_kp[scan] = K;
-    B.n_kpc[scan] = run;
-  }
-  __syncthreads();
+  merge_finish<FX_WG>(P, B, scan, C, n_c, L.parent, L.csize, L.croot, L.crec, L.rbase, L.kbase, L.s_w,
+                      [&](uint32_t i) { const float4 q = L.pt[i]; return make_float4(q.x, q.y, L.cz[i], q.w); });
   FX_STAMP(11);
   return true;
 }
@@ -1389,11 +1402,147 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_merge_small(FxDevParams P,
     }
   }
 }
-extern "C" __global__ __launch_bounds__(FX_WG) void k_merge_big(FxDevParams P, FxBuffers B, uint32_t cap) {
+extern "C" __global__ __launch_bounds__(FX_WG) void k_merge_big(FxDevParams P, FxBuffers B, uint32_t cap, uint32_t last) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const uint32_t n_big = B.counters[1];
   for (uint32_t w = blockIdx.x; w < n_big; w += gridDim.x) {
-    merge_body(P, B, B.big_merge[w], cap, smem, true);
+    const uint32_t scan = B.big_merge[w];
+    if (!merge_body(P, B, scan, cap, smem, last != 0)) {
+      if (threadIdx.x == 0) B.huge_merge[atomicAdd(&B.counters[9], 1u)] = scan;  // more candidates than LDS holds as points
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------- large merge tier
+// Scans with more per-ring candidates than one workgroup's LDS holds as points (dense many-ring sensors: a
+// 128-ring scan under the launch preset has ~5000).  LDS keeps only the union-find parents and a counting sort
+// of the candidate ids by xy cell; the coordinates stay in HBM (the scan's `cand` rows, L2 resident).
+//  * cells are `tolerance` wide, so every pair closer than the tolerance lies in the same or in adjacent cells
+//    (pseudo-z only adds distance); the 64 x 64 cell table is periodic — cells 64 apart share a bin, which only
+//    costs distance tests: every pair that could be an edge is examined and tested with the exact predicate;
+//  * every candidate tests the later candidates of the nine bins around it, skipping pairs already in one
+//    component; links go through the same lock-free union-find as the LDS tiers (root = smallest index = PCL's
+//    discovery order);
+//  * sizes, PCL's cluster order (cc_order) and the keypoints (merge_finish) are the code of the LDS tiers.
+#define FX_MHUGE_T 1024
+#define FX_MHUGE_BINS 4096
+#define FX_MHUGE_HEAD 160  // scratch words in front: block helpers, broadcast slots, sort stack
+__host__ __device__ inline uint32_t mhuge_aux_words(uint32_t cap) {
+  const uint32_t a = FX_MHUGE_BINS + 4 + (cap + 1) / 2;  // bin table + candidate ids (uint16), later the sizes
+  return a > cap ? a : cap;
+}
+__device__ __forceinline__ void merge_huge_body(const FxDevParams &P, const FxBuffers &B, uint32_t scan, uint32_t cap,
+                                                uint32_t ccap, uint32_t *smem) {
+  constexpr int NT = FX_MHUGE_T;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t R = (uint32_t)P.n_rings;
+  uint32_t *s_w = smem;
+  uint32_t *rbase = smem + FX_MHUGE_HEAD;  // [R + 1]
+  uint32_t *kbase = rbase + (R + 1);       // [R + 1]
+  uint32_t *parent = kbase + (R + 1);      // [cap]
+  uint32_t *aux = parent + cap;            // [mhuge_aux_words(cap)]
+  uint32_t *croot = aux + mhuge_aux_words(cap);  // [ccap]
+  uint32_t *crec = croot + ccap;                 // [ccap]
+  uint32_t *tmp = crec + ccap;                   // [ccap]
+  uint32_t *bin = aux;                                                   // [BINS + 1]: counts -> starts -> ends
+  uint16_t *sorted = reinterpret_cast<uint16_t *>(aux + FX_MHUGE_BINS + 4);  // candidate ids, bin by bin
+  uint32_t *csize = aux;                                                 // once the links are made
+  const uint32_t *rcnt = B.ring_cand_cnt + (size_t)scan * R;
+
+  uint32_t C = 0;
+  for (uint32_t b0 = 0; b0 < R; b0 += NT) {
+    const uint32_t r = b0 + tid;
+    const uint32_t c = r < R ? rcnt[r] : 0u;
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan<NT>(c, s_w, tot);
+    if (r < R) rbase[r] = C + ex;
+    C += tot;
+  }
+  if (tid == 0) rbase[R] = C;
+  for (uint32_t t = tid; t <= FX_MHUGE_BINS; t += NT) bin[t] = 0;
+  __syncthreads();
+  // (C <= cap == max_candidates: the LDS tiers flag larger scans themselves)
+
+  float4 *cand = B.cand + (size_t)scan * P.max_candidates;
+  uint32_t *cand_size = B.cand_size + (size_t)scan * P.max_candidates;
+  const float inv_w = 1.0f / (sqrtf(P.r2_merge) * 1.01f);
+  auto bin_of = [&](int cx, int cy) { return (uint32_t)((cx & 63) | ((cy & 63) << 6)); };
+  auto cell_x = [&](float x) { return (int)floorf((x - P.x_min) * inv_w); };
+  auto cell_y = [&](float y) { return (int)floorf((y - P.y_min) * inv_w); };
+  // ref: node.cpp:217  z = intensity*0.75*clusterRadiusThreshold/2  (double, left to right)
+  auto pseudo_z = [&](float el) { return (float)((double)el * 0.75 * P.crt / 2); };
+  for (uint32_t idx = tid; idx < C; idx += NT) {
+    const uint32_t r = prefix_owner(rbase, R, idx), j = idx - rbase[r];
+    const float4 v = B.ring_cand[((size_t)scan * R + r) * P.max_ring_cands + j];
+    cand[idx] = v;
+    cand_size[idx] = B.ring_cand_size[((size_t)scan * R + r) * P.max_ring_cands + j];
+    parent[idx] = idx;
+    atomicAdd(&bin[bin_of(cell_x(v.x), cell_y(v.y))], 1u);
+  }
+  __threadfence();  // `cand` is re-read below by other waves of this workgroup
+  __syncthreads();
+  if (tid < 64) {  // counts -> exclusive starts, in place, by one wavefront
+    constexpr uint32_t per = FX_MHUGE_BINS / 64;
+    uint32_t sum = 0;
+    for (uint32_t u = 0; u < per; ++u) sum += bin[tid * per + u];
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+      if ((int)tid >= d) incl += o;
+    }
+    uint32_t run = incl - sum;
+    for (uint32_t u = 0; u < per; ++u) {
+      const uint32_t c = bin[tid * per + u];
+      bin[tid * per + u] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  for (uint32_t idx = tid; idx < C; idx += NT) {  // each id to its bin: a start becomes the bin's end
+    const float4 v = cand[idx];
+    sorted[atomicAdd(&bin[bin_of(cell_x(v.x), cell_y(v.y))], 1u)] = (uint16_t)idx;
+  }
+  __syncthreads();
+  // ---- pcl::EuclideanClusterExtraction on (x, y, pseudo z) (ref: node.cpp:222-229)
+  for (uint32_t i = tid; i < C; i += NT) {
+    const float4 v = cand[i];
+    const float pz = pseudo_z(v.w);
+    const int cx = cell_x(v.x), cy = cell_y(v.y);
+    for (int d = 0; d < 9; ++d) {
+      const uint32_t b = bin_of(cx + d % 3 - 1, cy + d / 3 - 1);
+      const uint32_t q0 = b ? bin[b - 1] : 0u, q1 = bin[b];
+      for (uint32_t q = q0; q < q1; ++q) {
+        const uint32_t j = sorted[q];
+        if (j <= i) continue;  // every pair once
+        if (uf_find(parent, i) == uf_find(parent, j)) continue;
+        const float4 u = cand[j];
+        if (dist2(v.x, v.y, pz, u.x, u.y, pseudo_z(u.w)) < P.r2_merge) uf_union(parent, j, i);
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < C; i += NT) parent[i] = uf_find_ro(parent, i);
+  for (uint32_t i = tid; i < C; i += NT) csize[i] = 0u;  // (bin table and ids are done with)
+  __syncthreads();
+  for (uint32_t i = tid; i < C; i += NT) atomicAdd(&csize[parent[i]], 1u);
+  __syncthreads();
+  uint32_t n_c = 0;
+  if (C > 0) {
+    n_c = cc_order<NT>(C, parent, csize, P.ndc, P.secondary_max, croot, crec, tmp, ccap, s_w);
+    if (n_c > ccap) {  // more clusters than can be ordered here; ccap >= max_keypoints, so the scan overflows anyway
+      if (tid == 0) atomicOr(&B.flags[scan], FX_FLAG_KP_OVERFLOW);
+      n_c = 0;
+    }
+  }
+  merge_finish<NT>(P, B, scan, C, n_c, parent, csize, croot, crec, rbase, kbase, s_w, [&](uint32_t i) { return cand[i]; });
+}
+extern "C" __global__ __launch_bounds__(FX_MHUGE_T) void k_merge_huge(FxDevParams P, FxBuffers B, uint32_t cap, uint32_t ccap) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const uint32_t n_big = B.counters[9];
+  for (uint32_t w = blockIdx.x; w < n_big; w += gridDim.x) {
+    merge_huge_body(P, B, B.huge_merge[w], cap, ccap, smem);
     __syncthreads();
   }
 }
@@ -2871,14 +3020,19 @@ size_t fxk_ring_wave_lds_bytes(uint32_t cap, uint32_t ccap) {
 size_t fxk_merge_lds_bytes(uint32_t cap, uint32_t n_rings) {
   return (size_t)(SegCfg<FX_WG>::kWords + FX_MERGE_WORDS_PER_CAND * cap + 2 * (n_rings + 1)) * 4;
 }
+size_t fxk_merge_huge_lds_bytes(uint32_t cap, uint32_t ccap, uint32_t n_rings) {
+  return (size_t)(FX_MHUGE_HEAD + 2 * (n_rings + 1) + cap + mhuge_aux_words(cap) + 3 * ccap) * 4;
+}
 uint32_t fxk_huge_cap(void) { return FX_HUGE_CAP; }
 size_t fxk_gather_lds_bytes(uint32_t max_keypoints) {
   return (16 + 80 + 7 * (size_t)max_keypoints + FX_GATHER_BINS + FX_GATHER_STAGE + 4 + 4 * FX_GATHER_STAGE) * 4;
 }
 size_t fxk_desc_lds_bytes(uint32_t cap) { return (size_t)(16 + FX_DESC_WORDS_PER_POINT * cap + FX_DESC_BINS) * 4; }
 
-hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t desc_big) {
+hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t merge_huge, size_t desc_big) {
   hipError_t e;
+  e = hipFuncSetAttribute((const void *)k_merge_huge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)merge_huge);
+  if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void *)k_rings_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_big);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void *)k_merge_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)merge_big);
@@ -2912,8 +3066,11 @@ void fxk_rings_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint
 void fxk_merge_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap) {
   hipLaunchKernelGGL(k_merge_small, dim3(batch), dim3(FX_WG), fxk_merge_lds_bytes(cap, P.n_rings), s, P, B, cap);
 }
-void fxk_merge_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t grid) {
-  hipLaunchKernelGGL(k_merge_big, dim3(grid), dim3(FX_WG), fxk_merge_lds_bytes(cap, P.n_rings), s, P, B, cap);
+void fxk_merge_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t grid, uint32_t last) {
+  hipLaunchKernelGGL(k_merge_big, dim3(grid), dim3(FX_WG), fxk_merge_lds_bytes(cap, P.n_rings), s, P, B, cap, last);
+}
+void fxk_merge_huge(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t ccap, uint32_t grid) {
+  hipLaunchKernelGGL(k_merge_huge, dim3(grid), dim3(FX_MHUGE_T), fxk_merge_huge_lds_bytes(cap, ccap, P.n_rings), s, P, B, cap, ccap);
 }
 void fxk_offsets(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch) {
   hipLaunchKernelGGL(k_offsets, dim3(1), dim3(FX_WG), 0, s, P, B, batch);

@@ -32,16 +32,96 @@ def test_hdl64_style_scans(fxlib, oracle):
         ctx.close()
 
 
-def test_dense_128_ring_scan_radius_2m(fxlib, oracle):
-    """128 x 2048, R = 2 m (BASELINE config 5): long rings, long support lists."""
-    cfg = dict(n_rings=128, n_az=2048, el0_deg=-25.0, el_step_deg=40.0 / 127)
-    s = capi.synth_scan(capi.synth_cfg(50, n_poles=256, **cfg))
-    p = capi.params("default", n_rings=128, el0_deg=-25.0, el_step_deg=40.0 / 127, secondary_max=128, descriptor_radius=2.0)
-    ctx = capi.Context(p, capi.limits(1, 128 * 2048, max_candidates=3500, max_kpc_points=65536))
+DENSE = dict(n_rings=128, n_az=2048, el0_deg=-25.0, el_step_deg=40.0 / 127)
+
+
+def _dense_params(preset):
+    return capi.params(preset, n_rings=128, el0_deg=-25.0, el_step_deg=40.0 / 127, secondary_max=128, descriptor_radius=2.0)
+
+
+@pytest.mark.parametrize("preset", ["launch", "default"])
+def test_dense_128_ring_scan_radius_2m(fxlib, oracle, preset):
+    """128 x 2048, R = 2 m (BASELINE config 5): long rings, long support lists, and — under the launch preset,
+    the one SURVEY.md B-6 sized the config with — about 5000 per-ring candidates a scan, which is more than one
+    workgroup's LDS holds as points: the large merge tier takes those scans."""
+    s = capi.synth_scan(capi.synth_cfg(50, n_poles=256, **DENSE))
+    p = _dense_params(preset)
+    ctx = capi.Context(p, capi.limits(1, 128 * 2048, max_candidates=8192, max_kpc_points=65536, max_keypoints=512, max_total_keypoints=512))
     got = ctx.process_host([s], roll=0.02, pitch=-0.015)[0]
-    st = util.compare_scan(got, oracle.run(p, s, roll=0.02, pitch=-0.015), tag="128 rings")
+    ora = oracle.run(p, s, roll=0.02, pitch=-0.015)
+    st = util.compare_scan(got, ora, tag=f"128 rings {preset}")
     assert st["K"] > 0
+    if preset == "launch":
+        assert len(ora["candidates"]) > 4500  # really beyond the LDS tiers (<= ~3800)
     ctx.close()
+
+
+def test_large_merge_tier_on_vlp16_scans(fxlib, oracle, monkeypatch):
+    """The large merge tier (cell-sorted ids + union-find in LDS, coordinates in HBM) on ordinary scans: the test
+    hook lowers the LDS tier's capacity so that every scan with more than 16 candidates takes it."""
+    monkeypatch.setenv("FX_MERGE_BIG_CAP", "16")
+    scans = [util.vlp16_scan(1000 + b) for b in range(6)] + [np.zeros((0, 4), np.float32)]
+    for preset in ("launch", "default"):
+        p = capi.params(preset)
+        ctx = capi.Context(p, capi.limits(len(scans), 28800))
+        got = ctx.process_host(scans, roll=0.02, pitch=-0.015)
+        for b, sc in enumerate(scans):
+            util.compare_scan(got[b], oracle.run(p, sc, roll=0.02, pitch=-0.015), tag=f"large merge tier {preset} {b}")
+        ctx.close()
+    # more than 192 keypoints in one scan: the order replay beyond three words of lanes (one lane, sequentially)
+    crowded = [util.vlp16_scan(7 + b, n_poles=900) for b in range(2)]
+    p = capi.params("launch", number_detection_channels=1)
+    ctx = capi.Context(p, capi.limits(2, 28800, max_candidates=3500, max_keypoints=1024, max_total_keypoints=2048, max_kpc_points=8192))
+    got = ctx.process_host(crowded, roll=0.02, pitch=-0.015)
+    for b in range(2):
+        st = util.compare_scan(got[b], oracle.run(p, crowded[b], roll=0.02, pitch=-0.015), tag=f"large merge tier, crowded {b}")
+    assert got[0]["n_keypoints"] > 192
+    ctx.close()
+
+
+def _full_size(oracle, name, cfg, p, lim, B, n_uniq, sample):
+    """One BASELINE configuration at its stated batch size: flags 0, batch-position independence,
+    repeatability, and sampled parity against the oracle."""
+    import torch
+    uniq = [capi.synth_scan(capi.synth_cfg(10 + b, **cfg)) for b in range(n_uniq)]
+    dev = [torch.from_numpy(s).cuda() for s in uniq]
+    N = len(uniq[0])
+    ctx = capi.Context(p, lim)
+    descs = ctx.make_descs([dev[b % n_uniq].data_ptr() for b in range(B)], [N] * B, 16, 0.02, -0.015)
+    flags = capi.FX_IN_DEVICE | capi.FX_OUT_HOST | capi.FX_OUT_CLOUDS | capi.FX_OUT_DEBUG
+    res = ctx.unpack(ctx.process_raw(descs, B, flags))
+    assert all(r["flags"] == 0 for r in res), [hex(r["flags"]) for r in res if r["flags"]][:4]
+    for b in range(n_uniq, B):  # a scan's result does not depend on its position in the batch
+        a, c = res[b], res[b - n_uniq]
+        assert a["n_keypoints"] == c["n_keypoints"]
+        util.assert_bit_equal(a["keypoints"], c["keypoints"], f"{name} keypoints {b}")
+        util.assert_bit_equal(a["descriptors"], c["descriptors"], f"{name} descriptors {b}")
+        util.assert_bit_equal(a["kpc"], c["kpc"], f"{name} keypoint_cloud {b}")
+    k = 0
+    for b in sample:
+        st = util.compare_scan(res[b], oracle.run(p, uniq[b % n_uniq], roll=0.02, pitch=-0.015), tag=f"{name} scan {b}")
+        k += st["K"]
+    assert k > 0
+    res2 = ctx.unpack(ctx.process_raw(descs, B, flags))
+    for a, c in zip(res, res2):
+        util.assert_bit_equal(a["descriptors"], c["descriptors"], f"{name} repeatability")
+    ctx.close()
+
+
+def test_config3_hdl64_batch_256(fxlib, oracle):
+    """BASELINE config 3 at its stated size: 64 x 2048 scans, batch 256, launch preset."""
+    cfg = dict(n_rings=64, n_az=2048, el0_deg=-24.8, el_step_deg=26.8 / 63, n_poles=256)
+    p = capi.params("launch", n_rings=64, el0_deg=-24.8, el_step_deg=26.8 / 63, secondary_max=64)
+    lim = capi.limits(256, 64 * 2048, max_candidates=4096, max_kpc_points=32768, max_keypoints=512, max_total_keypoints=256 * 256)
+    _full_size(oracle, "config 3", cfg, p, lim, 256, 16, (0, 5, 11, 15, 16 + 3, 255))
+
+
+def test_config5_dense_batch_64_launch_preset(fxlib, oracle):
+    """BASELINE config 5 at its stated size and with the preset SURVEY.md B-6 sized it with: 128 x 2048 scans,
+    R = 2 m, batch 64, launch preset (~5000 candidates and ~150 keypoints a scan, support sets beyond 5000 points)."""
+    cfg = dict(n_poles=256, **DENSE)
+    lim = capi.limits(64, 128 * 2048, max_candidates=8192, max_kpc_points=65536, max_keypoints=512, max_total_keypoints=64 * 256)
+    _full_size(oracle, "config 5", cfg, _dense_params("launch"), lim, 64, 8, (0, 3, 7, 8 + 2, 63))
 
 
 def test_feature_records_and_keypoint_records(fxlib, oracle):

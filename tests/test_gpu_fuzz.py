@@ -40,8 +40,11 @@ def _case(seed):
     return np.ascontiguousarray(s), p, roll, pitch, dict(scene=scene, over=over, kind=kind)
 
 
+@pytest.mark.parametrize("merge_tier", ["lds", "large"])
 @pytest.mark.parametrize("block", range(8))
-def test_random_scenes_parameters_and_perturbations(fxlib, oracle, block):
+def test_random_scenes_parameters_and_perturbations(fxlib, oracle, block, merge_tier, monkeypatch):
+    if merge_tier == "large":  # test hook: scans with more than 16 candidates take the large merge tier
+        monkeypatch.setenv("FX_MERGE_BIG_CAP", "16")
     total_k = 0
     for seed in range(block * 10, block * 10 + 10):
         s, p, roll, pitch, what = _case(seed)
