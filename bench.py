@@ -12,14 +12,17 @@ owns `--batch` scans (weak scaling); there is no other data-path exchange.
          --master-port P bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant
-kernel, HIP-event timed on the launch stream inside the timed region) and `cpu_baseline`
-(the oracle's kd-tree restatement of the PCL path on the host cores; N=1 only).
+kernel, HIP-event timed on the launch stream inside the timed region), `cpu_baseline`
+(the oracle's kd-tree restatement of the PCL path on the host cores; N=1 only), and — N=1 only,
+after the timed region — `other_configs` (BASELINE.json configs 3 and 5 at their stated batch
+sizes) and `host_to_host_scans_per_s` (the same batch handed over and returned as host buffers).
 """
 import argparse
 import concurrent.futures as cf
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -29,12 +32,24 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured achievable)
 N_RINGS, N_AZ = 16, 1800
-REC_KP = 127  # keypoints carried per scan in the gathered record (1 header + 127 float4 = 2 KiB)
+
+# BASELINE.json configs 3 and 5 (n_rings / secondary_max beyond 16 are the build's extension:
+# the reference hard-codes 16, ref: node.cpp:195, 200, 227).  Config 5 runs the launch preset SURVEY.md B-6 sized it with.
+OTHER_CONFIGS = {
+    "config3_hdl64_64x2048_batch256": dict(
+        batch=256, n_uniq=16, synth=dict(n_rings=64, n_az=2048, el0_deg=-24.8, el_step_deg=26.8 / 63, n_poles=256),
+        preset="launch", params=dict(n_rings=64, el0_deg=-24.8, el_step_deg=26.8 / 63, secondary_max=64),
+        limits=dict(max_candidates=4096, max_kpc_points=32768, max_keypoints=512, max_total_keypoints=256 * 256)),
+    "config5_dense_128x2048_R2m_batch64": dict(
+        batch=64, n_uniq=8, synth=dict(n_rings=128, n_az=2048, el0_deg=-25.0, el_step_deg=40.0 / 127, n_poles=256),
+        preset="launch", params=dict(n_rings=128, el0_deg=-25.0, el_step_deg=40.0 / 127, secondary_max=128, descriptor_radius=2.0),
+        limits=dict(max_candidates=8192, max_kpc_points=65536, max_keypoints=512, max_total_keypoints=64 * 256)),
+}
 
 
-def make_scans(capi, seeds, threads):
+def make_scans(capi, seeds, threads, **over):
     def one(seed):
-        return capi.synth_scan(capi.synth_cfg(seed))
+        return capi.synth_scan(capi.synth_cfg(seed, **over))
     with cf.ThreadPoolExecutor(max_workers=threads) as ex:
         return list(ex.map(one, seeds))
 
@@ -53,7 +68,7 @@ def cpu_baseline(params, host, roll, pitch, threads, budget_s=12.0):
 
 def h2d_inclusive(ctx, capi, host, B, N, roll, pitch, steps=3):
     """Same batch handed over as HOST buffers (pageable numpy): the C-ABI copies it to the device
-    inside the call.  Reported beside the headline number, never as it."""
+    inside the call.  Results stay on the device.  Reported beside the headline number, never as it."""
     descs = ctx.make_descs([host.ctypes.data + b * N * 16 for b in range(B)], [N] * B, 16, roll, pitch)
     ctx.process_raw(descs, B, 0)
     ctx.synchronize()
@@ -62,6 +77,81 @@ def h2d_inclusive(ctx, capi, host, B, N, roll, pitch, steps=3):
         ctx.process_raw(descs, B, 0)
     ctx.synchronize()
     return B * steps / (time.perf_counter() - t0)
+
+
+def host_to_host(ctxs, capi, torch, host, B, N, roll, pitch, steps=4):
+    """What a caller of the node actually receives (ref: node.cpp:117-139): scans go in as host buffers and keypoints +
+    descriptors come back in (pinned) host buffers — H2D, every kernel and D2H inside fx_process_batch(FX_OUT_HOST).
+    One host thread per context (the C-ABI's threading model: one context per thread), each on its own stream, so the
+    upload of one batch, the kernels of another and the download of a third overlap; PCIe is full duplex.
+    The input lives in pinned host memory (what a driver that feeds a GPU would allocate)."""
+    pinned = torch.from_numpy(host).pin_memory()
+    base = pinned.data_ptr()
+    descs = ctxs[0].make_descs([base + b * N * 16 for b in range(B)], [N] * B, 16, roll, pitch)
+    for c in ctxs:  # first call allocates the pinned mirrors
+        c.process_raw(descs, B, capi.FX_OUT_HOST)
+    err = []
+
+    def worker(c):
+        try:
+            for _ in range(steps):
+                c.process_raw(descs, B, capi.FX_OUT_HOST)
+        except Exception as e:  # noqa: BLE001
+            err.append(e)
+    th = [threading.Thread(target=worker, args=(c,)) for c in ctxs]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    if err:
+        raise err[0]
+    return B * steps * len(ctxs) / dt
+
+
+def run_other_config(name, cfg, capi, torch, dev, threads, roll, pitch, steps=5):
+    """One of BASELINE.json's other configurations at its stated batch size: scans/s with inputs resident in HBM,
+    capacity flags, keypoints per scan.  One batch at a time; B distinct device buffers (n_uniq scenes cycled)."""
+    B, n_uniq = cfg["batch"], cfg["n_uniq"]
+    uniq = make_scans(capi, [10 + b for b in range(n_uniq)], min(threads, n_uniq), **cfg["synth"])
+    N = len(uniq[0])
+    d_in = torch.from_numpy(np.stack([uniq[b % n_uniq] for b in range(B)])).to(dev)
+    p = capi.params(cfg["preset"], **cfg["params"])
+    ctx = capi.Context(p, capi.limits(B, N, **cfg["limits"]), device=dev.index)
+    st = torch.cuda.Stream(device=dev)
+    ctx.set_stream(st.cuda_stream)
+    descs = ctx.make_descs([d_in.data_ptr() + b * N * 16 for b in range(B)], [N] * B, 16, roll, pitch)
+    torch.cuda.synchronize(dev)
+    for _ in range(2):
+        ctx.process_raw(descs, B, capi.FX_IN_DEVICE)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.process_raw(descs, B, capi.FX_IN_DEVICE)
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    ctx.set_profiling(3)
+    for _ in range(3):
+        ctx.process_raw(descs, B, capi.FX_IN_DEVICE)
+    ctx.synchronize()
+    acc = {}
+    for back in range(3):
+        ms, _tot = ctx.timings(back)
+        for k, v in ms.items():
+            acc[k] = acc.get(k, 0.0) + v / 3
+    ctx.set_profiling(0)
+    v = ctx.process_raw(descs, B, capi.FX_IN_DEVICE | capi.FX_OUT_HOST)
+    flags_or = int(np.bitwise_or.reduce(np.ctypeslib.as_array(v.h_flags, shape=(B,))))
+    k_total = int(v.total_keypoints)
+    alg = 16.0 * N * B + (16.0 + 7956.0) * k_total
+    out = {"scans_per_s": B * steps / dt, "ms_per_batch": dt / steps * 1e3, "batch": B, "points_per_scan": N,
+           "preset": cfg["preset"], "flags_or": flags_or, "keypoints_per_scan": k_total / B,
+           "alg_bytes_per_batch": alg, "path_frac_of_hbm_peak": alg / (dt / steps) / 1e9 / HBM_PEAK_GBS,
+           "kernel_ms": {k: round(x, 4) for k, x in acc.items()}}
+    ctx.close()
+    del d_in
+    return out
 
 
 def main():
@@ -74,12 +164,13 @@ def main():
     ap.add_argument("--contexts", type=int, default=3,
                     help="batches in flight per GPU: contexts (each on its own HIP stream) taking the steps in turn")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--check", type=int, default=4, help="scans of rank 0 checked against the oracle after timing")
+    ap.add_argument("--no-extras", action="store_true", help="skip other_configs and the host-to-host measurement")
+    ap.add_argument("--check", type=int, default=16, help="scans of rank 0 checked against the oracle after timing")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from feature_extraction_amd import build, capi
+    from feature_extraction_amd import build, capi, sharding
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -92,12 +183,16 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1 or os.environ.get("FX_BENCH_FORCE_DIST") == "1":
+    use_dist = world > 1 or os.environ.get("FX_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rank == 0:
+            print(f"[bench] torch.distributed backend {dist.get_backend()} (RCCL), world {dist.get_world_size()}", file=sys.stderr)
 
     B, N = args.batch, N_RINGS * N_AZ
+    REC_KP = sharding.REC_KP
     roll, pitch = 0.02, -0.015
     threads = os.cpu_count() or 1
     # ---- synthetic input (SURVEY.md Appendix C / BASELINE.md config 2), seed 1000 + global scan index
@@ -119,7 +214,6 @@ def main():
     descs = ctx.make_descs([base + b * N * 16 for b in range(B)], [N] * B, 16, roll, pitch)
     # keypoint records, one buffer per context: the gather of a batch (RCCL, its own stream) overlaps the
     # kernels of the batches behind it; a buffer is reused only after its collective has completed
-    use_dist = world > 1 or os.environ.get("FX_BENCH_FORCE_DIST") == "1"
     recs = [torch.zeros((B, 1 + REC_KP, 4), dtype=torch.float32, device=dev) for _ in range(K)]
     gathered = [torch.zeros((world * B, 1 + REC_KP, 4), dtype=torch.float32, device=dev) for _ in range(K)] if use_dist else None
     pending = [None] * K
@@ -135,8 +229,8 @@ def main():
                 pending[j] = None
             ctxs[j].process_raw(descs, B, capi.FX_IN_DEVICE)
             ctxs[j].pack_keypoint_records(recs[j].data_ptr(), REC_KP)
-            if use_dist:
-                pending[j] = dist.all_gather_into_tensor(gathered[j].view(-1), recs[j].view(-1), async_op=True)
+            if use_dist:  # the path's one collective (feature_extraction_amd/sharding.py; the gloo test runs the same function)
+                _tab, pending[j] = sharding.all_gather_records(recs[j], world, out=gathered[j], async_op=True)
 
     def drain():
         for j in range(K):
@@ -162,17 +256,22 @@ def main():
                     acc[k] = acc.get(k, 0.0) + v
         return {k: v / n for k, v in acc.items()}
 
-    # warm-up, with HIP events around every stage kernel: it names the dominant kernel.  Every event costs
-    # a few microseconds of stream time (13 of them: ~4 % of a batch), so the timed region below keeps only
-    # the events that bracket that kernel (and the batch); the other per-kernel durations are reported
-    # from a short profiled pass after it.
-    profile_all(1)
-    for _ in range(max(args.warmup, 2) * K):  # (at least two per context: the first pays for code upload and cold caches)
+    # ---- warm-up (untimed; the first step of a context pays for code upload and cold caches)
+    for _ in range(max(args.warmup, 2) * K):
         step()
     drain()
     torch.cuda.synchronize(dev)
-    warm = mean_timings(1)  # the last warm-up step of every context
-    dom = max(warm, key=warm.get)
+    # ---- which kernel dominates: HIP events around every stage kernel over `n_sel` steps per context, the largest
+    #      mean wins.  Every event costs a few microseconds of stream time (13 of them: ~4 % of a batch), so the
+    #      timed region below keeps only the events that bracket that kernel (and the batch).
+    n_sel = 5
+    profile_all(n_sel)
+    for _ in range(n_sel * K):
+        step()
+    drain()
+    torch.cuda.synchronize(dev)
+    stage_ms = mean_timings(n_sel)
+    dom = max(stage_ms, key=stage_ms.get)
     if use_dist:  # every rank times the same kernel
         names = list(capi.STAGE_NAMES)
         t = torch.tensor([names.index(dom)], dtype=torch.int64, device=dev)
@@ -198,14 +297,6 @@ def main():
 
     # ---- the dominant kernel's duration over the timed steps (HIP events recorded inside the timed region)
     dom_ms = mean_timings(per_ctx_steps)[dom]
-    # ---- all per-kernel durations, from a few more steps with every event on (outside the timed region)
-    n_prof = 4
-    profile_all(n_prof)
-    for _ in range(n_prof * K):
-        step()
-    drain()
-    torch.cuda.synchronize(dev)
-    stage_ms = mean_timings(n_prof)
     profile_all(0)
 
     # ---- what the batch produced (for the algorithmic byte count) + a parity spot check
@@ -223,6 +314,13 @@ def main():
         k_all = int(kt.item())
     else:
         k_all = k_total
+    if use_dist and rank == 0:
+        # the gathered table holds every rank's records in stream order: check this rank's block
+        last = (counter[0] - 1) % K
+        g = gathered[last][rank * B:(rank + 1) * B]
+        assert torch.equal(g, recs[last]), "gathered keypoint records differ from the local ones"
+        print(f"[bench] all-gather of keypoint records over {dist.get_backend()}: table {tuple(gathered[last].shape)}, "
+              f"this rank's block equals its local records", file=sys.stderr)
 
     result_line = None
     if rank == 0:
@@ -231,9 +329,10 @@ def main():
             from oracle import oracle_py as O
             from tests import util
             worst, kchk = 0.0, 0
+            with cf.ThreadPoolExecutor(max_workers=min(threads, n_chk)) as ex:  # (the oracle call releases the GIL)
+                oras = list(ex.map(lambda b: O.run(params, scans[b], roll=roll, pitch=pitch), range(n_chk)))
             for b in range(n_chk):
-                ora = O.run(params, scans[b], roll=roll, pitch=pitch)
-                st = util.compare_scan(res[b], ora, tag=f"bench scan {b}")  # raises on any mismatch
+                st = util.compare_scan(res[b], oras[b], tag=f"bench scan {b}")  # raises on any mismatch
                 worst = max(worst, st["max_abs"])
                 kchk += st["K"]
             parity = {"scans_checked": n_chk, "keypoints_checked": kchk, "keypoint_f1_vs_oracle": 1.0,
@@ -242,17 +341,21 @@ def main():
         # (16 N read + 16 K + 7956 K written per scan; K measured, this rank's batch)
         alg_bytes = 16.0 * N * B + (16.0 + 7956.0) * k_total
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
-        traffic = None
+        ms_per_step = elapsed / args.steps * 1e3
+        traffic = traffic_total = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom)
+                tj = json.load(open(tpath))
+                # stage -> kernels launched inside it (PMC rows are per kernel)
+                traffic = sum(tj.get(k, 0.0) for k in capi.STAGE_KERNELS.get(dom, (dom,))) or None
+                traffic_total = sum(x for k, x in tj.items() if k.startswith("k_"))
             except Exception:
-                traffic = None
+                traffic = traffic_total = None
         out = {
             "metric": "VLP-16 scans/sec (16x1800 pts), detector+descriptor", "value": world * B * args.steps / elapsed,
             "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"batch of {B} synthetic VLP-16 scans (16x1800 pts, 64 uniform poles) per GPU, "
                                    f"device-resident, preset '{args.preset}', roll/pitch 0.02/-0.015",
@@ -262,22 +365,39 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "alg_bytes_per_launch": alg_bytes, "kernel_ms": dom_ms,
-                         "timed": "HIP events around this kernel on the launch stream, inside the timed region"},
+                         "timed": "HIP events around this kernel on the launch stream, inside the timed region",
+                         "selected_by": f"largest mean of all stage kernels over {n_sel} profiled steps per context before the timed region",
+                         # the kernel's own measured HBM bytes over its duration, and the whole path against the peak
+                         "kernel_traffic_gbs": (traffic / (dom_ms * 1e-3) / 1e9) if traffic else None,
+                         "path_frac": alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "traffic_total": traffic_total},
             "kernel_ms": stage_ms,
-            "kernel_ms_source": f"all stages: {n_prof * K} extra profiled steps after the timed region, {K} batches in flight",
+            "kernel_ms_source": f"all stages: {n_sel * K} profiled steps before the timed region, {K} batches in flight",
             "parity": parity,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["h2d_inclusive_scans_per_s"] = h2d_inclusive(ctx, capi, host, B, N, roll, pitch)
-            out["cpu_baseline"] = cpu_baseline(params, host, roll, pitch, threads)
-        result_line = json.dumps(out)
-    if use_dist and rank == 0:
-        # the gathered table holds every rank's records in stream order: check this rank's block
-        last = (counter[0] - 1) % K
-        g = gathered[last][rank * B:(rank + 1) * B]
-        assert torch.equal(g, recs[last]), "gathered keypoint records differ from the local ones"
-    for c in ctxs:
+        result_line = out
+    for c in ctxs[1:] if (rank == 0 and world == 1 and not args.no_extras) else ctxs:
         c.close()
+    if rank == 0 and world == 1:
+        out = result_line
+        if not args.no_extras:
+            out["h2d_inclusive_scans_per_s"] = h2d_inclusive(ctx, capi, host, B, N, roll, pitch)
+            ctx.close()
+            h2h = [capi.Context(params, capi.limits(B, N), device=local_rank) for _ in range(3)]
+            hs = [torch.cuda.Stream(device=dev) for _ in h2h]
+            for c, st in zip(h2h, hs):
+                c.set_stream(st.cuda_stream)
+            out["host_to_host_scans_per_s"] = host_to_host(h2h, capi, torch, host, B, N, roll, pitch)
+            out["host_to_host_note"] = ("pinned host scans in, keypoints + descriptors out to pinned host buffers "
+                                        "(fx_process_batch with FX_OUT_HOST), 3 contexts on 3 host threads / streams")
+            for c in h2h:
+                c.close()
+            del d_in
+            torch.cuda.empty_cache()
+            out["other_configs"] = {name: run_other_config(name, cfg, capi, torch, dev, threads, roll, pitch)
+                                    for name, cfg in OTHER_CONFIGS.items()}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(params, host, roll, pitch, threads)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
@@ -287,7 +407,7 @@ def main():
         import ctypes
         sys.stdout.flush()
         ctypes.CDLL(None).fflush(None)
-        print(result_line, flush=True)
+        print(json.dumps(result_line), flush=True)
 
 
 if __name__ == "__main__":

@@ -26,6 +26,14 @@ STAGE_NAMES = ("k_prep", "k_bucket", "k_rings_small", "k_rings_big", "k_rings_bi
                "k_desc_wg(exact)", "desc_tail")
 
 
+# kernels launched inside each timed stage (rocprofv3 / PMC rows are per kernel name)
+STAGE_KERNELS = {"k_rings_big(large)+k_merge_small": ("k_merge_small",),
+                 "k_merge_big+k_offsets": ("k_merge_big", "k_merge_huge", "k_offsets"),
+                 "k_desc_wg_fast": ("k_desc_wg_fast", "k_desc_wg_xl"),
+                 "k_desc_wg(exact)": ("k_desc_wg",),
+                 "desc_tail": ("k_desc_huge", "k_desc_spill", "k_rng_ord")}
+
+
 class FxParams(C.Structure):
     _fields_ = [("cloud_leveling", C.c_int32),
                 ("x_min", C.c_double), ("x_max", C.c_double),

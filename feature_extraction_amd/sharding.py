@@ -51,13 +51,17 @@ def unpack_records(rec):
     return out
 
 
-def all_gather_records(rec_tensor, world):
-    """One collective per batch: every rank's record block, in rank (= stream) order."""
+def all_gather_records(rec_tensor, world, out=None, async_op=False):
+    """One collective per batch: every rank's record block, in rank (= stream) order.
+    out: preallocated [world * B, 1 + rec_kp, 4] table (steady state: no allocation); async_op: return
+    (table, work) with the collective still in flight on its own stream (bench.py overlaps it with the
+    kernels of the batches behind it).  This is the function both bench.py (RCCL) and the gloo test run."""
     import torch
     import torch.distributed as dist
-    if world == 1:
-        return rec_tensor
-    out = torch.empty((world * rec_tensor.shape[0],) + tuple(rec_tensor.shape[1:]), dtype=rec_tensor.dtype,
-                      device=rec_tensor.device)
-    dist.all_gather_into_tensor(out.view(-1), rec_tensor.contiguous().view(-1))
-    return out
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
+        return (rec_tensor, None) if async_op else rec_tensor
+    if out is None:
+        out = torch.empty((world * rec_tensor.shape[0],) + tuple(rec_tensor.shape[1:]), dtype=rec_tensor.dtype,
+                          device=rec_tensor.device)
+    work = dist.all_gather_into_tensor(out.view(-1), rec_tensor.contiguous().view(-1), async_op=async_op)
+    return (out, work) if async_op else out

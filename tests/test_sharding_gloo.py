@@ -41,6 +41,11 @@ def _worker(rank, world, port, out_path):
     span = sharding.shard_range(TOTAL, world, rank)
     rec = torch.from_numpy(_records_for(span))
     gathered = sharding.all_gather_records(rec, world)
+    # the form bench.py uses: preallocated table, collective left in flight, waited for later
+    table = torch.zeros((TOTAL, 1 + sharding.REC_KP, 4), dtype=torch.float32)
+    same, work = sharding.all_gather_records(rec, world, out=table, async_op=True)
+    work.wait()
+    assert same is table and torch.equal(table, gathered)
     # max-over-ranks timing plumbing used by bench.py
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -18,7 +18,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-n_batches = int(sys.argv[2]) if len(sys.argv) > 2 else 29  # 3 contexts: warm-up 6 + timed 10 + profiled 12 + the totals pass
+n_batches = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # 0: one k_prep launch per batch of the bench workload, counted below
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -51,6 +51,9 @@ def counter(pattern, cname):
 
 
 fetch, dur_f, calls = counter("fetch/**/*_counter_collection.csv", "FETCH_SIZE")
+if not n_batches:
+    n_batches = calls["k_prep"]
+print(f"{n_batches} batches in the counter passes")
 write, _, _ = counter("write/**/*_counter_collection.csv", "WRITE_SIZE")
 rows, traffic = [], {}
 for k in sorted(fetch, key=lambda k: -dur_f[k]):
