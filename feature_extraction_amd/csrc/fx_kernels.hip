@@ -1205,26 +1205,39 @@ extern "C" __global__ __launch_bounds__(FX_WG, 5) void k_rings_big(FxDevParams P
 }
 
 // ====================================================================== stage 3: merge
-struct MergeLds {
-  float4 *pt;  // (x, y, pseudo z, elevation) of each candidate
-  float *cz;   // true z
-  uint32_t *parent, *csize, *rid, *croot, *crec, *rbase, *kbase, *s_w;
-};
-#define FX_MERGE_WORDS_PER_CAND 10
-__device__ __forceinline__ MergeLds merge_carve(uint32_t *smem, uint32_t cap, uint32_t n_rings) {
-  MergeLds L;
-  L.s_w = smem;
-  uint32_t *p = smem + SegCfg<FX_WG>::kWords;
-  L.pt = reinterpret_cast<float4 *>(p), p += 4 * cap;
-  L.cz = (float *)p, p += cap;
-  L.parent = p, p += cap;
-  L.csize = p, p += cap;
-  L.rid = p, p += cap;
-  L.croot = p, p += cap;
-  L.crec = p, p += cap;
-  L.rbase = p, p += (n_rings + 1);
-  L.kbase = p, p += (n_rings + 1);
-  return L;
+// Secondary merge (ref: node.cpp:209-257): keypoints_full = the per-ring candidates in ring order (:205), z replaced
+// by the scaled elevation (:217), a second pcl::EuclideanClusterExtraction (:222-229), centroids of the clusters'
+// true xyz -> keypoints (:238-257); and the scan's keypoint_cloud chunks laid out in ring order (:206).
+//
+// Candidates are not azimuth ordered (each ring lists its clusters in PCL's size order), so the ring kernels' run
+// labelling finds nothing here.  Instead the candidate ids are counting-sorted by xy cell:
+//  * cells are `tolerance` wide, so every pair closer than the tolerance lies in the same or in adjacent cells (the
+//    pseudo z only adds distance); the cell table is periodic — cells a period apart share a bin, which only costs
+//    distance tests: every pair that could be an edge is examined, and tested with the exact predicate;
+//  * every candidate tests the later candidates of the nine bins around it, skipping pairs already in one
+//    component; links go through the lock-free union-find of the ring kernels (root = smallest index = PCL's
+//    discovery order, SURVEY.md A.5);
+//  * sizes, then PCL's cluster order (cc_order);
+//  * the members of every admissible cluster are listed, ranked by index within their cluster (each member counts
+//    the smaller ids of its list), and one lane per cluster adds them in ascending index order in fp64 — the
+//    reference's loop order (ref: node.cpp:242-253).
+// Three tiers share this code: coordinates in LDS (k_merge_small: <= 512 candidates, one workgroup per scan;
+// k_merge_big: what fits 160 KB), or — scans with more candidates than LDS holds as points (a 128-ring scan under the
+// launch preset has ~5000) — coordinates left in HBM (k_merge_huge: the scan's `cand` rows, L2 resident).
+#define FX_MERGE_HEAD 160  // scratch words in front: block helpers [0..15], broadcast [16..31], sort stack [32..151]
+__host__ __device__ inline uint32_t merge_bins(uint32_t cap) { return cap <= 1024u ? 1024u : 4096u; }
+__host__ __device__ inline uint32_t merge_aux_words(uint32_t cap) {
+  const uint32_t a = merge_bins(cap) + 4 + (cap + 1) / 2;  // bin table + candidate ids (uint16); later the sizes
+  return a > cap ? a : cap;
+}
+// LDS words: lds_pts tiers hold (x, y, pseudo z, elevation), true z and the member lists on chip
+__host__ __device__ inline size_t merge_words(uint32_t cap, uint32_t ccap, uint32_t n_rings, bool lds_pts) {
+  size_t w = FX_MERGE_HEAD + ((2 * (n_rings + 1) + 3) & ~3u);
+  if (lds_pts) w += 5 * (size_t)cap + cap;  // pt, cz, member lists (2 x uint16 per candidate)
+  w += cap;                                 // parent
+  w += merge_aux_words(cap);
+  w += 3 * (size_t)ccap;                    // croot, crec, tmp / member-list bases
+  return w;
 }
 
 // largest r with base[r] <= idx, base = exclusive prefix with base[R] = total > idx
@@ -1240,55 +1253,229 @@ __device__ __forceinline__ uint32_t prefix_owner(const uint32_t *base, uint32_t 
   return lo;
 }
 
-// Second half of the secondary merge, shared by the LDS tiers and the large tier: the clusters cc_order returned
-// (n_c of them, in PCL's order) become keypoints (fp64 centroid of the members' true xyz in ascending candidate
-// order, intensity of the first member: ref: node.cpp:238-257), every candidate learns its keypoint, and the
-// scan's keypoint_cloud chunks are laid out in ring order (ref: node.cpp:206).  point(i) = candidate i as
-// (x, y, true z, elevation).
-template <int NT, typename PointFn>
-__device__ __forceinline__ void merge_finish(const FxDevParams &P, const FxBuffers &B, uint32_t scan, uint32_t C, uint32_t n_c,
-                                             const uint32_t *parent, uint32_t *csize, const uint32_t *croot,
-                                             const uint32_t *crec, const uint32_t *rbase, uint32_t *kbase, uint32_t *s_w,
-                                             PointFn point) {
+// Returns false when the scan has more candidates than this tier holds (the caller defers it to the next one).
+template <int NT, bool LDS_PTS>
+__device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers &B, uint32_t scan, uint32_t cap, uint32_t ccap,
+                                           uint32_t *smem, bool last_tier) {
+  unsigned long long *const stamp_base = B.stamps ? B.stamps + 32 : nullptr;
+  FX_STAMP_INIT(stamp_base);
   const uint32_t tid = threadIdx.x;
   const uint32_t R = (uint32_t)P.n_rings;
+  const uint32_t NB = merge_bins(cap), nb_mask = NB == 1024u ? 31u : 63u, nb_shift = NB == 1024u ? 5u : 6u;
+  uint32_t *s_w = smem;
+  uint32_t *rbase = smem + FX_MERGE_HEAD;  // [R + 1]
+  uint32_t *kbase = rbase + (R + 1);       // [R + 1]
+  uint32_t *p = smem + FX_MERGE_HEAD + ((2 * (R + 1) + 3) & ~3u);
+  float4 *pt = nullptr;   // (x, y, pseudo z, elevation)
+  float *cz = nullptr;    // true z
+  uint16_t *mlist = nullptr;  // [2][cap]: members of the admissible clusters, unordered then ordered
+  if (LDS_PTS) {
+    pt = reinterpret_cast<float4 *>(p), p += 4 * cap;
+    cz = reinterpret_cast<float *>(p), p += cap;
+    mlist = reinterpret_cast<uint16_t *>(p), p += cap;
+  }
+  uint32_t *parent = p;
+  p += cap;
+  uint32_t *aux = p;
+  p += merge_aux_words(cap);
+  uint32_t *croot = p, *crec = croot + ccap, *tmp = crec + ccap;
+  uint32_t *bin = aux;                                                  // [NB + 1]: counts -> starts -> ends
+  uint16_t *sorted = reinterpret_cast<uint16_t *>(aux + NB + 4);       // candidate ids, bin by bin
+  uint32_t *csize = aux;                                                // once the links are made
+  const uint32_t *rcnt = B.ring_cand_cnt + (size_t)scan * R;
+
+  // ---- ring bases
+  uint32_t C = 0;
+  for (uint32_t b0 = 0; b0 < R; b0 += NT) {
+    const uint32_t r = b0 + tid;
+    const uint32_t c = r < R ? rcnt[r] : 0u;
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan<NT>(c, s_w, tot);
+    if (r < R) rbase[r] = C + ex;
+    C += tot;
+  }
+  if (tid == 0) rbase[R] = C;
+  if (C > P.max_candidates) {
+    if (tid == 0) {
+      atomicOr(&B.flags[scan], FX_FLAG_CAND_OVERFLOW);
+      B.n_cand[scan] = 0;
+      B.n_kp[scan] = 0;
+      B.n_kpc[scan] = 0;
+    }
+    return true;
+  }
+  if (C > cap && !last_tier) return false;  // (cap == max_candidates in the last tier)
+  for (uint32_t t = tid; t <= NB; t += NT) bin[t] = 0;
+  __syncthreads();
+
+  float4 *cand = B.cand + (size_t)scan * P.max_candidates;
+  uint32_t *cand_size = B.cand_size + (size_t)scan * P.max_candidates;
   int32_t *cand_kp = B.cand_kp + (size_t)scan * P.max_candidates;
+  if (!LDS_PTS) mlist = reinterpret_cast<uint16_t *>(cand_kp);  // the row is scratch until its values are written at the end
+  const float inv_w = 1.0f / (sqrtf(P.r2_merge) * 1.01f);
+  auto bin_of = [&](int cx, int cy) { return (uint32_t)((cx & (int)nb_mask) | ((cy & (int)nb_mask) << nb_shift)); };
+  auto cell_x = [&](float x) { return (int)floorf((x - P.x_min) * inv_w); };
+  auto cell_y = [&](float y) { return (int)floorf((y - P.y_min) * inv_w); };
+  // ref: node.cpp:217  z = intensity*0.75*clusterRadiusThreshold/2  (double, left to right)
+  auto pseudo_z = [&](float el) { return (float)((double)el * 0.75 * P.crt / 2); };
+  auto merge_pt = [&](uint32_t i) {  // (x, y, pseudo z, elevation)
+    if (LDS_PTS) return pt[i];
+    const float4 v = cand[i];
+    return make_float4(v.x, v.y, pseudo_z(v.w), v.w);
+  };
+  auto true_pt = [&](uint32_t i) {  // (x, y, true z, elevation)
+    if (LDS_PTS) {
+      const float4 q = pt[i];
+      return make_float4(q.x, q.y, cz[i], q.w);
+    }
+    return cand[i];
+  };
+  // all candidates in parallel (each finds its ring in the prefix table)
+  for (uint32_t idx = tid; idx < C; idx += NT) {
+    const uint32_t r = prefix_owner(rbase, R, idx), j = idx - rbase[r];
+    const float4 v = B.ring_cand[((size_t)scan * R + r) * P.max_ring_cands + j];
+    if (LDS_PTS) {
+      pt[idx] = make_float4(v.x, v.y, pseudo_z(v.w), v.w);
+      cz[idx] = v.z;
+    }
+    cand[idx] = v;
+    cand_size[idx] = B.ring_cand_size[((size_t)scan * R + r) * P.max_ring_cands + j];
+    parent[idx] = idx;
+    atomicAdd(&bin[bin_of(cell_x(v.x), cell_y(v.y))], 1u);
+  }
+  if (!LDS_PTS) __threadfence();  // `cand` is re-read below by other waves of this workgroup
+  __syncthreads();
+  FX_STAMP(1);
+  uint32_t n_c = 0;
+  if (C > 0) {  // ref: node.cpp:209-210
+    if (tid < 64) {  // counts -> exclusive starts, in place, by one wavefront
+      const uint32_t per = NB / 64;
+      uint32_t sum = 0;
+      for (uint32_t u = 0; u < per; ++u) sum += bin[tid * per + u];
+      uint32_t incl = sum;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+        if ((int)tid >= d) incl += o;
+      }
+      uint32_t run = incl - sum;
+      for (uint32_t u = 0; u < per; ++u) {
+        const uint32_t c = bin[tid * per + u];
+        bin[tid * per + u] = run;
+        run += c;
+      }
+    }
+    __syncthreads();
+    for (uint32_t idx = tid; idx < C; idx += NT) {  // each id to its bin: a start becomes the bin's end
+      const float4 v = merge_pt(idx);
+      sorted[atomicAdd(&bin[bin_of(cell_x(v.x), cell_y(v.y))], 1u)] = (uint16_t)idx;
+    }
+    __syncthreads();
+    FX_STAMP(2);
+    // ---- pcl::EuclideanClusterExtraction on (x, y, pseudo z) (ref: node.cpp:222-229)
+    // (one work item per (candidate, neighbouring bin): a wavefront's trip count is then the longest single bin of its
+    //  lanes, not the sum over nine bins of the longest; two entries per trip, loaded before either is used; the
+    //  distance test comes before any union-find lookup — one LDS round trip against several dependent ones)
+    for (uint32_t t = tid; t < 9u * C; t += NT) {
+      const uint32_t i = t / 9u, d = t - 9u * i;
+      const float4 v = merge_pt(i);
+      const uint32_t b = bin_of(cell_x(v.x) + (int)(d % 3u) - 1, cell_y(v.y) + (int)(d / 3u) - 1);
+      const uint32_t q0 = b ? bin[b - 1] : 0u, q1 = bin[b];
+      for (uint32_t q = q0; q < q1; q += 2) {
+        const uint32_t j0 = sorted[q], j1 = sorted[min(q + 1u, q1 - 1u)];
+        const float4 u0 = merge_pt(j0), u1 = merge_pt(j1);
+        // every pair once (j > i)
+        if (j0 > i && dist2(v.x, v.y, v.z, u0.x, u0.y, u0.z) < P.r2_merge) uf_union(parent, j0, i);
+        if (q + 1u < q1 && j1 > i && dist2(v.x, v.y, v.z, u1.x, u1.y, u1.z) < P.r2_merge) uf_union(parent, j1, i);
+      }
+    }
+    __syncthreads();
+    FX_STAMP(3);
+    for (uint32_t i = tid; i < C; i += NT) parent[i] = uf_find_ro(parent, i);
+    for (uint32_t i = tid; i < C; i += NT) csize[i] = 0u;  // (bin table and ids are done with)
+    __syncthreads();
+    for (uint32_t i = tid; i < C; i += NT) atomicAdd(&csize[parent[i]], 1u);
+    __syncthreads();
+    FX_STAMP(4);
+    n_c = cc_order<NT>(C, parent, csize, P.ndc, P.secondary_max, croot, crec, tmp, ccap, s_w, stamp_base);
+    if (n_c > ccap) {  // (large tier only: ccap >= max_keypoints there, so the scan overflows its keypoints anyway)
+      if (tid == 0) atomicOr(&B.flags[scan], FX_FLAG_KP_OVERFLOW);
+      n_c = 0;
+    }
+#ifdef FX_STAMPS
+    stamp_prev_ = __builtin_amdgcn_s_memtime();
+#endif
+  }
+
+  // ---- clusters -> keypoints (ref: node.cpp:238-257)
   uint32_t K = 0;
   if (C > 0) {
     K = n_c < P.max_keypoints ? n_c : P.max_keypoints;
     if (n_c > P.max_keypoints && tid == 0) atomicOr(&B.flags[scan], FX_FLAG_KP_OVERFLOW);
+    // position in PCL's order next to the size; crec[s] becomes (size, root index) and mbase[s] the start of the
+    // cluster's member list (tmp is free after cc_order; croot is free once the roots are in crec)
+    uint32_t *mbase = tmp, *mfill = croot;
+    uint32_t run = 0;
+    for (uint32_t b0 = 0; b0 < n_c; b0 += NT) {
+      const uint32_t s = b0 + tid;
+      uint32_t sz = 0, root = 0;
+      if (s < n_c) {
+        const uint32_t rec = crec[s];
+        sz = rec >> 16;
+        root = croot[rec & 0xffffu];
+        csize[root] |= (s + 1u) << 16;
+      }
+      uint32_t tot;
+      const uint32_t ex = block_excl_scan<NT>(sz, s_w, tot);
+      if (s < n_c) {
+        crec[s] = (sz << 16) | root;  // (root < 65536: candidate ids fit 16 bits)
+        mbase[s] = run + ex;
+      }
+      run += tot;
+    }
+    __syncthreads();
+    for (uint32_t s = tid; s < n_c; s += NT) mfill[s] = 0u;
+    __syncthreads();
+    uint16_t *unord = mlist, *ord = mlist + cap;
+    for (uint32_t i = tid; i < C; i += NT) {
+      const uint32_t pos = csize[parent[i]] >> 16;
+      if (pos == 0) continue;
+      unord[mbase[pos - 1u] + atomicAdd(&mfill[pos - 1u], 1u)] = (uint16_t)i;
+    }
+    if (!LDS_PTS) __threadfence();
+    __syncthreads();
+    for (uint32_t i = tid; i < C; i += NT) {  // rank within the cluster = members with a smaller index
+      const uint32_t pos = csize[parent[i]] >> 16;
+      if (pos == 0) continue;
+      const uint32_t s = pos - 1u, m0 = mbase[s], sz = crec[s] >> 16;
+      uint32_t rank = 0;
+      for (uint32_t m = 0; m < sz; ++m) rank += (uint32_t)unord[m0 + m] < i ? 1u : 0u;
+      ord[m0 + rank] = (uint16_t)i;
+    }
+    if (!LDS_PTS) __threadfence();
+    __syncthreads();
     float4 *kp = B.keypoints + (size_t)scan * P.max_keypoints;
     uint32_t *kps = B.kp_size + (size_t)scan * P.max_keypoints;
-    for (uint32_t s = tid; s < n_c; s += NT) {
+    for (uint32_t s = tid; s < K; s += NT) {
       const uint32_t rec = crec[s];
-      const uint32_t sz = rec >> 16, root = croot[rec & 0xffffu];
-      csize[root] |= (s + 1u) << 16;  // position in PCL's order, next to the size
-      if (s >= K) continue;
+      const uint32_t sz = rec >> 16, root = rec & 0xffffu, m0 = mbase[s];
       double sumx = 0.0, sumy = 0.0, sumz = 0.0;
-      uint32_t cnt = 0;
-      // (members are scattered over the candidate list: eight labels per LDS round trip)
-      for (uint32_t i = root; i < C && cnt < sz; i += 8) {
-        uint32_t pr[8];
-#pragma unroll
-        for (uint32_t u = 0; u < 8; ++u) pr[u] = parent[min(i + u, C - 1u)];
-#pragma unroll
-        for (uint32_t u = 0; u < 8; ++u) {
-          if (i + u >= C || pr[u] != root) continue;
-          const float4 q = point(i + u);
-          sumx += (double)q.x;
-          sumy += (double)q.y;
-          sumz += (double)q.z;
-          ++cnt;
-        }
+      for (uint32_t m = 0; m < sz; ++m) {
+        const float4 q = true_pt(ord[m0 + m]);
+        sumx += (double)q.x;
+        sumy += (double)q.y;
+        sumz += (double)q.z;
       }
-      kp[s] = make_float4((float)(sumx / (double)sz), (float)(sumy / (double)sz), (float)(sumz / (double)sz), point(root).w);
+      kp[s] = make_float4((float)(sumx / (double)sz), (float)(sumy / (double)sz), (float)(sumz / (double)sz), true_pt(root).w);
       kps[s] = sz;
     }
     __syncthreads();
+    FX_STAMP(8);
     for (uint32_t i = tid; i < C; i += NT) {
       const uint32_t pos = csize[parent[i]] >> 16;
       cand_kp[i] = (pos != 0 && pos - 1u < K) ? (int32_t)(pos - 1u) : -1;
     }
+    FX_STAMP(9);
   }
 
   // ---- keypoint_cloud: chunks into ring order, candidate slot -> ordinal in keypoints_full
@@ -1309,14 +1496,24 @@ __device__ __forceinline__ void merge_finish(const FxDevParams &P, const FxBuffe
   }
   if (tid == 0) kbase[R] = run;
   __syncthreads();
+  FX_STAMP(10);
   if (run > P.max_kpc) {
     if (tid == 0) atomicOr(&B.flags[scan], FX_FLAG_KPC_OVERFLOW);
     run = 0;
   }
-  for (uint32_t t = tid; t < run; t += NT) {
-    const uint32_t r = prefix_owner(kbase, R, t), j = t - kbase[r];
-    kpc[t] = pool[koff[r] + j];
-    kpc_c[t] = rbase[r] + pool_c[koff[r] + j];
+  // (four elements per trip, loaded before any is stored; the index is clamped so that no load is conditional)
+  for (uint32_t t0 = tid; t0 < run; t0 += 4 * NT) {
+    const uint32_t ta = t0, tb = min(t0 + NT, run - 1u), tc = min(t0 + 2 * NT, run - 1u), td = min(t0 + 3 * NT, run - 1u);
+    const uint32_t ra = prefix_owner(kbase, R, ta), rb = prefix_owner(kbase, R, tb), rc = prefix_owner(kbase, R, tc),
+                   rd = prefix_owner(kbase, R, td);
+    const uint32_t sa = koff[ra] + (ta - kbase[ra]), sb = koff[rb] + (tb - kbase[rb]), sc = koff[rc] + (tc - kbase[rc]),
+                   sd = koff[rd] + (td - kbase[rd]);
+    const float4 va = pool[sa], vb = pool[sb], vc = pool[sc], vd = pool[sd];
+    const uint32_t ca = rbase[ra] + pool_c[sa], cb = rbase[rb] + pool_c[sb], cc = rbase[rc] + pool_c[sc], cd = rbase[rd] + pool_c[sd];
+    kpc[ta] = va, kpc_c[ta] = ca;  // (clamped duplicates rewrite the last element with the same value)
+    kpc[tb] = vb, kpc_c[tb] = cb;
+    kpc[tc] = vc, kpc_c[tc] = cc;
+    kpc[td] = vd, kpc_c[td] = cd;
   }
   if (tid == 0) {
     B.n_cand[scan] = C;
@@ -1324,225 +1521,44 @@ __device__ __forceinline__ void merge_finish(const FxDevParams &P, const FxBuffe
     B.n_kpc[scan] = run;
   }
   __syncthreads();
-}
-
-// One scan: keypoints_full = per-ring candidates in ring order (ref: node.cpp:205), pseudo-z,
-// second Euclidean clustering, centroids -> keypoints (ref: node.cpp:212-257); then the
-// scan's keypoint_cloud chunks are laid out in ring order (ref: node.cpp:206).
-__device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers &B, uint32_t scan, uint32_t cap, uint32_t *smem,
-                           bool last_tier) {
-  MergeLds L = merge_carve(smem, cap, (uint32_t)P.n_rings);
-  unsigned long long *const stamp_base = B.stamps ? B.stamps + 32 : nullptr;
-  FX_STAMP_INIT(stamp_base);
-  const uint32_t tid = threadIdx.x;
-  const uint32_t R = (uint32_t)P.n_rings;
-  const uint32_t *rcnt = B.ring_cand_cnt + (size_t)scan * R;
-
-  // ---- ring bases
-  uint32_t C = 0;
-  for (uint32_t b0 = 0; b0 < R; b0 += FX_WG) {
-    const uint32_t r = b0 + tid;
-    const uint32_t c = r < R ? rcnt[r] : 0u;
-    uint32_t tot;
-    const uint32_t ex = block_excl_scan<FX_WG>(c, L.s_w, tot);
-    if (r < R) L.rbase[r] = C + ex;
-    C += tot;
-  }
-  if (tid == 0) L.rbase[R] = C;
-  __syncthreads();
-
-  if (C > P.max_candidates) {
-    if (tid == 0) {
-      atomicOr(&B.flags[scan], FX_FLAG_CAND_OVERFLOW);
-      B.n_cand[scan] = 0;
-      B.n_kp[scan] = 0;
-      B.n_kpc[scan] = 0;
-    }
-    return true;
-  }
-  if (C > cap && !last_tier) return false;  // (cap == max_candidates in the last tier)
-
-  float4 *cand = B.cand + (size_t)scan * P.max_candidates;
-  uint32_t *cand_size = B.cand_size + (size_t)scan * P.max_candidates;
-  // all candidates in parallel (each finds its ring in the prefix table)
-  for (uint32_t idx = tid; idx < C; idx += FX_WG) {
-    const uint32_t r = prefix_owner(L.rbase, R, idx), j = idx - L.rbase[r];
-    const float4 v = B.ring_cand[((size_t)scan * R + r) * P.max_ring_cands + j];
-    // ref: node.cpp:217  z = intensity*0.75*clusterRadiusThreshold/2  (double, left to right)
-    L.pt[idx] = make_float4(v.x, v.y, (float)((double)v.w * 0.75 * P.crt / 2), v.w);
-    L.cz[idx] = v.z;
-    cand[idx] = v;
-    cand_size[idx] = B.ring_cand_size[((size_t)scan * R + r) * P.max_ring_cands + j];
-  }
-  __syncthreads();
-
-  FX_STAMP(1);
-  uint32_t n_c = 0;
-  if (C > 0) {  // ref: node.cpp:209-210
-    cc_label<FX_WG>(L.pt, C, P.r2_merge, L.parent, L.csize, L.rid, L.s_w, stamp_base);
-    n_c = cc_order<FX_WG>(C, L.parent, L.csize, P.ndc, P.secondary_max, L.croot, L.crec, L.rid, cap, L.s_w, stamp_base);
-  }
-  merge_finish<FX_WG>(P, B, scan, C, n_c, L.parent, L.csize, L.croot, L.crec, L.rbase, L.kbase, L.s_w,
-                      [&](uint32_t i) { const float4 q = L.pt[i]; return make_float4(q.x, q.y, L.cz[i], q.w); });
   FX_STAMP(11);
   return true;
 }
 
-extern "C" __global__ __launch_bounds__(FX_WG) void k_merge_small(FxDevParams P, FxBuffers B, uint32_t cap) {
+#ifndef FX_MSMALL_T
+#define FX_MSMALL_T 256
+#endif
+extern "C" __global__ __launch_bounds__(FX_MSMALL_T) void k_merge_small(FxDevParams P, FxBuffers B, uint32_t cap) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   {  // the support-list counters of the batch are cleared here, a slice per scan (k_gather fills them)
     const uint32_t per = (P.max_total_kp + gridDim.x - 1) / gridDim.x;
     const uint32_t z0 = blockIdx.x * per, z1 = min(z0 + per, P.max_total_kp);
-    for (uint32_t t = z0 + threadIdx.x; t < z1; t += FX_WG) B.s_cnt[t] = 0u;
+    for (uint32_t t = z0 + threadIdx.x; t < z1; t += FX_MSMALL_T) B.s_cnt[t] = 0u;
   }
-  if (!merge_body(P, B, blockIdx.x, cap, smem, false)) {
+  if (!merge_body<FX_MSMALL_T, true>(P, B, blockIdx.x, cap, cap, smem, false)) {
     if (threadIdx.x == 0) {
       const uint32_t pos = atomicAdd(&B.counters[1], 1u);
       B.big_merge[pos] = blockIdx.x;
     }
   }
 }
-extern "C" __global__ __launch_bounds__(FX_WG) void k_merge_big(FxDevParams P, FxBuffers B, uint32_t cap, uint32_t last) {
+#define FX_MBIG_T 1024
+extern "C" __global__ __launch_bounds__(FX_MBIG_T) void k_merge_big(FxDevParams P, FxBuffers B, uint32_t cap, uint32_t last) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const uint32_t n_big = B.counters[1];
   for (uint32_t w = blockIdx.x; w < n_big; w += gridDim.x) {
     const uint32_t scan = B.big_merge[w];
-    if (!merge_body(P, B, scan, cap, smem, last != 0)) {
+    if (!merge_body<FX_MBIG_T, true>(P, B, scan, cap, cap, smem, last != 0)) {
       if (threadIdx.x == 0) B.huge_merge[atomicAdd(&B.counters[9], 1u)] = scan;  // more candidates than LDS holds as points
     }
     __syncthreads();
   }
 }
-
-// ---------------------------------------------------------------- large merge tier
-// Scans with more per-ring candidates than one workgroup's LDS holds as points (dense many-ring sensors: a
-// 128-ring scan under the launch preset has ~5000).  LDS keeps only the union-find parents and a counting sort
-// of the candidate ids by xy cell; the coordinates stay in HBM (the scan's `cand` rows, L2 resident).
-//  * cells are `tolerance` wide, so every pair closer than the tolerance lies in the same or in adjacent cells
-//    (pseudo-z only adds distance); the 64 x 64 cell table is periodic — cells 64 apart share a bin, which only
-//    costs distance tests: every pair that could be an edge is examined and tested with the exact predicate;
-//  * every candidate tests the later candidates of the nine bins around it, skipping pairs already in one
-//    component; links go through the same lock-free union-find as the LDS tiers (root = smallest index = PCL's
-//    discovery order);
-//  * sizes, PCL's cluster order (cc_order) and the keypoints (merge_finish) are the code of the LDS tiers.
-#define FX_MHUGE_T 1024
-#define FX_MHUGE_BINS 4096
-#define FX_MHUGE_HEAD 160  // scratch words in front: block helpers, broadcast slots, sort stack
-__host__ __device__ inline uint32_t mhuge_aux_words(uint32_t cap) {
-  const uint32_t a = FX_MHUGE_BINS + 4 + (cap + 1) / 2;  // bin table + candidate ids (uint16), later the sizes
-  return a > cap ? a : cap;
-}
-__device__ __forceinline__ void merge_huge_body(const FxDevParams &P, const FxBuffers &B, uint32_t scan, uint32_t cap,
-                                                uint32_t ccap, uint32_t *smem) {
-  constexpr int NT = FX_MHUGE_T;
-  const uint32_t tid = threadIdx.x;
-  const uint32_t R = (uint32_t)P.n_rings;
-  uint32_t *s_w = smem;
-  uint32_t *rbase = smem + FX_MHUGE_HEAD;  // [R + 1]
-  uint32_t *kbase = rbase + (R + 1);       // [R + 1]
-  uint32_t *parent = kbase + (R + 1);      // [cap]
-  uint32_t *aux = parent + cap;            // [mhuge_aux_words(cap)]
-  uint32_t *croot = aux + mhuge_aux_words(cap);  // [ccap]
-  uint32_t *crec = croot + ccap;                 // [ccap]
-  uint32_t *tmp = crec + ccap;                   // [ccap]
-  uint32_t *bin = aux;                                                   // [BINS + 1]: counts -> starts -> ends
-  uint16_t *sorted = reinterpret_cast<uint16_t *>(aux + FX_MHUGE_BINS + 4);  // candidate ids, bin by bin
-  uint32_t *csize = aux;                                                 // once the links are made
-  const uint32_t *rcnt = B.ring_cand_cnt + (size_t)scan * R;
-
-  uint32_t C = 0;
-  for (uint32_t b0 = 0; b0 < R; b0 += NT) {
-    const uint32_t r = b0 + tid;
-    const uint32_t c = r < R ? rcnt[r] : 0u;
-    uint32_t tot;
-    const uint32_t ex = block_excl_scan<NT>(c, s_w, tot);
-    if (r < R) rbase[r] = C + ex;
-    C += tot;
-  }
-  if (tid == 0) rbase[R] = C;
-  for (uint32_t t = tid; t <= FX_MHUGE_BINS; t += NT) bin[t] = 0;
-  __syncthreads();
-  // (C <= cap == max_candidates: the LDS tiers flag larger scans themselves)
-
-  float4 *cand = B.cand + (size_t)scan * P.max_candidates;
-  uint32_t *cand_size = B.cand_size + (size_t)scan * P.max_candidates;
-  const float inv_w = 1.0f / (sqrtf(P.r2_merge) * 1.01f);
-  auto bin_of = [&](int cx, int cy) { return (uint32_t)((cx & 63) | ((cy & 63) << 6)); };
-  auto cell_x = [&](float x) { return (int)floorf((x - P.x_min) * inv_w); };
-  auto cell_y = [&](float y) { return (int)floorf((y - P.y_min) * inv_w); };
-  // ref: node.cpp:217  z = intensity*0.75*clusterRadiusThreshold/2  (double, left to right)
-  auto pseudo_z = [&](float el) { return (float)((double)el * 0.75 * P.crt / 2); };
-  for (uint32_t idx = tid; idx < C; idx += NT) {
-    const uint32_t r = prefix_owner(rbase, R, idx), j = idx - rbase[r];
-    const float4 v = B.ring_cand[((size_t)scan * R + r) * P.max_ring_cands + j];
-    cand[idx] = v;
-    cand_size[idx] = B.ring_cand_size[((size_t)scan * R + r) * P.max_ring_cands + j];
-    parent[idx] = idx;
-    atomicAdd(&bin[bin_of(cell_x(v.x), cell_y(v.y))], 1u);
-  }
-  __threadfence();  // `cand` is re-read below by other waves of this workgroup
-  __syncthreads();
-  if (tid < 64) {  // counts -> exclusive starts, in place, by one wavefront
-    constexpr uint32_t per = FX_MHUGE_BINS / 64;
-    uint32_t sum = 0;
-    for (uint32_t u = 0; u < per; ++u) sum += bin[tid * per + u];
-    uint32_t incl = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
-      if ((int)tid >= d) incl += o;
-    }
-    uint32_t run = incl - sum;
-    for (uint32_t u = 0; u < per; ++u) {
-      const uint32_t c = bin[tid * per + u];
-      bin[tid * per + u] = run;
-      run += c;
-    }
-  }
-  __syncthreads();
-  for (uint32_t idx = tid; idx < C; idx += NT) {  // each id to its bin: a start becomes the bin's end
-    const float4 v = cand[idx];
-    sorted[atomicAdd(&bin[bin_of(cell_x(v.x), cell_y(v.y))], 1u)] = (uint16_t)idx;
-  }
-  __syncthreads();
-  // ---- pcl::EuclideanClusterExtraction on (x, y, pseudo z) (ref: node.cpp:222-229)
-  for (uint32_t i = tid; i < C; i += NT) {
-    const float4 v = cand[i];
-    const float pz = pseudo_z(v.w);
-    const int cx = cell_x(v.x), cy = cell_y(v.y);
-    for (int d = 0; d < 9; ++d) {
-      const uint32_t b = bin_of(cx + d % 3 - 1, cy + d / 3 - 1);
-      const uint32_t q0 = b ? bin[b - 1] : 0u, q1 = bin[b];
-      for (uint32_t q = q0; q < q1; ++q) {
-        const uint32_t j = sorted[q];
-        if (j <= i) continue;  // every pair once
-        if (uf_find(parent, i) == uf_find(parent, j)) continue;
-        const float4 u = cand[j];
-        if (dist2(v.x, v.y, pz, u.x, u.y, pseudo_z(u.w)) < P.r2_merge) uf_union(parent, j, i);
-      }
-    }
-  }
-  __syncthreads();
-  for (uint32_t i = tid; i < C; i += NT) parent[i] = uf_find_ro(parent, i);
-  for (uint32_t i = tid; i < C; i += NT) csize[i] = 0u;  // (bin table and ids are done with)
-  __syncthreads();
-  for (uint32_t i = tid; i < C; i += NT) atomicAdd(&csize[parent[i]], 1u);
-  __syncthreads();
-  uint32_t n_c = 0;
-  if (C > 0) {
-    n_c = cc_order<NT>(C, parent, csize, P.ndc, P.secondary_max, croot, crec, tmp, ccap, s_w);
-    if (n_c > ccap) {  // more clusters than can be ordered here; ccap >= max_keypoints, so the scan overflows anyway
-      if (tid == 0) atomicOr(&B.flags[scan], FX_FLAG_KP_OVERFLOW);
-      n_c = 0;
-    }
-  }
-  merge_finish<NT>(P, B, scan, C, n_c, parent, csize, croot, crec, rbase, kbase, s_w, [&](uint32_t i) { return cand[i]; });
-}
-extern "C" __global__ __launch_bounds__(FX_MHUGE_T) void k_merge_huge(FxDevParams P, FxBuffers B, uint32_t cap, uint32_t ccap) {
+extern "C" __global__ __launch_bounds__(FX_MBIG_T) void k_merge_huge(FxDevParams P, FxBuffers B, uint32_t cap, uint32_t ccap) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const uint32_t n_big = B.counters[9];
   for (uint32_t w = blockIdx.x; w < n_big; w += gridDim.x) {
-    merge_huge_body(P, B, B.huge_merge[w], cap, ccap, smem);
+    merge_body<FX_MBIG_T, false>(P, B, B.huge_merge[w], cap, ccap, smem, true);
     __syncthreads();
   }
 }
@@ -3017,12 +3033,8 @@ size_t fxk_ring_lds_bytes(uint32_t cap, uint32_t ccap) {
 size_t fxk_ring_wave_lds_bytes(uint32_t cap, uint32_t ccap) {
   return (size_t)(SegCfg<FX_RING_SMALL_T>::kWords + FX_RING_WORDS_PER_POINT * cap + FX_RING_WORDS_PER_CLUSTER * ccap) * 4;
 }
-size_t fxk_merge_lds_bytes(uint32_t cap, uint32_t n_rings) {
-  return (size_t)(SegCfg<FX_WG>::kWords + FX_MERGE_WORDS_PER_CAND * cap + 2 * (n_rings + 1)) * 4;
-}
-size_t fxk_merge_huge_lds_bytes(uint32_t cap, uint32_t ccap, uint32_t n_rings) {
-  return (size_t)(FX_MHUGE_HEAD + 2 * (n_rings + 1) + cap + mhuge_aux_words(cap) + 3 * ccap) * 4;
-}
+size_t fxk_merge_lds_bytes(uint32_t cap, uint32_t n_rings) { return merge_words(cap, cap, n_rings, true) * 4; }
+size_t fxk_merge_huge_lds_bytes(uint32_t cap, uint32_t ccap, uint32_t n_rings) { return merge_words(cap, ccap, n_rings, false) * 4; }
 uint32_t fxk_huge_cap(void) { return FX_HUGE_CAP; }
 size_t fxk_gather_lds_bytes(uint32_t max_keypoints) {
   return (16 + 80 + 7 * (size_t)max_keypoints + FX_GATHER_BINS + FX_GATHER_STAGE + 4 + 4 * FX_GATHER_STAGE) * 4;
@@ -3064,13 +3076,13 @@ void fxk_rings_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint
   hipLaunchKernelGGL(k_rings_big, dim3(grid), dim3(FX_WG), fxk_ring_lds_bytes(cap, ccap), s, P, B, cap, ccap, huge);
 }
 void fxk_merge_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap) {
-  hipLaunchKernelGGL(k_merge_small, dim3(batch), dim3(FX_WG), fxk_merge_lds_bytes(cap, P.n_rings), s, P, B, cap);
+  hipLaunchKernelGGL(k_merge_small, dim3(batch), dim3(FX_MSMALL_T), fxk_merge_lds_bytes(cap, P.n_rings), s, P, B, cap);
 }
 void fxk_merge_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t grid, uint32_t last) {
-  hipLaunchKernelGGL(k_merge_big, dim3(grid), dim3(FX_WG), fxk_merge_lds_bytes(cap, P.n_rings), s, P, B, cap, last);
+  hipLaunchKernelGGL(k_merge_big, dim3(grid), dim3(FX_MBIG_T), fxk_merge_lds_bytes(cap, P.n_rings), s, P, B, cap, last);
 }
 void fxk_merge_huge(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t ccap, uint32_t grid) {
-  hipLaunchKernelGGL(k_merge_huge, dim3(grid), dim3(FX_MHUGE_T), fxk_merge_huge_lds_bytes(cap, ccap, P.n_rings), s, P, B, cap, ccap);
+  hipLaunchKernelGGL(k_merge_huge, dim3(grid), dim3(FX_MBIG_T), fxk_merge_huge_lds_bytes(cap, ccap, P.n_rings), s, P, B, cap, ccap);
 }
 void fxk_offsets(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch) {
   hipLaunchKernelGGL(k_offsets, dim3(1), dim3(FX_WG), 0, s, P, B, batch);
