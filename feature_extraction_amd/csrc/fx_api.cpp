@@ -25,8 +25,9 @@ size_t fxk_desc_lds_bytes(uint32_t cap);
 size_t fxk_gather_lds_bytes(uint32_t max_keypoints);
 uint32_t fxk_huge_cap(void);
 size_t fxk_merge_huge_lds_bytes(uint32_t cap, uint32_t ccap, uint32_t n_rings);
-hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t merge_huge, size_t desc_big);
-void fxk_prep(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
+hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t merge_huge, size_t desc_big, size_t gather);
+uint32_t fxk_near_words(uint32_t max_points);
+void fxk_prep(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float near_margin);
 void fxk_bucket(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float el0, float inv_step);
 void fxk_rings_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t ccap,
                      uint32_t mid_cap, uint32_t grid);
@@ -184,7 +185,7 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof) {
     const uint32_t ring_small = L.max_ring_points < kRingCapSmall ? L.max_ring_points : kRingCapSmall;
     const uint32_t merge_small = L.max_candidates < kMergeCapSmall ? L.max_candidates : kMergeCapSmall;
     const uint32_t desc_grid = (uint32_t)c->n_cu * c->desc_wgs_per_cu;  // resident all at once (32 KB LDS each)
-    fxk_prep(s, P, B, batch);
+    fxk_prep(s, P, B, batch, c->box_margin);
     FX_HIP(mark(1));
     fxk_bucket(s, P, B, batch, (float)c->params.el0_deg, (float)(1.0 / c->params.el_step_deg));
     FX_HIP(mark(2));
@@ -334,8 +335,8 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   if (merge_big_cap < L.max_candidates &&
       (L.max_candidates > 65535 || fxk_merge_huge_lds_bytes(L.max_candidates, merge_huge_ccap, params->n_rings) > kLds))
     return fail(FX_ERR_INVALID_ARG, "max_candidates (with max_keypoints) exceeds the LDS budget of the large merge tier (<= ~16000)");
-  if (fxk_gather_lds_bytes(L.max_keypoints) > 64 * 1024)
-    return fail(FX_ERR_INVALID_ARG, "max_keypoints exceeds the LDS budget of the support gather (<= ~1500)");
+  if (fxk_gather_lds_bytes(L.max_keypoints) > 96 * 1024)
+    return fail(FX_ERR_INVALID_ARG, "max_keypoints exceeds the LDS budget of the support gather (<= ~1700)");
   if (fxk_desc_lds_bytes(L.max_neighbors) > kLds) return fail(FX_ERR_INVALID_ARG, "max_neighbors exceeds the LDS budget (<= ~4800)");
   if (L.max_keypoints > 65535 || L.max_candidates > 32768 || L.max_ring_points > 32768)
     return fail(FX_ERR_INVALID_ARG, "limit exceeds the 16-bit packing of the order replay");
@@ -395,6 +396,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   P.max_neighbors = L.max_neighbors;
   P.max_ring_points = L.max_ring_points;
   P.list_cap = L.max_neighbors < kListCap ? L.max_neighbors : kListCap;
+  P.near_words = fxk_near_words(L.max_points);
   P.huge_cap = fxk_huge_cap();
   if (const char *e = getenv("FX_HUGE_CAP")) {  // test hook: push large support sets on to the slab tier
     const uint32_t v = (uint32_t)atoi(e);
@@ -428,6 +430,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   b.xaxis = d_xa;
   FX_A(dev_alloc(c, &b.filt, B * L.max_points));
   FX_A(dev_alloc(c, &b.n_filt, B));
+  FX_A(dev_alloc(c, &b.near_bits, B * P.near_words));
   FX_A(dev_alloc(c, &b.ring_cand, B * R * L.max_ring_candidates));
   FX_A(dev_alloc(c, &b.ring_cand_size, B * R * L.max_ring_candidates));
   FX_A(dev_alloc(c, &b.ring_cand_cnt, B * R));
@@ -524,7 +527,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   {
     hipError_t ce = fxk_configure(fxk_ring_lds_bytes(L.max_ring_points, L.max_ring_points), fxk_merge_lds_bytes(c->merge_big_cap, params->n_rings),
                                   c->merge_big_cap < L.max_candidates ? fxk_merge_huge_lds_bytes(L.max_candidates, c->merge_huge_ccap, params->n_rings) : 0,
-                                  fxk_desc_lds_bytes(L.max_neighbors));
+                                  fxk_desc_lds_bytes(L.max_neighbors), fxk_gather_lds_bytes(L.max_keypoints));
     if (ce != hipSuccess) return bail(fail(FX_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(ce)));
   }
   if (hipMemset(b.counters, 0, FX_N_COUNTERS * sizeof(uint32_t)) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));

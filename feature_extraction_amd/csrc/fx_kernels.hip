@@ -706,26 +706,51 @@ __device__ __forceinline__ uint32_t cc_order(uint32_t n, const uint32_t *parent,
 // ====================================================================== stage 1: prep
 // One workgroup per scan streams the scan once: rotate (fp32, PCL's scalar order), apply
 // the three PassThrough predicates at once and compact the survivors of a tile, in input
-// order (wave ballot + prefix), into an LDS buffer.  The elevation angle (fp64 atan2) is computed
+// order (wave ballot + prefix), into an LDS buffer.  The elevation angle (fp64) is computed
 // by dense sweeps over the buffered survivors only — about one point in ten survives, and in
 // firing order the survivors are spread over every wavefront.
+// The same pass records, one bit per 64 consecutive points, whether any of them lies within the descriptor
+// stage's reach of the filter box (every keypoint is a centroid of filtered points, hence inside the box; a point
+// farther than the support radius from the box cannot support any keypoint): k_gather skips the others unread.
 #define FX_PREP_T 512
 #define FX_PREP_U 4
+#define FX_PREP_TILE (FX_PREP_T * FX_PREP_U)  // 2048 points = 32 groups of 64 = one word of near bits
 typedef float __attribute__((address_space(1))) gfloat;
-__global__ __launch_bounds__(FX_PREP_T) void k_prep(FxDevParams P, FxBuffers B) {
+
+// getElevationAngles (ref: node.cpp:147-156): az = atan2(y, x); xp = cos(az) x + sin(az) y;
+// intensity = atan2(z, xp) * 180 / M_PI in double, stored as float.  cos(az) x + sin(az) y is |xy| up to a few
+// ulp of double, so atan2(z, sqrt(x^2 + y^2)) rounds to the same float unless it falls within that error of a
+// float rounding boundary; only then (about one point in 10^4) is the reference's own expression evaluated.
+__device__ __forceinline__ float elevation_deg(float xf, float yf, float zf) {
+  const double x = xf, y = yf, z = zf;
+  const double e = atan2(z, sqrt(x * x + y * y)) * 180 / M_PI;
+  const float f = (float)e;
+  const float af = fabsf(f);
+  // distance from e to the nearer rounding boundary of f, with the smaller of f's two ulps (conservative)
+  const double ulp = (double)af - (double)__uint_as_float(__float_as_uint(af) - 1u);
+  const double slack = 0.5 * ulp - fabs(e - (double)f);
+  if (af >= FLT_MIN && af < INFINITY && slack > 1e-11 * fabs(e)) return f;
+  const double az = atan2(y, x);
+  const double xp = cos(az) * x + sin(az) * y;
+  return (float)(atan2(z, xp) * 180 / M_PI);
+}
+
+#ifndef FX_PREP_OCC
+#define FX_PREP_OCC 4  // waves per SIMD the register budget is held to: 4 = two workgroups per CU (129 registers would mean one)
+#endif
+__global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, FxBuffers B, float near_margin) {
   constexpr int NW = FX_PREP_T / 64;
-  constexpr uint32_t kTile = FX_PREP_T * FX_PREP_U;  // points per tile
-  constexpr uint32_t kKeep = 2 * kTile;              // survivors buffered between sweeps
+  constexpr uint32_t kTile = FX_PREP_TILE;           // points per tile; wave w owns [256 w, 256 w + 256) of it
+  constexpr uint32_t kKeep = kTile + kTile / 2;      // survivors buffered between sweeps
   const uint32_t scan = blockIdx.x;
   const FxScanMeta M = B.meta[scan];
-  __shared__ uint32_t s_cnt[2][FX_PREP_U * NW];  // per-wave survivor counts, double-buffered by tile parity
-  __shared__ float4 s_keep[kKeep];               // un-rotated survivors waiting for the elevation sweep
+  __shared__ uint32_t s_cnt[2][NW];                  // per wave: survivors of the tile | near nibble << 16; by tile parity
+  __shared__ float s_keep[3 * kKeep];                // un-rotated survivors (x, y, z) waiting for the elevation sweep
   float4 *out = B.filt + (size_t)scan * P.max_points;
+  uint32_t *near_bits = B.near_bits + (size_t)scan * P.near_words;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   uint32_t base = 0, buffered = 0, parity = 0;
   const uint32_t n = M.n;
-  // the loads of the next tile are issued before this tile's barrier, so the memory pipe stays full
-  // while the tile is compacted
   // (global address space stated: a generic-pointer load would be a flat load, which also counts as an
   //  LDS access and gets waited for at the next LDS instruction)
   const gfloat *gpts = (const gfloat *)M.pts;
@@ -737,42 +762,40 @@ __global__ __launch_bounds__(FX_PREP_T) void k_prep(FxDevParams P, FxBuffers B) 
     if (scan == 0 && tid < FX_N_COUNTERS) B.counters[tid] = 0u;
     return;
   }
+  // the loads of the next tile are issued before this tile's barrier, so the memory pipe stays full
+  // while the tile is compacted
   auto load_tile = [&](uint32_t t0, float4 (&v)[FX_PREP_U]) {
 #pragma unroll
     for (int u = 0; u < FX_PREP_U; ++u) {
-      const uint32_t i = t0 + u * FX_PREP_T + tid;
+      const uint32_t i = t0 + wave * (64 * FX_PREP_U) + u * 64 + lane;
       const gfloat *q = gpts + (size_t)min(i, n - 1u) * M.stride_f;  // clamped: no branch around the load
       const float4 w = make_float4(q[0], q[1], q[2], q[3]);
       v[u] = i < n ? w : make_float4(NAN, NAN, NAN, 0.f);
     }
   };
-  // The fp64 elevation (getElevationAngles, ref: node.cpp:147-156) is a long dependent chain: it runs
-  // over the buffered survivors only when the buffer could overflow on the next tile (about every tenth
-  // tile at the usual one-in-ten survival), with every lane busy, instead of after each tile with a few.
+  // The fp64 elevation is a long dependent chain: it runs over the buffered survivors only when the buffer could
+  // overflow on the next tile, with every lane busy, instead of after each tile with a few.
   // Called by the whole workgroup after a barrier.
   auto sweep = [&]() {
     for (uint32_t j = tid; j < buffered; j += FX_PREP_T) {
-      const float4 q = s_keep[j];
-      const float rx = ((M.R[0] * q.x + M.R[1] * q.y) + M.R[2] * q.z) + 0.0f;
-      const float ry = ((M.R[3] * q.x + M.R[4] * q.y) + M.R[5] * q.z) + 0.0f;
-      const float rz = ((M.R[6] * q.x + M.R[7] * q.y) + M.R[8] * q.z) + 0.0f;
-      // the reference's own expression on the un-rotated point, fp64 -> fp32 (ref: node.cpp:150-154):
-      //   az = atan2(y, x); xp = cos(az) x + sin(az) y; intensity = atan2(z, xp) * 180 / M_PI
-      const double x = q.x, y = q.y, z = q.z;
-      const double az = atan2(y, x);
-      const double xp = cos(az) * x + sin(az) * y;
-      const double el = atan2(z, xp) * 180 / M_PI;
-      out[base + j] = make_float4(rx, ry, rz, (float)el);
+      const float x = s_keep[3 * j], y = s_keep[3 * j + 1], z = s_keep[3 * j + 2];
+      const float rx = ((M.R[0] * x + M.R[1] * y) + M.R[2] * z) + 0.0f;
+      const float ry = ((M.R[3] * x + M.R[4] * y) + M.R[5] * z) + 0.0f;
+      const float rz = ((M.R[6] * x + M.R[7] * y) + M.R[8] * z) + 0.0f;
+      out[base + j] = make_float4(rx, ry, rz, elevation_deg(x, y, z));
     }
     base += buffered;
     buffered = 0;
   };
+  const float nx0 = P.x_min - near_margin, nx1 = P.x_max + near_margin, ny0 = P.y_min - near_margin,
+              ny1 = P.y_max + near_margin, nz0 = P.z_min - near_margin, nz1 = P.z_max + near_margin;
   float4 v[FX_PREP_U], nv[FX_PREP_U];
   load_tile(0, v);
   for (uint32_t t0 = 0; t0 < n; t0 += kTile) {
     load_tile(t0 + kTile, nv);
     bool keep[FX_PREP_U];
     unsigned long long mask[FX_PREP_U];
+    uint32_t wave_cnt = 0, nib = 0;
 #pragma unroll
     for (int u = 0; u < FX_PREP_U; ++u) {
       const float x = v[u].x, y = v[u].y, z = v[u].z;
@@ -780,32 +803,43 @@ __global__ __launch_bounds__(FX_PREP_T) void k_prep(FxDevParams P, FxBuffers B) 
       const float rx = ((M.R[0] * x + M.R[1] * y) + M.R[2] * z) + 0.0f;
       const float ry = ((M.R[3] * x + M.R[4] * y) + M.R[5] * z) + 0.0f;
       const float rz = ((M.R[6] * x + M.R[7] * y) + M.R[8] * z) + 0.0f;
-      bool k = isfinite(rx) && isfinite(ry) && isfinite(rz);
+      // (a NaN or an infinity fails one of the range tests of the wider box)
+      const bool near = rx >= nx0 && rx <= nx1 && ry >= ny0 && ry <= ny1 && rz >= nz0 && rz <= nz1;
+      bool k = near && isfinite(rx) && isfinite(ry) && isfinite(rz);
       k = k && !(rz < P.z_min || rz > P.z_max);
       k = k && !(ry < P.y_min || ry > P.y_max);
       k = k && !(rx < P.x_min || rx > P.x_max);
       keep[u] = k;
       mask[u] = __ballot(k);
-      if (lane == 0) s_cnt[parity][u * NW + wave] = (uint32_t)__popcll(mask[u]);
+      wave_cnt += (uint32_t)__popcll(mask[u]);
+      nib |= __ballot(near) ? (1u << u) : 0u;
     }
+    if (lane == 0) s_cnt[parity][wave] = wave_cnt | (nib << 16);
     // One barrier per tile: it orders this tile's counts before their readers, the previous sweep's
     // reads of s_keep before this tile's writes, and (a wave cannot be two tiles ahead of another) the
     // readers of the other parity's counts before they are overwritten next tile.
     __syncthreads();
-    // buffer slot = survivors already buffered + those of earlier slices of the tile + of earlier
-    //               waves in my slice + of earlier lanes of my wave: input order is kept
-    uint32_t tile_total = 0;
+    // buffer slot = survivors already buffered + those of earlier waves + of earlier slices of my wave
+    //               + of earlier lanes of my slice: input order is kept
+    uint32_t before = 0, tile_total = 0, bits = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const uint32_t c = s_cnt[parity][w];
+      before += (w < (int)wave) ? (c & 0xffffu) : 0u;
+      tile_total += c & 0xffffu;
+      bits |= (c >> 16) << (4 * w);
+    }
+    if (tid == 0) near_bits[t0 / kTile] = bits;
+    uint32_t pos = buffered + before;
 #pragma unroll
     for (int u = 0; u < FX_PREP_U; ++u) {
-      uint32_t before = 0, slice = 0;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) {
-        const uint32_t c = s_cnt[parity][u * NW + w];
-        before += (w < (int)wave) ? c : 0u;
-        slice += c;
+      if (keep[u]) {
+        const uint32_t d = 3u * (pos + lanes_below(mask[u]));
+        s_keep[d] = v[u].x;
+        s_keep[d + 1] = v[u].y;
+        s_keep[d + 2] = v[u].z;
       }
-      if (keep[u]) s_keep[buffered + tile_total + before + lanes_below(mask[u])] = v[u];
-      tile_total += slice;
+      pos += (uint32_t)__popcll(mask[u]);
     }
     buffered += tile_total;
     parity ^= 1u;
@@ -1698,24 +1732,43 @@ __device__ __forceinline__ unsigned long long sc3d_key(uint32_t bin, float d2, u
 }
 
 // ---------------------------------------------------------------- k_gather
-#define FX_GATHER_BINS 64
+// Keypoints of the scan are binned into xy cells at least one support radius wide, and every cell lists the
+// keypoints of the 3 x 3 cells around it: a point looks its cell up once and tests exactly the keypoints that can
+// be within reach.  Points with candidates are parked in a per-wavefront LDS queue and tested with all lanes busy
+// (in firing order only some lanes of a wavefront hold such points).  Groups of 64 points that k_prep found
+// wholly out of the filter box's reach are not even loaded.
+#define FX_GATHER_G 32  // cells per axis at most
+#define FX_GATHER_CELLS (FX_GATHER_G * FX_GATHER_G)
 #ifndef FX_GATHER_STAGE
 #define FX_GATHER_STAGE 512  // hits one workgroup stages between flushes (a larger stage costs more in occupancy than it saves in flushes)
 #endif
+#define FX_GATHER_QUEUE 96   // points one wavefront parks before it drains them (drained once more than 32 are waiting)
+__host__ __device__ inline uint32_t gather_words(uint32_t mk) {
+  uint32_t w = 32 + 4 * mk;                                   // scratch, keypoints
+  w += 2 * (FX_GATHER_CELLS + 4);                             // cell table, fill cursors
+  w += ((9 * mk + 1) / 2 + 3) & ~3u;                          // cell lists (uint16)
+  w += (2 * mk + 3) & ~3u;                                    // staged hits per keypoint, reserved list positions
+  w += FX_GATHER_STAGE + 4 * FX_GATHER_STAGE;                 // staged hits: meta, points
+  w += FX_NWAVE * FX_GATHER_QUEUE * 5;                        // per-wavefront queues: points, cell info
+  return w;
+}
 extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBuffers B, float box_margin) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  // LDS: [0..15] scratch, [16..16+BINS] bin starts, then keypoints (float4) and their x-sorted order
-  uint32_t *s_w = smem;
-  uint32_t *s_bin = smem + 16;                                    // [FX_GATHER_BINS + 1]
-  float4 *s_kp = reinterpret_cast<float4 *>(smem + 16 + 80);      // 16-byte aligned
-  uint32_t *s_ord = smem + 16 + 80 + 4 * P.max_keypoints;         // keypoint ids sorted by x bin
+  const uint32_t MK = P.max_keypoints;
+  uint32_t *s_w = smem;                                          // 0..5 keypoint box, 8 staged hits
+  float4 *s_kp = reinterpret_cast<float4 *>(smem + 32);          // 16-byte aligned
+  uint32_t *s_cell = smem + 32 + 4 * MK;                         // [CELLS + 4] list start | entries << 20
+  uint32_t *s_cur = s_cell + FX_GATHER_CELLS + 4;                // [CELLS + 4] fill cursors
+  uint16_t *s_flat = reinterpret_cast<uint16_t *>(s_cur + FX_GATHER_CELLS + 4);  // [9 MK] keypoint ids, cell by cell
   // hits are staged in LDS and appended to the keypoints' lists in bulk: one global atomic per
   // (keypoint, flush) reserves the slots instead of one returning atomic per hit
-  uint32_t *s_kcnt = s_ord + P.max_keypoints + FX_GATHER_BINS;    // [max_keypoints] staged hits per keypoint
-  uint32_t *s_kbase = s_kcnt + P.max_keypoints;                   // [max_keypoints] reserved list position
-  uint32_t *s_smeta = s_kbase + P.max_keypoints;                  // [FX_GATHER_STAGE] keypoint << 16 | staged ordinal
-  float4 *s_spt = reinterpret_cast<float4 *>(smem + ((16 + 80 + 7 * P.max_keypoints + FX_GATHER_BINS + FX_GATHER_STAGE + 3) & ~3u));
-  const uint32_t scan = blockIdx.y, slice = blockIdx.x, tid = threadIdx.x;
+  uint32_t *s_kcnt = reinterpret_cast<uint32_t *>(s_flat) + (((9 * MK + 1) / 2 + 3) & ~3u);  // [MK] staged hits per keypoint
+  uint32_t *s_kbase = s_kcnt + MK;                               // [MK] reserved list position
+  uint32_t *s_smeta = s_kcnt + ((2 * MK + 3) & ~3u);             // [STAGE] keypoint << 16 | staged ordinal
+  float4 *s_spt = reinterpret_cast<float4 *>(s_smeta + FX_GATHER_STAGE);
+  const uint32_t scan = blockIdx.y, slice = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float4 *q_pt = s_spt + FX_GATHER_STAGE + wave * FX_GATHER_QUEUE;                                         // this wavefront's queue
+  uint32_t *q_info = reinterpret_cast<uint32_t *>(s_spt + FX_GATHER_STAGE + FX_NWAVE * FX_GATHER_QUEUE) + wave * FX_GATHER_QUEUE;
   uint32_t K = B.n_kp[scan];
   if (K == 0) return;
   const uint32_t row0 = B.kp_offset[scan];
@@ -1727,11 +1780,13 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
     for (uint32_t k = tid; k < K; k += FX_WG) B.row_map[row0 + k] = make_uint2(scan, k);
   // keypoints of the scan -> LDS; their bounding box (ordered-uint atomics) for a cheap reject
   if (tid < 6) s_w[tid] = (tid & 1) ? f2ord(-INFINITY) : f2ord(INFINITY);
-  for (uint32_t b = tid; b <= FX_GATHER_BINS; b += FX_WG) s_bin[b] = 0;
+  if (tid == 0) s_w[8] = 0;  // staged hits
+  for (uint32_t c = tid; c < FX_GATHER_CELLS; c += FX_WG) s_cell[c] = 0;
   __syncthreads();
   for (uint32_t k = tid; k < K; k += FX_WG) {
     const float4 kp = B.keypoints[(size_t)scan * P.max_keypoints + k];
     s_kp[k] = kp;
+    s_kcnt[k] = 0;
     if (slice == 0) {
       B.row_kp[row0 + k] = kp;
       B.row_xa[row0 + k] = B.xaxis[k];
@@ -1744,36 +1799,56 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
     atomicMax(&s_w[5], f2ord(kp.z));
   }
   __syncthreads();
-  const float kx0 = ord2f(s_w[0]), kx1 = ord2f(s_w[1]);
+  const float kx0 = ord2f(s_w[0]), kx1 = ord2f(s_w[1]), ky0 = ord2f(s_w[2]), ky1 = ord2f(s_w[3]);
   const float bx0 = kx0 - box_margin, bx1 = kx1 + box_margin;
-  const float by0 = ord2f(s_w[2]) - box_margin, by1 = ord2f(s_w[3]) + box_margin;
+  const float by0 = ky0 - box_margin, by1 = ky1 + box_margin;
   const float bz0 = ord2f(s_w[4]) - box_margin, bz1 = ord2f(s_w[5]) + box_margin;
-  // keypoints binned along x; bin width >= the support radius (+ margin), so a point only has to
-  // look at the keypoints of its own bin and the two next to it
-  const float width = fmaxf(box_margin, (kx1 - kx0) / (float)(FX_GATHER_BINS - 1) * 1.0001f + 1e-6f);
-  const float inv_w = 1.0f / width;
+  // cell width >= the support radius (+ margin): a point within reach of a keypoint is in the keypoint's cell or
+  // in one next to it; wider when the keypoints spread over more than G cells of that width
+  const float wx = fmaxf(box_margin, (bx1 - bx0) / (float)(FX_GATHER_G - 1) * 1.0001f + 1e-6f);
+  const float wy = fmaxf(box_margin, (by1 - by0) / (float)(FX_GATHER_G - 1) * 1.0001f + 1e-6f);
+  const float inv_wx = 1.0f / wx, inv_wy = 1.0f / wy;
+  const int ncx = min((int)((bx1 - bx0) * inv_wx) + 1, FX_GATHER_G), ncy = min((int)((by1 - by0) * inv_wy) + 1, FX_GATHER_G);
+  auto cell_x = [&](float x) { return min(max((int)floorf((x - bx0) * inv_wx), 0), ncx - 1); };
+  auto cell_y = [&](float y) { return min(max((int)floorf((y - by0) * inv_wy), 0), ncy - 1); };
   for (uint32_t k = tid; k < K; k += FX_WG) {
-    const int b = min(max((int)((s_kp[k].x - kx0) * inv_w), 0), FX_GATHER_BINS - 1);
-    atomicAdd(&s_bin[b + 1], 1u);
+    const int cx = cell_x(s_kp[k].x), cy = cell_y(s_kp[k].y);
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx)
+        if (cx + dx >= 0 && cx + dx < ncx && cy + dy >= 0 && cy + dy < ncy) atomicAdd(&s_cell[(cy + dy) * ncx + cx + dx], 1u);
   }
   __syncthreads();
-  if (tid == 0) {
-    uint32_t run = 0;
-    for (int b = 0; b <= FX_GATHER_BINS; ++b) {
-      run += s_bin[b];
-      s_bin[b] = run;  // s_bin[b] = first slot of bin b (counts were stored one up)
+  if (tid < 64) {  // counts -> start | count << 20, and the fill cursors, by one wavefront
+    const uint32_t n_cells = (uint32_t)(ncx * ncy), per = (n_cells + 63) / 64;
+    uint32_t sum = 0;
+    for (uint32_t u = 0; u < per; ++u) {
+      const uint32_t ci = tid * per + u;
+      sum += ci < n_cells ? s_cell[ci] : 0u;
+    }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+      if ((int)tid >= d) incl += o;
+    }
+    uint32_t run = incl - sum;
+    for (uint32_t u = 0; u < per; ++u) {
+      const uint32_t ci = tid * per + u;
+      if (ci < n_cells) {
+        const uint32_t c = s_cell[ci];
+        s_cell[ci] = run | (c << 20);
+        s_cur[ci] = run;
+        run += c;
+      }
     }
   }
   __syncthreads();
-  uint32_t *s_fill = s_w + 8;  // unused scratch words are too few: fill cursors live behind the order array
-  s_fill = s_ord + P.max_keypoints;
-  for (uint32_t b = tid; b < FX_GATHER_BINS; b += FX_WG) s_fill[b] = 0;
-  for (uint32_t k = tid; k < K; k += FX_WG) s_kcnt[k] = 0;
-  if (tid == 0) s_w[8] = 0;  // staged hits
-  __syncthreads();
   for (uint32_t k = tid; k < K; k += FX_WG) {
-    const int b = min(max((int)((s_kp[k].x - kx0) * inv_w), 0), FX_GATHER_BINS - 1);
-    s_ord[s_bin[b] + atomicAdd(&s_fill[b], 1u)] = k;
+    const int cx = cell_x(s_kp[k].x), cy = cell_y(s_kp[k].y);
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx)
+        if (cx + dx >= 0 && cx + dx < ncx && cy + dy >= 0 && cy + dy < ncy)
+          s_flat[atomicAdd(&s_cur[(cy + dy) * ncx + cx + dx], 1u)] = (uint16_t)k;
   }
   __syncthreads();
 
@@ -1794,11 +1869,13 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
     z4 = reinterpret_cast<float4 *>(d + a4);
     zn = (uint32_t)((b4 - a4) / 4);
   }
+  constexpr uint32_t kTile = FX_WG * 4;  // 1024 points: wave w owns [256 w, 256 w + 256), 64 consecutive points per load
   const uint32_t n = M.n;
   uint32_t chunk = (n + gridDim.x - 1) / gridDim.x;
-  chunk = (chunk + FX_WG * 4 - 1) / (FX_WG * 4) * (FX_WG * 4);
+  chunk = (chunk + kTile - 1) / kTile * kTile;
   const uint32_t lo = slice * chunk;
   const uint32_t hi = lo + chunk < n ? lo + chunk : n;
+  const uint32_t *near_bits = B.near_bits + (size_t)scan * P.near_words;
   // called by the whole workgroup, after a barrier: reserve list positions, write the staged hits out
   auto flush = [&](uint32_t staged) {
     staged = min(staged, (uint32_t)FX_GATHER_STAGE);
@@ -1816,18 +1893,56 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
     if (tid == 0) s_w[8] = 0;
     __syncthreads();
   };
-  const uint32_t n_tiles = (hi > lo) ? (hi - lo + FX_WG * 4 - 1) / (FX_WG * 4) : 0u;
+  // this wavefront's parked points against the keypoints of their cells' lists, one point per lane
+  uint32_t qn = 0;
+  auto drain = [&]() {
+    wave_sync_lds();
+    for (uint32_t t = lane; t < qn; t += 64) {
+      const float4 pq = q_pt[t];
+      const uint32_t info = q_info[t], st = info & 0xfffffu, cnt = info >> 20;
+      for (uint32_t e = 0; e < cnt; ++e) {
+        const uint32_t k = s_flat[st + e];
+        const float4 kp = s_kp[k];
+        if (dist2(kp.x, kp.y, kp.z, pq.x, pq.y, pq.z) < P.r2_support) {
+          const uint32_t slot = atomicAdd(&s_w[8], 1u);
+          if (slot < FX_GATHER_STAGE) {
+            s_spt[slot] = pq;
+            s_smeta[slot] = (k << 16) | atomicAdd(&s_kcnt[k], 1u);
+          } else {  // stage full (a burst of hits within one tile): append directly
+            const uint32_t pos = atomicAdd(&B.s_cnt[row0 + k], 1u);
+            if (pos < P.list_cap) B.s_pts[(size_t)(row0 + k) * P.list_cap + pos] = pq;
+          }
+        }
+      }
+    }
+    wave_sync_lds();
+    qn = 0;
+  };
+  // the groups of a tile that hold a point within reach of the filter box (k_prep), this wavefront's four
+  auto near_nibble = [&](uint32_t i0) -> uint32_t {
+    if (i0 >= hi) return 0u;
+    const uint32_t word = near_bits[i0 / FX_PREP_TILE];
+    return (word >> ((i0 % FX_PREP_TILE) / 64 + wave * 4)) & 0xfu;
+  };
+  auto load_tile = [&](uint32_t i0, uint32_t nib, float4 (&v)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t i = i0 + wave * 256 + u * 64 + lane;
+      v[u] = make_float4(NAN, NAN, NAN, 0);
+      if (((nib >> u) & 1u) && i < hi) v[u] = *reinterpret_cast<const float4 *>(M.pts + (size_t)i * M.stride_f);
+    }
+  };
+  const uint32_t n_tiles = (hi > lo) ? (hi - lo + kTile - 1) / kTile : 0u;
   const uint32_t zslab = n_tiles ? (zn + n_tiles - 1) / n_tiles : 0u;
   if (n_tiles == 0)
     for (uint32_t t = tid; t < zn; t += FX_WG) z4[t] = make_float4(0.f, 0.f, 0.f, 0.f);
   uint32_t zdone = 0;
-  for (uint32_t i0 = lo; i0 < hi; i0 += FX_WG * 4) {
-    float4 v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const uint32_t i = i0 + u * FX_WG + tid;
-      v[u] = i < hi ? *reinterpret_cast<const float4 *>(M.pts + (size_t)i * M.stride_f) : make_float4(NAN, NAN, NAN, 0);
-    }
+  float4 v[4], nv[4];
+  uint32_t nib = near_nibble(lo), nnib = 0;
+  load_tile(lo, nib, v);
+  for (uint32_t i0 = lo; i0 < hi; i0 += kTile) {
+    nnib = near_nibble(i0 + kTile);
+    load_tile(i0 + kTile, nnib, nv);  // the next tile's loads are in flight while this one is tested
     {
       const uint32_t zend = min(zdone + zslab, zn);
       for (uint32_t t = zdone + tid; t < zend; t += FX_WG) z4[t] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1841,6 +1956,7 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
+      if (!((nib >> u) & 1u)) continue;  // (wave-uniform)
       const float x = v[u].x, y = v[u].y, z = v[u].z;
       const float rx = ((M.R[0] * x + M.R[1] * y) + M.R[2] * z) + 0.0f;
       const float ry = ((M.R[3] * x + M.R[4] * y) + M.R[5] * z) + 0.0f;
@@ -1848,28 +1964,25 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
       // non-finite points are not part of the search surface; NaN fails every comparison
       const bool near = rx >= bx0 && rx <= bx1 && ry >= by0 && ry <= by1 && rz >= bz0 && rz <= bz1 &&
                         isfinite(rx) && isfinite(ry) && isfinite(rz);
-      if (!near) continue;
-      const uint32_t idx = i0 + u * FX_WG + tid;
-      const int b = min(max((int)floorf((rx - kx0) * inv_w), -1), FX_GATHER_BINS);
-      const uint32_t s0 = s_bin[max(b - 1, 0)], s1 = s_bin[min(b + 2, FX_GATHER_BINS)];
-      for (uint32_t kk = s0; kk < s1; ++kk) {
-        const uint32_t k = s_ord[kk];
-        const float4 kp = s_kp[k];
-        const float d = dist2(kp.x, kp.y, kp.z, rx, ry, rz);
-        if (d < P.r2_support) {
-          const float4 hit = make_float4(rx, ry, rz, __uint_as_float(idx));
-          const uint32_t slot = atomicAdd(&s_w[8], 1u);
-          if (slot < FX_GATHER_STAGE) {
-            s_spt[slot] = hit;
-            s_smeta[slot] = (k << 16) | atomicAdd(&s_kcnt[k], 1u);
-          } else {  // stage full (a burst of hits within one tile): append directly
-            const uint32_t pos = atomicAdd(&B.s_cnt[row0 + k], 1u);
-            if (pos < P.list_cap) B.s_pts[(size_t)(row0 + k) * P.list_cap + pos] = hit;
-          }
+      uint32_t info = 0;
+      if (near) info = s_cell[cell_y(ry) * ncx + cell_x(rx)];
+      const bool has = (info >> 20) != 0u;
+      const unsigned long long m = __ballot(has);
+      if (m) {  // wave-uniform
+        if (has) {
+          const uint32_t slot = qn + lanes_below(m);
+          q_pt[slot] = make_float4(rx, ry, rz, __uint_as_float(i0 + wave * 256 + u * 64 + lane));
+          q_info[slot] = info;
         }
+        qn += (uint32_t)__popcll(m);
+        if (qn > FX_GATHER_QUEUE - 64) drain();
       }
     }
+    nib = nnib;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = nv[u];
   }
+  drain();
   __syncthreads();
   flush(s_w[8]);
 }
@@ -3036,14 +3149,14 @@ size_t fxk_ring_wave_lds_bytes(uint32_t cap, uint32_t ccap) {
 size_t fxk_merge_lds_bytes(uint32_t cap, uint32_t n_rings) { return merge_words(cap, cap, n_rings, true) * 4; }
 size_t fxk_merge_huge_lds_bytes(uint32_t cap, uint32_t ccap, uint32_t n_rings) { return merge_words(cap, ccap, n_rings, false) * 4; }
 uint32_t fxk_huge_cap(void) { return FX_HUGE_CAP; }
-size_t fxk_gather_lds_bytes(uint32_t max_keypoints) {
-  return (16 + 80 + 7 * (size_t)max_keypoints + FX_GATHER_BINS + FX_GATHER_STAGE + 4 + 4 * FX_GATHER_STAGE) * 4;
-}
+size_t fxk_gather_lds_bytes(uint32_t max_keypoints) { return (size_t)gather_words(max_keypoints) * 4; }
 size_t fxk_desc_lds_bytes(uint32_t cap) { return (size_t)(16 + FX_DESC_WORDS_PER_POINT * cap + FX_DESC_BINS) * 4; }
 
-hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t merge_huge, size_t desc_big) {
+hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t merge_huge, size_t desc_big, size_t gather) {
   hipError_t e;
   e = hipFuncSetAttribute((const void *)k_merge_huge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)merge_huge);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void *)k_gather, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gather);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void *)k_rings_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_big);
   if (e != hipSuccess) return e;
@@ -3057,8 +3170,9 @@ hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t merge_huge, s
   return e;
 }
 
-void fxk_prep(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch) {
-  hipLaunchKernelGGL(k_prep, dim3(batch), dim3(FX_PREP_T), 0, s, P, B);
+uint32_t fxk_near_words(uint32_t max_points) { return (max_points + FX_PREP_TILE - 1) / FX_PREP_TILE; }
+void fxk_prep(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float near_margin) {
+  hipLaunchKernelGGL(k_prep, dim3(batch), dim3(FX_PREP_T), 0, s, P, B, near_margin);
 }
 void fxk_bucket(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float el0, float inv_step) {
   const size_t lds = (48 + (size_t)P.n_rings * (2 + FX_BUCKET_NW) + 1) * 4;
