@@ -1621,7 +1621,7 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_offsets(FxDevParams P, FxB
 //   k_gather        one pass over each scan tests every (rotated) point against the keypoints of the
 //                   scan (binned along x) and appends the points within R + R/5 of a keypoint to that
 //                   keypoint's support list (a superset of the neighbour query and of every density query);
-//                   it also clears the scan's descriptor rows (the keypoint kernels write non-empty bins only)
+//                   (the rows themselves are cleared by k_desc_group, which sees every row once)
 //   k_desc_group    4 keypoints per wavefront: support sets of <= 64 points (the bulk)
 //   k_desc_fast     one wavefront per keypoint: 65..256 support points
 //   k_desc_wg_fast  one 1024-thread workgroup per keypoint: up to list_cap support points
@@ -1852,23 +1852,6 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
   }
   __syncthreads();
 
-  float4 *z4;   // 16-byte body of the share, cleared a slab per tile of the stream
-  uint32_t zn;
-  {
-    // this workgroup's share of the scan's descriptor rows is cleared here, in the shadow of the point
-    // stream below (descriptors are sparse: the keypoint kernels only write non-empty bins)
-    const size_t f0 = (size_t)row0 * FX_DESC_FLOATS, len = (size_t)K * FX_DESC_FLOATS;
-    const uint32_t n_slices = gridDim.x;  // workgroups per scan: 2 in throughput batches, more when few scans are in flight
-    size_t a = f0 + (len * slice / n_slices), b = f0 + (len * (slice + 1) / n_slices);
-    if (slice != 0) a &= ~(size_t)3;  // interior cuts on 16-byte boundaries
-    if (slice != n_slices - 1) b &= ~(size_t)3;
-    const size_t a4 = min((a + 3) & ~(size_t)3, b), b4 = max(b & ~(size_t)3, a4);
-    float *d = B.desc;
-    if (tid < a4 - a) d[a + tid] = 0.0f;
-    if (tid < b - b4) d[b4 + tid] = 0.0f;
-    z4 = reinterpret_cast<float4 *>(d + a4);
-    zn = (uint32_t)((b4 - a4) / 4);
-  }
   constexpr uint32_t kTile = FX_WG * 4;  // 1024 points: wave w owns [256 w, 256 w + 256), 64 consecutive points per load
   const uint32_t n = M.n;
   uint32_t chunk = (n + gridDim.x - 1) / gridDim.x;
@@ -1932,22 +1915,12 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
       if (((nib >> u) & 1u) && i < hi) v[u] = *reinterpret_cast<const float4 *>(M.pts + (size_t)i * M.stride_f);
     }
   };
-  const uint32_t n_tiles = (hi > lo) ? (hi - lo + kTile - 1) / kTile : 0u;
-  const uint32_t zslab = n_tiles ? (zn + n_tiles - 1) / n_tiles : 0u;
-  if (n_tiles == 0)
-    for (uint32_t t = tid; t < zn; t += FX_WG) z4[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-  uint32_t zdone = 0;
   float4 v[4], nv[4];
   uint32_t nib = near_nibble(lo), nnib = 0;
   load_tile(lo, nib, v);
   for (uint32_t i0 = lo; i0 < hi; i0 += kTile) {
     nnib = near_nibble(i0 + kTile);
     load_tile(i0 + kTile, nnib, nv);  // the next tile's loads are in flight while this one is tested
-    {
-      const uint32_t zend = min(zdone + zslab, zn);
-      for (uint32_t t = zdone + tid; t < zend; t += FX_WG) z4[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-      zdone = zend;
-    }
     if (i0 != lo) {  // flush when the next tile might not fit any more (workgroup-uniform decision)
       __syncthreads();
       const uint32_t staged = s_w[8];
@@ -1990,6 +1963,15 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
 // ---------------------------------------------------------------- k_desc_fast
 #define FX_WAVE_CAP 256
 #define FX_WAVE_WORDS (FX_WAVE_CAP * 8)
+// Clears one descriptor row (1989 floats, 4-byte aligned) with `stride` lanes: 16-byte stores over its aligned body.
+__device__ __forceinline__ void desc_zero_row(float *out, uint32_t lane, uint32_t stride) {
+  const uint32_t head = (uint32_t)((16u - ((uintptr_t)out & 15u)) & 15u) / 4u;  // floats before the first 16-byte boundary
+  const uint32_t n4 = (FX_DESC_FLOATS - head) / 4u, tail0 = head + 4u * n4;
+  if (lane < head) out[lane] = 0.0f;
+  if (lane < FX_DESC_FLOATS - tail0) out[tail0 + lane] = 0.0f;
+  float4 *body = reinterpret_cast<float4 *>(out + head);
+  for (uint32_t t = lane; t < n4; t += stride) body[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
 __device__ __forceinline__ void desc_fill_nan(float *out, uint32_t lane, uint32_t stride) {
   for (uint32_t t = lane; t < FX_DESC_FLOATS; t += stride) out[t] = t < FX_DESC_BINS ? NAN : 0.0f;
 }
@@ -2102,7 +2084,7 @@ __device__ __forceinline__ void desc_wave_body(const FxDevParams &P, const FxBuf
       desc_fill_nan(out, lane, 64);
       continue;
     }
-    // the output rows were zeroed in bulk by k_gather; only the non-empty bins are written here.
+    // the output rows were cleared by k_desc_group; only the non-empty bins are written here.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -2189,6 +2171,10 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_group(FxDevParams P, 
         if (gl + u * FX_GLANES < P.list_cap) lv[u] = B.s_pts[(size_t)row * P.list_cap + gl + u * FX_GLANES];
       scan = rm.x, k = rm.y;
     }
+    float *out = B.desc + (size_t)row * FX_DESC_FLOATS;
+    // Every descriptor row is cleared here, whichever tier ends up computing it (the keypoint kernels write
+    // non-empty bins only): this kernel sees every row once and waits on latencies with its memory pipe idle.
+    if (live) desc_zero_row(out, gl, FX_GLANES);
     if (live) {
       if (nS > FX_GROUP_CAP || nS > P.list_cap) {  // too long for a group (or truncated): wavefront / workgroup / re-gather tiers
         if (gl == 0) {
@@ -2199,7 +2185,6 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_group(FxDevParams P, 
         live = false;
       }
     }
-    float *out = B.desc + (size_t)row * FX_DESC_FLOATS;
     if (!live) nS = 0;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -2245,6 +2230,9 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_group(FxDevParams P, 
       live = false;
       nM = 0;
     }
+    // (s_waitcnt vmcnt(0): the clearing stores are acknowledged before anything else is written to the row; a wider
+    //  scope would write the whole L2 back)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (live) {
       if (gl == 0) B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = nAll;
       if (nAll == 0) {  // no neighbours: NaN descriptor, no RNG draw (A.8-3)
@@ -2281,7 +2269,7 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_group(FxDevParams P, 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // one lane per bin run adds its weights in sorted order (the rows were zeroed by k_gather)
+    // one lane per bin run adds its weights in sorted order (the row was cleared at the top of this trip)
     for (uint32_t e = gl; e < nM; e += FX_GLANES) {
       const uint32_t bin = (uint32_t)(skey[e] >> 52);
       if (e > 0 && (uint32_t)(skey[e - 1] >> 52) == bin) continue;
