@@ -1740,14 +1740,16 @@ __device__ __forceinline__ unsigned long long sc3d_key(uint32_t bin, float d2, u
 #define FX_GATHER_G 32  // cells per axis at most
 #define FX_GATHER_CELLS (FX_GATHER_G * FX_GATHER_G)
 #ifndef FX_GATHER_STAGE
-#define FX_GATHER_STAGE 512  // hits one workgroup stages between flushes (a larger stage costs more in occupancy than it saves in flushes)
+#define FX_GATHER_STAGE 384  // hits one workgroup stages between flushes (a larger stage costs more in occupancy than it saves in flushes)
 #endif
-#define FX_GATHER_QUEUE 96   // points one wavefront parks before it drains them (drained once more than 32 are waiting)
+#ifndef FX_GATHER_QUEUE
+#define FX_GATHER_QUEUE 80   // points one wavefront parks before it drains them (drained once more than 16 are waiting)
+#endif
 __host__ __device__ inline uint32_t gather_words(uint32_t mk) {
   uint32_t w = 32 + 4 * mk;                                   // scratch, keypoints
-  w += 2 * (FX_GATHER_CELLS + 4);                             // cell table, fill cursors
+  w += FX_GATHER_CELLS + 4;                                   // cell table (the fill cursors borrow the staging area)
   w += ((9 * mk + 1) / 2 + 3) & ~3u;                          // cell lists (uint16)
-  w += (2 * mk + 3) & ~3u;                                    // staged hits per keypoint, reserved list positions
+  w += (3 * mk + 3) & ~3u;                                    // staged hits per keypoint, reserved list positions, list lengths
   w += FX_GATHER_STAGE + 4 * FX_GATHER_STAGE;                 // staged hits: meta, points
   w += FX_NWAVE * FX_GATHER_QUEUE * 5;                        // per-wavefront queues: points, cell info
   return w;
@@ -1758,14 +1760,16 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
   uint32_t *s_w = smem;                                          // 0..5 keypoint box, 8 staged hits
   float4 *s_kp = reinterpret_cast<float4 *>(smem + 32);          // 16-byte aligned
   uint32_t *s_cell = smem + 32 + 4 * MK;                         // [CELLS + 4] list start | entries << 20
-  uint32_t *s_cur = s_cell + FX_GATHER_CELLS + 4;                // [CELLS + 4] fill cursors
-  uint16_t *s_flat = reinterpret_cast<uint16_t *>(s_cur + FX_GATHER_CELLS + 4);  // [9 MK] keypoint ids, cell by cell
+  uint16_t *s_flat = reinterpret_cast<uint16_t *>(s_cell + FX_GATHER_CELLS + 4);  // [9 MK] keypoint ids, cell by cell
   // hits are staged in LDS and appended to the keypoints' lists in bulk: one global atomic per
   // (keypoint, flush) reserves the slots instead of one returning atomic per hit
   uint32_t *s_kcnt = reinterpret_cast<uint32_t *>(s_flat) + (((9 * MK + 1) / 2 + 3) & ~3u);  // [MK] staged hits per keypoint
   uint32_t *s_kbase = s_kcnt + MK;                               // [MK] reserved list position
-  uint32_t *s_smeta = s_kcnt + ((2 * MK + 3) & ~3u);             // [STAGE] keypoint << 16 | staged ordinal
+  uint32_t *s_kpos = s_kbase + MK;                               // [MK] list length so far (one workgroup per scan)
+  uint32_t *s_smeta = s_kcnt + ((3 * MK + 3) & ~3u);             // [STAGE] keypoint << 16 | staged ordinal
+  const bool solo = gridDim.x == 1;
   float4 *s_spt = reinterpret_cast<float4 *>(s_smeta + FX_GATHER_STAGE);
+  uint32_t *s_cur = reinterpret_cast<uint32_t *>(s_spt);        // [CELLS] fill cursors while the lists are built (4 STAGE >= CELLS words)
   const uint32_t scan = blockIdx.y, slice = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float4 *q_pt = s_spt + FX_GATHER_STAGE + wave * FX_GATHER_QUEUE;                                         // this wavefront's queue
   uint32_t *q_info = reinterpret_cast<uint32_t *>(s_spt + FX_GATHER_STAGE + FX_NWAVE * FX_GATHER_QUEUE) + wave * FX_GATHER_QUEUE;
@@ -1787,6 +1791,7 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
     const float4 kp = B.keypoints[(size_t)scan * P.max_keypoints + k];
     s_kp[k] = kp;
     s_kcnt[k] = 0;
+    s_kpos[k] = 0;
     if (slice == 0) {
       B.row_kp[row0 + k] = kp;
       B.row_xa[row0 + k] = B.xaxis[k];
@@ -1864,7 +1869,14 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
     staged = min(staged, (uint32_t)FX_GATHER_STAGE);
     for (uint32_t k = tid; k < K; k += FX_WG) {
       const uint32_t c = s_kcnt[k];
-      if (c) s_kbase[k] = atomicAdd(&B.s_cnt[row0 + k], c);
+      if (c) {
+        if (solo) {  // this workgroup is the only writer of the scan's lists: positions are its own running counts
+          s_kbase[k] = s_kpos[k];
+          s_kpos[k] += c;
+        } else {
+          s_kbase[k] = atomicAdd(&B.s_cnt[row0 + k], c);
+        }
+      }
       s_kcnt[k] = 0;
     }
     __syncthreads();
@@ -1892,7 +1904,7 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
             s_spt[slot] = pq;
             s_smeta[slot] = (k << 16) | atomicAdd(&s_kcnt[k], 1u);
           } else {  // stage full (a burst of hits within one tile): append directly
-            const uint32_t pos = atomicAdd(&B.s_cnt[row0 + k], 1u);
+            const uint32_t pos = solo ? atomicAdd(&s_kpos[k], 1u) : atomicAdd(&B.s_cnt[row0 + k], 1u);
             if (pos < P.list_cap) B.s_pts[(size_t)(row0 + k) * P.list_cap + pos] = pq;
           }
         }
@@ -1958,6 +1970,8 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
   drain();
   __syncthreads();
   flush(s_w[8]);
+  if (solo)
+    for (uint32_t k = tid; k < K; k += FX_WG) B.s_cnt[row0 + k] = s_kpos[k];
 }
 
 // ---------------------------------------------------------------- k_desc_fast
@@ -3190,8 +3204,12 @@ void fxk_offsets(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32
   hipLaunchKernelGGL(k_offsets, dim3(1), dim3(FX_WG), 0, s, P, B, batch);
 }
 void fxk_gather(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float box_margin) {
-  // a scan is split over 2 workgroups when the batch fills the GPU anyway, over more when it does not (streaming)
-  const uint32_t slices = batch >= 128 ? 2u : (batch >= 16 ? 4u : 16u);
+  // one workgroup per scan when the batch fills the GPU anyway (it is then the only writer of the scan's lists: no
+  // global atomics), several when it does not (streaming)
+#ifndef FX_GATHER_SLICES
+#define FX_GATHER_SLICES 1u
+#endif
+  const uint32_t slices = batch >= 128 ? FX_GATHER_SLICES : (batch >= 16 ? 4u : 16u);
   hipLaunchKernelGGL(k_gather, dim3(slices, batch), dim3(FX_WG),
                      fxk_gather_lds_bytes(P.max_keypoints), s, P, B, box_margin);
 }
