@@ -46,6 +46,36 @@ def build_cli(force=False, verbose=False):
     return CLI
 
 
+MULTI = os.path.join(HERE, "bin", "fx_multi_cli")
+SELFTEST = os.path.join(HERE, "bin", "fx_shard_selftest")
+
+
+def _newer(target, deps):
+    return os.path.exists(target) and all(os.path.getmtime(d) <= os.path.getmtime(target) for d in deps)
+
+
+def build_multi(force=False, verbose=False):
+    """C++ multi-GPU driver (csrc/fx_multi.hpp: one thread + context per device, RCCL all-gather of keypoint records)
+    and the CPU self-test of its sharding plan / record layout (csrc/fx_shard.hpp)."""
+    os.makedirs(os.path.dirname(MULTI), exist_ok=True)
+    deps = [os.path.join(CSRC, s) for s in ("fx_shard_selftest.cpp", "fx_shard.hpp")]
+    if force or not _newer(SELFTEST, deps):
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-o", SELFTEST, os.path.join(CSRC, "fx_shard_selftest.cpp")]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    deps = [os.path.join(CSRC, s) for s in ("fx_multi_cli.cpp", "fx_multi.hpp", "fx_shard.hpp")] + [LIB]
+    if force or not _newer(MULTI, deps):
+        rocm_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc()))), "lib")
+        cmd = [hipcc(), "-O2", "-std=c++17", "-o", MULTI, os.path.join(CSRC, "fx_multi_cli.cpp"), "-L" + os.path.dirname(LIB),
+               "-lfx_hip", "-L" + rocm_lib, "-lrccl", "-pthread", "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath," + os.path.dirname(LIB),
+               "-Wl,-rpath," + rocm_lib]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return MULTI
+
+
 def build(force=False, verbose=False):
     if force or stale():
         os.makedirs(os.path.dirname(LIB), exist_ok=True)
@@ -54,6 +84,7 @@ def build(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd)
     build_cli(force, verbose)
+    build_multi(force, verbose)
     return LIB
 
 

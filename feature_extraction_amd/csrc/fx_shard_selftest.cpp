@@ -1,0 +1,39 @@
+// fx_shard_selftest — CPU check of the C++ sharding plan and record layout (fx_shard.hpp), run as one process per rank
+// by tests/test_cpp_sharding.py:  fx_shard_selftest TOTAL WORLD RANK IN.bin OUT.bin
+// IN.bin: TOTAL records of keypoints as the test wrote them ({u32 n, n x float4} per scan); the rank packs the records of
+// its block exactly as fx_pack_keypoint_records lays them out and writes them to OUT.bin; stdout: "first last".
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "fx_shard.hpp"
+
+int main(int argc, char **argv) {
+  if (argc != 6) return 2;
+  const uint64_t total = std::strtoull(argv[1], nullptr, 10);
+  const uint32_t world = (uint32_t)std::atoi(argv[2]), rank = (uint32_t)std::atoi(argv[3]);
+  const auto span = fx::shard_range(total, world, rank);
+  for (uint64_t s = 0; s < total; ++s) {  // the plan is a partition: every scan has exactly one owner, consistent with the ranges
+    const uint32_t o = fx::owner_of(s, total, world);
+    const auto os = fx::shard_range(total, world, o);
+    if (s < os.first || s >= os.second) return 3;
+  }
+  FILE *in = std::fopen(argv[4], "rb"), *out = std::fopen(argv[5], "wb");
+  if (!in || !out) return 4;
+  std::vector<float> rec(fx::record_floats(fx::kRecKeypoints));
+  for (uint64_t s = 0; s < total; ++s) {
+    uint32_t n = 0;
+    if (std::fread(&n, 4, 1, in) != 1) return 5;
+    std::vector<float> kp((size_t)n * 4);
+    if (n && std::fread(kp.data(), 16, n, in) != n) return 5;
+    if (s < span.first || s >= span.second) continue;
+    fx::pack_record(rec.data(), kp.data(), n, 0u);
+    const fx::KeypointRecordView v = fx::record_of(rec.data(), 0);
+    if (v.n_keypoints() != (n < fx::kRecKeypoints ? n : fx::kRecKeypoints)) return 6;
+    std::fwrite(rec.data(), sizeof(float), rec.size(), out);
+  }
+  std::fclose(in);
+  std::fclose(out);
+  std::printf("%llu %llu\n", (unsigned long long)span.first, (unsigned long long)span.second);
+  return 0;
+}

@@ -1,0 +1,41 @@
+"""The C++ host's sharding plan and record layout (csrc/fx_shard.hpp — what csrc/fx_multi.hpp shards and gathers with)
+on CPU: one process per rank packs the records of its block of a stream; concatenated in rank order they must equal the
+unsharded table, and the Python plan (feature_extraction_amd/sharding.py, which bench.py and the gloo test use) must
+agree with the C++ one.  The RCCL collective itself runs in tests/test_gpu_multi.py (one rank on the 1-GPU box)."""
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from feature_extraction_amd import build, sharding
+
+
+@pytest.mark.parametrize("total,world", [(6, 2), (7, 2), (5, 3), (3, 4)])
+def test_ranks_tile_the_stream_and_records_match(tmp_path, total, world):
+    build.build_multi()
+    exe = build.SELFTEST
+    rng = np.random.default_rng(total * 10 + world)
+    kps = [rng.normal(size=(int(rng.integers(0, 140)), 4)).astype(np.float32) for _ in range(total)]  # some beyond 127
+    src = tmp_path / "in.bin"
+    with open(src, "wb") as f:
+        for kp in kps:
+            f.write(struct.pack("<I", len(kp)))
+            f.write(kp.tobytes())
+    procs = []
+    for r in range(world):  # one process per rank, as on a node with `world` GPUs
+        procs.append(subprocess.Popen([exe, str(total), str(world), str(r), str(src), str(tmp_path / f"out{r}.bin")],
+                                      stdout=subprocess.PIPE, text=True))
+    spans = []
+    for r, pr in enumerate(procs):
+        out, _ = pr.communicate(timeout=60)
+        assert pr.returncode == 0, (r, pr.returncode)
+        spans.append(tuple(int(x) for x in out.split()))
+    assert spans == [sharding.shard_range(total, world, r) for r in range(world)]
+    assert spans[0][0] == 0 and spans[-1][1] == total and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    got = np.concatenate([np.fromfile(tmp_path / f"out{r}.bin", np.float32) for r in range(world)])
+    want = sharding.pack_records(kps, [0] * total)
+    assert np.array_equal(got.view(np.uint32), want.reshape(-1).view(np.uint32))
+    for s in range(total):
+        o = sharding.owner_of(s, total, world)
+        assert spans[o][0] <= s < spans[o][1]
