@@ -75,7 +75,9 @@ void fx_limits_default(fx_limits *l, uint32_t max_batch, uint32_t max_points) {
   l->max_ring_candidates = 256;
   l->max_candidates = 2048;
   l->max_keypoints = 256;
-  l->max_neighbors = 4096;
+  // support-list entries per descriptor row (16 B each; the pool is max_total_keypoints rows): VLP-16-sized scans
+  // stay far below 1024 (longer sets take the re-gather / whole-CU tiers); dense many-ring scans get 4096
+  l->max_neighbors = max_points > 65536u ? 4096u : 1024u;
   l->max_total_keypoints = max_batch * 64u;
   l->max_kpc_points = 4096;
 }

@@ -81,10 +81,12 @@ typedef struct fx_limits {
   uint32_t max_points;          /* points per scan                                  */
   uint32_t max_ring_points;     /* points per (scan, ring) held in LDS   (def 2048) */
   uint32_t max_ring_candidates; /* candidates one ring may emit          (def 256)  */
-  uint32_t max_candidates;      /* per-ring candidates per scan, all rings (def 2048) */
+  uint32_t max_candidates;      /* per-ring candidates per scan, all rings (def 2048; <= ~3800 live in LDS as points,
+                                 * beyond that — up to ~16000 — the large merge tier keeps the coordinates in HBM) */
   uint32_t max_keypoints;       /* keypoints per scan                    (def 256)  */
-  uint32_t max_neighbors;       /* support-set points per keypoint the list tiers hold (def 4096; 64 KB of list per
-                                 * descriptor row); larger sets take the whole-CU tier (<= 12288) or HBM slabs */
+  uint32_t max_neighbors;       /* support-set points per keypoint the list tiers hold (def 1024, 4096 for scans of more
+                                 * than 65536 points; 16 B of list per entry and descriptor row); larger sets take the
+                                 * re-gather / whole-CU tiers (<= 12288) or HBM slabs */
   uint32_t max_total_keypoints; /* keypoints per batch (descriptor pool) (def max_batch*64) */
   uint32_t max_kpc_points;      /* keypoint_cloud points per scan        (def 4096) */
 } fx_limits;

@@ -18,7 +18,10 @@ import torch
 capi.load()
 scans = [capi.synth_scan(capi.synth_cfg(1000 + b)) for b in range(B)]
 dev = [torch.from_numpy(s).cuda() for s in scans]
-ctx = capi.Context(capi.params("launch"), capi.limits(B, 28800))
+over = {}
+if os.environ.get("FX_MAX_NEIGHBORS"):
+    over["max_neighbors"] = int(os.environ["FX_MAX_NEIGHBORS"])
+ctx = capi.Context(capi.params(os.environ.get("FX_PRESET", "launch")), capi.limits(B, 28800, **over))
 descs = ctx.make_descs([d.data_ptr() for d in dev], [len(s) for s in scans], 16, 0.02, -0.015)
 ctx.set_profiling(steps)
 for _ in range(3):
