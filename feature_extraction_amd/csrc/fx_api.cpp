@@ -237,7 +237,8 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof) {
         if (P.list_cap > split) fxk_desc_wg_xl(s, P, B, batch, P.list_cap, split, big_grid);
       }
       FX_HIP(mark(10));
-      fxk_desc_wg(s, P, B, batch, P.list_cap, big_grid, 0, 2);
+      // (no exact redo pass any more: the fast tiers evaluate the exact angles themselves for the rare neighbour next
+      //  to a bin edge; the exact kernel stays for the re-gather tier and the RNG second pass below)
       FX_HIP(mark(11));
       fxk_desc_wg(s, P, B, batch, L.max_neighbors, big_grid, 0, 0);
       fxk_desc_huge(s, P, B, batch, c->spill_grid, 0, c->spill_slab);

@@ -1648,13 +1648,19 @@ __device__ __forceinline__ uint32_t scan_of_row(const uint32_t *kp_offset, uint3
 // (j, k, l) bin and lookup-table weight of one neighbour.
 // kp = keypoint (origin), b = neighbour, xa = the keypoint's 3DSC x-axis (z component is -0).
 // FAST = false: phi / theta through fp64 atan2 / acos rounded once to fp32 (the oracle's policy).
-// FAST = true: fp32 atan2f / acosf; `amb` is raised when an angle is within FX_FAST_EPS_DEG of a
-// bin edge, i.e. when fp32 could put the neighbour into another bin than the exact evaluation
+// FAST = true: fp32 atan2f / acosf; when an angle is within FX_FAST_EPS_DEG of a bin edge, i.e. when fp32 could put
+// the neighbour into another bin than the exact evaluation, the exact evaluation is made for that neighbour
 // (everywhere else the two agree on the bin, and the bin is all that is used downstream).
 #define FX_FAST_EPS_DEG 5e-4f
 __device__ __forceinline__ bool near_multiple(float v, float step, float inv_step) {
   const float t = v * inv_step;
   return fabsf(t - rintf(t)) * step < FX_FAST_EPS_DEG;
+}
+// the exact angles (fp64 atan2 / acos rounded once: the oracle's policy) for the rare neighbour whose fp32 angle
+// falls next to a bin edge; kept out of line so that its registers and code stay out of the fast kernels' loops
+__device__ __noinline__ void sc3d_angles_exact(float cn, float xd, float tc, float *phi, float *theta) {
+  *phi = (float)atan2((double)cn, (double)xd) * 57.29578f;
+  *theta = (float)acos((double)tc) * 57.29578f;
 }
 template <bool FAST>
 __device__ __forceinline__ uint32_t sc3d_bin(const float4 kp, float bx, float by, float bz, float d2, const float2 xa,
@@ -1703,8 +1709,17 @@ __device__ __forceinline__ uint32_t sc3d_bin(const float4 kp, float bx, float by
   theta = (FAST ? acosf(tc) : (float)acos((double)tc)) * 57.29578f;
   if (FAST) {
     // edges: phi_div = 30 l, theta_div = l * (180/11) (A.8-2); non-finite angles go the exact way too
-    amb = amb || !(phi == phi) || !(theta == theta) || near_multiple(phi, 30.0f, 1.0f / 30.0f) ||
-          near_multiple(theta, 180.0f / 11.0f, 11.0f / 180.0f);
+    if (!(phi == phi) || !(theta == theta) || near_multiple(phi, 30.0f, 1.0f / 30.0f) ||
+        near_multiple(theta, 180.0f / 11.0f, 11.0f / 180.0f)) {
+#ifdef FX_EXACT_PASS
+      amb = true;  // (diagnostic build: hand the keypoint to the exact kernel instead)
+#else
+      float pe, te;
+      sc3d_angles_exact(cn, xd, tc, &pe, &te);
+      phi = cdn < 0.f ? (360.0f - pe) : pe;
+      theta = te;
+#endif
+    }
   }
 
   // PCL scans each edge table for the first edge >= the value and falls back to bin 0 when there is
