@@ -98,7 +98,7 @@ struct fx_ctx {
   float box_margin = 0.f;
   uint32_t ring_waves_per_cu = 16;
   uint32_t desc_wgs_per_cu = 10;
-  uint32_t spill_grid = 0, spill_slab = 0;
+  uint32_t spill_grid = 0, spill_slab = 0, tail_grid = 0;
   uint32_t merge_big_cap = 0;    // candidates the LDS merge tier holds as points (<= max_candidates)
   uint32_t merge_huge_ccap = 0;  // clusters the large merge tier can order (>= max_keypoints)
   // host-input staging
@@ -215,43 +215,40 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof) {
       if (per_cu < 1) per_cu = 1;
       fxk_rings_big(s, P, B, ring_mid, ring_mid / 4, (big_grid * per_cu + 7) / 8 * 8, 0);
     }
-    FX_HIP(mark(4));
     fxk_rings_big(s, P, B, L.max_ring_points, L.max_ring_points, (big_grid + 7) / 8 * 8, 1);
+    FX_HIP(mark(4));
     fxk_merge_small(s, P, B, batch, merge_small);
-    FX_HIP(mark(5));
     fxk_merge_big(s, P, B, c->merge_big_cap, big_grid, c->merge_big_cap >= L.max_candidates);
     if (c->merge_big_cap < L.max_candidates) fxk_merge_huge(s, P, B, L.max_candidates, c->merge_huge_ccap, big_grid);
     fxk_offsets(s, P, B, batch);
+    FX_HIP(mark(5));
     if (P.estimate_descriptors) {
-      FX_HIP(mark(6));
       fxk_gather(s, P, B, batch, c->box_margin);
-      FX_HIP(mark(7));
+      FX_HIP(mark(6));
       fxk_desc_group(s, P, B, batch, desc_grid);
-      FX_HIP(mark(8));
+      FX_HIP(mark(7));
       fxk_desc_fast(s, P, B, batch, big_grid * 4);
-      FX_HIP(mark(9));
+      FX_HIP(mark(8));
       {
         // lists of up to kListSplit entries: four keypoints per CU in flight; longer ones: one per CU
         const uint32_t split = P.list_cap < kListSplit ? P.list_cap : kListSplit;
         fxk_desc_wg_fast(s, P, B, batch, split, big_grid * 4);
         if (P.list_cap > split) fxk_desc_wg_xl(s, P, B, batch, P.list_cap, split, big_grid);
       }
-      FX_HIP(mark(10));
-      // (no exact redo pass any more: the fast tiers evaluate the exact angles themselves for the rare neighbour next
-      //  to a bin edge; the exact kernel stays for the re-gather tier and the RNG second pass below)
-      FX_HIP(mark(11));
-      fxk_desc_wg(s, P, B, batch, L.max_neighbors, big_grid, 0, 0);
+      // (no exact redo pass: the fast tiers evaluate the exact angles themselves for the rare neighbour next to a bin
+      //  edge; the exact kernel stays for the re-gather tier and the RNG second pass)
+      fxk_desc_wg(s, P, B, batch, L.max_neighbors, c->tail_grid, 0, 0);
       fxk_desc_huge(s, P, B, batch, c->spill_grid, 0, c->spill_slab);
       fxk_desc_spill(s, P, B, batch, c->spill_grid, 0, c->spill_slab);
       fxk_rng_ord(s, P, B, batch);
       // second pass: only keypoints whose RNG ordinal moved (an earlier keypoint had no neighbours)
-      fxk_desc_wg(s, P, B, batch, L.max_neighbors, big_grid, 1, 0);
+      fxk_desc_wg(s, P, B, batch, L.max_neighbors, c->tail_grid, 1, 0);
       fxk_desc_huge(s, P, B, batch, c->spill_grid, 1, c->spill_slab);
       fxk_desc_spill(s, P, B, batch, c->spill_grid, 1, c->spill_slab);
     } else {
-      for (int i = 6; i <= 11; ++i) FX_HIP(mark(i));
+      for (int i = 6; i <= 8; ++i) FX_HIP(mark(i));
     }
-    FX_HIP(mark(12));
+    FX_HIP(mark(9));
     FX_HIP(hipGetLastError());
   } else {
     for (int i = 1; i <= FX_N_STAGES; ++i) FX_HIP(mark(i));
@@ -477,6 +474,8 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
     while (slab < L.max_points) slab <<= 1;
     c->spill_slab = slab;
     c->spill_grid = (uint32_t)c->n_cu;
+    if (const char *e = getenv("FX_TAIL_GRID")) c->spill_grid = (uint32_t)atoi(e);  // experiment: grid of the rare descriptor tiers
+    c->tail_grid = c->spill_grid;
     const size_t n = (size_t)c->spill_grid * slab;
     FX_A(dev_alloc(c, &b.spill_pts, n));
     FX_A(dev_alloc(c, &b.spill_d2, n));

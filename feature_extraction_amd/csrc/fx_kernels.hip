@@ -2163,7 +2163,10 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_fast(FxDevParams P, F
 #define FX_GROUPS (64 / FX_GLANES)
 #define FX_GROUP_CAP 64
 #define FX_GROUP_WORDS (FX_GROUP_CAP * 8 + 8)  // per group: support float4, keys, weights, indices + 8 counters
-extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_group(FxDevParams P, FxBuffers B, uint32_t batch) {
+#ifndef FX_GROUP_OCC
+#define FX_GROUP_OCC 4
+#endif
+extern "C" __global__ __launch_bounds__(FX_WG, FX_GROUP_OCC) void k_desc_group(FxDevParams P, FxBuffers B, uint32_t batch) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t gl = lane % FX_GLANES, g = lane / FX_GLANES;

@@ -22,7 +22,7 @@ extern "C" {
 #endif
 
 #define FX_VERSION_MAJOR 0
-#define FX_VERSION_MINOR 1
+#define FX_VERSION_MINOR 2
 
 /* pcl::ShapeContext1980: 12 azimuth x 11 elevation x 15 radius bins + rf[9]
  * (ref: include/feature_extraction/feature_extraction_node.h:35-53,75). */
@@ -152,11 +152,11 @@ typedef struct fx_batch_view {
 } fx_batch_view;
 
 /* Per-stage device time of the last batch (HIP events on the context's stream). */
-#define FX_N_STAGES 12
+#define FX_N_STAGES 9
 typedef struct fx_timings {
-  /* k_prep, k_bucket, k_rings_small, k_rings_big (mid tier), large ring tier + k_merge_small,
-   * k_merge_big + k_offsets, k_gather, k_desc_group, k_desc_fast, k_desc_wg_fast,
-   * k_desc_wg (exact redo of near-edge keypoints), tail (re-gather / spill tiers, k_rng_ord, second pass) */
+  /* k_prep, k_bucket, k_rings_small, k_rings_big (mid and large ring tiers), k_merge (small / big / large tiers +
+   * k_offsets), k_gather, k_desc_group, k_desc_fast, k_desc_wg (every workgroup-per-keypoint tier: list, re-gather,
+   * whole-CU, slab; k_rng_ord and the second pass) */
   float ms[FX_N_STAGES];
   float total_ms;
 } fx_timings;
