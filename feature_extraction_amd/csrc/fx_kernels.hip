@@ -2762,21 +2762,32 @@ extern "C" __global__ __launch_bounds__(FX_HUGE_T) void k_desc_huge(FxDevParams 
           const float ry = ((M.R[3] * x + M.R[4] * y) + M.R[5] * z) + 0.0f;
           const float rz = ((M.R[6] * x + M.R[7] * y) + M.R[8] * z) + 0.0f;
           const float d = dist2(kp.x, kp.y, kp.z, rx, ry, rz);
-          if (!(d < P.r2_support && isfinite(rx) && isfinite(ry) && isfinite(rz))) continue;
-          const uint32_t ce = cell_of(rx, ry);
+          // (the counters every support point bumps are bumped once per wavefront: thousands of LDS atomics on one
+          //  address serialise across the whole workgroup)
+          const bool in = d < P.r2_support && isfinite(rx) && isfinite(ry) && isfinite(rz);
+          const unsigned long long m_in = __ballot(in);
+          if (!m_in) continue;  // (wave-uniform)
+          const uint32_t ce = in ? cell_of(rx, ry) : 0u;
           if (pass == 0) {
-            atomicAdd(&cell_fill[ce], 1u);
-            atomicAdd(&s_w[0], 1u);
+            if (in) atomicAdd(&cell_fill[ce], 1u);
+            if ((threadIdx.x & 63) == 0) atomicAdd(&s_w[0], (uint32_t)__popcll(m_in));
           } else {
-            const uint32_t slot = cell_start[ce] + atomicAdd(&cell_fill[ce], 1u);
-            xyz[3 * slot + 0] = rx;
-            xyz[3 * slot + 1] = ry;
-            xyz[3 * slot + 2] = rz;
-            sd2[slot] = d;
-            sidx[slot] = i0 + u * FX_HUGE_T + tid;
-            if (d < P.r2_search) {
-              atomicAdd(&s_w[2], 1u);
-              if (!sc3d_is_origin(d)) nlist[atomicAdd(&s_w[1], 1u)] = slot;
+            const bool nb = in && d < P.r2_search, bin_nb = nb && !sc3d_is_origin(d);
+            const unsigned long long m_nb = __ballot(nb), m_bin = __ballot(bin_nb);
+            uint32_t nl_base = 0;
+            if ((threadIdx.x & 63) == 0) {
+              if (m_nb) atomicAdd(&s_w[2], (uint32_t)__popcll(m_nb));
+              if (m_bin) nl_base = atomicAdd(&s_w[1], (uint32_t)__popcll(m_bin));
+            }
+            nl_base = (uint32_t)__shfl((int)nl_base, 0, 64);
+            if (in) {
+              const uint32_t slot = cell_start[ce] + atomicAdd(&cell_fill[ce], 1u);
+              xyz[3 * slot + 0] = rx;
+              xyz[3 * slot + 1] = ry;
+              xyz[3 * slot + 2] = rz;
+              sd2[slot] = d;
+              sidx[slot] = i0 + u * FX_HUGE_T + tid;
+              if (bin_nb) nlist[nl_base + lanes_below(m_bin)] = slot;
             }
           }
         }

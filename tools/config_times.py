@@ -15,16 +15,15 @@ which = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 if len(sys.argv) > 3:
     capi.LIB_PATH = os.path.join(os.path.dirname(capi.LIB_PATH), sys.argv[3])
 capi.load()
-if which == 3:
-    B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-    cfg = dict(n_rings=64, n_az=2048, el0_deg=-24.8, el_step_deg=26.8 / 63, n_poles=256)
-    p = capi.params("launch", n_rings=64, el0_deg=-24.8, el_step_deg=26.8 / 63, secondary_max=64)
-    lim = capi.limits(B, 64 * 2048, max_candidates=3500, max_kpc_points=32768, max_keypoints=512, max_total_keypoints=B * 512)
-else:
-    B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-    cfg = dict(n_rings=128, n_az=2048, el0_deg=-25.0, el_step_deg=40.0 / 127, n_poles=256)
-    p = capi.params("default", n_rings=128, el0_deg=-25.0, el_step_deg=40.0 / 127, secondary_max=128, descriptor_radius=2.0)
-    lim = capi.limits(B, 128 * 2048, max_candidates=3500, max_kpc_points=65536, max_keypoints=512, max_total_keypoints=B * 512)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # the configurations bench.py reports as other_configs
+
+name = [n for n in bench.OTHER_CONFIGS if n.startswith(f"config{which}")][0]
+C = bench.OTHER_CONFIGS[name]
+B = int(sys.argv[2]) if len(sys.argv) > 2 else C["batch"]
+cfg = C["synth"]
+p = capi.params(C["preset"], **C["params"])
+lim = capi.limits(B, cfg["n_rings"] * cfg["n_az"], **dict(C["limits"], max_total_keypoints=B * 256))
 uniq = [capi.synth_scan(capi.synth_cfg(10 + b, **cfg)) for b in range(min(B, 16))]
 dev = [torch.from_numpy(s).cuda() for s in uniq]
 ctx = capi.Context(p, lim)
