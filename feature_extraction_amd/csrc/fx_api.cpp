@@ -27,7 +27,7 @@ uint32_t fxk_huge_cap(void);
 size_t fxk_merge_huge_lds_bytes(uint32_t cap, uint32_t ccap, uint32_t n_rings);
 hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t merge_huge, size_t desc_big, size_t gather);
 uint32_t fxk_near_words(uint32_t max_points);
-void fxk_prep(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float near_margin);
+void fxk_prep(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float near_margin, float el0, float inv_step);
 void fxk_bucket(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float el0, float inv_step);
 void fxk_rings_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t ccap,
                      uint32_t mid_cap, uint32_t grid);
@@ -185,7 +185,7 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof) {
     const uint32_t ring_small = L.max_ring_points < kRingCapSmall ? L.max_ring_points : kRingCapSmall;
     const uint32_t merge_small = L.max_candidates < kMergeCapSmall ? L.max_candidates : kMergeCapSmall;
     const uint32_t desc_grid = (uint32_t)c->n_cu * c->desc_wgs_per_cu;  // resident all at once (32 KB LDS each)
-    fxk_prep(s, P, B, batch, c->box_margin);
+    fxk_prep(s, P, B, batch, c->box_margin, (float)c->params.el0_deg, (float)(1.0 / c->params.el_step_deg));
     FX_HIP(mark(1));
     fxk_bucket(s, P, B, batch, (float)c->params.el0_deg, (float)(1.0 / c->params.el_step_deg));
     FX_HIP(mark(2));

@@ -713,6 +713,7 @@ __device__ __forceinline__ uint32_t cc_order(uint32_t n, const uint32_t *parent,
 // stage's reach of the filter box (every keypoint is a centroid of filtered points, hence inside the box; a point
 // farther than the support radius from the box cannot support any keypoint): k_gather skips the others unread.
 #define FX_PREP_T 512
+#define FX_MAX_RINGS 1024  // fx_create checks n_rings against it
 #define FX_PREP_U 4
 #define FX_PREP_TILE (FX_PREP_T * FX_PREP_U)  // 2048 points = 32 groups of 64 = one word of near bits
 typedef float __attribute__((address_space(1))) gfloat;
@@ -735,10 +736,29 @@ __device__ __forceinline__ float elevation_deg(float xf, float yf, float zf) {
   return (float)(atan2(z, xp) * 180 / M_PI);
 }
 
+// rings a point belongs to (ref: node.cpp:200-201): used by k_prep (counts) and k_bucket (the split)
+__device__ __forceinline__ uint32_t ring_membership(float el, const float2 *win, int n_rings, float el0, float inv_step,
+                                                    int &r_first) {
+  // candidate rings: the nearest centre and its two neighbours; membership by the exact windows
+  const float t = (el - el0) * inv_step + 0.5f;
+  int r0 = (t > -4.0f && t < 1.0e6f) ? (int)floorf(t) : -4;
+  r_first = r0 - 1;
+  uint32_t mask = 0;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const int r = r_first + d;
+    if (r >= 0 && r < n_rings) {
+      const float2 w = win[r];
+      if (!(el < w.x || el > w.y)) mask |= 1u << d;
+    }
+  }
+  return mask;
+}
+
 #ifndef FX_PREP_OCC
 #define FX_PREP_OCC 4  // waves per SIMD the register budget is held to: 4 = two workgroups per CU (129 registers would mean one)
 #endif
-__global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, FxBuffers B, float near_margin) {
+__global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, FxBuffers B, float near_margin, float el0, float inv_step) {
   constexpr int NW = FX_PREP_T / 64;
   constexpr uint32_t kTile = FX_PREP_TILE;           // points per tile; wave w owns [256 w, 256 w + 256) of it
   constexpr uint32_t kKeep = kTile + kTile / 2;      // survivors buffered between sweeps
@@ -746,6 +766,7 @@ __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, 
   const FxScanMeta M = B.meta[scan];
   __shared__ uint32_t s_cnt[2][NW];                  // per wave: survivors of the tile | near nibble << 16; by tile parity
   __shared__ float s_keep[3 * kKeep];                // un-rotated survivors (x, y, z) waiting for the elevation sweep
+  __shared__ uint32_t s_ring[FX_MAX_RINGS];          // survivors per ring (a window-boundary point counts in both rings)
   float4 *out = B.filt + (size_t)scan * P.max_points;
   uint32_t *near_bits = B.near_bits + (size_t)scan * P.near_words;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -754,14 +775,17 @@ __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, 
   // (global address space stated: a generic-pointer load would be a flat load, which also counts as an
   //  LDS access and gets waited for at the next LDS instruction)
   const gfloat *gpts = (const gfloat *)M.pts;
+  const uint32_t R = (uint32_t)P.n_rings;
   if (n == 0) {  // empty scan (ref: node.cpp:209-210, 263-264): its pointer may be null — nothing is loaded
     if (tid == 0) {
       B.n_filt[scan] = 0u;
       B.flags[scan] = 0u;
     }
+    for (uint32_t r = tid; r < R; r += FX_PREP_T) B.ring_cnt[(size_t)scan * R + r] = 0u;
     if (scan == 0 && tid < FX_N_COUNTERS) B.counters[tid] = 0u;
     return;
   }
+  for (uint32_t r = tid; r < R; r += FX_PREP_T) s_ring[r] = 0u;  // (ordered before the first sweep by the tile barriers)
   // the loads of the next tile are issued before this tile's barrier, so the memory pipe stays full
   // while the tile is compacted
   auto load_tile = [&](uint32_t t0, float4 (&v)[FX_PREP_U]) {
@@ -782,7 +806,14 @@ __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, 
       const float rx = ((M.R[0] * x + M.R[1] * y) + M.R[2] * z) + 0.0f;
       const float ry = ((M.R[3] * x + M.R[4] * y) + M.R[5] * z) + 0.0f;
       const float rz = ((M.R[6] * x + M.R[7] * y) + M.R[8] * z) + 0.0f;
-      out[base + j] = make_float4(rx, ry, rz, elevation_deg(x, y, z));
+      const float el = elevation_deg(x, y, z);
+      out[base + j] = make_float4(rx, ry, rz, el);
+      // ring counts for k_bucket's split (it then reads the filtered cloud once, not twice)
+      int r_first;
+      const uint32_t mask = isfinite(el) ? ring_membership(el, B.ring_win, P.n_rings, el0, inv_step, r_first) : 0u;
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+        if (mask & (1u << d)) atomicAdd(&s_ring[r_first + d], 1u);
     }
     base += buffered;
     buffered = 0;
@@ -852,6 +883,8 @@ __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, 
   }
   __syncthreads();
   sweep();
+  __syncthreads();
+  for (uint32_t r = tid; r < R; r += FX_PREP_T) B.ring_cnt[(size_t)scan * R + r] = s_ring[r];
   if (tid == 0) {
     B.n_filt[scan] = base;
     B.flags[scan] = 0u;
@@ -864,24 +897,6 @@ __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, 
 // filtered cloud.  Here one workgroup per scan deals the filtered points to their rings in
 // one stable pass (a point on a window boundary belongs to both rings, A.3), so the ring
 // workgroups read exactly their own points, already in ring order.
-__device__ __forceinline__ uint32_t ring_membership(float el, const float2 *win, int n_rings, float el0, float inv_step,
-                                                    int &r_first) {
-  // candidate rings: the nearest centre and its two neighbours; membership by the exact windows
-  const float t = (el - el0) * inv_step + 0.5f;
-  int r0 = (t > -4.0f && t < 1.0e6f) ? (int)floorf(t) : -4;
-  r_first = r0 - 1;
-  uint32_t mask = 0;
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    const int r = r_first + d;
-    if (r >= 0 && r < n_rings) {
-      const float2 w = win[r];
-      if (!(el < w.x || el > w.y)) mask |= 1u << d;
-    }
-  }
-  return mask;
-}
-
 #define FX_BUCKET_T 512
 #define FX_BUCKET_NW (FX_BUCKET_T / 64)
 extern "C" __global__ __launch_bounds__(FX_BUCKET_T) void k_bucket(FxDevParams P, FxBuffers B, float el0, float inv_step) {
@@ -894,16 +909,7 @@ extern "C" __global__ __launch_bounds__(FX_BUCKET_T) void k_bucket(FxDevParams P
   const uint32_t scan = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t nf = B.n_filt[scan];
   const float4 *f = B.filt + (size_t)scan * P.max_points;
-  for (uint32_t r = tid; r < R; r += FX_BUCKET_T) cnt[r] = 0;
-  __syncthreads();
-  for (uint32_t i = tid; i < nf; i += FX_BUCKET_T) {
-    const float el = f[i].w;
-    int r_first;
-    uint32_t mask = isfinite(el) ? ring_membership(el, B.ring_win, P.n_rings, el0, inv_step, r_first) : 0u;
-#pragma unroll
-    for (int d = 0; d < 3; ++d)
-      if (mask & (1u << d)) atomicAdd(&cnt[r_first + d], 1u);
-  }
+  for (uint32_t r = tid; r < R; r += FX_BUCKET_T) cnt[r] = B.ring_cnt[(size_t)scan * R + r];  // counted by k_prep's sweep
   __syncthreads();
   uint32_t total = 0;
   for (uint32_t b0 = 0; b0 < R; b0 += FX_BUCKET_T) {
@@ -3202,8 +3208,8 @@ hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t merge_huge, s
 }
 
 uint32_t fxk_near_words(uint32_t max_points) { return (max_points + FX_PREP_TILE - 1) / FX_PREP_TILE; }
-void fxk_prep(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float near_margin) {
-  hipLaunchKernelGGL(k_prep, dim3(batch), dim3(FX_PREP_T), 0, s, P, B, near_margin);
+void fxk_prep(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float near_margin, float el0, float inv_step) {
+  hipLaunchKernelGGL(k_prep, dim3(batch), dim3(FX_PREP_T), 0, s, P, B, near_margin, el0, inv_step);
 }
 void fxk_bucket(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float el0, float inv_step) {
   const size_t lds = (48 + (size_t)P.n_rings * (2 + FX_BUCKET_NW) + 1) * 4;
