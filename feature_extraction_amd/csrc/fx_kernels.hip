@@ -2173,6 +2173,9 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_fast(FxDevParams P, F
 #define FX_GROUPS (64 / FX_GLANES)
 #define FX_GROUP_CAP 64
 #define FX_GROUP_WORDS (FX_GROUP_CAP * 8 + 8)  // per group: support float4, keys, weights, indices + 8 counters
+#ifndef FX_GROUP_UNROLL
+#define FX_GROUP_UNROLL 8
+#endif
 #ifndef FX_GROUP_OCC
 #define FX_GROUP_OCC 4
 #endif
@@ -2253,7 +2256,7 @@ extern "C" __global__ __launch_bounds__(FX_WG, FX_GROUP_OCC) void k_desc_group(F
       const uint32_t bin = sc3d_bin<true>(kp, b.x, b.y, b.z, d2, xa, T, lut, amb);
       if (amb) cnt[2] = 1u;
       uint32_t dens = 0;  // support points within R/5 of this neighbour (itself included)
-#pragma unroll 8
+#pragma unroll FX_GROUP_UNROLL
       for (uint32_t q = 0; q < nS; ++q) {
         const float4 s = sp[q];
         dens += (dist2(b.x, b.y, b.z, s.x, s.y, s.z) < P.r2_density) ? 1u : 0u;
@@ -2294,7 +2297,7 @@ extern "C" __global__ __launch_bounds__(FX_WG, FX_GROUP_OCC) void k_desc_group(F
         my_key[u] = nkey[e];
         my_w[u] = nw[e];
         uint32_t rank = 0;
-#pragma unroll 8
+#pragma unroll FX_GROUP_UNROLL
         for (uint32_t q = 0; q < nM; ++q) rank += (nkey[q] < my_key[u]) ? 1u : 0u;
         my_rank[u] = rank;
       }
