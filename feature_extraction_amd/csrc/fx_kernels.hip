@@ -2472,14 +2472,27 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
   //      per-neighbour pass below overwrites slot m with the real key and weight.
   uint32_t *nlist = reinterpret_cast<uint32_t *>(L.nw);
   uint32_t *dens = reinterpret_cast<uint32_t *>(L.nkey);  // dens[2 * m]
-  for (uint32_t e = tid; e < nS; e += NT) {
-    const float d2 = L.sp[e].w;
-    if (!(d2 < P.r2_search)) continue;
-    atomicAdd(&L.s_w[2], 1u);
-    if (sc3d_is_origin(d2)) continue;
-    const uint32_t m = atomicAdd(&L.s_w[1], 1u);
-    nlist[m] = e;
-    dens[2 * m] = 0u;
+  // (a stable compaction: the list keeps the support set's order, which for a list-fed set is its cell order —
+  //  the lanes of a wavefront then hold neighbours of the same few cells, whose density queries scan the same rows:
+  //  equal trip counts and LDS broadcast reads instead of a wavefront paying every row's longest lane)
+  {
+    uint32_t *scratch = reinterpret_cast<uint32_t *>(L.img) + FX_DESC_BINS - 32;  // (behind the cell table and the 3DSC tables)
+    uint32_t n_use = 0;
+    for (uint32_t e0 = 0; e0 < nS; e0 += NT) {
+      const uint32_t e = e0 + tid;
+      const float d2 = e < nS ? L.sp[e].w : INFINITY;
+      const bool nb = d2 < P.r2_search, use = nb && !sc3d_is_origin(d2);
+      const unsigned long long m_nb = __ballot(nb);
+      if ((tid & 63u) == 0 && m_nb) atomicAdd(&L.s_w[2], (uint32_t)__popcll(m_nb));
+      uint32_t tot;
+      const uint32_t r = block_rank<NT>(use, scratch, tot);
+      if (use) {
+        nlist[n_use + r] = e;
+        dens[2 * (n_use + r)] = 0u;
+      }
+      n_use += tot;
+    }
+    if (tid == 0) L.s_w[1] = n_use;
   }
   __syncthreads();
   FX_STAMP(6);
