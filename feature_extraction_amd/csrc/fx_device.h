@@ -32,7 +32,7 @@ struct FxDevParams {
   uint32_t max_points, max_ring_cands, max_candidates, max_keypoints, max_total_kp, max_kpc, max_neighbors,
       max_ring_points, list_cap, ring_slot_cap;
   uint32_t ring_list_cap;  // entries per XCD class of the deferred-ring lists
-  uint32_t near_words;  // words of near bits per scan: one bit per 64 consecutive points (k_prep -> k_gather)
+  uint32_t near_words;  // words of near bits per scan: one bit per 4 consecutive points = one 64-byte sector (k_prep -> k_gather)
   uint32_t huge_cap;  // support points k_desc_huge takes (<= its LDS capacity; tests lower it to reach the slab tier)
 };
 
@@ -56,7 +56,7 @@ struct FxBuffers {
   // stage 1
   float4 *filt;          // [B][max_points]
   uint32_t *n_filt;      // [B]
-  uint32_t *near_bits;   // [B][near_words]  bit g: some point of the scan's g-th group of 64 is within the descriptor stage's reach of the filter box
+  uint32_t *near_bits;   // [B][near_words]  bit: some point of that sector (4 points) is within the descriptor stage's reach of the filter box
   // stage 2a: ring-major copy of the filtered cloud
   float4 *ring_pts;         // [B][ring_slot_cap]
   uint32_t *ring_off;       // [B][n_rings]

@@ -766,7 +766,7 @@ __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, 
   constexpr uint32_t kKeep = kTile + kTile / 2;      // survivors buffered between sweeps
   const uint32_t scan = blockIdx.x;
   const FxScanMeta M = B.meta[scan];
-  __shared__ uint32_t s_cnt[2][NW];                  // per wave: survivors of the tile | near nibble << 16; by tile parity
+  __shared__ uint32_t s_cnt[2][NW];                  // per wave: survivors of the tile; by tile parity
   __shared__ float s_keep[3 * kKeep];                // un-rotated survivors (x, y, z) waiting for the elevation sweep
   __shared__ uint32_t s_ring[FX_MAX_RINGS];          // survivors per ring (a window-boundary point counts in both rings)
   float4 *out = B.filt + (size_t)scan * P.max_points;
@@ -830,7 +830,8 @@ __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, 
     load_tile(t0 + kTile, nv);
     bool keep[FX_PREP_U];
     unsigned long long mask[FX_PREP_U];
-    uint32_t wave_cnt = 0, nib = 0;
+    uint32_t wave_cnt = 0;
+    unsigned long long sect = 0;  // one bit per four consecutive points (one 64-byte sector) of this wave's 256
 #pragma unroll
     for (int u = 0; u < FX_PREP_U; ++u) {
       const float x = v[u].x, y = v[u].y, z = v[u].z;
@@ -847,24 +848,35 @@ __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, 
       keep[u] = k;
       mask[u] = __ballot(k);
       wave_cnt += (uint32_t)__popcll(mask[u]);
-      nib |= __ballot(near) ? (1u << u) : 0u;
+      {
+        // sector s of this load holds lanes 4 s .. 4 s + 3: bits 0, 4, 8, ... of the OR, squeezed to 16 adjacent bits
+        unsigned long long x = __ballot(near);
+        x = (x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x1111111111111111ull;
+        x = (x | (x >> 3)) & 0x0303030303030303ull;
+        x = (x | (x >> 6)) & 0x000f000f000f000full;
+        x = (x | (x >> 12)) & 0x000000ff000000ffull;
+        x = (x | (x >> 24)) & 0xffffull;
+        sect |= x << (16 * u);
+      }
     }
-    if (lane == 0) s_cnt[parity][wave] = wave_cnt | (nib << 16);
+    if (lane == 0) {
+      s_cnt[parity][wave] = wave_cnt;
+      near_bits[(t0 / kTile) * (2 * NW) + 2 * wave] = (uint32_t)sect;
+      near_bits[(t0 / kTile) * (2 * NW) + 2 * wave + 1] = (uint32_t)(sect >> 32);
+    }
     // One barrier per tile: it orders this tile's counts before their readers, the previous sweep's
     // reads of s_keep before this tile's writes, and (a wave cannot be two tiles ahead of another) the
     // readers of the other parity's counts before they are overwritten next tile.
     __syncthreads();
     // buffer slot = survivors already buffered + those of earlier waves + of earlier slices of my wave
     //               + of earlier lanes of my slice: input order is kept
-    uint32_t before = 0, tile_total = 0, bits = 0;
+    uint32_t before = 0, tile_total = 0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
       const uint32_t c = s_cnt[parity][w];
-      before += (w < (int)wave) ? (c & 0xffffu) : 0u;
-      tile_total += c & 0xffffu;
-      bits |= (c >> 16) << (4 * w);
+      before += (w < (int)wave) ? c : 0u;
+      tile_total += c;
     }
-    if (tid == 0) near_bits[t0 / kTile] = bits;
     uint32_t pos = buffered + before;
 #pragma unroll
     for (int u = 0; u < FX_PREP_U; ++u) {
@@ -1938,25 +1950,26 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
     wave_sync_lds();
     qn = 0;
   };
-  // the groups of a tile that hold a point within reach of the filter box (k_prep), this wavefront's four
-  auto near_nibble = [&](uint32_t i0) -> uint32_t {
-    if (i0 >= hi) return 0u;
-    const uint32_t word = near_bits[i0 / FX_PREP_TILE];
-    return (word >> ((i0 % FX_PREP_TILE) / 64 + wave * 4)) & 0xfu;
+  // the 64-byte sectors (four points) of a tile that hold a point within reach of the filter box (k_prep): this
+  // wavefront's 256 points = the 64 sector bits one wavefront of k_prep wrote (its tiles are two of these)
+  auto near_sectors = [&](uint32_t i0) -> unsigned long long {
+    if (i0 >= hi) return 0ull;
+    const uint32_t w = (i0 / FX_PREP_TILE) * (FX_PREP_TILE / 128) + 2u * (((i0 % FX_PREP_TILE) / 1024u) * 4u + wave);
+    return (unsigned long long)near_bits[w] | ((unsigned long long)near_bits[w + 1] << 32);
   };
-  auto load_tile = [&](uint32_t i0, uint32_t nib, float4 (&v)[4]) {
+  auto load_tile = [&](uint32_t i0, unsigned long long sect, float4 (&v)[4]) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const uint32_t i = i0 + wave * 256 + u * 64 + lane;
       v[u] = make_float4(NAN, NAN, NAN, 0);
-      if (((nib >> u) & 1u) && i < hi) v[u] = *reinterpret_cast<const float4 *>(M.pts + (size_t)i * M.stride_f);
+      if (((sect >> (16 * u + (lane >> 2))) & 1ull) && i < hi) v[u] = *reinterpret_cast<const float4 *>(M.pts + (size_t)i * M.stride_f);
     }
   };
   float4 v[4], nv[4];
-  uint32_t nib = near_nibble(lo), nnib = 0;
+  unsigned long long nib = near_sectors(lo), nnib = 0;
   load_tile(lo, nib, v);
   for (uint32_t i0 = lo; i0 < hi; i0 += kTile) {
-    nnib = near_nibble(i0 + kTile);
+    nnib = near_sectors(i0 + kTile);
     load_tile(i0 + kTile, nnib, nv);  // the next tile's loads are in flight while this one is tested
     if (i0 != lo) {  // flush when the next tile might not fit any more (workgroup-uniform decision)
       __syncthreads();
@@ -1966,7 +1979,7 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      if (!((nib >> u) & 1u)) continue;  // (wave-uniform)
+      if (!((nib >> (16 * u)) & 0xffffull)) continue;  // (wave-uniform: none of the load's sixteen sectors was loaded)
       const float x = v[u].x, y = v[u].y, z = v[u].z;
       const float rx = ((M.R[0] * x + M.R[1] * y) + M.R[2] * z) + 0.0f;
       const float ry = ((M.R[3] * x + M.R[4] * y) + M.R[5] * z) + 0.0f;
@@ -3227,7 +3240,7 @@ hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t merge_huge, s
   return e;
 }
 
-uint32_t fxk_near_words(uint32_t max_points) { return (max_points + FX_PREP_TILE - 1) / FX_PREP_TILE; }
+uint32_t fxk_near_words(uint32_t max_points) { return (max_points + FX_PREP_TILE - 1) / FX_PREP_TILE * (FX_PREP_TILE / 128); }  // one bit per 4 points
 void fxk_prep(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float near_margin, float el0, float inv_step) {
   hipLaunchKernelGGL(k_prep, dim3(batch), dim3(FX_PREP_T), 0, s, P, B, near_margin, el0, inv_step);
 }
