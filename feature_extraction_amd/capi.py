@@ -23,6 +23,8 @@ FX_FLAG_NAMES = {0x1: "RING_OVERFLOW", 0x2: "CAND_OVERFLOW", 0x4: "KP_OVERFLOW",
 FX_N_STAGES = 9
 STAGE_NAMES = ("k_prep", "k_bucket", "k_rings_small", "k_rings_big", "k_merge", "k_gather", "k_desc_group", "k_desc_fast",
                "k_desc_wg")
+# stages that are one kernel launch (eligible as the roofline line's dominant kernel: their HIP-event span is that kernel)
+SINGLE_LAUNCH_STAGES = ("k_prep", "k_bucket", "k_rings_small", "k_gather", "k_desc_group", "k_desc_fast")
 # kernels launched inside each timed stage (rocprofv3 / PMC rows are per kernel name)
 STAGE_KERNELS = {"k_merge": ("k_merge_small", "k_merge_big", "k_merge_huge", "k_offsets"),
                  "k_desc_wg": ("k_desc_wg_fast", "k_desc_wg_xl", "k_desc_wg", "k_desc_huge", "k_desc_spill", "k_rng_ord")}
@@ -77,7 +79,7 @@ class FxPc2Layout(C.Structure):
 
 
 class FxTimings(C.Structure):
-    _fields_ = [("ms", C.c_float * FX_N_STAGES), ("total_ms", C.c_float)]
+    _fields_ = [("ms", C.c_float * FX_N_STAGES), ("total_ms", C.c_float), ("k_prep_exec_ms", C.c_float)]
 
 
 class FxSynthCfg(C.Structure):
@@ -262,6 +264,7 @@ class Context:
         """Per-kernel device ms (HIP events on the launch stream) of the batch `back` calls ago."""
         t = FxTimings()
         check(self.lib.fx_get_timings(self.handle, back, C.byref(t)))
+        self.last_k_prep_exec_ms = t.k_prep_exec_ms
         return {STAGE_NAMES[i]: t.ms[i] for i in range(FX_N_STAGES)}, t.total_ms
 
     def pack_keypoint_records(self, dst_device_ptr, rec_keypoints):

@@ -27,8 +27,9 @@ uint32_t fxk_huge_cap(void);
 size_t fxk_merge_huge_lds_bytes(uint32_t cap, uint32_t ccap, uint32_t n_rings);
 hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t merge_huge, size_t desc_big, size_t gather);
 uint32_t fxk_near_words(uint32_t max_points);
-void fxk_prep(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float near_margin, float el0, float inv_step);
-void fxk_bucket(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float el0, float inv_step);
+void fxk_prep(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float near_margin, float el0, float inv_step,
+              uint32_t clk_slot);
+void fxk_bucket(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float el0, float inv_step, uint32_t clk_next);
 void fxk_rings_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t ccap,
                      uint32_t mid_cap, uint32_t grid);
 void fxk_rings_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t ccap, uint32_t grid,
@@ -117,6 +118,9 @@ struct fx_ctx {
   uint32_t ev_depth = 0, ev_count = 0;
   uint32_t prof_mask = ~0u;        // stages that get events (bit i = stage i); fx_set_profiling_stages
   std::vector<uint32_t> ev_mask;   // the mask each ring slot was recorded with
+  std::vector<uint64_t> ev_seq;    // the batch sequence number each ring slot belongs to (k_prep's clock slot)
+  uint64_t batch_seq = 0;          // batches enqueued so far
+  double clk_khz = 100000.0;       // rate of the device's constant clock
   hipEvent_t *ev = nullptr;  // set of the batch being enqueued
   uint32_t last_batch = 0;
   // HIP graphs of the stage sequence, one per batch size (batches up to graph_max_batch)
@@ -167,6 +171,7 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof) {
   if (prof) {
     c->ev = &c->ev_ring[(size_t)(c->ev_count % c->ev_depth) * (FX_N_STAGES + 1)];
     c->ev_mask[c->ev_count % c->ev_depth] = c->prof_mask;
+    c->ev_seq[c->ev_count % c->ev_depth] = c->batch_seq;
   }
   const uint32_t pmask = c->prof_mask;
   auto mark = [&](int i) -> hipError_t {
@@ -185,9 +190,11 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof) {
     const uint32_t ring_small = L.max_ring_points < kRingCapSmall ? L.max_ring_points : kRingCapSmall;
     const uint32_t merge_small = L.max_candidates < kMergeCapSmall ? L.max_candidates : kMergeCapSmall;
     const uint32_t desc_grid = (uint32_t)c->n_cu * c->desc_wgs_per_cu;  // resident all at once (32 KB LDS each)
-    fxk_prep(s, P, B, batch, c->box_margin, (float)c->params.el0_deg, (float)(1.0 / c->params.el_step_deg));
+    fxk_prep(s, P, B, batch, c->box_margin, (float)c->params.el0_deg, (float)(1.0 / c->params.el_step_deg),
+             (uint32_t)(c->batch_seq % FX_CLK_SLOTS));
     FX_HIP(mark(1));
-    fxk_bucket(s, P, B, batch, (float)c->params.el0_deg, (float)(1.0 / c->params.el_step_deg));
+    fxk_bucket(s, P, B, batch, (float)c->params.el0_deg, (float)(1.0 / c->params.el_step_deg),
+               (uint32_t)((c->batch_seq + 1) % FX_CLK_SLOTS));
     FX_HIP(mark(2));
     const uint32_t ring_mid = L.max_ring_points < kRingCapMid ? L.max_ring_points : kRingCapMid;
     {
@@ -484,6 +491,14 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
     FX_A(dev_alloc(c, &b.spill_w, n));
   }
   FX_A(dev_alloc(c, &b.counters, FX_N_COUNTERS));
+  FX_A(dev_alloc(c, &b.clk, 2 * FX_CLK_SLOTS));
+  {
+    std::vector<unsigned long long> init(2 * FX_CLK_SLOTS);
+    for (int i = 0; i < FX_CLK_SLOTS; ++i) init[2 * i] = ~0ull, init[2 * i + 1] = 0ull;
+    if (hipMemcpy(b.clk, init.data(), init.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemcpy"));
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device_id) == hipSuccess && khz > 0) c->clk_khz = khz;
+  }
   FX_A(dev_alloc(c, &b.stamps, 64 * 64));
   if (hipMemset(b.stamps, 0, 64 * 64 * 8) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
 
@@ -576,6 +591,7 @@ fx_status fx_set_profiling(fx_ctx *c, int depth) {
   c->profiling = depth > 0;
   c->ev_ring.resize((size_t)depth * (FX_N_STAGES + 1), nullptr);
   c->ev_mask.assign((size_t)depth, ~0u);
+  c->ev_seq.assign((size_t)depth, 0);
   for (hipEvent_t &e : c->ev_ring) FX_HIP(hipEventCreate(&e));
   return FX_OK;
 }
@@ -600,6 +616,14 @@ fx_status fx_get_timings(fx_ctx *c, uint32_t back, fx_timings *t) {
   for (int i = 0; i < FX_N_STAGES; ++i)
     if ((mask >> i) & 1u) FX_HIP(hipEventElapsedTime(&t->ms[i], ev[i], ev[i + 1]));  // (stages without events stay 0)
   FX_HIP(hipEventElapsedTime(&t->total_ms, ev[0], ev[FX_N_STAGES]));
+  {  // k_prep's own execution span (the batch has completed: its clock slot is final, and not yet reused)
+    const uint64_t seq = c->ev_seq[(c->ev_count - 1 - back) % c->ev_depth];
+    unsigned long long span[2] = {0, 0};
+    if (c->batch_seq - seq < FX_CLK_SLOTS - 1) {
+      FX_HIP(hipMemcpy(span, c->buf.clk + 2 * (seq % FX_CLK_SLOTS), sizeof(span), hipMemcpyDeviceToHost));
+      if (span[1] > span[0]) t->k_prep_exec_ms = (float)((double)(span[1] - span[0]) / c->clk_khz);
+    }
+  }
   return FX_OK;
 }
 fx_status fx_synchronize(fx_ctx *c) {
@@ -687,6 +711,7 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
   else
     FX_TRY(enqueue_stages(c, s, batch, prof));
   if (prof) ++c->ev_count;
+  ++c->batch_seq;
   c->last_batch = batch;
 
   // ---- view

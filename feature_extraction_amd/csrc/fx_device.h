@@ -45,6 +45,7 @@ struct FxScTables {
 };
 
 // Every device buffer of a context.
+#define FX_CLK_SLOTS 64
 #define FX_N_COUNTERS 32
 #define FX_CNT_MID 16    // counters[16 + c]: rings of XCD class c deferred to the mid tier
 #define FX_CNT_LARGE 24  // counters[24 + c]: ... to the large tier
@@ -108,6 +109,7 @@ struct FxBuffers {
   uint2 *row_map;         // [max_total_kp]  (scan, keypoint ordinal) of each descriptor row
   float4 *row_kp;         // [max_total_kp]  the row's keypoint and its 3DSC x-axis (first-pass ordinal), so that the
   float2 *row_xa;         //                 per-keypoint kernels fetch everything a row needs in one round trip
+  unsigned long long *clk;     // [FX_CLK_SLOTS][2] k_prep's first start / last end on the device's constant-rate clock, by batch
   unsigned long long *stamps;  // [32] diagnostic build only (-DFX_STAMPS)
   uint32_t *counters;     // [FX_N_COUNTERS]: 16.. deferred rings per XCD class (8 mid, 8 large); 0 big_rings, 1 big_merge, 2 big_desc, 3 need_rng_fix, 4 list_desc, 5 huge_rings, 6 spill_desc, 7 exact_desc, 8 wave_desc, 9 huge_merge, 12 huge_desc
 };

@@ -760,7 +760,7 @@ __device__ __forceinline__ uint32_t ring_membership(float el, const float2 *win,
 #ifndef FX_PREP_OCC
 #define FX_PREP_OCC 4  // waves per SIMD the register budget is held to: 4 = two workgroups per CU (129 registers would mean one)
 #endif
-__global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, FxBuffers B, float near_margin, float el0, float inv_step) {
+__global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, FxBuffers B, float near_margin, float el0, float inv_step, uint32_t clk_slot) {
   constexpr int NW = FX_PREP_T / 64;
   constexpr uint32_t kTile = FX_PREP_TILE;           // points per tile; wave w owns [256 w, 256 w + 256) of it
   constexpr uint32_t kKeep = kTile + kTile / 2;      // survivors buffered between sweeps
@@ -777,6 +777,9 @@ __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, 
   // (global address space stated: a generic-pointer load would be a flat load, which also counts as an
   //  LDS access and gets waited for at the next LDS instruction)
   const gfloat *gpts = (const gfloat *)M.pts;
+  // execution span of this launch on the device's constant-rate clock (first workgroup's start, last workgroup's end):
+  // what rocprofv3 reports as the kernel's duration; HIP events around the launch also count its wait for free CUs
+  if (tid == 0) atomicMin(&B.clk[2 * clk_slot], (unsigned long long)wall_clock64());
   const uint32_t R = (uint32_t)P.n_rings;
   if (n == 0) {  // empty scan (ref: node.cpp:209-210, 263-264): its pointer may be null — nothing is loaded
     if (tid == 0) {
@@ -906,6 +909,7 @@ __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, 
     B.flags[scan] = 0u;
   }
   if (scan == 0 && tid < FX_N_COUNTERS) B.counters[tid] = 0u;  // work-list counters of the batch (used from k_rings_small on)
+  if (tid == 0) atomicMax(&B.clk[2 * clk_slot + 1], (unsigned long long)wall_clock64());
 }
 
 // ====================================================================== stage 2a: ring buckets
@@ -915,7 +919,7 @@ __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, 
 // workgroups read exactly their own points, already in ring order.
 #define FX_BUCKET_T 512
 #define FX_BUCKET_NW (FX_BUCKET_T / 64)
-extern "C" __global__ __launch_bounds__(FX_BUCKET_T) void k_bucket(FxDevParams P, FxBuffers B, float el0, float inv_step) {
+extern "C" __global__ __launch_bounds__(FX_BUCKET_T) void k_bucket(FxDevParams P, FxBuffers B, float el0, float inv_step, uint32_t clk_next) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const uint32_t R = (uint32_t)P.n_rings;
   uint32_t *s_w = smem;            // 48: block helpers, per-wave ring ranges
@@ -923,6 +927,10 @@ extern "C" __global__ __launch_bounds__(FX_BUCKET_T) void k_bucket(FxDevParams P
   uint32_t *off = cnt + R;         // [R + 1]
   uint32_t *cw = off + R + 1;      // [FX_BUCKET_NW][R] per-wave counts of the current chunk
   const uint32_t scan = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (scan == 0 && tid == 0) {  // the clock slot the next batch's k_prep stamps
+    B.clk[2 * clk_next] = ~0ull;
+    B.clk[2 * clk_next + 1] = 0ull;
+  }
   const uint32_t nf = B.n_filt[scan];
   const float4 *f = B.filt + (size_t)scan * P.max_points;
   for (uint32_t r = tid; r < R; r += FX_BUCKET_T) cnt[r] = B.ring_cnt[(size_t)scan * R + r];  // counted by k_prep's sweep
@@ -3241,12 +3249,14 @@ hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t merge_huge, s
 }
 
 uint32_t fxk_near_words(uint32_t max_points) { return (max_points + FX_PREP_TILE - 1) / FX_PREP_TILE * (FX_PREP_TILE / 128); }  // one bit per 4 points
-void fxk_prep(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float near_margin, float el0, float inv_step) {
-  hipLaunchKernelGGL(k_prep, dim3(batch), dim3(FX_PREP_T), 0, s, P, B, near_margin, el0, inv_step);
+void fxk_prep(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float near_margin, float el0, float inv_step,
+              uint32_t clk_slot) {
+  hipLaunchKernelGGL(k_prep, dim3(batch), dim3(FX_PREP_T), 0, s, P, B, near_margin, el0, inv_step, clk_slot);
 }
-void fxk_bucket(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float el0, float inv_step) {
+void fxk_bucket(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float el0, float inv_step,
+                uint32_t clk_next) {
   const size_t lds = (48 + (size_t)P.n_rings * (2 + FX_BUCKET_NW) + 1) * 4;
-  hipLaunchKernelGGL(k_bucket, dim3(batch), dim3(FX_BUCKET_T), lds, s, P, B, el0, inv_step);
+  hipLaunchKernelGGL(k_bucket, dim3(batch), dim3(FX_BUCKET_T), lds, s, P, B, el0, inv_step, clk_next);
 }
 void fxk_rings_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t ccap,
                      uint32_t mid_cap, uint32_t grid) {

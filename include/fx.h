@@ -159,6 +159,10 @@ typedef struct fx_timings {
    * whole-CU, slab; k_rng_ord and the second pass) */
   float ms[FX_N_STAGES];
   float total_ms;
+  /* k_prep's execution span on the device's constant-rate clock: first workgroup's start to last workgroup's end — what
+   * rocprofv3 reports as the kernel's duration.  The HIP-event span ms[0] also counts the launch's wait for free CUs,
+   * which matters when several contexts keep the GPU busy.  0 when the batch is too old for its clock slot. */
+  float k_prep_exec_ms;
 } fx_timings;
 
 typedef struct fx_ctx fx_ctx;

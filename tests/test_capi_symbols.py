@@ -31,7 +31,7 @@ def test_struct_sizes_match_header(fxlib):
     assert C.sizeof(capi.FxParams) == 128
     assert C.sizeof(capi.FxLimits) == 9 * 4
     assert C.sizeof(capi.FxScanDesc) == 32
-    assert C.sizeof(capi.FxTimings) == (capi.FX_N_STAGES + 1) * 4
+    assert C.sizeof(capi.FxTimings) == (capi.FX_N_STAGES + 2) * 4
 
 
 def test_version_and_status_strings(fxlib):

@@ -18,7 +18,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-n_batches = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # 0: one k_prep launch per batch of the bench workload, counted below
+n_batches = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 0  # 0: one k_prep launch per batch of the bench workload, counted below
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -32,6 +32,17 @@ def one(pattern):
 
 
 shutil.copy(one("trace/**/*_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
+# the kernel with the largest average launch duration in that summary: the one bench.py's roofline line is about
+best = None
+for row in csv.DictReader(open(os.path.join(dst, f"{tag}_kernel_stats.csv"))):
+    name = row["Name"].split("(")[0]
+    if name.startswith("k_") and (best is None or float(row["AverageNs"]) > best[1]):
+        best = (name, float(row["AverageNs"]), int(row["Calls"]))
+if best and "--set-dominant" in sys.argv:
+    json.dump({"kernel": best[0], "average_ns": best[1], "calls": best[2],
+               "source": f"top AverageNs row among the path's kernels in profiles/{tag}_kernel_stats.csv (rocprofv3 --kernel-trace --stats of bench.py)"},
+              open(os.path.join(dst, "dominant.json"), "w"), indent=1)
+    print("dominant kernel:", best)
 
 
 def short(name):
