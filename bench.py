@@ -161,7 +161,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="scans per GPU per step")
     ap.add_argument("--preset", default="launch", choices=["default", "launch"])
-    ap.add_argument("--contexts", type=int, default=4,
+    ap.add_argument("--contexts", type=int, default=3,
                     help="batches in flight per GPU: contexts (each on its own HIP stream) taking the steps in turn")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip other_configs and the host-to-host measurement")
