@@ -2772,6 +2772,7 @@ extern "C" __global__ __launch_bounds__(FX_HUGE_T) void k_desc_huge(FxDevParams 
   const float r_sup = sqrtf(P.r2_support);
   const float cell_w = fmaxf(sqrtf(P.r2_density) * 1.001f, 2.0f * r_sup / (float)(G - 1) * 1.0001f);
   const float inv_cw = 1.0f / cell_w;
+  FX_STAMP_INIT(B.stamps ? B.stamps + 48 : nullptr);
   for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
     const uint32_t row = B.spill_desc[it];
     const uint2 rm = B.row_map[row];
@@ -2783,6 +2784,9 @@ extern "C" __global__ __launch_bounds__(FX_HUGE_T) void k_desc_huge(FxDevParams 
     const float2 xa = B.xaxis[ord];
     float *out = B.desc + (size_t)row * FX_DESC_FLOATS;
     const float gx0 = kp.x - r_sup, gy0 = kp.y - r_sup;
+#ifdef FX_STAMPS
+    stamp_prev_ = __builtin_amdgcn_s_memtime();
+#endif
     auto cell_of = [&](float x, float y) {
       const uint32_t cx = (uint32_t)min(max((int)floorf((x - gx0) * inv_cw), 0), (int)G - 1);
       const uint32_t cy = (uint32_t)min(max((int)floorf((y - gy0) * inv_cw), 0), (int)G - 1);
@@ -2819,14 +2823,9 @@ extern "C" __global__ __launch_bounds__(FX_HUGE_T) void k_desc_huge(FxDevParams 
             if (in) atomicAdd(&cell_fill[ce], 1u);
             if ((threadIdx.x & 63) == 0) atomicAdd(&s_w[0], (uint32_t)__popcll(m_in));
           } else {
-            const bool nb = in && d < P.r2_search, bin_nb = nb && !sc3d_is_origin(d);
-            const unsigned long long m_nb = __ballot(nb), m_bin = __ballot(bin_nb);
-            uint32_t nl_base = 0;
-            if ((threadIdx.x & 63) == 0) {
-              if (m_nb) atomicAdd(&s_w[2], (uint32_t)__popcll(m_nb));
-              if (m_bin) nl_base = atomicAdd(&s_w[1], (uint32_t)__popcll(m_bin));
-            }
-            nl_base = (uint32_t)__shfl((int)nl_base, 0, 64);
+            const bool nb = in && d < P.r2_search;
+            const unsigned long long m_nb = __ballot(nb);
+            if ((threadIdx.x & 63) == 0 && m_nb) atomicAdd(&s_w[2], (uint32_t)__popcll(m_nb));
             if (in) {
               const uint32_t slot = cell_start[ce] + atomicAdd(&cell_fill[ce], 1u);
               xyz[3 * slot + 0] = rx;
@@ -2834,7 +2833,6 @@ extern "C" __global__ __launch_bounds__(FX_HUGE_T) void k_desc_huge(FxDevParams 
               xyz[3 * slot + 2] = rz;
               sd2[slot] = d;
               sidx[slot] = i0 + u * FX_HUGE_T + tid;
-              if (bin_nb) nlist[nl_base + lanes_below(m_bin)] = slot;
             }
           }
         }
@@ -2872,6 +2870,7 @@ extern "C" __global__ __launch_bounds__(FX_HUGE_T) void k_desc_huge(FxDevParams 
         __syncthreads();
       }
     }
+    FX_STAMP(1);
     const uint32_t nS = s_w[0];
     if (nS > P.huge_cap) {  // does not fit even here: the slab tier
       if (tid == 0) B.huge_desc[atomicAdd(&B.counters[12], 1u)] = row;
@@ -2879,6 +2878,24 @@ extern "C" __global__ __launch_bounds__(FX_HUGE_T) void k_desc_huge(FxDevParams 
     }
     __threadfence();  // the slab arrays are re-read by other waves of this workgroup
     __syncthreads();
+    {
+      // the binned neighbours in cell order (a stable compaction over the cell-sorted support set): the lanes of a
+      // wavefront then hold neighbours of the same few cells, whose density queries read the same LDS words — one
+      // broadcast per instruction instead of 64 scattered reads (the scan is LDS-bandwidth bound)
+      uint32_t n_use = 0;
+      for (uint32_t q0 = 0; q0 < nS; q0 += FX_HUGE_T) {
+        const uint32_t q = q0 + tid;
+        const float d = q < nS ? sd2[q] : INFINITY;
+        const bool use = d < P.r2_search && !sc3d_is_origin(d);
+        uint32_t tot;
+        const uint32_t r = block_rank<FX_HUGE_T>(use, cell_fill, tot);  // (the fill cursors are done with: scratch)
+        if (use) nlist[n_use + r] = q;
+        n_use += tot;
+      }
+      if (tid == 0) s_w[1] = n_use;
+      __threadfence();
+      __syncthreads();
+    }
     const uint32_t nM = s_w[1], nAll = s_w[2];
     if (tid == 0) B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = nAll;
     if (nAll == 0) {
@@ -2911,6 +2928,12 @@ extern "C" __global__ __launch_bounds__(FX_HUGE_T) void k_desc_huge(FxDevParams 
     }
     __threadfence();
     __syncthreads();
+    FX_STAMP(7);
+    if (tid == 0) {
+      FX_COUNT(12, 1);
+      FX_COUNT(13, nS);
+      FX_COUNT(14, nM);
+    }
     // ---- sort the keys (bin, d2, index) in LDS: the support copy is done with, and 2^14 keys fit where it
     //      was; the weights stay in the slab, addressed by point index (the low bits of a key)
     uint32_t p2 = 1;
@@ -2934,6 +2957,7 @@ extern "C" __global__ __launch_bounds__(FX_HUGE_T) void k_desc_huge(FxDevParams 
         __syncthreads();
       }
     }
+    FX_STAMP(3);
     // ---- every sorted key fetches its weight (in parallel) and becomes (bin, weight) in place
     for (uint32_t t = tid; t < nM; t += FX_HUGE_T) {
       const unsigned long long key = sk[t];
@@ -2955,6 +2979,7 @@ extern "C" __global__ __launch_bounds__(FX_HUGE_T) void k_desc_huge(FxDevParams 
     }
     __syncthreads();
     for (uint32_t t = tid; t < FX_DESC_FLOATS; t += FX_HUGE_T) out[t] = t < FX_DESC_BINS ? img[t] : 0.0f;  // rf = 0
+    FX_STAMP(4);
   }
 }
 
