@@ -20,6 +20,8 @@
 extern "C" {
 size_t fxk_ring_lds_bytes(uint32_t cap, uint32_t ccap);
 size_t fxk_ring_wave_lds_bytes(uint32_t cap, uint32_t ccap);
+size_t fxk_ring_large_lds_bytes(uint32_t cap, uint32_t ccap);
+void fxk_rings_large(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t ccap, uint32_t grid);
 size_t fxk_merge_lds_bytes(uint32_t cap, uint32_t n_rings);
 size_t fxk_desc_lds_bytes(uint32_t cap);
 size_t fxk_gather_lds_bytes(uint32_t max_keypoints);
@@ -222,7 +224,7 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof) {
       if (per_cu < 1) per_cu = 1;
       fxk_rings_big(s, P, B, ring_mid, ring_mid / 4, (big_grid * per_cu + 7) / 8 * 8, 0);
     }
-    fxk_rings_big(s, P, B, L.max_ring_points, L.max_ring_points, (big_grid + 7) / 8 * 8, 1);
+    fxk_rings_large(s, P, B, L.max_ring_points, L.max_ring_points, (big_grid + 7) / 8 * 8);
     FX_HIP(mark(4));
     fxk_merge_small(s, P, B, batch, merge_small);
     fxk_merge_big(s, P, B, c->merge_big_cap, big_grid, c->merge_big_cap >= L.max_candidates);
@@ -326,8 +328,8 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   if (L.max_ring_candidates > L.max_ring_points) L.max_ring_candidates = L.max_ring_points;
   // LDS budget of the large tiers (160 KiB per workgroup on gfx950)
   const size_t kLds = 160 * 1024;
-  if (fxk_ring_lds_bytes(L.max_ring_points, L.max_ring_points) > kLds)
-    return fail(FX_ERR_INVALID_ARG, "max_ring_points exceeds the LDS budget (<= 2600)");
+  if (fxk_ring_large_lds_bytes(L.max_ring_points, L.max_ring_points) > kLds)
+    return fail(FX_ERR_INVALID_ARG, "max_ring_points exceeds the LDS budget (<= 2400)");
   // merge tiers: up to merge_big_cap candidates a scan live in LDS as points; beyond that (dense many-ring scans)
   // the large tier keeps only parents and a cell sort in LDS
   uint32_t merge_big_cap = L.max_candidates;
@@ -540,7 +542,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
     return bail(fail(FX_ERR_HIP, "hipStreamCreate"));
   c->stream = c->own_stream;
   {
-    hipError_t ce = fxk_configure(fxk_ring_lds_bytes(L.max_ring_points, L.max_ring_points), fxk_merge_lds_bytes(c->merge_big_cap, params->n_rings),
+    hipError_t ce = fxk_configure(fxk_ring_large_lds_bytes(L.max_ring_points, L.max_ring_points), fxk_merge_lds_bytes(c->merge_big_cap, params->n_rings),
                                   c->merge_big_cap < L.max_candidates ? fxk_merge_huge_lds_bytes(L.max_candidates, c->merge_huge_ccap, params->n_rings) : 0,
                                   fxk_desc_lds_bytes(L.max_neighbors), fxk_gather_lds_bytes(L.max_keypoints));
     if (ce != hipSuccess) return bail(fail(FX_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(ce)));

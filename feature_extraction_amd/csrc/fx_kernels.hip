@@ -1268,6 +1268,21 @@ extern "C" __global__ __launch_bounds__(FX_WG, 5) void k_rings_big(FxDevParams P
   }
 }
 
+// large tier: rings beyond the mid tier's capacity (dense many-ring sensors: ground rings of a thousand points and
+// more) get a whole 1024-thread workgroup — one per CU anyway, by LDS
+#define FX_RING_LARGE_T 1024
+extern "C" __global__ __launch_bounds__(FX_RING_LARGE_T) void k_rings_large(FxDevParams P, FxBuffers B, uint32_t cap, uint32_t ccap) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const uint32_t cls = blockIdx.x & 7u;
+  const uint32_t n_big = B.counters[FX_CNT_LARGE + cls];
+  const uint32_t *items = B.huge_rings + (size_t)cls * P.ring_list_cap;
+  for (uint32_t w = blockIdx.x >> 3; w < n_big; w += gridDim.x >> 3) {
+    const uint32_t item = items[w];
+    ring_body<FX_RING_LARGE_T>(P, B, item / P.n_rings, item % P.n_rings, cap, ccap, smem, true);
+    __syncthreads();
+  }
+}
+
 // ====================================================================== stage 3: merge
 // Secondary merge (ref: node.cpp:209-257): keypoints_full = the per-ring candidates in ring order (:205), z replaced
 // by the scaled elevation (:217), a second pcl::EuclideanClusterExtraction (:222-229), centroids of the clusters'
@@ -3246,6 +3261,12 @@ extern "C" {
 size_t fxk_ring_lds_bytes(uint32_t cap, uint32_t ccap) {
   return (size_t)(SegCfg<FX_WG>::kWords + FX_RING_WORDS_PER_POINT * cap + FX_RING_WORDS_PER_CLUSTER * ccap) * 4;
 }
+size_t fxk_ring_large_lds_bytes(uint32_t cap, uint32_t ccap) {
+  return (size_t)(SegCfg<FX_RING_LARGE_T>::kWords + FX_RING_WORDS_PER_POINT * cap + FX_RING_WORDS_PER_CLUSTER * ccap) * 4;
+}
+void fxk_rings_large(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t ccap, uint32_t grid) {
+  hipLaunchKernelGGL(k_rings_large, dim3(grid), dim3(FX_RING_LARGE_T), fxk_ring_large_lds_bytes(cap, ccap), s, P, B, cap, ccap);
+}
 size_t fxk_ring_wave_lds_bytes(uint32_t cap, uint32_t ccap) {
   return (size_t)(SegCfg<FX_RING_SMALL_T>::kWords + FX_RING_WORDS_PER_POINT * cap + FX_RING_WORDS_PER_CLUSTER * ccap) * 4;
 }
@@ -3262,6 +3283,8 @@ hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t merge_huge, s
   e = hipFuncSetAttribute((const void *)k_gather, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gather);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void *)k_rings_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_big);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void *)k_rings_large, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_big);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void *)k_merge_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)merge_big);
   if (e != hipSuccess) return e;
