@@ -26,7 +26,8 @@ STAGE_NAMES = ("k_prep", "k_bucket", "k_rings_small", "k_rings_big", "k_merge", 
 # stages that are one kernel launch (eligible as the roofline line's dominant kernel: their HIP-event span is that kernel)
 SINGLE_LAUNCH_STAGES = ("k_prep", "k_bucket", "k_rings_small", "k_gather", "k_desc_group", "k_desc_fast")
 # kernels launched inside each timed stage (rocprofv3 / PMC rows are per kernel name)
-STAGE_KERNELS = {"k_merge": ("k_merge_small", "k_merge_big", "k_merge_huge", "k_offsets"),
+STAGE_KERNELS = {"k_rings_big": ("k_rings_big", "k_rings_large"),
+                 "k_merge": ("k_merge_small", "k_merge_big", "k_merge_huge", "k_offsets"),
                  "k_desc_wg": ("k_desc_wg_fast", "k_desc_wg_xl", "k_desc_wg", "k_desc_huge", "k_desc_spill", "k_rng_ord")}
 
 
