@@ -36,6 +36,9 @@ N_RINGS, N_AZ = 16, 1800
 # BASELINE.json configs 3 and 5 (n_rings / secondary_max beyond 16 are the build's extension:
 # the reference hard-codes 16, ref: node.cpp:195, 200, 227).  Config 5 runs the launch preset SURVEY.md B-6 sized it with.
 OTHER_CONFIGS = {
+    # the headline workload under the node's constructor defaults (ref: node.cpp:9-34) instead of the launch file's preset
+    "config2_vlp16_default_preset_batch1024": dict(
+        batch=1024, n_uniq=64, synth=dict(), preset="default", params=dict(), limits=dict()),
     "config3_hdl64_64x2048_batch256": dict(
         batch=256, n_uniq=16, synth=dict(n_rings=64, n_az=2048, el0_deg=-24.8, el_step_deg=26.8 / 63, n_poles=256),
         preset="launch", params=dict(n_rings=64, el0_deg=-24.8, el_step_deg=26.8 / 63, secondary_max=64),
