@@ -46,6 +46,7 @@ void fxk_desc_fast(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint
 void fxk_desc_wg(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t grid,
                  uint32_t mode, uint32_t src);
 void fxk_desc_wg_fast(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t grid);
+void fxk_desc_mid(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t n_wg, uint32_t n_wave);
 void fxk_desc_wg_xl(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t ns_lo,
                     uint32_t grid);
 void fxk_desc_spill(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t mode,
@@ -236,14 +237,14 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof) {
       FX_HIP(mark(6));
       fxk_desc_group(s, P, B, batch, desc_grid);
       FX_HIP(mark(7));
-      fxk_desc_fast(s, P, B, batch, big_grid * 4);
-      FX_HIP(mark(8));
       {
-        // lists of up to kListSplit entries: four keypoints per CU in flight; longer ones: one per CU
+        // lists of up to kListSplit entries (four keypoints per CU in flight) and the wave rows share a launch;
+        // longer lists: one 1024-thread workgroup per CU
         const uint32_t split = P.list_cap < kListSplit ? P.list_cap : kListSplit;
-        fxk_desc_wg_fast(s, P, B, batch, split, big_grid * 4);
+        fxk_desc_mid(s, P, B, batch, split, big_grid * 4, big_grid * 4);
         if (P.list_cap > split) fxk_desc_wg_xl(s, P, B, batch, P.list_cap, split, big_grid);
       }
+      FX_HIP(mark(8));
       // (no exact redo pass: the fast tiers evaluate the exact angles themselves for the rare neighbour next to a bin
       //  edge; the exact kernel stays for the re-gather tier and the RNG second pass)
       fxk_desc_wg(s, P, B, batch, L.max_neighbors, c->tail_grid, 0, 0);

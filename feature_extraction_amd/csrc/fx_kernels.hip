@@ -2067,7 +2067,7 @@ __device__ __forceinline__ const FxScTables *tables_to_lds(const FxBuffers &B, u
 // the result is the exact one either way.
 template <bool FAST>
 __device__ __forceinline__ void desc_wave_body(const FxDevParams &P, const FxBuffers &B, uint32_t batch,
-                                               uint32_t *smem) {
+                                               uint32_t *smem, uint32_t bid, uint32_t nblk) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t *base = smem + wave * FX_WAVE_WORDS;
   // per-wave LDS: support set as float4 (x, y, z, d2) + point index, unsorted (key, weight); the
@@ -2083,7 +2083,7 @@ __device__ __forceinline__ void desc_wave_body(const FxDevParams &P, const FxBuf
   uint32_t total = B.kp_offset[batch];
   if (total > P.max_total_kp) total = P.max_total_kp;
   const uint32_t n_items = FAST ? B.counters[8] : B.counters[7];
-  for (uint32_t it = blockIdx.x * FX_NWAVE + wave; it < n_items; it += gridDim.x * FX_NWAVE) {
+  for (uint32_t it = bid * FX_NWAVE + wave; it < n_items; it += nblk * FX_NWAVE) {
     const uint32_t row = FAST ? B.wave_desc[it] : B.exact_desc[it];
     const uint2 rm = B.row_map[row];
     const uint32_t scan = rm.x, k = rm.y;
@@ -2196,7 +2196,7 @@ __device__ __forceinline__ void desc_wave_body(const FxDevParams &P, const FxBuf
 }
 extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_fast(FxDevParams P, FxBuffers B, uint32_t batch) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  desc_wave_body<true>(P, B, batch, smem);
+  desc_wave_body<true>(P, B, batch, smem, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------- k_desc_group
@@ -2684,7 +2684,8 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
 // src 2: rows with an angle near a bin edge (exact_desc): from the list, exact angles
 template <bool FAST, int NT>
 __device__ __forceinline__ void desc_wg_loop(const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap,
-                                             uint32_t mode, uint32_t src, uint32_t *smem, uint32_t ns_lo = 0) {
+                                             uint32_t mode, uint32_t src, uint32_t *smem, uint32_t ns_lo, uint32_t bid,
+                                             uint32_t nblk) {
   // a support set that does not fit `cap` goes to the spill tier
   auto spill = [&](uint32_t row, uint32_t scan, uint32_t k) {
     if (threadIdx.x == 0) {
@@ -2704,7 +2705,7 @@ __device__ __forceinline__ void desc_wg_loop(const FxDevParams &P, const FxBuffe
     if (B.counters[3] == 0) return;
     uint32_t total = B.kp_offset[batch];
     if (total > P.max_total_kp) total = P.max_total_kp;
-    for (uint32_t row = blockIdx.x; row < total; row += gridDim.x) {
+    for (uint32_t row = bid; row < total; row += nblk) {
       const uint2 rm = B.row_map[row];
       const uint32_t scan = rm.x, k = rm.y;
       const uint32_t ord = B.rng_ord[(size_t)scan * P.max_keypoints + k];
@@ -2716,7 +2717,7 @@ __device__ __forceinline__ void desc_wg_loop(const FxDevParams &P, const FxBuffe
   }
   const uint32_t n_items = B.counters[src == 0 ? 2 : (src == 1 ? 4 : 7)];
   const uint32_t *items = src == 0 ? B.big_desc : (src == 1 ? B.list_desc : B.exact_desc);
-  for (uint32_t i = blockIdx.x; i < n_items; i += gridDim.x) {
+  for (uint32_t i = bid; i < n_items; i += nblk) {
     const uint32_t row = items[i];
     const uint2 rm = B.row_map[row];
     const uint32_t scan = rm.x, k = rm.y;
@@ -2734,19 +2735,31 @@ __device__ __forceinline__ void desc_wg_loop(const FxDevParams &P, const FxBuffe
 extern "C" __global__ __launch_bounds__(FX_DESC_WG_EXACT_T) void k_desc_wg(FxDevParams P, FxBuffers B, uint32_t batch,
                                                                             uint32_t cap, uint32_t mode, uint32_t src) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  desc_wg_loop<false, FX_DESC_WG_EXACT_T>(P, B, batch, cap, mode, src, smem);
+  desc_wg_loop<false, FX_DESC_WG_EXACT_T>(P, B, batch, cap, mode, src, smem, 0u, blockIdx.x, gridDim.x);
 }
 extern "C" __global__ __launch_bounds__(FX_DESC_WG_FAST_T) void k_desc_wg_fast(FxDevParams P, FxBuffers B, uint32_t batch,
                                                                                 uint32_t cap) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  desc_wg_loop<true, FX_DESC_WG_FAST_T>(P, B, batch, cap, 0u, 1u, smem);
+  desc_wg_loop<true, FX_DESC_WG_FAST_T>(P, B, batch, cap, 0u, 1u, smem, 0u, blockIdx.x, gridDim.x);
+}
+// Both middle tiers in one launch: the first n_wg workgroups take list rows (257..cap support points, one keypoint per
+// workgroup at a time), the others take wave rows (65..256, one keypoint per wavefront).  Neither tier fills the chip
+// alone (1600 and 900 of the 8192 wave slots on the VLP-16 bench) and neither depends on the other: one after the
+// other they cost 0.135 + 0.075 ms, together about the longer of the two.
+extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_mid(FxDevParams P, FxBuffers B, uint32_t batch, uint32_t cap,
+                                                                uint32_t n_wg) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  if (blockIdx.x < n_wg)
+    desc_wg_loop<true, FX_DESC_WG_FAST_T>(P, B, batch, cap, 0u, 1u, smem, 0u, blockIdx.x, n_wg);
+  else
+    desc_wave_body<true>(P, B, batch, smem, blockIdx.x - n_wg, gridDim.x - n_wg);
 }
 // the longest lists (beyond FX_LIST_SPLIT entries, up to list_cap): one 1024-thread workgroup per CU
 #define FX_DESC_WG_XL_T 1024
 extern "C" __global__ __launch_bounds__(FX_DESC_WG_XL_T) void k_desc_wg_xl(FxDevParams P, FxBuffers B, uint32_t batch,
                                                                             uint32_t cap, uint32_t ns_lo) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  desc_wg_loop<true, FX_DESC_WG_XL_T>(P, B, batch, cap, 0u, 1u, smem, ns_lo);
+  desc_wg_loop<true, FX_DESC_WG_XL_T>(P, B, batch, cap, 0u, 1u, smem, ns_lo, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------- spill tier
@@ -3292,6 +3305,8 @@ hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t merge_huge, s
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void *)k_desc_wg_xl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)desc_big);
   if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void *)k_desc_mid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)desc_big);
+  if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void *)k_desc_huge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FX_HUGE_WORDS * 4));
   return e;
 }
@@ -3352,6 +3367,11 @@ void fxk_desc_wg(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32
 void fxk_desc_wg_xl(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t ns_lo,
                     uint32_t grid) {
   hipLaunchKernelGGL(k_desc_wg_xl, dim3(grid), dim3(FX_DESC_WG_XL_T), fxk_desc_lds_bytes(cap), s, P, B, batch, cap, ns_lo);
+}
+void fxk_desc_mid(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t n_wg,
+                  uint32_t n_wave) {
+  const size_t lds_wave = (size_t)(FX_NWAVE * FX_WAVE_WORDS + FX_TABLE_WORDS) * 4, lds_wg = fxk_desc_lds_bytes(cap);
+  hipLaunchKernelGGL(k_desc_mid, dim3(n_wg + n_wave), dim3(FX_WG), lds_wave > lds_wg ? lds_wave : lds_wg, s, P, B, batch, cap, n_wg);
 }
 void fxk_desc_wg_fast(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t grid) {
   hipLaunchKernelGGL(k_desc_wg_fast, dim3(grid), dim3(FX_DESC_WG_FAST_T), fxk_desc_lds_bytes(cap), s, P, B, batch, cap);

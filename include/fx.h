@@ -155,8 +155,8 @@ typedef struct fx_batch_view {
 #define FX_N_STAGES 9
 typedef struct fx_timings {
   /* k_prep, k_bucket, k_rings_small, k_rings_big (mid and large ring tiers), k_merge (small / big / large tiers +
-   * k_offsets), k_gather, k_desc_group, k_desc_fast, k_desc_wg (every workgroup-per-keypoint tier: list, re-gather,
-   * whole-CU, slab; k_rng_ord and the second pass) */
+   * k_offsets), k_gather, k_desc_group, k_desc_mid (wave rows and list rows in one launch; + the longest lists),
+   * k_desc_rare (re-gather, whole-CU and slab tiers; k_rng_ord and the second pass) */
   float ms[FX_N_STAGES];
   float total_ms;
   /* k_prep's execution span on the device's constant-rate clock: first workgroup's start to last workgroup's end — what
