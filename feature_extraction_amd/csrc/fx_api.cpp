@@ -225,8 +225,8 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof) {
       if (per_cu < 1) per_cu = 1;
       fxk_rings_big(s, P, B, ring_mid, ring_mid / 4, (big_grid * per_cu + 7) / 8 * 8, 0);
     }
-    fxk_rings_large(s, P, B, L.max_ring_points, L.max_ring_points, (big_grid + 7) / 8 * 8);
     FX_HIP(mark(4));
+    fxk_rings_large(s, P, B, L.max_ring_points, L.max_ring_points, (big_grid + 7) / 8 * 8);
     fxk_merge_small(s, P, B, batch, merge_small);
     fxk_merge_big(s, P, B, c->merge_big_cap, big_grid, c->merge_big_cap >= L.max_candidates);
     if (c->merge_big_cap < L.max_candidates) fxk_merge_huge(s, P, B, L.max_candidates, c->merge_huge_ccap, big_grid);

@@ -28,7 +28,7 @@ def one(pattern):
     hits = glob.glob(os.path.join(src, pattern), recursive=True)
     if not hits:
         raise SystemExit("missing " + pattern)
-    return hits[0]
+    return max(hits, key=os.path.getmtime)  # (gpurun merges runs into the same directory: take the latest)
 
 
 shutil.copy(one("trace/**/*_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
