@@ -221,6 +221,10 @@ def main():
     gathered = [torch.zeros((world * B, 1 + REC_KP, 4), dtype=torch.float32, device=dev) for _ in range(K)] if use_dist else None
     pending = [None] * K
     counter = [0]
+    # the collective goes straight on the context's stream through RCCL's C API (sharding.RcclGather);
+    # FX_BENCH_TORCH_GATHER=1 takes torch.distributed's all_gather_into_tensor instead (sharding.all_gather_records, the
+    # function the gloo test runs)
+    rccl = sharding.RcclGather(world, rank, dev, n_comms=K) if use_dist and os.environ.get("FX_BENCH_TORCH_GATHER") != "1" else None
     torch.cuda.synchronize(dev)  # inputs and zeroed buffers are in place before any side stream starts
 
     def step():
@@ -232,7 +236,9 @@ def main():
                 pending[j] = None
             ctxs[j].process_raw(descs, B, capi.FX_IN_DEVICE)
             ctxs[j].pack_keypoint_records(recs[j].data_ptr(), REC_KP)
-            if use_dist:  # the path's one collective (feature_extraction_amd/sharding.py; the gloo test runs the same function)
+            if rccl is not None:  # the path's one collective, an ordinary kernel of this context's stream
+                rccl.all_gather(recs[j], gathered[j], streams[j].cuda_stream, comm=j)
+            elif use_dist:
                 _tab, pending[j] = sharding.all_gather_records(recs[j], world, out=gathered[j], async_op=True)
 
     def drain():
@@ -342,7 +348,7 @@ def main():
         last = (counter[0] - 1) % K
         g = gathered[last][rank * B:(rank + 1) * B]
         assert torch.equal(g, recs[last]), "gathered keypoint records differ from the local ones"
-        print(f"[bench] all-gather of keypoint records over {dist.get_backend()}: table {tuple(gathered[last].shape)}, "
+        print(f"[bench] all-gather of keypoint records over {'RCCL (ncclAllGather on the context stream)' if rccl is not None else dist.get_backend()}: table {tuple(gathered[last].shape)}, "
               f"this rank's block equals its local records", file=sys.stderr)
 
     result_line = None
@@ -404,6 +410,9 @@ def main():
             "parity": parity,
         }
         result_line = out
+    if rccl is not None:
+        torch.cuda.synchronize(dev)
+        rccl.close()
     for c in ctxs[1:] if (rank == 0 and world == 1 and not args.no_extras) else ctxs:
         c.close()
     if rank == 0 and world == 1:
