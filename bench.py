@@ -224,7 +224,20 @@ def main():
     # the collective goes straight on the context's stream through RCCL's C API (sharding.RcclGather);
     # FX_BENCH_TORCH_GATHER=1 takes torch.distributed's all_gather_into_tensor instead (sharding.all_gather_records, the
     # function the gloo test runs)
-    rccl = sharding.RcclGather(world, rank, dev, n_comms=K) if use_dist and os.environ.get("FX_BENCH_TORCH_GATHER") != "1" else None
+    rccl = None
+    if use_dist and os.environ.get("FX_BENCH_TORCH_GATHER") != "1":
+        ok = 1
+        try:
+            rccl = sharding.RcclGather(world, rank, dev, n_comms=K)
+        except Exception as e:  # noqa: BLE001  (e.g. a torch build without its own librccl.so): torch.distributed's gather then
+            print(f"[bench] rank {rank}: direct RCCL gather unavailable ({e}); using torch.distributed", file=sys.stderr)
+            ok = 0
+        if world > 1:  # every rank takes the same path
+            t = torch.tensor([ok], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if int(t.item()) == 0 and rccl is not None:
+                rccl.close()
+                rccl = None
     torch.cuda.synchronize(dev)  # inputs and zeroed buffers are in place before any side stream starts
 
     def step():
