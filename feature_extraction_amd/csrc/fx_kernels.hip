@@ -1668,8 +1668,8 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_offsets(FxDevParams P, FxB
 //                   keypoint's support list (a superset of the neighbour query and of every density query);
 //                   (the rows themselves are cleared by k_desc_group, which sees every row once)
 //   k_desc_group    4 keypoints per wavefront: support sets of <= 64 points (the bulk)
-//   k_desc_fast     one wavefront per keypoint: 65..256 support points
-//   k_desc_wg_fast  one 1024-thread workgroup per keypoint: up to list_cap support points
+//   k_desc_mid      one launch: one wavefront per keypoint (65..256 support points) and one 256-thread
+//                   workgroup per keypoint (lists of up to 1024 entries); k_desc_wg_xl: longer lists
 //                   -- all three: bins + density + weight per neighbour, sort by (bin, d2, index) ==
 //                      PCL's accumulation order, sequential fp32 sum per bin; angles in fp32 --
 //   k_desc_wg       exact fp64-angle redo of keypoints the fp32 passes flagged (angle near a bin
@@ -2035,7 +2035,7 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
     for (uint32_t k = tid; k < K; k += FX_WG) B.s_cnt[row0 + k] = s_kpos[k];
 }
 
-// ---------------------------------------------------------------- k_desc_fast
+// ---------------------------------------------------------------- wavefront tier (runs inside k_desc_mid)
 #define FX_WAVE_CAP 256
 #define FX_WAVE_WORDS (FX_WAVE_CAP * 8)
 // Clears one descriptor row (1989 floats, 4-byte aligned) with `stride` lanes: 16-byte stores over its aligned body.
@@ -2194,16 +2194,12 @@ __device__ __forceinline__ void desc_wave_body(const FxDevParams &P, const FxBuf
     __builtin_amdgcn_wave_barrier();
   }
 }
-extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_fast(FxDevParams P, FxBuffers B, uint32_t batch) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  desc_wave_body<true>(P, B, batch, smem, blockIdx.x, gridDim.x);
-}
 
 // ---------------------------------------------------------------- k_desc_group
 // Most keypoints have a small support set (median < 10 points on the VLP-16 scenes, 90 % < 64):
 // a whole wavefront per keypoint leaves its lanes idle and pays the per-keypoint latency 64-wide.
 // Here a wavefront works on FX_GROUPS keypoints at once, FX_GLANES lanes each (fp32 angles, same
-// exactness contract as k_desc_fast).  Rows with more than FX_GROUP_CAP support points go to the
+// exactness contract as the wavefront tier).  Rows with more than FX_GROUP_CAP support points go to the
 // wave list, rows with an angle near a bin edge to the exact list.
 #define FX_GLANES 16
 #define FX_GROUPS (64 / FX_GLANES)
@@ -2736,11 +2732,6 @@ extern "C" __global__ __launch_bounds__(FX_DESC_WG_EXACT_T) void k_desc_wg(FxDev
                                                                             uint32_t cap, uint32_t mode, uint32_t src) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   desc_wg_loop<false, FX_DESC_WG_EXACT_T>(P, B, batch, cap, mode, src, smem, 0u, blockIdx.x, gridDim.x);
-}
-extern "C" __global__ __launch_bounds__(FX_DESC_WG_FAST_T) void k_desc_wg_fast(FxDevParams P, FxBuffers B, uint32_t batch,
-                                                                                uint32_t cap) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  desc_wg_loop<true, FX_DESC_WG_FAST_T>(P, B, batch, cap, 0u, 1u, smem, 0u, blockIdx.x, gridDim.x);
 }
 // Both middle tiers in one launch: the first n_wg workgroups take list rows (257..cap support points, one keypoint per
 // workgroup at a time), the others take wave rows (65..256, one keypoint per wavefront).  Neither tier fills the chip
@@ -3357,9 +3348,6 @@ void fxk_gather(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_
 void fxk_desc_group(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid) {
   hipLaunchKernelGGL(k_desc_group, dim3(grid), dim3(FX_WG), (size_t)(FX_NWAVE * FX_GROUPS * FX_GROUP_WORDS + FX_TABLE_WORDS) * 4, s, P, B, batch);
 }
-void fxk_desc_fast(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid) {
-  hipLaunchKernelGGL(k_desc_fast, dim3(grid), dim3(FX_WG), (size_t)(FX_NWAVE * FX_WAVE_WORDS + FX_TABLE_WORDS) * 4, s, P, B, batch);
-}
 void fxk_desc_wg(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t grid,
                  uint32_t mode, uint32_t src) {
   hipLaunchKernelGGL(k_desc_wg, dim3(grid), dim3(FX_DESC_WG_EXACT_T), fxk_desc_lds_bytes(cap), s, P, B, batch, cap, mode, src);
@@ -3372,9 +3360,6 @@ void fxk_desc_mid(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint3
                   uint32_t n_wave) {
   const size_t lds_wave = (size_t)(FX_NWAVE * FX_WAVE_WORDS + FX_TABLE_WORDS) * 4, lds_wg = fxk_desc_lds_bytes(cap);
   hipLaunchKernelGGL(k_desc_mid, dim3(n_wg + n_wave), dim3(FX_WG), lds_wave > lds_wg ? lds_wave : lds_wg, s, P, B, batch, cap, n_wg);
-}
-void fxk_desc_wg_fast(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t grid) {
-  hipLaunchKernelGGL(k_desc_wg_fast, dim3(grid), dim3(FX_DESC_WG_FAST_T), fxk_desc_lds_bytes(cap), s, P, B, batch, cap);
 }
 void fxk_desc_huge(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t mode,
                    uint32_t slab_pts) {
