@@ -19,7 +19,6 @@
 
 extern "C" {
 size_t fxk_ring_lds_bytes(uint32_t cap, uint32_t ccap);
-size_t fxk_ring_wave_lds_bytes(uint32_t cap, uint32_t ccap);
 size_t fxk_ring_large_lds_bytes(uint32_t cap, uint32_t ccap);
 void fxk_rings_large(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t ccap, uint32_t grid);
 size_t fxk_merge_lds_bytes(uint32_t cap, uint32_t n_rings);
@@ -32,8 +31,9 @@ uint32_t fxk_near_words(uint32_t max_points);
 void fxk_prep(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float near_margin, float el0, float inv_step,
               uint32_t clk_slot);
 void fxk_bucket(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float el0, float inv_step, uint32_t clk_next);
-void fxk_rings_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t ccap,
-                     uint32_t mid_cap, uint32_t grid);
+size_t fxk_ring_runs_lds_bytes(void);
+void fxk_rings_runs(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t mid_cap, uint32_t max_pts,
+                    uint32_t grid);
 void fxk_rings_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t ccap, uint32_t grid,
                    uint32_t huge);
 void fxk_merge_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap);
@@ -78,7 +78,7 @@ fx_status fail(fx_status s, const std::string &msg) {
   } while (0)
 
 constexpr int kMetaSlots = 8;
-constexpr uint32_t kRingCapSmall = 256, kRingCapMid = 640, kMergeCapSmall = 512, kListCap = 4096, kListSplit = 1024;
+constexpr uint32_t kRingCapMid = 640, kMergeCapSmall = 512, kListCap = 4096, kListSplit = 1024;
 }  // namespace
 
 struct fx_ctx {
@@ -98,7 +98,6 @@ struct fx_ctx {
   int meta_next = 0;
   FxScanMeta *d_meta = nullptr;
   float box_margin = 0.f;
-  uint32_t ring_waves_per_cu = 16;
   uint32_t desc_wgs_per_cu = 10;
   uint32_t spill_grid = 0, spill_slab = 0, tail_grid = 0;
   uint32_t merge_big_cap = 0;    // candidates the LDS merge tier holds as points (<= max_candidates)
@@ -188,7 +187,6 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof) {
   FX_HIP(mark(0));
   if (!batch) FX_HIP(hipMemsetAsync(B.counters, 0, FX_N_COUNTERS * sizeof(uint32_t), s));  // (k_prep clears them otherwise)
   if (batch) {
-    const uint32_t ring_small = L.max_ring_points < kRingCapSmall ? L.max_ring_points : kRingCapSmall;
     const uint32_t merge_small = L.max_candidates < kMergeCapSmall ? L.max_candidates : kMergeCapSmall;
     const uint32_t desc_grid = (uint32_t)c->n_cu * c->desc_wgs_per_cu;  // resident all at once (32 KB LDS each)
     fxk_prep(s, P, B, batch, c->box_margin, (float)c->params.el0_deg, (float)(1.0 / c->params.el_step_deg),
@@ -198,24 +196,9 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof) {
                (uint32_t)((c->batch_seq + 1) % FX_CLK_SLOTS));
     FX_HIP(mark(2));
     const uint32_t ring_mid = L.max_ring_points < kRingCapMid ? L.max_ring_points : kRingCapMid;
-    {
-      // persistent one-wave workgroups: as many per CU as their LDS footprint admits
-      // (LDS appears to be handed out in 2 KiB granules: a workgroup too many per CU queues behind the others)
-      uint32_t per_cu = (uint32_t)(160 * 1024 / ((fxk_ring_wave_lds_bytes(ring_small, ring_small / 4) + 2047) / 2048 * 2048));
-      if (per_cu > c->ring_waves_per_cu) per_cu = c->ring_waves_per_cu;
-      // The items are (scan, ring) in scan-major order and a workgroup strides over them by the grid
-      // size: a grid that is a multiple of n_rings would hand it the same ring index of every scan (rings
-      // differ a lot in cost).  Make the stride step the ring index by about 0.38 n_rings instead.
-      uint32_t grid = (uint32_t)c->n_cu * per_cu;
-      const uint32_t R = (uint32_t)c->params.n_rings;
-      uint32_t per_cls = grid / 8;  // blocks per XCD class (k_rings_small deals the scans by class)
-      if (R > 1 && per_cls > 2 * R) {
-        const uint32_t want = ((uint32_t)(0.381966 * R) | 1u) % R;
-        per_cls -= (per_cls % R + R - want) % R;
-      }
-      grid = per_cls ? per_cls * 8 : 8;
-      fxk_rings_small(s, P, B, batch, ring_small, ring_small / 4, ring_mid, grid);
-    }
+    // one wavefront per (scan, ring): the hardware dispatcher balances the rings, whose costs differ a lot
+    // (persistent wavefronts striding over the items: 0.18 ms instead of 0.14)
+    fxk_rings_runs(s, P, B, batch, ring_mid, L.max_ring_points, (batch * (uint32_t)c->params.n_rings + 7) / 8 * 8);
     FX_HIP(mark(3));
     {
       uint32_t per_cu = (uint32_t)(160 * 1024 / ((fxk_ring_lds_bytes(ring_mid, ring_mid / 4) + 2047) / 2048 * 2048));
@@ -354,7 +337,6 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   c->device = device_id;
   c->merge_big_cap = merge_big_cap;
   c->merge_huge_ccap = merge_huge_ccap;
-  if (const char *e = getenv("FX_RING_WAVES_PER_CU")) c->ring_waves_per_cu = (uint32_t)atoi(e);
   if (const char *e = getenv("FX_DESC_WGS_PER_CU")) c->desc_wgs_per_cu = (uint32_t)atoi(e);
   if (const char *e = getenv("FX_DEBUG_SYNC")) c->debug_sync = atoi(e) != 0;
   if (const char *e = getenv("FX_GRAPH_MAX_BATCH")) c->graph_max_batch = (uint32_t)atoi(e);

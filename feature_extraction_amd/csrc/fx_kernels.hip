@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include <math.h>
+#include <type_traits>
 
 #include "fx_device.h"
 #include "fx_sort_replay.h"
@@ -671,7 +672,7 @@ __device__ __forceinline__ uint32_t cc_order(uint32_t n, const uint32_t *parent,
       uint16_t *pos = reinterpret_cast<uint16_t *>(tmp);
       if (n_c <= 64) {
         sort_partition_wave<1>(crec, (int)n_c, (int *)(s_w + 32), pos, pos + n_c);
-      } else if (NT > 64 && n_c <= 128) {
+      } else if (n_c <= 128) {
         sort_partition_wave<2>(crec, (int)n_c, (int *)(s_w + 32), pos, pos + n_c);
       } else if (NT > 64 && n_c <= 192) {
         sort_partition_wave<3>(crec, (int)n_c, (int *)(s_w + 32), pos, pos + n_c);
@@ -908,7 +909,7 @@ __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, 
     B.n_filt[scan] = base;
     B.flags[scan] = 0u;
   }
-  if (scan == 0 && tid < FX_N_COUNTERS) B.counters[tid] = 0u;  // work-list counters of the batch (used from k_rings_small on)
+  if (scan == 0 && tid < FX_N_COUNTERS) B.counters[tid] = 0u;  // work-list counters of the batch (used from k_rings_runs on)
   if (tid == 0) atomicMax(&B.clk[2 * clk_slot + 1], (unsigned long long)wall_clock64());
 }
 
@@ -1222,37 +1223,462 @@ __device__ __forceinline__ bool ring_body(const FxDevParams &P, const FxBuffers 
   return true;
 }
 
-// small tier: ONE WAVEFRONT per (scan, ring) — every block-level step is wave-synchronous, so the
-// many short dependent phases of a ring cost no workgroup barriers
-#define FX_RING_SMALL_T 64
-extern "C" __global__ __launch_bounds__(FX_RING_SMALL_T) void k_rings_small(FxDevParams P, FxBuffers B, uint32_t cap,
-                                                                            uint32_t ccap, uint32_t mid_cap, uint32_t n_items) {
+// ---------------------------------------------------------------- run tier
+// getCylinderSegments on one wavefront with nothing per point in LDS.  A ring arrives azimuth ordered, so its
+// clusters are unions of RUNS (maximal chains of consecutive points closer than the tolerance): the tier keeps a table
+// of runs and of their segments (start, xy box) and does everything else on it —
+//   * run labelling streams the points from L2 (they were just written ring-major by k_bucket), each chunk of 64
+//     beside its predecessor; the union-find runs over run indices (root = smallest run = the run holding the
+//     component's smallest point index: PCL's indices[0] and discovery order);
+//   * cross-run edges as in cc_label: near run pairs from the run boxes, the points of the earlier run against the
+//     later run's box, then its segments' boxes, then its points (read from L2) — every pair that could be an edge
+//     is examined;
+//   * sizes are sums of run lengths, cluster boxes folds of segment boxes; cc_order (PCL's order) runs on the run
+//     table unchanged; one lane per gate-passing cluster walks its runs' points in ascending order for the fp64
+//     centroid; members are copied out segment by segment.
+// LDS per ring is 10 KB whatever the ring's size (the point-holding wave tier needed 13 KB for 256 points, the
+// workgroup tier 32 KB for 640), so 15 rings per CU are in flight instead of 11 + 5, and rings of several hundred points
+// — ground and wall arcs: a handful of long runs — no longer need a workgroup.  Rings with more than 128 runs or
+// segments, more than 64 admissible clusters or too many near run pairs (unordered input) go to the workgroup tiers.
+#define FX_RR_SEGS 128
+#define FX_RR_RUNS 128
+#define FX_RR_CCAP 128  // (= FX_RR_RUNS: a cluster is at least a run)
+#define FX_RR_QUEUE 96
+#define FX_RR_CACHE 170
+#define FX_RR_WORDS (152 + 4 * FX_RR_RUNS + FX_RR_QUEUE + (FX_RR_SEGS + 4) + 4 * FX_RR_SEGS + (FX_RR_RUNS + 1) + 4 * FX_RR_RUNS + 4 * FX_RR_CCAP + 3 * FX_RR_CACHE)  // 3067 words: six 2 KiB granules
+__device__ __forceinline__ bool ring_runs_body(const FxDevParams &P, const FxBuffers &B, uint32_t scan, uint32_t ring, uint32_t max_pts,
+                                               uint32_t *smem) {
+  constexpr uint32_t S = FX_RR_SEGS, RN = FX_RR_RUNS, CC = FX_RR_CCAP;
+  const uint32_t lane = threadIdx.x;
+  unsigned long long *const stamp_base = B.stamps ? B.stamps : nullptr;
+  FX_STAMP_INIT(stamp_base);
+  uint32_t *s_w = smem;                    // [152]: block helpers, broadcast slots, sort stack / near-pair list
+  uint32_t *rbox = smem + 152;             // [RN][min x, max x, min y, max y] run boxes ...
+  float4 *cc = reinterpret_cast<float4 *>(rbox);  // ... and, once the edges are in, [CC] cluster boxes, then centroids (16-byte aligned)
+  uint32_t *wq = rbox + 4 * RN;            // [FX_RR_QUEUE] parked (point, run) items
+  uint32_t *seg_tab = wq + FX_RR_QUEUE;    // [S + 1 (+ 3: alignment)] first point of each segment | its run << 16; seg_tab[n_segs] = n
+  uint32_t *seg_box = seg_tab + S + 4;     // [S][min x, max x, min y, max y] (ordered uints, then float bits)
+  uint32_t *rseg = seg_box + 4 * S;        // [RN + 1] first segment of each run; rseg[n_runs] = n_segs
+  uint32_t *rparent = rseg + RN + 1;       // [RN] union-find over runs
+  uint32_t *rsize = rparent + RN;          // [RN] points of the component (at its root) | position in PCL's order << 16
+  uint32_t *roff = rsize + RN;             // [RN] offset of the run's points inside its cluster
+  float *rw = reinterpret_cast<float *>(roff + RN);  // [RN] elevation angle of the run's first point
+  uint32_t *croot = roff + 2 * RN, *crec = croot + CC, *ctmp = crec + CC, *cslot = ctmp + CC;
+  // the ring's first NC points (x, y, z): nine rings in ten fit whole, and every later phase then reads LDS only
+  constexpr uint32_t NC = FX_RR_CACHE;
+  float *px = reinterpret_cast<float *>(cslot + CC), *py = px + NC, *pz = py + NC;
+  auto sst = [&](uint32_t sg) { return seg_tab[sg] & 0xffffu; };
+  auto srun = [&](uint32_t sg) { return seg_tab[sg] >> 16; };
+  const size_t ring_slot = (size_t)scan * P.n_rings + ring;
+  const uint32_t n = B.ring_cnt[ring_slot], off = B.ring_off[ring_slot];
+  if (n == 0) {  // ref: node.cpp:263-264
+    if (lane == 0) {
+      B.ring_cand_cnt[ring_slot] = 0;
+      B.kpc_ring_cnt[ring_slot] = 0;
+    }
+    return true;
+  }
+  if (n > 65535u || n > max_pts) return false;  // (beyond limits.max_ring_points: the last workgroup tier flags the scan)
+  const float4 *src = B.ring_pts + (size_t)scan * P.ring_slot_cap + off;
+  const float r2 = P.r2_cluster;
+  for (uint32_t t = lane; t < S; t += 64) {
+    seg_box[4 * t + 0] = f2ord(INFINITY), seg_box[4 * t + 1] = f2ord(-INFINITY);
+    seg_box[4 * t + 2] = f2ord(INFINITY), seg_box[4 * t + 3] = f2ord(-INFINITY);
+  }
+  for (uint32_t t = lane; t < RN; t += 64) {
+    rbox[4 * t + 0] = f2ord(INFINITY), rbox[4 * t + 1] = f2ord(-INFINITY);
+    rbox[4 * t + 2] = f2ord(INFINITY), rbox[4 * t + 3] = f2ord(-INFINITY);
+  }
+  wave_sync_lds();
+  FX_STAMP(1);
+  // ---- run labelling: a point starts a run when it is not closer than the tolerance to its predecessor
+  const uint32_t seg_len = max(8u, (n + 95u) / 96u);
+  const unsigned long long le_mask = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+  uint32_t n_runs = 0, n_segs = 0, head_carry = 0;
+  float4 prev_last = make_float4(0, 0, 0, 0);
+  float4 qv[4];     // the first four chunks stay in registers for the member copy at the end,
+  uint32_t sgv[4];  // each point with its segment
+#pragma unroll
+  for (uint32_t k = 0; k < 4; ++k) qv[k] = make_float4(0, 0, 0, 0), sgv[k] = 0;
+  float4 nxt = lane < n ? src[lane] : make_float4(0, 0, 0, 0);
+  for (uint32_t b0 = 0; b0 < n; b0 += 64) {
+    const uint32_t i = b0 + lane;
+    const bool in = i < n;
+    const float4 q = nxt;
+    if (b0 + 64 < n) nxt = (i + 64 < n) ? src[i + 64] : make_float4(0, 0, 0, 0);  // the next chunk is in flight
+    float4 p;
+    p.x = __shfl_up(q.x, 1, 64), p.y = __shfl_up(q.y, 1, 64), p.z = __shfl_up(q.z, 1, 64);
+    if (lane == 0) p = prev_last;
+    const bool start = in && (i == 0 || !(dist2(q.x, q.y, q.z, p.x, p.y, p.z) < r2));
+    const unsigned long long m = __ballot(start);
+    const unsigned long long below = m & le_mask;
+    const uint32_t head = below ? b0 + (63u - (uint32_t)__clzll((long long)below)) : head_carry;
+    const uint32_t r = n_runs + (uint32_t)__popcll(below) - 1u;
+    const bool seg_first = in && (start || ((i - head) % seg_len) == 0u);
+    const unsigned long long ms = __ballot(seg_first);
+    const uint32_t sg = n_segs + (uint32_t)__popcll(ms & le_mask) - 1u;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+      if (b0 == 64 * k) qv[k] = q, sgv[k] = sg;
+    }
+    if (i < NC && in) px[i] = q.x, py[i] = q.y, pz[i] = q.z;
+    if (in && sg < S && r < RN) {
+      if (seg_first) {
+        seg_tab[sg] = i | (r << 16);
+        if (start) rseg[r] = sg, rw[r] = q.w;
+      }
+      const uint32_t ox = f2ord(q.x), oy = f2ord(q.y);
+      atomicMin(&seg_box[4 * sg + 0], ox);
+      atomicMax(&seg_box[4 * sg + 1], ox);
+      atomicMin(&seg_box[4 * sg + 2], oy);
+      atomicMax(&seg_box[4 * sg + 3], oy);
+    }
+    if (m) head_carry = b0 + (63u - (uint32_t)__clzll((long long)m));
+    n_runs += (uint32_t)__popcll(m);
+    n_segs += (uint32_t)__popcll(ms);
+    prev_last.x = __shfl(q.x, 63, 64), prev_last.y = __shfl(q.y, 63, 64), prev_last.z = __shfl(q.z, 63, 64);
+  }
+  if (n_runs > RN || n_segs > S) return false;  // (wave-uniform) unordered or very fragmented ring: workgroup tiers
+  wave_sync_lds();
+  FX_STAMP(2);
+  if (lane == 0) {
+    FX_COUNT(12, 1);
+    FX_COUNT(13, n_runs);
+    FX_COUNT(14, n_segs);
+  }
+  // ---- segment boxes -> floats, folded into the run boxes; union-find over runs
+  for (uint32_t sg = lane; sg < n_segs; sg += 64) {
+    const uint32_t r = srun(sg);
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+      const uint32_t o = seg_box[4 * sg + k];
+      seg_box[4 * sg + k] = __float_as_uint(ord2f(o));
+      if (k & 1)
+        atomicMax(&rbox[4 * r + k], o);
+      else
+        atomicMin(&rbox[4 * r + k], o);
+    }
+  }
+  if (lane == 0) {
+    seg_tab[n_segs] = n;
+    rseg[n_runs] = n_segs;
+    s_w[16] = 0;
+  }
+  wave_sync_lds();
+  for (uint32_t r = lane; r < n_runs; r += 64) {
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) rbox[4 * r + k] = __float_as_uint(ord2f(rbox[4 * r + k]));
+    rparent[r] = r;
+    rsize[r] = 0;
+  }
+  wave_sync_lds();
+  const float4 *sbox4 = reinterpret_cast<const float4 *>(seg_box);
+  auto rb = [&](uint32_t k, uint32_t r) { return __uint_as_float(rbox[4 * r + k]); };
+  // points i .. i + U - 1, clamped to last: from the LDS copy when it holds them all, else U loads from L2 in flight
+  auto fetch = [&](auto U_, uint32_t i, uint32_t last, float *x, float *y, float *z) {
+    constexpr uint32_t U = decltype(U_)::value;
+    if (last < NC) {
+#pragma unroll
+      for (uint32_t u = 0; u < U; ++u) {
+        const uint32_t j = min(i + u, last);
+        x[u] = px[j], y[u] = py[j], z[u] = pz[j];
+      }
+    } else {
+#pragma unroll
+      for (uint32_t u = 0; u < U; ++u) {
+        const float4 t = src[min(i + u, last)];
+        x[u] = t.x, y[u] = t.y, z[u] = t.z;
+      }
+    }
+  };
+  if (n_runs > 1) {
+    const float r2_pad = r2 * 1.001f;  // box distances are lower bounds; pad them against fp32 rounding
+    // near run pairs (azimuth-ordered rings have few): the list borrows the sort stack, idle until cc_order
+    uint32_t *rp = s_w + 32;
+    constexpr uint32_t kPairCap = FX_SORT_STACK_WORDS;
+    // a run per lane, its box in registers, against every later run: one 16-byte broadcast read per trip
+    const float4 *rbox4 = reinterpret_cast<const float4 *>(rbox);
+    for (uint32_t a0 = 0; a0 + 1u < n_runs; a0 += 64) {
+      const uint32_t a = a0 + lane;
+      const float4 ba = rbox4[min(a, n_runs - 1u)];
+      for (uint32_t b0 = a0 + 1u; b0 < n_runs; b0 += 8) {  // (eight reads in flight: the wavefront has little company on its SIMD)
+        float4 bx[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) bx[u] = rbox4[min(b0 + u, n_runs - 1u)];
+        uint32_t near = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+          const float dx = fmaxf(fmaxf(bx[u].x - ba.y, ba.x - bx[u].y), 0.0f);
+          const float dy = fmaxf(fmaxf(bx[u].z - ba.w, ba.z - bx[u].w), 0.0f);
+          near |= (b0 + u < n_runs && b0 + u > a && !(dx * dx + dy * dy > r2_pad)) ? (1u << u) : 0u;
+        }
+        while (near) {  // (rare)
+          const uint32_t u = (uint32_t)__ffs((int)near) - 1u;
+          near &= near - 1u;
+          const uint32_t slot = atomicAdd(&s_w[16], 1u);
+          if (slot < kPairCap) rp[slot] = (a << 16) | (b0 + u);
+        }
+      }
+    }
+    wave_sync_lds();
+    const uint32_t n_rp = s_w[16];
+    if (lane == 0) {
+      FX_COUNT(15, n_rp);
+    }
+    if (n_rp > kPairCap) return false;  // runs all over each other (unordered input): workgroup tiers
+    uint32_t wq_n = 0;
+    auto drain = [&]() {
+      wave_sync_lds();
+      for (uint32_t t = lane; t < wq_n; t += 64) {
+        const uint32_t item = wq[t];
+        const uint32_t i = item & 0xffffu, b = (item >> 16) & 0xffu, a = item >> 24;
+        if (uf_find(rparent, a) == uf_find(rparent, b)) continue;  // already one component
+        float3 q;
+        fetch(std::integral_constant<uint32_t, 1>{}, i, i, &q.x, &q.y, &q.z);
+        bool linked = false;
+        for (uint32_t sg = rseg[b]; sg < rseg[b + 1] && !linked; ++sg) {
+          const float4 sb = sbox4[sg];
+          const float dx = fmaxf(fmaxf(sb.x - q.x, q.x - sb.y), 0.0f);
+          const float dy = fmaxf(fmaxf(sb.z - q.y, q.y - sb.w), 0.0f);
+          if (dx * dx + dy * dy > r2_pad) continue;
+          const uint32_t j1 = sst(sg + 1);
+          for (uint32_t j = sst(sg); j < j1 && !linked; j += 8) {
+            float jx[8], jy[8], jz[8];
+            fetch(std::integral_constant<uint32_t, 8>{}, j, j1 - 1u, jx, jy, jz);
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) linked |= dist2(q.x, q.y, q.z, jx[u], jy[u], jz[u]) < r2;
+          }
+          if (linked) uf_union(rparent, b, a);  // the two runs are one component now; more edges add nothing
+        }
+      }
+      wave_sync_lds();
+      wq_n = 0;
+    };
+    // the points of the earlier run of every near pair against the later run's box: the (pair, point) items are
+    // laid end to end (roff, idle until the centroids, holds the pairs' first item) so that one trip tests 64 of
+    // them whatever the runs' lengths
+    uint32_t n_items = 0;
+    for (uint32_t t0 = 0; t0 < n_rp; t0 += 64) {
+      const uint32_t t = t0 + lane;
+      uint32_t len = 0;
+      if (t < n_rp) {
+        const uint32_t a = rp[t] >> 16;
+        len = sst(rseg[a + 1]) - sst(rseg[a]);
+      }
+      uint32_t tot;
+      const uint32_t ex = block_excl_scan<64>(len, s_w, tot);
+      if (t < n_rp) roff[t] = n_items + ex;
+      n_items += tot;
+    }
+    wave_sync_lds();
+    for (uint32_t w0 = 0; w0 < n_items; w0 += 64) {
+      const uint32_t w = w0 + lane;
+      bool ok = false;
+      uint32_t item = 0;
+      if (w < n_items) {
+        uint32_t lo = 0, hi = n_rp - 1u;  // the pair of item w: the last one starting at or before it
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi + 1u) >> 1;
+          if (roff[mid] <= w)
+            lo = mid;
+          else
+            hi = mid - 1u;
+        }
+        const uint32_t a = rp[lo] >> 16, b = rp[lo] & 0xffffu;
+        const uint32_t i = sst(rseg[a]) + (w - roff[lo]);
+        float3 q;
+        fetch(std::integral_constant<uint32_t, 1>{}, i, i, &q.x, &q.y, &q.z);
+        const float dx = fmaxf(fmaxf(rb(0, b) - q.x, q.x - rb(1, b)), 0.0f);
+        const float dy = fmaxf(fmaxf(rb(2, b) - q.y, q.y - rb(3, b)), 0.0f);
+        ok = !(dx * dx + dy * dy > r2_pad);
+        item = i | (b << 16) | (a << 24);
+      }
+      const unsigned long long mk = __ballot(ok);
+      if (mk) {
+        if (ok) wq[wq_n + lanes_below(mk)] = item;
+        wq_n += (uint32_t)__popcll(mk);
+        if (wq_n > FX_RR_QUEUE - 64) drain();
+      }
+    }
+    if (wq_n) drain();
+  }
+  wave_sync_lds();
+  FX_STAMP(3);
+  // ---- roots (read-only finds, then the owners overwrite), sizes = sums of run lengths
+  uint32_t my_root[(RN + 63) / 64];
+#pragma unroll
+  for (uint32_t u = 0; u < (RN + 63) / 64; ++u) {
+    const uint32_t r = lane + 64 * u;
+    my_root[u] = r < n_runs ? uf_find_ro(rparent, r) : 0u;
+  }
+  wave_sync_lds();
+#pragma unroll
+  for (uint32_t u = 0; u < (RN + 63) / 64; ++u) {
+    const uint32_t r = lane + 64 * u;
+    if (r < n_runs) {
+      rparent[r] = my_root[u];
+      atomicAdd(&rsize[my_root[u]], sst(rseg[r + 1]) - sst(rseg[r]));
+    }
+  }
+  wave_sync_lds();
+  FX_STAMP(4);
+  // ---- PCL's cluster order (unchanged code: the "points" are the runs, a component's root its smallest run)
+  const uint32_t n_c = cc_order<64>(n_runs, rparent, rsize, P.min_count, P.max_count, croot, crec, ctmp, CC, s_w, stamp_base);
+  if (n_c > CC) return false;
+#ifdef FX_STAMPS
+  stamp_prev_ = __builtin_amdgcn_s_memtime();
+#endif
+  uint32_t *bb = reinterpret_cast<uint32_t *>(cc);  // [s][min x, max x, min y, max y] until the centroids go there
+  for (uint32_t sI = lane; sI < n_c; sI += 64) {
+    const uint32_t root = croot[crec[sI] & 0xffffu];
+    rsize[root] |= (sI + 1u) << 16;  // position in PCL's order, next to the size
+    bb[4 * sI + 0] = f2ord(1000.0f);  // ref: node.cpp:289-290
+    bb[4 * sI + 1] = f2ord(-1000.0f);
+    bb[4 * sI + 2] = f2ord(1000.0f);
+    bb[4 * sI + 3] = f2ord(-1000.0f);
+  }
+  wave_sync_lds();
+  for (uint32_t sg = lane; sg < n_segs; sg += 64) {
+    const uint32_t pos = rsize[rparent[srun(sg)]] >> 16;
+    if (pos == 0) continue;  // not a size-admissible cluster
+    uint32_t *bx = bb + 4 * (pos - 1u);
+    const float4 sb = sbox4[sg];
+    atomicMin(&bx[0], f2ord(sb.x));
+    atomicMax(&bx[1], f2ord(sb.y));
+    atomicMin(&bx[2], f2ord(sb.z));
+    atomicMax(&bx[3], f2ord(sb.w));
+  }
+  wave_sync_lds();
+  FX_STAMP(7);
+  // ---- diameter gate per cluster, in PCL's cluster order (ref: node.cpp:314-316)
+  for (uint32_t sI = lane; sI < n_c; sI += 64) {
+    const double minx = ord2f(bb[4 * sI + 0]), maxx = ord2f(bb[4 * sI + 1]);
+    const double miny = ord2f(bb[4 * sI + 2]), maxy = ord2f(bb[4 * sI + 3]);
+    const double ddx = maxx - minx, ddy = maxy - miny;
+    cslot[sI] = (sqrt(ddx * ddx + ddy * ddy) < P.gate_diameter) ? 1u : 0u;
+  }
+  wave_sync_lds();
+  FX_STAMP(8);
+  // ---- centroid of the clusters that pass: fp64 sums in ascending member order = the cluster's runs in run order,
+  //      each run's points in turn (ref: node.cpp:293-297, 317-320)
+  for (uint32_t sI = lane; sI < n_c; sI += 64) {
+    if (cslot[sI] == 0u) continue;
+    const uint32_t rec = crec[sI];
+    const uint32_t sz = rec >> 16, root = croot[rec & 0xffffu];
+    double sumx = 0.0, sumy = 0.0, sumz = 0.0;
+    uint32_t cnt = 0;
+    for (uint32_t r = root; r < n_runs && cnt < sz; ++r) {
+      if (rparent[r] != root) continue;
+      roff[r] = cnt;
+      const uint32_t i0 = sst(rseg[r]), i1 = sst(rseg[r + 1]);
+      for (uint32_t i = i0; i < i1; i += 4) {
+        float x[4], y[4], z[4];
+        fetch(std::integral_constant<uint32_t, 4>{}, i, i1 - 1u, x, y, z);
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+          if (i + u >= i1) continue;
+          sumx += (double)x[u];
+          sumy += (double)y[u];
+          sumz += (double)z[u];
+        }
+      }
+      cnt += i1 - i0;
+    }
+    cc[sI] = make_float4((float)(sumx / (double)sz), (float)(sumy / (double)sz), (float)(sumz / (double)sz), rw[root]);
+  }
+  wave_sync_lds();
+  FX_STAMP(9);
+  // ---- slots of the gate-passing clusters and offsets of their member runs
+  uint32_t n_pass = 0, n_mem = 0;
+  for (uint32_t b0 = 0; b0 < n_c; b0 += 64) {
+    const uint32_t sI = b0 + lane;
+    const bool pass = sI < n_c && cslot[sI] != 0u;
+    const uint32_t sz = pass ? (crec[sI] >> 16) : 0u;
+    uint32_t tot_p, tot_m;
+    const uint32_t slot = block_rank<64>(pass, s_w, tot_p);
+    const uint32_t koff = block_excl_scan<64>(sz, s_w, tot_m);
+    if (sI < n_c) {
+      cslot[sI] = pass ? (n_pass + slot) : FX_NONE;
+      ctmp[sI] = n_mem + koff;
+    }
+    n_pass += tot_p;
+    n_mem += tot_m;
+  }
+  wave_sync_lds();
+  FX_STAMP(10);
+  // ---- candidates of this ring (cylinderCentroids, ref: node.cpp:322)
+  float4 *rc = B.ring_cand + ring_slot * P.max_ring_cands;
+  uint32_t *rcs = B.ring_cand_size + ring_slot * P.max_ring_cands;
+  for (uint32_t sI = lane; sI < n_c; sI += 64) {
+    const uint32_t slot = cslot[sI];
+    if (slot < P.max_ring_cands) {
+      rc[slot] = cc[sI];
+      rcs[slot] = crec[sI] >> 16;
+    }
+  }
+  if (lane == 0) {
+    if (n_pass > P.max_ring_cands) atomicOr(&B.flags[scan], FX_FLAG_CAND_OVERFLOW);
+    B.ring_cand_cnt[ring_slot] = n_pass < P.max_ring_cands ? n_pass : P.max_ring_cands;
+    B.kpc_ring_cnt[ring_slot] = n_mem;
+  }
+  // ---- member points (cylinderCloud, ref: node.cpp:310, 323), a point per lane: the first 256 are still in registers
+  if (n_mem) {
+    float4 *pool = B.kpc_pool + (size_t)scan * P.ring_slot_cap + off;
+    uint32_t *pool_c = B.kpc_pool_cand + (size_t)scan * P.ring_slot_cap + off;
+    auto emit = [&](uint32_t i, const float4 &q, uint32_t sg) {
+      const uint32_t r = srun(sg);
+      const uint32_t pos = rsize[rparent[r]] >> 16;
+      if (pos == 0) return;
+      const uint32_t slot = cslot[pos - 1u];
+      if (slot == FX_NONE) return;
+      const uint32_t dst = ctmp[pos - 1u] + roff[r] + (i - sst(rseg[r]));
+      pool[dst] = q;
+      pool_c[dst] = slot;
+    };
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+      if (64 * k + lane < n) emit(64 * k + lane, qv[k], sgv[k]);
+    }
+    for (uint32_t i = 256 + lane; i < n; i += 64) {
+      const float4 q = src[i];
+      uint32_t lo = 0, hi = n_segs - 1u;  // the segment of point i: the last one starting at or before it
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1u) >> 1;
+        if (sst(mid) <= i)
+          lo = mid;
+        else
+          hi = mid - 1u;
+      }
+      emit(i, q, lo);
+    }
+  }
+  wave_sync_lds();
+  FX_STAMP(11);
+  return true;
+}
+extern "C" __global__ __launch_bounds__(64) void k_rings_runs(FxDevParams P, FxBuffers B, uint32_t mid_cap, uint32_t max_pts, uint32_t n_items) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  // Persistent wavefronts over the (scan, ring) items.  Blocks are dealt round-robin over the 8 XCDs
-  // (observed, for speed only): block b works on scans s = b (mod 8), whose ring-major points the
-  // k_bucket block s wrote into that same XCD's L2.  Within its class a block strides over (scan, ring).
+  // persistent wavefronts over the (scan, ring) items, dealt by XCD class
   const uint32_t R = (uint32_t)P.n_rings, n_scans = n_items / R;
   const uint32_t cls = blockIdx.x & 7u, slot = blockIdx.x >> 3, per_cls = gridDim.x >> 3;  // (grid is a multiple of 8)
   const uint32_t cls_items = ((n_scans + 7u - cls) / 8u) * R;
   for (uint32_t q = slot; q < cls_items; q += per_cls) {
     const uint32_t scan = cls + 8u * (q / R), ring = q % R;
     const uint32_t item = scan * R + ring;
-    if (!ring_body<FX_RING_SMALL_T>(P, B, scan, ring, cap, ccap, smem, false)) {
+    if (!ring_runs_body(P, B, scan, ring, max_pts, smem)) {
       if (threadIdx.x == 0) {
-        // too big for one wavefront: workgroup tiers (mid: fits mid_cap points, else the large one)
-        // (one list per XCD class, so that the larger tier too finds the ring's points in its own L2)
         const bool mid = B.ring_cnt[item] <= mid_cap;
         const uint32_t pos = atomicAdd(&B.counters[(mid ? FX_CNT_MID : FX_CNT_LARGE) + cls], 1u);
         (mid ? B.big_rings : B.huge_rings)[(size_t)cls * P.ring_list_cap + pos] = item;
       }
     }
-    __syncthreads();
+    wave_sync_lds();
   }
 }
 extern "C" __global__ __launch_bounds__(FX_WG, 5) void k_rings_big(FxDevParams P, FxBuffers B, uint32_t cap, uint32_t ccap,
                                                                  uint32_t huge) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  // block b takes the list of XCD class b mod 8 (the grid is a multiple of 8): see k_rings_small
+  // block b takes the list of XCD class b mod 8 (the grid is a multiple of 8): see k_rings_runs
   const uint32_t cls = blockIdx.x & 7u;
   const uint32_t n_big = B.counters[(huge ? FX_CNT_LARGE : FX_CNT_MID) + cls];
   const uint32_t *items = (huge ? B.huge_rings : B.big_rings) + (size_t)cls * P.ring_list_cap;
@@ -3271,9 +3697,6 @@ size_t fxk_ring_large_lds_bytes(uint32_t cap, uint32_t ccap) {
 void fxk_rings_large(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t ccap, uint32_t grid) {
   hipLaunchKernelGGL(k_rings_large, dim3(grid), dim3(FX_RING_LARGE_T), fxk_ring_large_lds_bytes(cap, ccap), s, P, B, cap, ccap);
 }
-size_t fxk_ring_wave_lds_bytes(uint32_t cap, uint32_t ccap) {
-  return (size_t)(SegCfg<FX_RING_SMALL_T>::kWords + FX_RING_WORDS_PER_POINT * cap + FX_RING_WORDS_PER_CLUSTER * ccap) * 4;
-}
 size_t fxk_merge_lds_bytes(uint32_t cap, uint32_t n_rings) { return merge_words(cap, cap, n_rings, true) * 4; }
 size_t fxk_merge_huge_lds_bytes(uint32_t cap, uint32_t ccap, uint32_t n_rings) { return merge_words(cap, ccap, n_rings, false) * 4; }
 uint32_t fxk_huge_cap(void) { return FX_HUGE_CAP; }
@@ -3312,12 +3735,12 @@ void fxk_bucket(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_
   const size_t lds = (48 + (size_t)P.n_rings * (2 + FX_BUCKET_NW) + 1) * 4;
   hipLaunchKernelGGL(k_bucket, dim3(batch), dim3(FX_BUCKET_T), lds, s, P, B, el0, inv_step, clk_next);
 }
-void fxk_rings_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t ccap,
-                     uint32_t mid_cap, uint32_t grid) {
+size_t fxk_ring_runs_lds_bytes(void) { return (size_t)FX_RR_WORDS * 4; }
+void fxk_rings_runs(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t mid_cap, uint32_t max_pts,
+                    uint32_t grid) {
   const uint32_t n_items = batch * (uint32_t)P.n_rings;
-  if (grid > n_items) grid = n_items;
-  hipLaunchKernelGGL(k_rings_small, dim3(grid), dim3(FX_RING_SMALL_T), fxk_ring_wave_lds_bytes(cap, ccap), s, P, B, cap, ccap,
-                     mid_cap, n_items);
+  if (grid > n_items) grid = (n_items + 7) / 8 * 8;
+  hipLaunchKernelGGL(k_rings_runs, dim3(grid), dim3(64), fxk_ring_runs_lds_bytes(), s, P, B, mid_cap, max_pts, n_items);
 }
 void fxk_rings_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t ccap, uint32_t grid,
                    uint32_t huge) {

@@ -26,7 +26,7 @@ capi.check(lib.fx_debug_stamps(ctx.handle, out))
 v = np.array(list(out), dtype=np.float64)
 names = {1: "ring split", 2: "run labelling", 3: "all pairs", 4: "find+sizes", 5: "discovery compaction",
          6: "sort replay (1 lane)", 7: "bbox", 8: "gate", 9: "centroid walks", 10: "slot scans", 11: "outputs"}
-for tier, base in (("wave tier (n <= 256)", 0), ("workgroup tiers", 16), ("merge (per scan x16)", 32)):
+for tier, base in (("run tier (one wavefront per ring)", 0), ("workgroup tiers", 16), ("merge (per scan x16)", 32)):
     tot = v[base:base + 16].sum()
     print(f"-- {tier}: {tot / (3 * B * 16):.0f} cycles per (scan, ring) slot")
     for k, nm in names.items():
