@@ -28,7 +28,8 @@ SINGLE_LAUNCH_STAGES = ("k_prep", "k_bucket", "k_rings_runs", "k_rings_big", "k_
 # kernels launched inside each timed stage (rocprofv3 / PMC rows are per kernel name)
 STAGE_KERNELS = {"k_merge": ("k_rings_large", "k_merge_small", "k_merge_big", "k_merge_huge", "k_offsets"),
                  "k_desc_mid": ("k_desc_mid", "k_desc_wg_xl"),
-                 "k_desc_rare": ("k_desc_wg", "k_desc_huge", "k_desc_spill", "k_rng_ord")}
+                 "k_gather": ("k_gather", "k_rng_ord"),  # (k_rng_ord only when several workgroups share a scan: small batches)
+                 "k_desc_rare": ("k_desc_wg", "k_desc_huge", "k_desc_spill")}
 
 
 class FxParams(C.Structure):

@@ -40,17 +40,16 @@ void fxk_merge_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, ui
 void fxk_merge_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t grid, uint32_t last);
 void fxk_merge_huge(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t ccap, uint32_t grid);
 void fxk_offsets(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
+uint32_t fxk_gather_slices(uint32_t batch);
 void fxk_gather(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float box_margin);
 void fxk_desc_group(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid);
 void fxk_desc_wg(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t grid,
-                 uint32_t mode, uint32_t src);
+                 uint32_t src);
 void fxk_desc_mid(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t n_wg, uint32_t n_wave);
 void fxk_desc_wg_xl(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t ns_lo,
                     uint32_t grid);
-void fxk_desc_spill(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t mode,
-                    uint32_t slab_pts);
-void fxk_desc_huge(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t mode,
-                   uint32_t slab_pts);
+void fxk_desc_spill(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t slab_pts);
+void fxk_desc_huge(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t slab_pts);
 void fxk_pack_kp_records(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, void *dst,
                          uint32_t rec_kp);
 void fxk_rng_ord(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
@@ -215,6 +214,7 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof) {
     FX_HIP(mark(5));
     if (P.estimate_descriptors) {
       fxk_gather(s, P, B, batch, c->box_margin);
+      if (fxk_gather_slices(batch) > 1) fxk_rng_ord(s, P, B, batch);  // (one workgroup per scan settles the RNG ordinals itself)
       FX_HIP(mark(6));
       fxk_desc_group(s, P, B, batch, desc_grid);
       FX_HIP(mark(7));
@@ -227,15 +227,10 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof) {
       }
       FX_HIP(mark(8));
       // (no exact redo pass: the fast tiers evaluate the exact angles themselves for the rare neighbour next to a bin
-      //  edge; the exact kernel stays for the re-gather tier and the RNG second pass)
-      fxk_desc_wg(s, P, B, batch, L.max_neighbors, c->tail_grid, 0, 0);
-      fxk_desc_huge(s, P, B, batch, c->spill_grid, 0, c->spill_slab);
-      fxk_desc_spill(s, P, B, batch, c->spill_grid, 0, c->spill_slab);
-      fxk_rng_ord(s, P, B, batch);
-      // second pass: only keypoints whose RNG ordinal moved (an earlier keypoint had no neighbours)
-      fxk_desc_wg(s, P, B, batch, L.max_neighbors, c->tail_grid, 1, 0);
-      fxk_desc_huge(s, P, B, batch, c->spill_grid, 1, c->spill_slab);
-      fxk_desc_spill(s, P, B, batch, c->spill_grid, 1, c->spill_slab);
+      //  edge; the exact kernel stays for the re-gather tier)
+      fxk_desc_wg(s, P, B, batch, L.max_neighbors, c->tail_grid, 0);
+      fxk_desc_huge(s, P, B, batch, c->spill_grid, c->spill_slab);
+      fxk_desc_spill(s, P, B, batch, c->spill_grid, c->spill_slab);
     } else {
       for (int i = 6; i <= 8; ++i) FX_HIP(mark(i));
     }
@@ -435,7 +430,6 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   FX_A(dev_alloc(c, &b.keypoints, B * L.max_keypoints));
   FX_A(dev_alloc(c, &b.kp_size, B * L.max_keypoints));
   FX_A(dev_alloc(c, &b.kp_nbrs, B * L.max_keypoints));
-  FX_A(dev_alloc(c, &b.rng_ord, B * L.max_keypoints));
   FX_A(dev_alloc(c, &b.n_kp, B));
   FX_A(dev_alloc(c, &b.kp_offset, B + 1));
   FX_A(dev_alloc(c, &b.kpc, B * L.max_kpc_points));

@@ -77,7 +77,6 @@ struct FxBuffers {
   float4 *keypoints;      // [B][max_keypoints]
   uint32_t *kp_size;      // [B][max_keypoints]
   uint32_t *kp_nbrs;      // [B][max_keypoints]
-  uint32_t *rng_ord;      // [B][max_keypoints]
   uint32_t *n_kp;         // [B]
   uint32_t *kp_offset;    // [B+1]
   float4 *kpc;            // [B][max_kpc]
@@ -111,7 +110,7 @@ struct FxBuffers {
   float2 *row_xa;         //                 per-keypoint kernels fetch everything a row needs in one round trip
   unsigned long long *clk;     // [FX_CLK_SLOTS][2] k_prep's first start / last end on the device's constant-rate clock, by batch
   unsigned long long *stamps;  // [32] diagnostic build only (-DFX_STAMPS)
-  uint32_t *counters;     // [FX_N_COUNTERS]: 16.. deferred rings per XCD class (8 mid, 8 large); 0 big_rings, 1 big_merge, 2 big_desc, 3 need_rng_fix, 4 list_desc, 5 huge_rings, 6 spill_desc, 7 exact_desc, 8 wave_desc, 9 huge_merge, 12 huge_desc
+  uint32_t *counters;     // [FX_N_COUNTERS]: 16.. deferred rings per XCD class (8 mid, 8 large); 0 big_rings, 1 big_merge, 2 big_desc, 3 -, 4 list_desc, 5 huge_rings, 6 spill_desc, 7 exact_desc, 8 wave_desc, 9 huge_merge, 12 huge_desc
 };
 
 #endif

@@ -1973,6 +1973,7 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
       }
       kp[s] = make_float4((float)(sumx / (double)sz), (float)(sumy / (double)sz), (float)(sumz / (double)sz), true_pt(root).w);
       kps[s] = sz;
+      B.kp_nbrs[(size_t)scan * P.max_keypoints + s] = 0u;  // (k_gather flags the keypoints that have a neighbour; the descriptor kernels count)
     }
     __syncthreads();
     FX_STAMP(8);
@@ -2101,7 +2102,8 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_offsets(FxDevParams P, FxB
 //   k_desc_wg       exact fp64-angle redo of keypoints the fp32 passes flagged (angle near a bin
 //                   edge), and re-gather tier for lists that overflowed list_cap
 //   k_desc_spill    support sets beyond LDS: slabs in HBM
-//   k_rng_ord       3DSC's RNG ordinal rule; a second pass redoes the (rare) affected keypoints
+//   (3DSC's RNG ordinal rule — a keypoint without neighbours draws no x-axis — is applied by k_gather, which knows
+//    which keypoints have one before any descriptor is computed; k_rng_ord when several workgroups share a scan)
 
 // Which scan does global keypoint row w belong to?  kp_offset is an exclusive prefix.
 __device__ __forceinline__ uint32_t scan_of_row(const uint32_t *kp_offset, uint32_t batch, uint32_t w) {
@@ -2235,7 +2237,7 @@ __host__ __device__ inline uint32_t gather_words(uint32_t mk) {
   uint32_t w = 32 + 4 * mk;                                   // scratch, keypoints
   w += FX_GATHER_CELLS + 4;                                   // cell table (the fill cursors borrow the staging area)
   w += ((9 * mk + 1) / 2 + 3) & ~3u;                          // cell lists (uint16)
-  w += (3 * mk + 3) & ~3u;                                    // staged hits per keypoint, reserved list positions, list lengths
+  w += (4 * mk + 3) & ~3u;                                    // staged hits per keypoint, reserved list positions, list lengths, has-a-neighbour flags
   w += FX_GATHER_STAGE + 4 * FX_GATHER_STAGE;                 // staged hits: meta, points
   w += FX_NWAVE * FX_GATHER_QUEUE * 5;                        // per-wavefront queues: points, cell info
   return w;
@@ -2252,7 +2254,8 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
   uint32_t *s_kcnt = reinterpret_cast<uint32_t *>(s_flat) + (((9 * MK + 1) / 2 + 3) & ~3u);  // [MK] staged hits per keypoint
   uint32_t *s_kbase = s_kcnt + MK;                               // [MK] reserved list position
   uint32_t *s_kpos = s_kbase + MK;                               // [MK] list length so far (one workgroup per scan)
-  uint32_t *s_smeta = s_kcnt + ((3 * MK + 3) & ~3u);             // [STAGE] keypoint << 16 | staged ordinal
+  uint32_t *s_knbr = s_kpos + MK;                                // [MK] 1: some point lies within the search radius (one workgroup per scan)
+  uint32_t *s_smeta = s_kcnt + ((4 * MK + 3) & ~3u);             // [STAGE] keypoint << 16 | staged ordinal
   const bool solo = gridDim.x == 1;
   float4 *s_spt = reinterpret_cast<float4 *>(s_smeta + FX_GATHER_STAGE);
   uint32_t *s_cur = reinterpret_cast<uint32_t *>(s_spt);        // [CELLS] fill cursors while the lists are built (4 STAGE >= CELLS words)
@@ -2278,10 +2281,8 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
     s_kp[k] = kp;
     s_kcnt[k] = 0;
     s_kpos[k] = 0;
-    if (slice == 0) {
-      B.row_kp[row0 + k] = kp;
-      B.row_xa[row0 + k] = B.xaxis[k];
-    }
+    s_knbr[k] = 0;
+    if (slice == 0) B.row_kp[row0 + k] = kp;
     atomicMin(&s_w[0], f2ord(kp.x));
     atomicMax(&s_w[1], f2ord(kp.x));
     atomicMin(&s_w[2], f2ord(kp.y));
@@ -2384,7 +2385,15 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
       for (uint32_t e = 0; e < cnt; ++e) {
         const uint32_t k = s_flat[st + e];
         const float4 kp = s_kp[k];
-        if (dist2(kp.x, kp.y, kp.z, pq.x, pq.y, pq.z) < P.r2_support) {
+        const float d2 = dist2(kp.x, kp.y, kp.z, pq.x, pq.y, pq.z);
+        if (d2 < P.r2_support) {
+          // 3DSC draws its x-axis only for keypoints that have a neighbour (d2 < R^2: the descriptor kernels' count)
+          if (d2 < P.r2_search) {
+            if (solo)
+              s_knbr[k] = 1u;
+            else
+              B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = 1u;  // (cleared by the merge stage; k_rng_ord reads it)
+          }
           const uint32_t slot = atomicAdd(&s_w[8], 1u);
           if (slot < FX_GATHER_STAGE) {
             s_spt[slot] = pq;
@@ -2457,8 +2466,20 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
   drain();
   __syncthreads();
   flush(s_w[8]);
-  if (solo)
+  if (solo) {
     for (uint32_t k = tid; k < K; k += FX_WG) B.s_cnt[row0 + k] = s_kpos[k];
+    // RNG ordinals: keypoint k takes the x-axis number (keypoints before it that have a neighbour)
+    __syncthreads();
+    if (wave == 0) {
+      uint32_t base = 0;
+      for (uint32_t k0 = 0; k0 < K; k0 += 64) {
+        const uint32_t k = k0 + lane;
+        const unsigned long long m = __ballot(k < K && s_knbr[k] != 0u);
+        if (k < K) B.row_xa[row0 + k] = B.xaxis[base + lanes_below(m)];
+        base += (uint32_t)__popcll(m);
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------- wavefront tier (runs inside k_desc_mid)
@@ -2816,7 +2837,7 @@ __device__ __forceinline__ DescLds desc_carve(uint32_t *smem, uint32_t cap) {
 // Returns false if the support set does not fit `cap` (only possible when !from_list).
 template <bool FAST, int NT>
 __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers &B, uint32_t row, uint32_t scan, uint32_t k,
-                          uint32_t ord, uint32_t cap, uint32_t *smem, bool from_list) {
+                          uint32_t cap, uint32_t *smem, bool from_list) {
   DescLds L = desc_carve(smem, cap);
   FX_STAMP_INIT(B.stamps && FAST ? B.stamps + 48 : nullptr);
   const uint32_t tid = threadIdx.x;
@@ -2924,7 +2945,7 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
   FX_STAMP(1);
 
   const FxScTables *T = reinterpret_cast<const FxScTables *>(tl);
-  const float2 xa = B.xaxis[ord];
+  const float2 xa = B.row_xa[row];
   // ---- neighbours (d2 < R^2, not the keypoint itself) packed densely: nlist[m] = support position.
   //      The list lives in the weight array and the density counters in the key array until the
   //      per-neighbour pass below overwrites slot m with the real key and weight.
@@ -3106,8 +3127,7 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
 // src 2: rows with an angle near a bin edge (exact_desc): from the list, exact angles
 template <bool FAST, int NT>
 __device__ __forceinline__ void desc_wg_loop(const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap,
-                                             uint32_t mode, uint32_t src, uint32_t *smem, uint32_t ns_lo, uint32_t bid,
-                                             uint32_t nblk) {
+                                             uint32_t src, uint32_t *smem, uint32_t ns_lo, uint32_t bid, uint32_t nblk) {
   // a support set that does not fit `cap` goes to the spill tier
   auto spill = [&](uint32_t row, uint32_t scan, uint32_t k) {
     if (threadIdx.x == 0) {
@@ -3121,22 +3141,6 @@ __device__ __forceinline__ void desc_wg_loop(const FxDevParams &P, const FxBuffe
     }
     if (!B.spill_pts) desc_fill_nan(B.desc + (size_t)row * FX_DESC_FLOATS, threadIdx.x, NT);
   };
-  if (mode == 1) {
-    // second pass (rare): every keypoint whose RNG ordinal moved is redone here, whatever tier computed
-    // it first — from its list when that holds the whole support set, else re-gathered
-    if (B.counters[3] == 0) return;
-    uint32_t total = B.kp_offset[batch];
-    if (total > P.max_total_kp) total = P.max_total_kp;
-    for (uint32_t row = bid; row < total; row += nblk) {
-      const uint2 rm = B.row_map[row];
-      const uint32_t scan = rm.x, k = rm.y;
-      const uint32_t ord = B.rng_ord[(size_t)scan * P.max_keypoints + k];
-      if (ord == k) continue;
-      if (!desc_body<FAST, NT>(P, B, row, scan, k, ord, cap, smem, B.s_cnt[row] <= P.list_cap)) spill(row, scan, k);
-      __syncthreads();
-    }
-    return;
-  }
   const uint32_t n_items = B.counters[src == 0 ? 2 : (src == 1 ? 4 : 7)];
   const uint32_t *items = src == 0 ? B.big_desc : (src == 1 ? B.list_desc : B.exact_desc);
   for (uint32_t i = bid; i < n_items; i += nblk) {
@@ -3146,7 +3150,7 @@ __device__ __forceinline__ void desc_wg_loop(const FxDevParams &P, const FxBuffe
     const uint32_t nS = B.s_cnt[row];
     if (nS > P.list_cap && src != 0) continue;     // (exact_desc rows always fit; list rows too)
     if (src == 1 && (nS <= ns_lo || nS > cap)) continue;  // list rows are split by length over two launches
-    if (!desc_body<FAST, NT>(P, B, row, scan, k, k, cap, smem, src != 0)) spill(row, scan, k);
+    if (!desc_body<FAST, NT>(P, B, row, scan, k, cap, smem, src != 0)) spill(row, scan, k);
     __syncthreads();
   }
 }
@@ -3155,9 +3159,9 @@ __device__ __forceinline__ void desc_wg_loop(const FxDevParams &P, const FxBuffe
 #define FX_DESC_WG_FAST_T 256
 #define FX_DESC_WG_EXACT_T 512
 extern "C" __global__ __launch_bounds__(FX_DESC_WG_EXACT_T) void k_desc_wg(FxDevParams P, FxBuffers B, uint32_t batch,
-                                                                            uint32_t cap, uint32_t mode, uint32_t src) {
+                                                                            uint32_t cap, uint32_t src) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  desc_wg_loop<false, FX_DESC_WG_EXACT_T>(P, B, batch, cap, mode, src, smem, 0u, blockIdx.x, gridDim.x);
+  desc_wg_loop<false, FX_DESC_WG_EXACT_T>(P, B, batch, cap, src, smem, 0u, blockIdx.x, gridDim.x);
 }
 // Both middle tiers in one launch: the first n_wg workgroups take list rows (257..cap support points, one keypoint per
 // workgroup at a time), the others take wave rows (65..256, one keypoint per wavefront).  Neither tier fills the chip
@@ -3167,7 +3171,7 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_mid(FxDevParams P, Fx
                                                                 uint32_t n_wg) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   if (blockIdx.x < n_wg)
-    desc_wg_loop<true, FX_DESC_WG_FAST_T>(P, B, batch, cap, 0u, 1u, smem, 0u, blockIdx.x, n_wg);
+    desc_wg_loop<true, FX_DESC_WG_FAST_T>(P, B, batch, cap, 1u, smem, 0u, blockIdx.x, n_wg);
   else
     desc_wave_body<true>(P, B, batch, smem, blockIdx.x - n_wg, gridDim.x - n_wg);
 }
@@ -3176,7 +3180,7 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_mid(FxDevParams P, Fx
 extern "C" __global__ __launch_bounds__(FX_DESC_WG_XL_T) void k_desc_wg_xl(FxDevParams P, FxBuffers B, uint32_t batch,
                                                                             uint32_t cap, uint32_t ns_lo) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  desc_wg_loop<true, FX_DESC_WG_XL_T>(P, B, batch, cap, 0u, 1u, smem, ns_lo, blockIdx.x, gridDim.x);
+  desc_wg_loop<true, FX_DESC_WG_XL_T>(P, B, batch, cap, 1u, smem, ns_lo, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------- spill tier
@@ -3195,7 +3199,7 @@ extern "C" __global__ __launch_bounds__(FX_DESC_WG_XL_T) void k_desc_wg_xl(FxDev
 #define FX_HUGE_T 1024
 #define FX_HUGE_CAP 12288   // support points (3 floats each)
 #define FX_HUGE_WORDS (16 + 2 * FX_DGRID * FX_DGRID + 2 + FX_TABLE_WORDS + 3 * FX_HUGE_CAP + FX_DESC_BINS)
-extern "C" __global__ __launch_bounds__(FX_HUGE_T) void k_desc_huge(FxDevParams P, FxBuffers B, uint32_t batch, uint32_t mode,
+extern "C" __global__ __launch_bounds__(FX_HUGE_T) void k_desc_huge(FxDevParams P, FxBuffers B, uint32_t batch,
                                                                      uint32_t slab_pts) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   constexpr uint32_t G = FX_DGRID, kCells = G * G;
@@ -3205,7 +3209,6 @@ extern "C" __global__ __launch_bounds__(FX_HUGE_T) void k_desc_huge(FxDevParams 
   uint32_t *tl = smem + 16 + 2 * kCells + 2;      // (keeps what follows 16-byte aligned)
   float *xyz = reinterpret_cast<float *>(tl + FX_TABLE_WORDS);  // [3 * FX_HUGE_CAP]; later the sort arrays
   float *img = xyz + 3 * FX_HUGE_CAP;
-  if (mode == 1 && B.counters[3] == 0) return;
   const uint32_t tid = threadIdx.x;
   const uint32_t n_items = B.counters[6];
   float *sd2 = B.spill_d2 + (size_t)blockIdx.x * slab_pts;                 // squared distance to the keypoint
@@ -3222,11 +3225,9 @@ extern "C" __global__ __launch_bounds__(FX_HUGE_T) void k_desc_huge(FxDevParams 
     const uint32_t row = B.spill_desc[it];
     const uint2 rm = B.row_map[row];
     const uint32_t scan = rm.x, k = rm.y;
-    const uint32_t ord = mode == 1 ? B.rng_ord[(size_t)scan * P.max_keypoints + k] : k;
-    if (mode == 1 && ord == k) continue;
     const FxScanMeta M = B.meta[scan];
     const float4 kp = B.keypoints[(size_t)scan * P.max_keypoints + k];
-    const float2 xa = B.xaxis[ord];
+    const float2 xa = B.row_xa[row];
     float *out = B.desc + (size_t)row * FX_DESC_FLOATS;
     const float gx0 = kp.x - r_sup, gy0 = kp.y - r_sup;
 #ifdef FX_STAMPS
@@ -3429,11 +3430,10 @@ extern "C" __global__ __launch_bounds__(FX_HUGE_T) void k_desc_huge(FxDevParams 
 }
 
 #define FX_SPILL_TILE 1024
-extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_spill(FxDevParams P, FxBuffers B, uint32_t batch, uint32_t mode,
+extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_spill(FxDevParams P, FxBuffers B, uint32_t batch,
                                                                   uint32_t slab_pts) {
   __shared__ float t_x[FX_SPILL_TILE], t_y[FX_SPILL_TILE], t_z[FX_SPILL_TILE];
   __shared__ uint32_t s_cnt[4];
-  if (mode == 1 && B.counters[3] == 0) return;
   const uint32_t tid = threadIdx.x;
   const uint32_t n_items = B.counters[12];  // what k_desc_huge could not hold
   float4 *sp = B.spill_pts + (size_t)blockIdx.x * slab_pts;              // support set (x, y, z, index bits)
@@ -3446,11 +3446,9 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_spill(FxDevParams P, 
     const uint32_t row = B.huge_desc[it];
     const uint2 rm = B.row_map[row];
     const uint32_t scan = rm.x, k = rm.y;
-    const uint32_t ord = mode == 1 ? B.rng_ord[(size_t)scan * P.max_keypoints + k] : k;
-    if (mode == 1 && ord == k) continue;
     const FxScanMeta M = B.meta[scan];
     const float4 kp = B.keypoints[(size_t)scan * P.max_keypoints + k];
-    const float2 xa = B.xaxis[ord];
+    const float2 xa = B.row_xa[row];
     float *out = B.desc + (size_t)row * FX_DESC_FLOATS;
     if (tid < 4) s_cnt[tid] = 0;
     __syncthreads();
@@ -3566,26 +3564,23 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_spill(FxDevParams P, 
 }
 
 
-// RNG ordinals: 3DSC draws its three numbers only for keypoints that have neighbours.
+// RNG ordinals when several workgroups of k_gather shared a scan (small batches): 3DSC draws its three numbers only for
+// keypoints that have neighbours; k_gather left a flag per keypoint in kp_nbrs (the descriptor kernels then store the counts).
 extern "C" __global__ __launch_bounds__(FX_WG) void k_rng_ord(FxDevParams P, FxBuffers B, uint32_t batch) {
   // one wavefront per scan: ordinal of keypoint k = number of earlier keypoints that have neighbours
   const uint32_t b = (blockIdx.x * FX_WG + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (b >= batch) return;
-  const uint32_t K = B.n_kp[b];
+  uint32_t K = B.n_kp[b];
+  const uint32_t row0 = B.kp_offset[b];
+  if (row0 >= P.max_total_kp) return;
+  if (row0 + K > P.max_total_kp) K = P.max_total_kp - row0;
   uint32_t base = 0;
-  bool fix = false;
   for (uint32_t k0 = 0; k0 < K; k0 += 64) {
     const uint32_t k = k0 + lane;
-    const bool draws = k < K && B.kp_nbrs[(size_t)b * P.max_keypoints + k] != 0u;
-    const unsigned long long m = __ballot(draws);
-    const uint32_t ord = base + lanes_below(m);
-    if (k < K) {
-      B.rng_ord[(size_t)b * P.max_keypoints + k] = ord;
-      fix = fix || (ord != k);
-    }
+    const unsigned long long m = __ballot(k < K && B.kp_nbrs[(size_t)b * P.max_keypoints + k] != 0u);
+    if (k < K) B.row_xa[row0 + k] = B.xaxis[base + lanes_below(m)];
     base += (uint32_t)__popcll(m);
   }
-  if (__ballot(fix) && lane == 0) atomicAdd(&B.counters[3], 1u);
 }
 
 // pcl::concatenateFields(keypoints, descriptors) -> pcl::PointDescriptor records (ref: node.cpp:119).
@@ -3758,13 +3753,14 @@ void fxk_merge_huge(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uin
 void fxk_offsets(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch) {
   hipLaunchKernelGGL(k_offsets, dim3(1), dim3(FX_WG), 0, s, P, B, batch);
 }
-void fxk_gather(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float box_margin) {
-  // one workgroup per scan when the batch fills the GPU anyway (it is then the only writer of the scan's lists: no
-  // global atomics), several when it does not (streaming)
+// one workgroup per scan when the batch fills the GPU anyway (it is then the only writer of the scan's lists: no
+// global atomics, and it settles the RNG ordinals itself), several when it does not (streaming)
 #ifndef FX_GATHER_SLICES
 #define FX_GATHER_SLICES 1u
 #endif
-  const uint32_t slices = batch >= 128 ? FX_GATHER_SLICES : (batch >= 16 ? 4u : 16u);
+uint32_t fxk_gather_slices(uint32_t batch) { return batch >= 128 ? FX_GATHER_SLICES : (batch >= 16 ? 4u : 16u); }
+void fxk_gather(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float box_margin) {
+  const uint32_t slices = fxk_gather_slices(batch);
   hipLaunchKernelGGL(k_gather, dim3(slices, batch), dim3(FX_WG),
                      fxk_gather_lds_bytes(P.max_keypoints), s, P, B, box_margin);
 }
@@ -3772,8 +3768,8 @@ void fxk_desc_group(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uin
   hipLaunchKernelGGL(k_desc_group, dim3(grid), dim3(FX_WG), (size_t)(FX_NWAVE * FX_GROUPS * FX_GROUP_WORDS + FX_TABLE_WORDS) * 4, s, P, B, batch);
 }
 void fxk_desc_wg(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t grid,
-                 uint32_t mode, uint32_t src) {
-  hipLaunchKernelGGL(k_desc_wg, dim3(grid), dim3(FX_DESC_WG_EXACT_T), fxk_desc_lds_bytes(cap), s, P, B, batch, cap, mode, src);
+                 uint32_t src) {
+  hipLaunchKernelGGL(k_desc_wg, dim3(grid), dim3(FX_DESC_WG_EXACT_T), fxk_desc_lds_bytes(cap), s, P, B, batch, cap, src);
 }
 void fxk_desc_wg_xl(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t ns_lo,
                     uint32_t grid) {
@@ -3784,13 +3780,11 @@ void fxk_desc_mid(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint3
   const size_t lds_wave = (size_t)(FX_NWAVE * FX_WAVE_WORDS + FX_TABLE_WORDS) * 4, lds_wg = fxk_desc_lds_bytes(cap);
   hipLaunchKernelGGL(k_desc_mid, dim3(n_wg + n_wave), dim3(FX_WG), lds_wave > lds_wg ? lds_wave : lds_wg, s, P, B, batch, cap, n_wg);
 }
-void fxk_desc_huge(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t mode,
-                   uint32_t slab_pts) {
-  hipLaunchKernelGGL(k_desc_huge, dim3(grid), dim3(FX_HUGE_T), (size_t)FX_HUGE_WORDS * 4, s, P, B, batch, mode, slab_pts);
+void fxk_desc_huge(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t slab_pts) {
+  hipLaunchKernelGGL(k_desc_huge, dim3(grid), dim3(FX_HUGE_T), (size_t)FX_HUGE_WORDS * 4, s, P, B, batch, slab_pts);
 }
-void fxk_desc_spill(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t mode,
-                    uint32_t slab_pts) {
-  hipLaunchKernelGGL(k_desc_spill, dim3(grid), dim3(FX_WG), 0, s, P, B, batch, mode, slab_pts);
+void fxk_desc_spill(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t slab_pts) {
+  hipLaunchKernelGGL(k_desc_spill, dim3(grid), dim3(FX_WG), 0, s, P, B, batch, slab_pts);
 }
 void fxk_test_sort_replay(hipStream_t s, const uint32_t *sizes, uint32_t n_seq, uint32_t n, uint32_t *perm) {
   hipLaunchKernelGGL(k_test_sort_replay, dim3(n_seq), dim3(64), 0, s, sizes, n, perm);

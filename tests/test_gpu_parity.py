@@ -92,14 +92,23 @@ def test_other_radii_and_tolerances(fxlib, oracle):
 
 def test_keypoints_without_neighbours_shift_the_rng_stream(fxlib, oracle):
     """A keypoint with no neighbour inside R gets a NaN descriptor and draws no x-axis, so every later
-    keypoint's RNG ordinal moves: the second pass redoes those rows."""
+    keypoint's RNG ordinal moves: k_gather knows which keypoints have a neighbour before any descriptor
+    is computed and hands every row its x-axis (k_rng_ord when several workgroups of it share a scan)."""
     scans = [util.vlp16_scan(1000 + b) for b in range(3)]
-    for radius in (0.04, 0.1):
+    ora_small = None
+    for radius in (0.1, 0.04):
         p = capi.params("launch", descriptor_radius=radius)
-        ora = [oracle.run(p, s, roll=0.02, pitch=-0.015) for s in scans]
+        ora = ora_small = [oracle.run(p, s, roll=0.02, pitch=-0.015) for s in scans]
         assert any((o["kp_neighbors"] == 0).any() and (o["kp_neighbors"] > 0).any() for o in ora)
         ctx = capi.Context(p, capi.limits(3, 28800))
         got = ctx.process_host(scans, roll=0.02, pitch=-0.015)
         for b in range(3):
             util.compare_scan(got[b], ora[b], tag=f"rng shift R={radius} scan {b}")
         ctx.close()
+    # a batch large enough for k_gather to run one workgroup per scan, which then settles the ordinals itself
+    p = capi.params("launch", descriptor_radius=0.04)
+    ctx = capi.Context(p, capi.limits(128, 28800))
+    got = ctx.process_host([scans[b % 3] for b in range(128)], roll=0.02, pitch=-0.015)
+    for b in (0, 1, 2, 64, 127):
+        util.compare_scan(got[b], ora_small[b % 3], tag=f"rng shift, one workgroup per scan, scan {b}")
+    ctx.close()
