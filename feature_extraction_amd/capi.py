@@ -21,12 +21,12 @@ FX_IN_DEVICE, FX_OUT_HOST, FX_OUT_DEBUG, FX_OUT_CLOUDS = 1, 2, 4, 8
 FX_FLAG_NAMES = {0x1: "RING_OVERFLOW", 0x2: "CAND_OVERFLOW", 0x4: "KP_OVERFLOW", 0x8: "NBR_OVERFLOW",
                  0x10: "TOTAL_KP_OVERFLOW", 0x20: "KPC_OVERFLOW"}
 FX_N_STAGES = 9
-STAGE_NAMES = ("k_prep", "k_bucket", "k_rings_runs", "k_rings_big", "k_merge", "k_gather", "k_desc_group", "k_desc_mid",
+STAGE_NAMES = ("k_prep", "k_bucket", "k_rings_runs", "k_rings_large", "k_merge", "k_gather", "k_desc_group", "k_desc_mid",
                "k_desc_rare")
 # stages that are one kernel launch (eligible as the roofline line's dominant kernel: their HIP-event span is that kernel)
-SINGLE_LAUNCH_STAGES = ("k_prep", "k_bucket", "k_rings_runs", "k_rings_big", "k_gather", "k_desc_group", "k_desc_mid")
+SINGLE_LAUNCH_STAGES = ("k_prep", "k_bucket", "k_rings_runs", "k_rings_large", "k_gather", "k_desc_group", "k_desc_mid")
 # kernels launched inside each timed stage (rocprofv3 / PMC rows are per kernel name)
-STAGE_KERNELS = {"k_merge": ("k_rings_large", "k_merge_small", "k_merge_big", "k_merge_huge", "k_offsets"),
+STAGE_KERNELS = {"k_merge": ("k_merge_small", "k_merge_big", "k_merge_huge", "k_offsets"),
                  "k_desc_mid": ("k_desc_mid", "k_desc_wg_xl"),
                  "k_gather": ("k_gather", "k_rng_ord"),  # (k_rng_ord only when several workgroups share a scan: small batches)
                  "k_desc_rare": ("k_desc_wg", "k_desc_huge", "k_desc_spill")}

@@ -18,7 +18,6 @@
 #include "fx_device.h"
 
 extern "C" {
-size_t fxk_ring_lds_bytes(uint32_t cap, uint32_t ccap);
 size_t fxk_ring_large_lds_bytes(uint32_t cap, uint32_t ccap);
 void fxk_rings_large(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t ccap, uint32_t grid);
 size_t fxk_merge_lds_bytes(uint32_t cap, uint32_t n_rings);
@@ -32,10 +31,7 @@ void fxk_prep(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t 
               uint32_t clk_slot);
 void fxk_bucket(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float el0, float inv_step, uint32_t clk_next);
 size_t fxk_ring_runs_lds_bytes(void);
-void fxk_rings_runs(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t mid_cap, uint32_t max_pts,
-                    uint32_t grid);
-void fxk_rings_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t ccap, uint32_t grid,
-                   uint32_t huge);
+void fxk_rings_runs(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t max_pts, uint32_t grid);
 void fxk_merge_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap);
 void fxk_merge_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t grid, uint32_t last);
 void fxk_merge_huge(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t ccap, uint32_t grid);
@@ -77,7 +73,7 @@ fx_status fail(fx_status s, const std::string &msg) {
   } while (0)
 
 constexpr int kMetaSlots = 8;
-constexpr uint32_t kRingCapMid = 640, kMergeCapSmall = 512, kListCap = 4096, kListSplit = 1024;
+constexpr uint32_t kMergeCapSmall = 512, kListCap = 4096, kListSplit = 1024;
 }  // namespace
 
 struct fx_ctx {
@@ -194,19 +190,12 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof) {
     fxk_bucket(s, P, B, batch, (float)c->params.el0_deg, (float)(1.0 / c->params.el_step_deg),
                (uint32_t)((c->batch_seq + 1) % FX_CLK_SLOTS));
     FX_HIP(mark(2));
-    const uint32_t ring_mid = L.max_ring_points < kRingCapMid ? L.max_ring_points : kRingCapMid;
     // one wavefront per (scan, ring): the hardware dispatcher balances the rings, whose costs differ a lot
     // (persistent wavefronts striding over the items: 0.18 ms instead of 0.14)
-    fxk_rings_runs(s, P, B, batch, ring_mid, L.max_ring_points, (batch * (uint32_t)c->params.n_rings + 7) / 8 * 8);
+    fxk_rings_runs(s, P, B, batch, L.max_ring_points, (batch * (uint32_t)c->params.n_rings + 7) / 8 * 8);
     FX_HIP(mark(3));
-    {
-      uint32_t per_cu = (uint32_t)(160 * 1024 / ((fxk_ring_lds_bytes(ring_mid, ring_mid / 4) + 2047) / 2048 * 2048));
-      if (per_cu > 8) per_cu = 8;
-      if (per_cu < 1) per_cu = 1;
-      fxk_rings_big(s, P, B, ring_mid, ring_mid / 4, (big_grid * per_cu + 7) / 8 * 8, 0);
-    }
-    FX_HIP(mark(4));
     fxk_rings_large(s, P, B, L.max_ring_points, L.max_ring_points, (big_grid + 7) / 8 * 8);
+    FX_HIP(mark(4));
     fxk_merge_small(s, P, B, batch, merge_small);
     fxk_merge_big(s, P, B, c->merge_big_cap, big_grid, c->merge_big_cap >= L.max_candidates);
     if (c->merge_big_cap < L.max_candidates) fxk_merge_huge(s, P, B, L.max_candidates, c->merge_huge_ccap, big_grid);
@@ -437,7 +426,6 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   FX_A(dev_alloc(c, &b.n_kpc, B));
   FX_A(dev_alloc(c, &b.desc, (size_t)L.max_total_keypoints * FX_DESC_FLOATS + 4));
   FX_A(dev_alloc(c, &b.flags, B));
-  FX_A(dev_alloc(c, &b.big_rings, (size_t)8 * P.ring_list_cap));
   FX_A(dev_alloc(c, &b.huge_rings, (size_t)8 * P.ring_list_cap));
   FX_A(dev_alloc(c, &b.big_merge, B));
   FX_A(dev_alloc(c, &b.huge_merge, B));
@@ -813,11 +801,8 @@ fx_status fx_debug_counters(fx_ctx *c, uint32_t *out8 /* 16 words */) {
   uint32_t all[FX_N_COUNTERS];
   FX_HIP(hipMemcpy(all, c->buf.counters, sizeof(all), hipMemcpyDeviceToHost));
   std::memcpy(out8, all, 16 * 4);
-  out8[0] = out8[5] = 0;  // the deferred rings are counted per XCD class
-  for (int k = 0; k < 8; ++k) {
-    out8[0] += all[FX_CNT_MID + k];
-    out8[5] += all[FX_CNT_LARGE + k];
-  }
+  out8[0] = out8[5] = 0;  // the rings handed to the workgroup tier are counted per XCD class (word 0: unused)
+  for (int k = 0; k < 8; ++k) out8[5] += all[FX_CNT_LARGE + k];
   return FX_OK;
 }
 

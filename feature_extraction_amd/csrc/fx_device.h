@@ -47,7 +47,6 @@ struct FxScTables {
 // Every device buffer of a context.
 #define FX_CLK_SLOTS 64
 #define FX_N_COUNTERS 32
-#define FX_CNT_MID 16    // counters[16 + c]: rings of XCD class c deferred to the mid tier
 #define FX_CNT_LARGE 24  // counters[24 + c]: ... to the large tier
 struct FxBuffers {
   const FxScanMeta *meta;
@@ -86,8 +85,7 @@ struct FxBuffers {
   float *desc;            // [max_total_kp][1989]
   uint32_t *flags;        // [B]
   // work lists for the large-capacity tiers
-  uint32_t *big_rings;    // [B*n_rings]  rings for the mid workgroup tier
-  uint32_t *huge_rings;   // [B*n_rings]  rings for the large workgroup tier
+  uint32_t *huge_rings;   // [B*n_rings]  rings for the workgroup tier (k_rings_large), by XCD class
   uint32_t *big_merge;    // [B]
   uint32_t *huge_merge;   // [B]  scans with more candidates than the LDS merge tiers hold
   uint32_t *big_desc;     // [max_total_kp]  rows whose support list overflowed list_cap
@@ -110,7 +108,7 @@ struct FxBuffers {
   float2 *row_xa;         //                 per-keypoint kernels fetch everything a row needs in one round trip
   unsigned long long *clk;     // [FX_CLK_SLOTS][2] k_prep's first start / last end on the device's constant-rate clock, by batch
   unsigned long long *stamps;  // [32] diagnostic build only (-DFX_STAMPS)
-  uint32_t *counters;     // [FX_N_COUNTERS]: 16.. deferred rings per XCD class (8 mid, 8 large); 0 big_rings, 1 big_merge, 2 big_desc, 3 -, 4 list_desc, 5 huge_rings, 6 spill_desc, 7 exact_desc, 8 wave_desc, 9 huge_merge, 12 huge_desc
+  uint32_t *counters;     // [FX_N_COUNTERS]: 24.. rings handed to the workgroup tier per XCD class; 0 -, 1 big_merge, 2 big_desc, 3 -, 4 list_desc, 5 huge_rings, 6 spill_desc, 7 exact_desc, 8 wave_desc, 9 huge_merge, 12 huge_desc
 };
 
 #endif

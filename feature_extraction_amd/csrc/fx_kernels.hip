@@ -1656,7 +1656,7 @@ __device__ __forceinline__ bool ring_runs_body(const FxDevParams &P, const FxBuf
   FX_STAMP(11);
   return true;
 }
-extern "C" __global__ __launch_bounds__(64) void k_rings_runs(FxDevParams P, FxBuffers B, uint32_t mid_cap, uint32_t max_pts, uint32_t n_items) {
+extern "C" __global__ __launch_bounds__(64) void k_rings_runs(FxDevParams P, FxBuffers B, uint32_t max_pts, uint32_t n_items) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   // persistent wavefronts over the (scan, ring) items, dealt by XCD class
   const uint32_t R = (uint32_t)P.n_rings, n_scans = n_items / R;
@@ -1666,40 +1666,21 @@ extern "C" __global__ __launch_bounds__(64) void k_rings_runs(FxDevParams P, FxB
     const uint32_t scan = cls + 8u * (q / R), ring = q % R;
     const uint32_t item = scan * R + ring;
     if (!ring_runs_body(P, B, scan, ring, max_pts, smem)) {
-      if (threadIdx.x == 0) {
-        const bool mid = B.ring_cnt[item] <= mid_cap;
-        const uint32_t pos = atomicAdd(&B.counters[(mid ? FX_CNT_MID : FX_CNT_LARGE) + cls], 1u);
-        (mid ? B.big_rings : B.huge_rings)[(size_t)cls * P.ring_list_cap + pos] = item;
+      if (threadIdx.x == 0) {  // the workgroup tier's list of this XCD class (it too then finds the ring's points in its own L2)
+        const uint32_t pos = atomicAdd(&B.counters[FX_CNT_LARGE + cls], 1u);
+        B.huge_rings[(size_t)cls * P.ring_list_cap + pos] = item;
       }
     }
     wave_sync_lds();
   }
 }
-extern "C" __global__ __launch_bounds__(FX_WG, 5) void k_rings_big(FxDevParams P, FxBuffers B, uint32_t cap, uint32_t ccap,
-                                                                 uint32_t huge) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  // block b takes the list of XCD class b mod 8 (the grid is a multiple of 8): see k_rings_runs
-  const uint32_t cls = blockIdx.x & 7u;
-  const uint32_t n_big = B.counters[(huge ? FX_CNT_LARGE : FX_CNT_MID) + cls];
-  const uint32_t *items = (huge ? B.huge_rings : B.big_rings) + (size_t)cls * P.ring_list_cap;
-  for (uint32_t w = blockIdx.x >> 3; w < n_big; w += gridDim.x >> 3) {
-    const uint32_t item = items[w];
-    if (!ring_body<FX_WG>(P, B, item / P.n_rings, item % P.n_rings, cap, ccap, smem, huge != 0)) {
-      if (threadIdx.x == 0) {  // mid tier only: more clusters than it holds
-        const uint32_t pos = atomicAdd(&B.counters[FX_CNT_LARGE + cls], 1u);
-        B.huge_rings[(size_t)cls * P.ring_list_cap + pos] = item;
-      }
-    }
-    __syncthreads();
-  }
-}
-
-// large tier: rings beyond the mid tier's capacity (dense many-ring sensors: ground rings of a thousand points and
-// more) get a whole 1024-thread workgroup — one per CU anyway, by LDS
+// workgroup tier: the rings the run tier hands over (more than 128 runs, segments or clusters: unordered input, dense
+// many-ring sensors) get a whole 1024-thread workgroup with every point in LDS — one per CU, by LDS.  (A 256-thread tier
+// between the two, five per CU, made BASELINE configs 3 and 5 slower, not faster, once the run tier existed.)
 #define FX_RING_LARGE_T 1024
 extern "C" __global__ __launch_bounds__(FX_RING_LARGE_T) void k_rings_large(FxDevParams P, FxBuffers B, uint32_t cap, uint32_t ccap) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  const uint32_t cls = blockIdx.x & 7u;
+  const uint32_t cls = blockIdx.x & 7u;  // block b takes the list of XCD class b mod 8 (the grid is a multiple of 8): see k_rings_runs
   const uint32_t n_big = B.counters[FX_CNT_LARGE + cls];
   const uint32_t *items = B.huge_rings + (size_t)cls * P.ring_list_cap;
   for (uint32_t w = blockIdx.x >> 3; w < n_big; w += gridDim.x >> 3) {
@@ -3683,9 +3664,6 @@ extern "C" __global__ __launch_bounds__(64) void k_test_sort_replay(const uint32
 
 extern "C" {
 
-size_t fxk_ring_lds_bytes(uint32_t cap, uint32_t ccap) {
-  return (size_t)(SegCfg<FX_WG>::kWords + FX_RING_WORDS_PER_POINT * cap + FX_RING_WORDS_PER_CLUSTER * ccap) * 4;
-}
 size_t fxk_ring_large_lds_bytes(uint32_t cap, uint32_t ccap) {
   return (size_t)(SegCfg<FX_RING_LARGE_T>::kWords + FX_RING_WORDS_PER_POINT * cap + FX_RING_WORDS_PER_CLUSTER * ccap) * 4;
 }
@@ -3703,8 +3681,6 @@ hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t merge_huge, s
   e = hipFuncSetAttribute((const void *)k_merge_huge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)merge_huge);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void *)k_gather, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gather);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void *)k_rings_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_big);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void *)k_rings_large, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_big);
   if (e != hipSuccess) return e;
@@ -3731,15 +3707,10 @@ void fxk_bucket(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_
   hipLaunchKernelGGL(k_bucket, dim3(batch), dim3(FX_BUCKET_T), lds, s, P, B, el0, inv_step, clk_next);
 }
 size_t fxk_ring_runs_lds_bytes(void) { return (size_t)FX_RR_WORDS * 4; }
-void fxk_rings_runs(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t mid_cap, uint32_t max_pts,
-                    uint32_t grid) {
+void fxk_rings_runs(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t max_pts, uint32_t grid) {
   const uint32_t n_items = batch * (uint32_t)P.n_rings;
   if (grid > n_items) grid = (n_items + 7) / 8 * 8;
-  hipLaunchKernelGGL(k_rings_runs, dim3(grid), dim3(64), fxk_ring_runs_lds_bytes(), s, P, B, mid_cap, max_pts, n_items);
-}
-void fxk_rings_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t ccap, uint32_t grid,
-                   uint32_t huge) {
-  hipLaunchKernelGGL(k_rings_big, dim3(grid), dim3(FX_WG), fxk_ring_lds_bytes(cap, ccap), s, P, B, cap, ccap, huge);
+  hipLaunchKernelGGL(k_rings_runs, dim3(grid), dim3(64), fxk_ring_runs_lds_bytes(), s, P, B, max_pts, n_items);
 }
 void fxk_merge_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap) {
   hipLaunchKernelGGL(k_merge_small, dim3(batch), dim3(FX_MSMALL_T), fxk_merge_lds_bytes(cap, P.n_rings), s, P, B, cap);

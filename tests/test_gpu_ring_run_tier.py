@@ -67,12 +67,12 @@ def _run(oracle, scans, tag, **lim_over):
     for b, s in enumerate(scans):
         util.compare_scan(got[b], oracle.run(p, s), tag=f"{tag} scan {b}")
     ctx.close()
-    return got, {"mid": cnt[0], "large": cnt[5]}
+    return got, {"workgroup": cnt[5]}
 
 
 def test_long_ring_and_members_beyond_the_register_held_points(fxlib, oracle):
     got, tiers = _run(oracle, [long_ring_with_late_poles()], "long ring")
-    assert got[0]["flags"] == 0 and tiers == {"mid": 0, "large": 0}
+    assert got[0]["flags"] == 0 and tiers == {"workgroup": 0}
     assert len(got[0]["candidates"]) == 5  # the poles; the arc fails the diameter gate
 
 
@@ -82,7 +82,7 @@ def test_run_table_boundary(fxlib, oracle):
                                np.concatenate([isolated_points(9, 128), isolated_points(10, 129), isolated_points(11, 127)])],
                       "run table", max_ring_candidates=512, max_keypoints=512, max_total_keypoints=4096)
     assert [g["flags"] for g in got] == [0, 0, 0]
-    assert tiers["mid"] + tiers["large"] == 2
+    assert tiers["workgroup"] == 2
     assert [len(g["candidates"]) for g in got][:2] == [128, 129]
 
 
@@ -92,12 +92,12 @@ def test_edges_between_non_consecutive_runs(fxlib, oracle):
     got, tiers = _run(oracle, [interleaved_arc(6, 30), interleaved_arc(6, 100), np.concatenate([interleaved_arc(5, 40), interleaved_arc(6, 30)])],
                       "interleaved")
     assert [g["flags"] for g in got] == [0, 0, 0]
-    assert tiers["mid"] + tiers["large"] >= 1
+    assert tiers["workgroup"] >= 1
 
 
 def test_members_beyond_the_cached_points(fxlib, oracle):
     got, tiers = _run(oracle, [two_arcs_in_blocks(7)], "two arcs")
-    assert got[0]["flags"] == 0 and tiers == {"mid": 0, "large": 0}
+    assert got[0]["flags"] == 0 and tiers == {"workgroup": 0}
     assert len(got[0]["candidates"]) == 2
 
 
