@@ -2526,7 +2526,7 @@ __device__ __forceinline__ void desc_wave_body(const FxDevParams &P, const FxBuf
     for (uint32_t u = 0; u < FX_WAVE_CAP / 64; ++u)
       if (lane + u * 64 < P.list_cap) lv[u] = B.s_pts[(size_t)row * P.list_cap + lane + u * 64];
     if (nS > FX_WAVE_CAP || nS > P.list_cap) {  // long (or truncated) list: workgroup tiers
-      if (FAST && lane == 0) {
+      if (FAST && lane == 0) {  // (k_desc_group sends these rows to their tiers itself; kept for rows listed here by mistake)
         const uint32_t pos = atomicAdd(&B.counters[nS > P.list_cap ? 2 : 4], 1u);
         (nS > P.list_cap ? B.big_desc : B.list_desc)[pos] = row;
       }
@@ -2683,8 +2683,10 @@ extern "C" __global__ __launch_bounds__(FX_WG, FX_GROUP_OCC) void k_desc_group(F
     if (live) {
       if (nS > FX_GROUP_CAP || nS > P.list_cap) {  // too long for a group (or truncated): wavefront / workgroup / re-gather tiers
         if (gl == 0) {
-          const uint32_t c = nS > P.list_cap ? 2u : (nS > FX_WAVE_CAP ? 4u : 8u);
-          uint32_t *list = nS > P.list_cap ? B.big_desc : (nS > FX_WAVE_CAP ? B.list_desc : B.wave_desc);
+          // (a support set beyond limits.max_neighbors cannot fit the re-gather tier either: straight to the whole-CU tier)
+          const bool whole_cu = nS > P.list_cap && nS > P.max_neighbors && B.spill_pts != nullptr;
+          const uint32_t c = whole_cu ? 6u : (nS > P.list_cap ? 2u : (nS > FX_WAVE_CAP ? 4u : 8u));
+          uint32_t *list = whole_cu ? B.spill_desc : (nS > P.list_cap ? B.big_desc : (nS > FX_WAVE_CAP ? B.list_desc : B.wave_desc));
           list[atomicAdd(&B.counters[c], 1u)] = row;
         }
         live = false;
