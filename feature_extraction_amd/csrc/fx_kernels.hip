@@ -713,9 +713,13 @@ __device__ __forceinline__ uint32_t cc_order(uint32_t n, const uint32_t *parent,
 // The same pass records, one bit per 64 consecutive points, whether any of them lies within the descriptor
 // stage's reach of the filter box (every keypoint is a centroid of filtered points, hence inside the box; a point
 // farther than the support radius from the box cannot support any keypoint): k_gather skips the others unread.
+#ifndef FX_PREP_T
 #define FX_PREP_T 512
+#endif
 #define FX_MAX_RINGS 1024  // fx_create checks n_rings against it
+#ifndef FX_PREP_U
 #define FX_PREP_U 4
+#endif
 #define FX_PREP_TILE (FX_PREP_T * FX_PREP_U)  // 2048 points = 32 groups of 64 = one word of near bits
 typedef float __attribute__((address_space(1))) gfloat;
 
@@ -764,7 +768,10 @@ __device__ __forceinline__ uint32_t ring_membership(float el, const float2 *win,
 __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, FxBuffers B, float near_margin, float el0, float inv_step, uint32_t clk_slot) {
   constexpr int NW = FX_PREP_T / 64;
   constexpr uint32_t kTile = FX_PREP_TILE;           // points per tile; wave w owns [256 w, 256 w + 256) of it
-  constexpr uint32_t kKeep = kTile + kTile / 2;      // survivors buffered between sweeps
+#ifndef FX_PREP_KEEP
+#define FX_PREP_KEEP (FX_PREP_TILE + FX_PREP_TILE / 2)
+#endif
+  constexpr uint32_t kKeep = FX_PREP_KEEP;           // survivors buffered between sweeps
   const uint32_t scan = blockIdx.x;
   const FxScanMeta M = B.meta[scan];
   __shared__ uint32_t s_cnt[2][NW];                  // per wave: survivors of the tile; by tile parity
@@ -835,7 +842,7 @@ __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, 
     bool keep[FX_PREP_U];
     unsigned long long mask[FX_PREP_U];
     uint32_t wave_cnt = 0;
-    unsigned long long sect = 0;  // one bit per four consecutive points (one 64-byte sector) of this wave's 256
+    unsigned long long sect[(FX_PREP_U + 3) / 4] = {};  // one bit per four consecutive points (one 64-byte sector) of this wave's 64 U
 #pragma unroll
     for (int u = 0; u < FX_PREP_U; ++u) {
       const float x = v[u].x, y = v[u].y, z = v[u].z;
@@ -860,13 +867,15 @@ __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, 
         x = (x | (x >> 6)) & 0x000f000f000f000full;
         x = (x | (x >> 12)) & 0x000000ff000000ffull;
         x = (x | (x >> 24)) & 0xffffull;
-        sect |= x << (16 * u);
+        sect[u / 4] |= x << (16 * (u % 4));
       }
     }
     if (lane == 0) {
       s_cnt[parity][wave] = wave_cnt;
-      near_bits[(t0 / kTile) * (2 * NW) + 2 * wave] = (uint32_t)sect;
-      near_bits[(t0 / kTile) * (2 * NW) + 2 * wave + 1] = (uint32_t)(sect >> 32);
+      // (pure sector order: bit s of the scan is bit s % 32 of word s / 32)
+#pragma unroll
+      for (int h = 0; h < FX_PREP_U / 2; ++h)
+        near_bits[(t0 / kTile) * (kTile / 128) + wave * (FX_PREP_U / 2) + h] = (uint32_t)(sect[h / 2] >> (32 * (h % 2)));
     }
     // One barrier per tile: it orders this tile's counts before their readers, the previous sweep's
     // reads of s_keep before this tile's writes, and (a wave cannot be two tiles ahead of another) the
@@ -2393,7 +2402,7 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
   // wavefront's 256 points = the 64 sector bits one wavefront of k_prep wrote (its tiles are two of these)
   auto near_sectors = [&](uint32_t i0) -> unsigned long long {
     if (i0 >= hi) return 0ull;
-    const uint32_t w = (i0 / FX_PREP_TILE) * (FX_PREP_TILE / 128) + 2u * (((i0 % FX_PREP_TILE) / 1024u) * 4u + wave);
+    const uint32_t w = (i0 + wave * 256u) / 128u;  // (sector order: this wavefront's 256 points are 64 sectors = two words)
     return (unsigned long long)near_bits[w] | ((unsigned long long)near_bits[w + 1] << 32);
   };
   auto load_tile = [&](uint32_t i0, unsigned long long sect, float4 (&v)[4]) {
