@@ -10,7 +10,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from feature_extraction_amd import capi
 
-capi.LIB_PATH = os.path.join(os.path.dirname(capi.LIB_PATH), "libfx_hip_stamps.so")
+capi.LIB_PATH = os.path.join(os.path.dirname(capi.LIB_PATH), os.environ.get("FX_STAMPS_LIB", "libfx_hip_stamps.so"))
 lib = capi.load()
 preset = sys.argv[1] if len(sys.argv) > 1 else "launch"
 B = 256
