@@ -2215,6 +2215,10 @@ __device__ __forceinline__ unsigned long long sc3d_key(uint32_t bin, float d2, u
 // be within reach.  Points with candidates are parked in a per-wavefront LDS queue and tested with all lanes busy
 // (in firing order only some lanes of a wavefront hold such points).  Groups of 64 points that k_prep found
 // wholly out of the filter box's reach are not even loaded.
+#ifndef FX_GATHER_T
+#define FX_GATHER_T 256  // (384 and 512 threads measured: see DESIGN.md)
+#endif
+#define FX_GATHER_NW (FX_GATHER_T / 64)
 #define FX_GATHER_G 32  // cells per axis at most
 #define FX_GATHER_CELLS (FX_GATHER_G * FX_GATHER_G)
 #ifndef FX_GATHER_STAGE
@@ -2229,10 +2233,10 @@ __host__ __device__ inline uint32_t gather_words(uint32_t mk) {
   w += ((9 * mk + 1) / 2 + 3) & ~3u;                          // cell lists (uint16)
   w += (4 * mk + 3) & ~3u;                                    // staged hits per keypoint, reserved list positions, list lengths, has-a-neighbour flags
   w += FX_GATHER_STAGE + 4 * FX_GATHER_STAGE;                 // staged hits: meta, points
-  w += FX_NWAVE * FX_GATHER_QUEUE * 5;                        // per-wavefront queues: points, cell info
+  w += FX_GATHER_NW * FX_GATHER_QUEUE * 5;                    // per-wavefront queues: points, cell info
   return w;
 }
-extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBuffers B, float box_margin) {
+extern "C" __global__ __launch_bounds__(FX_GATHER_T) void k_gather(FxDevParams P, FxBuffers B, float box_margin) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const uint32_t MK = P.max_keypoints;
   uint32_t *s_w = smem;                                          // 0..5 keypoint box, 8 staged hits
@@ -2251,7 +2255,7 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
   uint32_t *s_cur = reinterpret_cast<uint32_t *>(s_spt);        // [CELLS] fill cursors while the lists are built (4 STAGE >= CELLS words)
   const uint32_t scan = blockIdx.y, slice = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float4 *q_pt = s_spt + FX_GATHER_STAGE + wave * FX_GATHER_QUEUE;                                         // this wavefront's queue
-  uint32_t *q_info = reinterpret_cast<uint32_t *>(s_spt + FX_GATHER_STAGE + FX_NWAVE * FX_GATHER_QUEUE) + wave * FX_GATHER_QUEUE;
+  uint32_t *q_info = reinterpret_cast<uint32_t *>(s_spt + FX_GATHER_STAGE + FX_GATHER_NW * FX_GATHER_QUEUE) + wave * FX_GATHER_QUEUE;
   uint32_t K = B.n_kp[scan];
   if (K == 0) return;
   const uint32_t row0 = B.kp_offset[scan];
@@ -2260,13 +2264,13 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
   const FxScanMeta M = B.meta[scan];
   // row -> (scan, keypoint) map for the per-keypoint kernels (one load instead of a binary search)
   if (slice == 0)
-    for (uint32_t k = tid; k < K; k += FX_WG) B.row_map[row0 + k] = make_uint2(scan, k);
+    for (uint32_t k = tid; k < K; k += FX_GATHER_T) B.row_map[row0 + k] = make_uint2(scan, k);
   // keypoints of the scan -> LDS; their bounding box (ordered-uint atomics) for a cheap reject
   if (tid < 6) s_w[tid] = (tid & 1) ? f2ord(-INFINITY) : f2ord(INFINITY);
   if (tid == 0) s_w[8] = 0;  // staged hits
-  for (uint32_t c = tid; c < FX_GATHER_CELLS; c += FX_WG) s_cell[c] = 0;
+  for (uint32_t c = tid; c < FX_GATHER_CELLS; c += FX_GATHER_T) s_cell[c] = 0;
   __syncthreads();
-  for (uint32_t k = tid; k < K; k += FX_WG) {
+  for (uint32_t k = tid; k < K; k += FX_GATHER_T) {
     const float4 kp = B.keypoints[(size_t)scan * P.max_keypoints + k];
     s_kp[k] = kp;
     s_kcnt[k] = 0;
@@ -2293,7 +2297,7 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
   const int ncx = min((int)((bx1 - bx0) * inv_wx) + 1, FX_GATHER_G), ncy = min((int)((by1 - by0) * inv_wy) + 1, FX_GATHER_G);
   auto cell_x = [&](float x) { return min(max((int)floorf((x - bx0) * inv_wx), 0), ncx - 1); };
   auto cell_y = [&](float y) { return min(max((int)floorf((y - by0) * inv_wy), 0), ncy - 1); };
-  for (uint32_t k = tid; k < K; k += FX_WG) {
+  for (uint32_t k = tid; k < K; k += FX_GATHER_T) {
     const int cx = cell_x(s_kp[k].x), cy = cell_y(s_kp[k].y);
     for (int dy = -1; dy <= 1; ++dy)
       for (int dx = -1; dx <= 1; ++dx)
@@ -2325,7 +2329,7 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
     }
   }
   __syncthreads();
-  for (uint32_t k = tid; k < K; k += FX_WG) {
+  for (uint32_t k = tid; k < K; k += FX_GATHER_T) {
     const int cx = cell_x(s_kp[k].x), cy = cell_y(s_kp[k].y);
     for (int dy = -1; dy <= 1; ++dy)
       for (int dx = -1; dx <= 1; ++dx)
@@ -2334,7 +2338,7 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
   }
   __syncthreads();
 
-  constexpr uint32_t kTile = FX_WG * 4;  // 1024 points: wave w owns [256 w, 256 w + 256), 64 consecutive points per load
+  constexpr uint32_t kTile = FX_GATHER_T * 4;  // 1024 points: wave w owns [256 w, 256 w + 256), 64 consecutive points per load
   const uint32_t n = M.n;
   uint32_t chunk = (n + gridDim.x - 1) / gridDim.x;
   chunk = (chunk + kTile - 1) / kTile * kTile;
@@ -2344,7 +2348,7 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
   // called by the whole workgroup, after a barrier: reserve list positions, write the staged hits out
   auto flush = [&](uint32_t staged) {
     staged = min(staged, (uint32_t)FX_GATHER_STAGE);
-    for (uint32_t k = tid; k < K; k += FX_WG) {
+    for (uint32_t k = tid; k < K; k += FX_GATHER_T) {
       const uint32_t c = s_kcnt[k];
       if (c) {
         if (solo) {  // this workgroup is the only writer of the scan's lists: positions are its own running counts
@@ -2357,7 +2361,7 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
       s_kcnt[k] = 0;
     }
     __syncthreads();
-    for (uint32_t e = tid; e < staged; e += FX_WG) {
+    for (uint32_t e = tid; e < staged; e += FX_GATHER_T) {
       const uint32_t meta = s_smeta[e], k = meta >> 16;
       const uint32_t pos = s_kbase[k] + (meta & 0xffffu);
       if (pos < P.list_cap) B.s_pts[(size_t)(row0 + k) * P.list_cap + pos] = s_spt[e];
@@ -2457,7 +2461,7 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_gather(FxDevParams P, FxBu
   __syncthreads();
   flush(s_w[8]);
   if (solo) {
-    for (uint32_t k = tid; k < K; k += FX_WG) B.s_cnt[row0 + k] = s_kpos[k];
+    for (uint32_t k = tid; k < K; k += FX_GATHER_T) B.s_cnt[row0 + k] = s_kpos[k];
     // RNG ordinals: keypoint k takes the x-axis number (keypoints before it that have a neighbour)
     __syncthreads();
     if (wave == 0) {
@@ -3743,7 +3747,7 @@ void fxk_offsets(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32
 uint32_t fxk_gather_slices(uint32_t batch) { return batch >= 128 ? FX_GATHER_SLICES : (batch >= 16 ? 4u : 16u); }
 void fxk_gather(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float box_margin) {
   const uint32_t slices = fxk_gather_slices(batch);
-  hipLaunchKernelGGL(k_gather, dim3(slices, batch), dim3(FX_WG),
+  hipLaunchKernelGGL(k_gather, dim3(slices, batch), dim3(FX_GATHER_T),
                      fxk_gather_lds_bytes(P.max_keypoints), s, P, B, box_margin);
 }
 void fxk_desc_group(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid) {
