@@ -19,7 +19,9 @@
 
 extern "C" {
 size_t fxk_ring_large_lds_bytes(uint32_t cap, uint32_t ccap);
-void fxk_rings_large(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t ccap, uint32_t grid);
+void fxk_rings_large(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t ccap, uint32_t grid,
+                     uint32_t after_runs2);
+void fxk_rings_runs2(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t max_pts, uint32_t grid);
 size_t fxk_merge_lds_bytes(uint32_t cap, uint32_t n_rings);
 size_t fxk_desc_lds_bytes(uint32_t cap);
 size_t fxk_gather_lds_bytes(uint32_t max_keypoints);
@@ -194,7 +196,10 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof) {
     // (persistent wavefronts striding over the items: 0.18 ms instead of 0.14)
     fxk_rings_runs(s, P, B, batch, L.max_ring_points, (batch * (uint32_t)c->params.n_rings + 7) / 8 * 8);
     FX_HIP(mark(3));
-    fxk_rings_large(s, P, B, L.max_ring_points, L.max_ring_points, (big_grid + 7) / 8 * 8);
+    // sensors of more than the reference's 16 rings: dense rings, many of which need longer run tables than the first tier's
+    const bool runs2 = c->params.n_rings > 16;
+    if (runs2) fxk_rings_runs2(s, P, B, L.max_ring_points, (big_grid * 6 + 7) / 8 * 8);
+    fxk_rings_large(s, P, B, L.max_ring_points, L.max_ring_points, (big_grid + 7) / 8 * 8, runs2 ? 1u : 0u);
     FX_HIP(mark(4));
     fxk_merge_small(s, P, B, batch, merge_small);
     fxk_merge_big(s, P, B, c->merge_big_cap, big_grid, c->merge_big_cap >= L.max_candidates);
@@ -427,6 +432,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   FX_A(dev_alloc(c, &b.desc, (size_t)L.max_total_keypoints * FX_DESC_FLOATS + 4));
   FX_A(dev_alloc(c, &b.flags, B));
   FX_A(dev_alloc(c, &b.huge_rings, (size_t)8 * P.ring_list_cap));
+  FX_A(dev_alloc(c, &b.huge_rings2, (size_t)8 * P.ring_list_cap));
   FX_A(dev_alloc(c, &b.big_merge, B));
   FX_A(dev_alloc(c, &b.huge_merge, B));
   FX_A(dev_alloc(c, &b.big_desc, L.max_total_keypoints));
@@ -801,8 +807,12 @@ fx_status fx_debug_counters(fx_ctx *c, uint32_t *out8 /* 16 words */) {
   uint32_t all[FX_N_COUNTERS];
   FX_HIP(hipMemcpy(all, c->buf.counters, sizeof(all), hipMemcpyDeviceToHost));
   std::memcpy(out8, all, 16 * 4);
-  out8[0] = out8[5] = 0;  // the rings handed to the workgroup tier are counted per XCD class (word 0: unused)
-  for (int k = 0; k < 8; ++k) out8[5] += all[FX_CNT_LARGE + k];
+  out8[0] = out8[5] = 0;  // the rings handed on are counted per XCD class: 0 to the second run tier, 5 to the workgroup tier
+  const bool runs2 = c->params.n_rings > 16;
+  for (int k = 0; k < 8; ++k) {
+    if (runs2) out8[0] += all[FX_CNT_LARGE + k];
+    out8[5] += all[(runs2 ? FX_CNT_LARGE2 : FX_CNT_LARGE) + k];
+  }
   return FX_OK;
 }
 

@@ -47,6 +47,7 @@ struct FxScTables {
 // Every device buffer of a context.
 #define FX_CLK_SLOTS 64
 #define FX_N_COUNTERS 32
+#define FX_CNT_LARGE2 16  // counters[16 + c]: rings of XCD class c the second run tier hands to the workgroup tier
 #define FX_CNT_LARGE 24  // counters[24 + c]: ... to the large tier
 struct FxBuffers {
   const FxScanMeta *meta;
@@ -86,6 +87,7 @@ struct FxBuffers {
   uint32_t *flags;        // [B]
   // work lists for the large-capacity tiers
   uint32_t *huge_rings;   // [B*n_rings]  rings for the workgroup tier (k_rings_large), by XCD class
+  uint32_t *huge_rings2;  // [B*n_rings]  rings the second run tier hands to the workgroup tier, by XCD class
   uint32_t *big_merge;    // [B]
   uint32_t *huge_merge;   // [B]  scans with more candidates than the LDS merge tiers hold
   uint32_t *big_desc;     // [max_total_kp]  rows whose support list overflowed list_cap

@@ -674,8 +674,10 @@ __device__ __forceinline__ uint32_t cc_order(uint32_t n, const uint32_t *parent,
         sort_partition_wave<1>(crec, (int)n_c, (int *)(s_w + 32), pos, pos + n_c);
       } else if (n_c <= 128) {
         sort_partition_wave<2>(crec, (int)n_c, (int *)(s_w + 32), pos, pos + n_c);
-      } else if (NT > 64 && n_c <= 192) {
+      } else if (n_c <= 192) {
         sort_partition_wave<3>(crec, (int)n_c, (int *)(s_w + 32), pos, pos + n_c);
+      } else if (n_c <= 256) {
+        sort_partition_wave<4>(crec, (int)n_c, (int *)(s_w + 32), pos, pos + n_c);
       } else if (threadIdx.x == 0) {  // more clusters than three words of lanes: one lane, sequentially
         fx_sort_detail::RevView v{crec, (int)n_c};
         fx_sort_partition_phase(v, (int)n_c, (int *)(s_w + 32));
@@ -1249,15 +1251,19 @@ __device__ __forceinline__ bool ring_body(const FxDevParams &P, const FxBuffers 
 // workgroup tier 32 KB for 640), so 15 rings per CU are in flight instead of 11 + 5, and rings of several hundred points
 // — ground and wall arcs: a handful of long runs — no longer need a workgroup.  Rings with more than 128 runs or
 // segments, more than 64 admissible clusters or too many near run pairs (unordered input) go to the workgroup tiers.
-#define FX_RR_SEGS 128
-#define FX_RR_RUNS 128
-#define FX_RR_CCAP 128  // (= FX_RR_RUNS: a cluster is at least a run)
+// Two instances: 128 segments / 128 runs and clusters (a cluster is at least a run) for every ring first — 3067 words, six 2 KiB
+// granules —, and 384 / 256 (24 KB) behind it for the rings of dense many-ring sensors, which otherwise need a 1024-thread
+// workgroup each.
 #define FX_RR_QUEUE 96
 #define FX_RR_CACHE 170
-#define FX_RR_WORDS (152 + 4 * FX_RR_RUNS + FX_RR_QUEUE + (FX_RR_SEGS + 4) + 4 * FX_RR_SEGS + (FX_RR_RUNS + 1) + 4 * FX_RR_RUNS + 4 * FX_RR_CCAP + 3 * FX_RR_CACHE)  // 3067 words: six 2 KiB granules
+template <uint32_t S, uint32_t RN>
+__host__ __device__ constexpr uint32_t rr_words() {
+  return 152 + 4 * RN + FX_RR_QUEUE + (S + 4) + 4 * S + (RN + 1) + 4 * RN + 4 * RN + 3 * FX_RR_CACHE;
+}
+template <uint32_t S, uint32_t RN>
 __device__ __forceinline__ bool ring_runs_body(const FxDevParams &P, const FxBuffers &B, uint32_t scan, uint32_t ring, uint32_t max_pts,
                                                uint32_t *smem) {
-  constexpr uint32_t S = FX_RR_SEGS, RN = FX_RR_RUNS, CC = FX_RR_CCAP;
+  constexpr uint32_t CC = RN;
   const uint32_t lane = threadIdx.x;
   unsigned long long *const stamp_base = B.stamps ? B.stamps : nullptr;
   FX_STAMP_INIT(stamp_base);
@@ -1674,8 +1680,8 @@ extern "C" __global__ __launch_bounds__(64) void k_rings_runs(FxDevParams P, FxB
   for (uint32_t q = slot; q < cls_items; q += per_cls) {
     const uint32_t scan = cls + 8u * (q / R), ring = q % R;
     const uint32_t item = scan * R + ring;
-    if (!ring_runs_body(P, B, scan, ring, max_pts, smem)) {
-      if (threadIdx.x == 0) {  // the workgroup tier's list of this XCD class (it too then finds the ring's points in its own L2)
+    if (!ring_runs_body<128, 128>(P, B, scan, ring, max_pts, smem)) {
+      if (threadIdx.x == 0) {  // the next tier's list of this XCD class (it too then finds the ring's points in its own L2)
         const uint32_t pos = atomicAdd(&B.counters[FX_CNT_LARGE + cls], 1u);
         B.huge_rings[(size_t)cls * P.ring_list_cap + pos] = item;
       }
@@ -1683,15 +1689,35 @@ extern "C" __global__ __launch_bounds__(64) void k_rings_runs(FxDevParams P, FxB
     wave_sync_lds();
   }
 }
+// second run tier (sensors of more than 16 rings only): the rings the first one handed over, with tables twice to three
+// times as long; what does not fit these either goes on to the workgroup tier
+extern "C" __global__ __launch_bounds__(64) void k_rings_runs2(FxDevParams P, FxBuffers B, uint32_t max_pts) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const uint32_t cls = blockIdx.x & 7u;  // block b takes the list of XCD class b mod 8 (the grid is a multiple of 8)
+  const uint32_t n_big = B.counters[FX_CNT_LARGE + cls];
+  const uint32_t *items = B.huge_rings + (size_t)cls * P.ring_list_cap;
+  for (uint32_t w = blockIdx.x >> 3; w < n_big; w += gridDim.x >> 3) {
+    const uint32_t item = items[w];
+    if (!ring_runs_body<384, 256>(P, B, item / P.n_rings, item % P.n_rings, max_pts, smem)) {
+      if (threadIdx.x == 0) {
+        const uint32_t pos = atomicAdd(&B.counters[FX_CNT_LARGE2 + cls], 1u);
+        B.huge_rings2[(size_t)cls * P.ring_list_cap + pos] = item;
+      }
+    }
+    wave_sync_lds();
+  }
+}
+
 // workgroup tier: the rings the run tier hands over (more than 128 runs, segments or clusters: unordered input, dense
 // many-ring sensors) get a whole 1024-thread workgroup with every point in LDS — one per CU, by LDS.  (A 256-thread tier
 // between the two, five per CU, made BASELINE configs 3 and 5 slower, not faster, once the run tier existed.)
 #define FX_RING_LARGE_T 1024
-extern "C" __global__ __launch_bounds__(FX_RING_LARGE_T) void k_rings_large(FxDevParams P, FxBuffers B, uint32_t cap, uint32_t ccap) {
+extern "C" __global__ __launch_bounds__(FX_RING_LARGE_T) void k_rings_large(FxDevParams P, FxBuffers B, uint32_t cap, uint32_t ccap,
+                                                                           uint32_t after_runs2) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const uint32_t cls = blockIdx.x & 7u;  // block b takes the list of XCD class b mod 8 (the grid is a multiple of 8): see k_rings_runs
-  const uint32_t n_big = B.counters[FX_CNT_LARGE + cls];
-  const uint32_t *items = B.huge_rings + (size_t)cls * P.ring_list_cap;
+  const uint32_t n_big = B.counters[(after_runs2 ? FX_CNT_LARGE2 : FX_CNT_LARGE) + cls];
+  const uint32_t *items = (after_runs2 ? B.huge_rings2 : B.huge_rings) + (size_t)cls * P.ring_list_cap;
   for (uint32_t w = blockIdx.x >> 3; w < n_big; w += gridDim.x >> 3) {
     const uint32_t item = items[w];
     ring_body<FX_RING_LARGE_T>(P, B, item / P.n_rings, item % P.n_rings, cap, ccap, smem, true);
@@ -3682,8 +3708,9 @@ extern "C" {
 size_t fxk_ring_large_lds_bytes(uint32_t cap, uint32_t ccap) {
   return (size_t)(SegCfg<FX_RING_LARGE_T>::kWords + FX_RING_WORDS_PER_POINT * cap + FX_RING_WORDS_PER_CLUSTER * ccap) * 4;
 }
-void fxk_rings_large(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t ccap, uint32_t grid) {
-  hipLaunchKernelGGL(k_rings_large, dim3(grid), dim3(FX_RING_LARGE_T), fxk_ring_large_lds_bytes(cap, ccap), s, P, B, cap, ccap);
+void fxk_rings_large(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t ccap, uint32_t grid,
+                     uint32_t after_runs2) {
+  hipLaunchKernelGGL(k_rings_large, dim3(grid), dim3(FX_RING_LARGE_T), fxk_ring_large_lds_bytes(cap, ccap), s, P, B, cap, ccap, after_runs2);
 }
 size_t fxk_merge_lds_bytes(uint32_t cap, uint32_t n_rings) { return merge_words(cap, cap, n_rings, true) * 4; }
 size_t fxk_merge_huge_lds_bytes(uint32_t cap, uint32_t ccap, uint32_t n_rings) { return merge_words(cap, ccap, n_rings, false) * 4; }
@@ -3721,7 +3748,11 @@ void fxk_bucket(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_
   const size_t lds = (48 + (size_t)P.n_rings * (2 + FX_BUCKET_NW) + 1) * 4;
   hipLaunchKernelGGL(k_bucket, dim3(batch), dim3(FX_BUCKET_T), lds, s, P, B, el0, inv_step, clk_next);
 }
-size_t fxk_ring_runs_lds_bytes(void) { return (size_t)FX_RR_WORDS * 4; }
+size_t fxk_ring_runs_lds_bytes(void) { return (size_t)rr_words<128, 128>() * 4; }
+void fxk_rings_runs2(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t max_pts, uint32_t grid) {
+  constexpr size_t lds = (size_t)rr_words<384, 256>() * 4;
+  hipLaunchKernelGGL(k_rings_runs2, dim3(grid), dim3(64), lds, s, P, B, max_pts);
+}
 void fxk_rings_runs(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t max_pts, uint32_t grid) {
   const uint32_t n_items = batch * (uint32_t)P.n_rings;
   if (grid > n_items) grid = (n_items + 7) / 8 * 8;

@@ -154,7 +154,7 @@ typedef struct fx_batch_view {
 /* Per-stage device time of the last batch (HIP events on the context's stream). */
 #define FX_N_STAGES 9
 typedef struct fx_timings {
-  /* k_prep, k_bucket, k_rings_runs (one wavefront per ring), k_rings_large (the workgroup ring tier), k_merge (merge tiers
+  /* k_prep, k_bucket, k_rings_runs (one wavefront per ring), k_rings_large (the second run tier of many-ring sensors + the workgroup ring tier), k_merge (merge tiers
    * small / big / large, k_offsets), k_gather (+ k_rng_ord on small batches), k_desc_group, k_desc_mid (wave rows and list
    * rows in one launch; + the longest lists), k_desc_rare (re-gather, whole-CU and slab tiers) */
   float ms[FX_N_STAGES];

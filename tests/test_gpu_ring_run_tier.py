@@ -57,8 +57,8 @@ def two_arcs_in_blocks(ring):
     return np.concatenate(blocks + [pole(ring, 40.0, 30.0), pole(ring, 50.0, 24.0, k=7)])
 
 
-def _run(oracle, scans, tag, **lim_over):
-    p = capi.params("launch")
+def _run(oracle, scans, tag, p=None, **lim_over):
+    p = p or capi.params("launch")
     ctx = capi.Context(p, capi.limits(len(scans), 28800, **lim_over))
     got = ctx.process_host(scans)
     cnt = (C.c_uint32 * 16)()
@@ -67,12 +67,12 @@ def _run(oracle, scans, tag, **lim_over):
     for b, s in enumerate(scans):
         util.compare_scan(got[b], oracle.run(p, s), tag=f"{tag} scan {b}")
     ctx.close()
-    return got, {"workgroup": cnt[5]}
+    return got, {"second": cnt[0], "workgroup": cnt[5]}
 
 
 def test_long_ring_and_members_beyond_the_register_held_points(fxlib, oracle):
     got, tiers = _run(oracle, [long_ring_with_late_poles()], "long ring")
-    assert got[0]["flags"] == 0 and tiers == {"workgroup": 0}
+    assert got[0]["flags"] == 0 and tiers == {"second": 0, "workgroup": 0}
     assert len(got[0]["candidates"]) == 5  # the poles; the arc fails the diameter gate
 
 
@@ -97,7 +97,7 @@ def test_edges_between_non_consecutive_runs(fxlib, oracle):
 
 def test_members_beyond_the_cached_points(fxlib, oracle):
     got, tiers = _run(oracle, [two_arcs_in_blocks(7)], "two arcs")
-    assert got[0]["flags"] == 0 and tiers == {"workgroup": 0}
+    assert got[0]["flags"] == 0 and tiers == {"second": 0, "workgroup": 0}
     assert len(got[0]["candidates"]) == 2
 
 
@@ -106,3 +106,15 @@ def test_all_shapes_in_one_batch(fxlib, oracle):
              np.concatenate([long_ring_with_late_poles(), two_arcs_in_blocks(9), interleaved_arc(6, 36), isolated_points(10, 128)])]
     got, _ = _run(oracle, scans, "mixed", max_ring_candidates=512, max_keypoints=512, max_total_keypoints=4096)
     assert [g["flags"] for g in got] == [0] * len(scans)
+
+
+def test_second_run_tier_of_many_ring_sensors(fxlib, oracle):
+    """Sensors of more than 16 rings get a second run tier (384 segments, 256 runs and clusters) behind the first: 200
+    single-point runs stay there, 257 need the workgroup tier; an interleaved arc beyond the near-pair list too."""
+    p = capi.params("launch", n_rings=32, el0_deg=-15.0, el_step_deg=1.0, secondary_max=32, cluster_tolerance=0.5)
+    scans = [isolated_points(9, 200), isolated_points(9, 256), isolated_points(9, 257), interleaved_arc(6, 100, step_m=0.15),
+             np.concatenate([isolated_points(7, 180), long_ring_with_late_poles(), two_arcs_in_blocks(9)])]
+    got, tiers = _run(oracle, scans, "second run tier", p=p, max_ring_candidates=512, max_keypoints=512, max_total_keypoints=4096)
+    assert [g["flags"] for g in got] == [0] * len(scans)
+    assert [len(g["candidates"]) for g in got][:3] == [200, 256, 257]
+    assert tiers["second"] >= 5 and 1 <= tiers["workgroup"] <= 3

@@ -51,7 +51,7 @@ out = (C.c_uint32 * 16)()
 lib = capi.load()
 lib.fx_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
 capi.check(lib.fx_debug_counters(ctx.handle, out))
-names = ["-", "scans -> big merge", "rows -> re-gather tier", "-", "rows -> list tier",
+names = ["rings -> second run tier", "scans -> big merge", "rows -> re-gather tier", "-", "rows -> list tier",
          "rings -> workgroup tier", "rows -> spill tier", "rows -> exact angle pass", "rows -> wavefront tier", "-", "-", "-", "rows -> slab tier"]
 print("  " + ", ".join(f"{n}: {c}" for n, c in zip(names, out)) + f", rows total {int(nk.sum())}")
 nb = np.ctypeslib.as_array(v.h_kp_neighbors, shape=(B, lim.max_keypoints)) if v.h_kp_neighbors else None
