@@ -3220,17 +3220,18 @@ extern "C" __global__ __launch_bounds__(FX_DESC_WG_XL_T) void k_desc_wg_xl(FxDev
 // Anything larger still goes to k_desc_spill.
 #define FX_HUGE_T 1024
 #define FX_HUGE_CAP 12288   // support points (3 floats each)
-#define FX_HUGE_WORDS (16 + 2 * FX_DGRID * FX_DGRID + 2 + FX_TABLE_WORDS + 3 * FX_HUGE_CAP + FX_DESC_BINS)
+#define FX_DGRID_Z 7        // layers of its density grid
+#define FX_HUGE_WORDS (16 + 2 * FX_DGRID * FX_DGRID * FX_DGRID_Z + 2 + FX_TABLE_WORDS + 3 * FX_HUGE_CAP)  // (the image borrows the cell tables)
 extern "C" __global__ __launch_bounds__(FX_HUGE_T) void k_desc_huge(FxDevParams P, FxBuffers B, uint32_t batch,
                                                                      uint32_t slab_pts) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  constexpr uint32_t G = FX_DGRID, kCells = G * G;
+  constexpr uint32_t G = FX_DGRID, GZ = FX_DGRID_Z, kCells = G * G * GZ;  // x fastest: three x-neighbours are one run of the sorted set
   uint32_t *s_w = smem;                         // 0 support, 1 binned neighbours, 2 all neighbours
   uint32_t *cell_start = smem + 16;             // [kCells + 1]
   uint32_t *cell_fill = cell_start + kCells + 1;  // [kCells]
   uint32_t *tl = smem + 16 + 2 * kCells + 2;      // (keeps what follows 16-byte aligned)
   float *xyz = reinterpret_cast<float *>(tl + FX_TABLE_WORDS);  // [3 * FX_HUGE_CAP]; later the sort arrays
-  float *img = xyz + 3 * FX_HUGE_CAP;
+  float *img = reinterpret_cast<float *>(cell_start);  // (the cell tables are done with when the bins are summed)
   const uint32_t tid = threadIdx.x;
   const uint32_t n_items = B.counters[6];
   float *sd2 = B.spill_d2 + (size_t)blockIdx.x * slab_pts;                 // squared distance to the keypoint
@@ -3242,6 +3243,9 @@ extern "C" __global__ __launch_bounds__(FX_HUGE_T) void k_desc_huge(FxDevParams 
   const float r_sup = sqrtf(P.r2_support);
   const float cell_w = fmaxf(sqrtf(P.r2_density) * 1.001f, 2.0f * r_sup / (float)(G - 1) * 1.0001f);
   const float inv_cw = 1.0f / cell_w;
+  // (layers at least a density radius high: walls and poles put thousands of points into a few xy cells)
+  const float cell_h = fmaxf(sqrtf(P.r2_density) * 1.001f, 2.0f * r_sup / (float)(GZ - 1) * 1.0001f);
+  const float inv_ch = 1.0f / cell_h;
   FX_STAMP_INIT(B.stamps ? B.stamps + 48 : nullptr);
   for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
     const uint32_t row = B.spill_desc[it];
@@ -3255,10 +3259,12 @@ extern "C" __global__ __launch_bounds__(FX_HUGE_T) void k_desc_huge(FxDevParams 
 #ifdef FX_STAMPS
     stamp_prev_ = __builtin_amdgcn_s_memtime();
 #endif
-    auto cell_of = [&](float x, float y) {
+    const float gz0 = kp.z - r_sup;
+    auto cell_of = [&](float x, float y, float z) {
       const uint32_t cx = (uint32_t)min(max((int)floorf((x - gx0) * inv_cw), 0), (int)G - 1);
       const uint32_t cy = (uint32_t)min(max((int)floorf((y - gy0) * inv_cw), 0), (int)G - 1);
-      return cy * G + cx;
+      const uint32_t cz = (uint32_t)min(max((int)floorf((z - gz0) * inv_ch), 0), (int)GZ - 1);
+      return (cz * G + cy) * G + cx;
     };
     __syncthreads();
     if (tid < 4) s_w[tid] = 0;
@@ -3286,7 +3292,7 @@ extern "C" __global__ __launch_bounds__(FX_HUGE_T) void k_desc_huge(FxDevParams 
           const bool in = d < P.r2_support && isfinite(rx) && isfinite(ry) && isfinite(rz);
           const unsigned long long m_in = __ballot(in);
           if (!m_in) continue;  // (wave-uniform)
-          const uint32_t ce = in ? cell_of(rx, ry) : 0u;
+          const uint32_t ce = in ? cell_of(rx, ry, rz) : 0u;
           if (pass == 0) {
             if (in) atomicAdd(&cell_fill[ce], 1u);
             if ((threadIdx.x & 63) == 0) atomicAdd(&s_w[0], (uint32_t)__popcll(m_in));
@@ -3377,12 +3383,13 @@ extern "C" __global__ __launch_bounds__(FX_HUGE_T) void k_desc_huge(FxDevParams 
       const float d2 = sd2[e];
       const uint32_t cx = (uint32_t)min(max((int)floorf((bx - gx0) * inv_cw), 0), (int)G - 1);
       const uint32_t cy = (uint32_t)min(max((int)floorf((by - gy0) * inv_cw), 0), (int)G - 1);
+      const uint32_t cz = (uint32_t)min(max((int)floorf((bz - gz0) * inv_ch), 0), (int)GZ - 1);
       const uint32_t xa0 = cx > 0 ? cx - 1 : 0, xa1 = min(cx + 1, G - 1);
       uint32_t dens = 0;
-      for (uint32_t rowi = 0; rowi < 3; ++rowi) {
-        const uint32_t yy = cy + rowi - 1u;
-        if (yy >= G) continue;
-        const uint32_t q0 = cell_start[yy * G + xa0], q1 = cell_start[yy * G + xa1 + 1];
+      for (uint32_t rowi = 0; rowi < 9; ++rowi) {  // three z layers of three y rows of three x cells
+        const uint32_t yy = cy + rowi % 3u - 1u, zz = cz + rowi / 3u - 1u;
+        if (yy >= G || zz >= GZ) continue;
+        const uint32_t q0 = cell_start[(zz * G + yy) * G + xa0], q1 = cell_start[(zz * G + yy) * G + xa1 + 1];
 #pragma unroll 8
         for (uint32_t q = q0; q < q1; ++q)
           dens += (dist2(bx, by, bz, xyz[3 * q], xyz[3 * q + 1], xyz[3 * q + 2]) < P.r2_density) ? 1u : 0u;
