@@ -210,7 +210,12 @@ def main():
     K = max(1, args.contexts)
     ctxs = [capi.Context(params, capi.limits(B, N), device=local_rank) for _ in range(K)]
     ctx = ctxs[0]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(K)]
+    # the contexts' own HIP streams, wrapped for torch (streams from torch's pool can share a hardware queue: two such
+    # contexts then do not overlap at all; FX_BENCH_TORCH_STREAMS=1 brings them back)
+    if os.environ.get("FX_BENCH_TORCH_STREAMS") == "1":
+        streams = [torch.cuda.Stream(device=dev) for _ in range(K)]
+    else:
+        streams = [torch.cuda.ExternalStream(c.stream_ptr(), device=dev) for c in ctxs]
     for c, st in zip(ctxs, streams):
         c.set_stream(st.cuda_stream)
     base = d_in.data_ptr()

@@ -94,7 +94,7 @@ class FxSynthCfg(C.Structure):
 
 # every symbol include/fx.h declares (tests/test_capi_symbols.py checks the list against the header)
 EXPORTS = ("fx_version", "fx_status_str", "fx_last_error", "fx_params_default", "fx_params_launch",
-           "fx_limits_default", "fx_create", "fx_destroy", "fx_set_stream", "fx_set_graph_batch", "fx_set_profiling", "fx_set_profiling_stages", "fx_get_timings",
+           "fx_limits_default", "fx_create", "fx_destroy", "fx_set_stream", "fx_get_stream", "fx_set_graph_batch", "fx_set_profiling", "fx_set_profiling_stages", "fx_get_timings",
            "fx_get_limits", "fx_process_batch", "fx_synchronize", "fx_pack_features", "fx_pack_keypoint_records",
            "fx_rotation_from_roll_pitch", "fx_sc3d_tables", "fx_sc3d_xaxis", "fx_synth_cfg_vlp16",
            "fx_synth_scan", "fx_test_sort_replay", "fx_test_sort_replay_ranked", "fx_test_sort_replay_lists", "fx_test_sort_replay_device", "fx_unpack_pointcloud2",
@@ -135,6 +135,8 @@ def load():
     lib.fx_set_profiling.argtypes = [C.c_void_p, C.c_int]
     lib.fx_set_profiling_stages.argtypes = [C.c_void_p, C.c_uint32]
     lib.fx_set_graph_batch.argtypes = [C.c_void_p, C.c_uint32]
+    lib.fx_get_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.fx_get_stream.restype = C.c_int
     lib.fx_get_timings.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(FxTimings)]
     lib.fx_get_limits.argtypes = [C.c_void_p, C.POINTER(FxLimits)]
     lib.fx_process_batch.argtypes = [C.c_void_p, C.POINTER(FxScanDesc), C.c_uint32, C.c_uint32,
@@ -253,6 +255,12 @@ class Context:
 
     def set_stream(self, stream_ptr):
         check(self.lib.fx_set_stream(self.handle, C.c_void_p(stream_ptr)))
+
+    def stream_ptr(self):
+        """The hipStream_t the context launches on, as an integer (torch.cuda.ExternalStream(ptr) wraps it)."""
+        p = C.c_void_p()
+        check(self.lib.fx_get_stream(self.handle, C.byref(p)))
+        return p.value or 0
 
     def set_graph_batch(self, max_batch):
         check(self.lib.fx_set_graph_batch(self.handle, int(max_batch)))

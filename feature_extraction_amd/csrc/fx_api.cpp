@@ -545,6 +545,11 @@ fx_status fx_set_stream(fx_ctx *c, void *hip_stream) {
   c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
   return FX_OK;
 }
+fx_status fx_get_stream(fx_ctx *c, void **hip_stream) {
+  if (!c || !hip_stream) return fail(FX_ERR_INVALID_ARG, "null argument");
+  *hip_stream = (void *)c->stream;
+  return FX_OK;
+}
 fx_status fx_set_graph_batch(fx_ctx *c, uint32_t max_batch) {
   if (!c) return fail(FX_ERR_INVALID_ARG, "null ctx");
   c->graph_max_batch = max_batch;

@@ -22,7 +22,7 @@ extern "C" {
 #endif
 
 #define FX_VERSION_MAJOR 0
-#define FX_VERSION_MINOR 2
+#define FX_VERSION_MINOR 3
 
 /* pcl::ShapeContext1980: 12 azimuth x 11 elevation x 15 radius bins + rf[9]
  * (ref: include/feature_extraction/feature_extraction_node.h:35-53,75). */
@@ -184,6 +184,9 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
 void fx_destroy(fx_ctx *ctx);
 /* hipStream_t to launch on (NULL = the context's own stream). */
 fx_status fx_set_stream(fx_ctx *ctx, void *hip_stream);
+/* The hipStream_t the context launches on (its own unless fx_set_stream gave it another): for event waits and for wrapping
+ * it in the caller's framework (torch.cuda.ExternalStream). */
+fx_status fx_get_stream(fx_ctx *ctx, void **hip_stream);
 /* Streaming mode: batches of up to max_batch scans are replayed as one HIP graph per
  * batch size instead of ~30 separate launches (0 = never).  Needs a non-NULL stream; ignored while
  * profiling is on.  Results are identical either way. */
