@@ -11,10 +11,14 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
-def dense_case(seed):
+def dense_case(seed, n_az_override=None, rings_override=None):
     rng = np.random.default_rng(seed)
     R = int(rng.choice([32, 64]))
     n_az = int(rng.choice([512, 768, 1024]))
+    if rings_override:
+        R = int(rings_override)
+    if n_az_override:
+        n_az = int(n_az_override)
     el_span = float(rng.uniform(20.0, 40.0))
     el0 = -float(rng.uniform(12.0, 25.0))
     cfg = capi.synth_cfg(int(rng.integers(1, 1 << 30)), n_rings=R, n_az=n_az, el0_deg=el0, el_step_deg=el_span / (R - 1),

@@ -1,7 +1,7 @@
 """Diagnostic: differential fuzz on dense many-ring sensors (32 / 64 rings, 512-1024 azimuths): random scenes x random node
 parameters against the oracle.  These scans exercise what the VLP-16 fuzz does not: the second run tier, the workgroup ring
 tier, the large merge tier, the long-list, whole-CU and slab descriptor tiers.
-  python tools/fuzz_dense.py FIRST LAST"""
+  python tools/fuzz_dense.py FIRST LAST [N_AZ [RINGS]]      (e.g. 2048 128: BASELINE config 5's shape, seconds per case)"""
 import os
 import sys
 import time
@@ -22,7 +22,7 @@ import ctypes as C
 bad = total_k = flagged = 0
 tiers = np.zeros(16, np.int64)
 for seed in range(lo, hi):
-    s, p, roll, pitch, lim, what = dense_case(seed)
+    s, p, roll, pitch, lim, what = dense_case(seed, int(sys.argv[3]) if len(sys.argv) > 3 else None, int(sys.argv[4]) if len(sys.argv) > 4 else None)
     R, n_az, over = what["R"], what["n_az"], what["over"]
     ctx = capi.Context(p, lim)
     got = ctx.process_host([s], roll=roll, pitch=pitch)[0]
