@@ -28,9 +28,9 @@ SINGLE_LAUNCH_STAGES = ("k_prep", "k_bucket", "k_rings_runs", "k_gather", "k_des
 # kernels launched inside each timed stage (rocprofv3 / PMC rows are per kernel name)
 STAGE_KERNELS = {"k_rings_large": ("k_rings_runs2", "k_rings_large"),  # (k_rings_runs2: sensors of more than 16 rings)
                  "k_merge": ("k_merge_small", "k_merge_big", "k_merge_huge", "k_offsets"),
-                 "k_desc_mid": ("k_desc_mid", "k_desc_wg_xl"),
+                 "k_desc_mid": ("k_desc_mid",),
                  "k_gather": ("k_gather", "k_rng_ord"),  # (k_rng_ord only when several workgroups share a scan: small batches)
-                 "k_desc_rare": ("k_desc_wg", "k_desc_huge", "k_desc_spill")}
+                 "k_desc_rare": ("k_dense_sort", "k_dense_density", "k_dense_finish_s", "k_dense_finish_l")}
 
 
 class FxParams(C.Structure):
@@ -51,7 +51,7 @@ class FxParams(C.Structure):
 class FxLimits(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in
                 ("max_batch", "max_points", "max_ring_points", "max_ring_candidates", "max_candidates",
-                 "max_keypoints", "max_neighbors", "max_total_keypoints", "max_kpc_points")]
+                 "max_keypoints", "max_neighbors", "max_total_keypoints", "max_kpc_points", "max_dense_points")]
 
 
 class FxScanDesc(C.Structure):

@@ -25,7 +25,8 @@ void fxk_rings_runs2(hipStream_t s, const FxDevParams &P, const FxBuffers &B, ui
 size_t fxk_merge_lds_bytes(uint32_t cap, uint32_t n_rings);
 size_t fxk_desc_lds_bytes(uint32_t cap);
 size_t fxk_gather_lds_bytes(uint32_t max_keypoints);
-uint32_t fxk_huge_cap(void);
+uint32_t fxk_dense_cells(void);
+void fxk_dense(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t n_cu);
 size_t fxk_merge_huge_lds_bytes(uint32_t cap, uint32_t ccap, uint32_t n_rings);
 hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t merge_huge, size_t desc_big, size_t gather);
 uint32_t fxk_near_words(uint32_t max_points);
@@ -41,13 +42,7 @@ void fxk_offsets(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32
 uint32_t fxk_gather_slices(uint32_t batch);
 void fxk_gather(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float box_margin);
 void fxk_desc_group(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid);
-void fxk_desc_wg(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t grid,
-                 uint32_t src);
 void fxk_desc_mid(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t n_wg, uint32_t n_wave);
-void fxk_desc_wg_xl(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t ns_lo,
-                    uint32_t grid);
-void fxk_desc_spill(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t slab_pts);
-void fxk_desc_huge(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t slab_pts);
 void fxk_pack_kp_records(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, void *dst,
                          uint32_t rec_kp);
 void fxk_rng_ord(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
@@ -75,7 +70,7 @@ fx_status fail(fx_status s, const std::string &msg) {
   } while (0)
 
 constexpr int kMetaSlots = 8;
-constexpr uint32_t kMergeCapSmall = 512, kListCap = 4096, kListSplit = 1024;
+constexpr uint32_t kMergeCapSmall = 512, kListCap = 4096, kDenseMin = 1024;
 }  // namespace
 
 struct fx_ctx {
@@ -96,7 +91,6 @@ struct fx_ctx {
   FxScanMeta *d_meta = nullptr;
   float box_margin = 0.f;
   uint32_t desc_wgs_per_cu = 10;
-  uint32_t spill_grid = 0, spill_slab = 0, tail_grid = 0;
   uint32_t merge_big_cap = 0;    // candidates the LDS merge tier holds as points (<= max_candidates)
   uint32_t merge_huge_ccap = 0;  // clusters the large merge tier can order (>= max_keypoints)
   // host-input staging
@@ -212,19 +206,11 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof) {
       FX_HIP(mark(6));
       fxk_desc_group(s, P, B, batch, desc_grid);
       FX_HIP(mark(7));
-      {
-        // lists of up to kListSplit entries (four keypoints per CU in flight) and the wave rows share a launch;
-        // longer lists: one 1024-thread workgroup per CU
-        const uint32_t split = P.list_cap < kListSplit ? P.list_cap : kListSplit;
-        fxk_desc_mid(s, P, B, batch, split, big_grid * 4, big_grid * 4);
-        if (P.list_cap > split) fxk_desc_wg_xl(s, P, B, batch, P.list_cap, split, big_grid);
-      }
+      // wave rows and list rows (lists of up to dense_min entries, four keypoints per CU in flight) share a launch
+      fxk_desc_mid(s, P, B, batch, P.list_cap < P.dense_min ? P.list_cap : P.dense_min, big_grid * 4, big_grid * 4);
       FX_HIP(mark(8));
-      // (no exact redo pass: the fast tiers evaluate the exact angles themselves for the rare neighbour next to a bin
-      //  edge; the exact kernel stays for the re-gather tier)
-      fxk_desc_wg(s, P, B, batch, L.max_neighbors, c->tail_grid, 0);
-      fxk_desc_huge(s, P, B, batch, c->spill_grid, c->spill_slab);
-      fxk_desc_spill(s, P, B, batch, c->spill_grid, c->spill_slab);
+      // the dense tier: larger support sets and overflowed lists (empty launches on sparse scans)
+      fxk_dense(s, P, B, big_grid);
     } else {
       for (int i = 6; i <= 8; ++i) FX_HIP(mark(i));
     }
@@ -290,6 +276,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   if (!L.max_neighbors) L.max_neighbors = D.max_neighbors;
   if (!L.max_total_keypoints) L.max_total_keypoints = D.max_total_keypoints;
   if (!L.max_kpc_points) L.max_kpc_points = D.max_kpc_points;
+  if (!L.max_dense_points) L.max_dense_points = D.max_dense_points;
   if (L.max_batch == 0 || L.max_points == 0) return fail(FX_ERR_INVALID_ARG, "max_batch and max_points must be > 0");
   if (L.max_batch > 65535) return fail(FX_ERR_INVALID_ARG, "max_batch > 65535 (one grid row per scan in the support gather)");
   if (L.max_points > (1u << 20)) return fail(FX_ERR_INVALID_ARG, "max_points > 2^20 (descriptor sort key packs the point index in 20 bits)");
@@ -315,7 +302,6 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
     return fail(FX_ERR_INVALID_ARG, "max_candidates (with max_keypoints) exceeds the LDS budget of the large merge tier (<= ~16000)");
   if (fxk_gather_lds_bytes(L.max_keypoints) > 96 * 1024)
     return fail(FX_ERR_INVALID_ARG, "max_keypoints exceeds the LDS budget of the support gather (<= ~1700)");
-  if (fxk_desc_lds_bytes(L.max_neighbors) > kLds) return fail(FX_ERR_INVALID_ARG, "max_neighbors exceeds the LDS budget (<= ~4800)");
   if (L.max_keypoints > 65535 || L.max_candidates > 32768 || L.max_ring_points > 32768)
     return fail(FX_ERR_INVALID_ARG, "limit exceeds the 16-bit packing of the order replay");
 
@@ -374,10 +360,20 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   P.max_ring_points = L.max_ring_points;
   P.list_cap = L.max_neighbors < kListCap ? L.max_neighbors : kListCap;
   P.near_words = fxk_near_words(L.max_points);
-  P.huge_cap = fxk_huge_cap();
-  if (const char *e = getenv("FX_HUGE_CAP")) {  // test hook: push large support sets on to the slab tier
-    const uint32_t v = (uint32_t)atoi(e);
-    if (v < P.huge_cap) P.huge_cap = v;
+  // dense tier pools (fx_limits.max_dense_points; default: as many entries as the batch has points)
+  P.dense_min = kDenseMin;
+  P.ovf_cap = L.max_points;
+  {
+    const unsigned long long want = L.max_dense_points ? L.max_dense_points : (unsigned long long)L.max_batch * L.max_points;
+    P.dense_cap = (uint32_t)(want > 0xfff00000ull ? 0xfff00000ull : (want < 4096ull ? 4096ull : want));
+    const uint32_t per_row = P.list_cap < P.dense_min ? P.list_cap : P.dense_min;  // a dense row has more support points than this
+    const unsigned long long rows = (unsigned long long)P.dense_cap / (per_row ? per_row : 1u) + 1ull;
+    P.max_dense_rows = (uint32_t)(rows < L.max_total_keypoints ? rows : L.max_total_keypoints);
+  }
+  P.dense_lds_keys = 14336u;  // FX_DFIN_KL of fx_kernels.hip
+  if (const char *e = getenv("FX_DENSE_LDS_KEYS")) {  // test hook: push rows on to the global-memory key sort (can only lower the cap)
+    const int v = atoi(e);
+    if (v >= 1 && (uint32_t)v < P.dense_lds_keys) P.dense_lds_keys = (uint32_t)v;
   }
   P.ring_slot_cap = 2 * L.max_points;  // worst case: every point on a window boundary, i.e. in two rings
   P.ring_list_cap = ((L.max_batch + 7) / 8) * (uint32_t)params->n_rings;  // rings of the scans of one XCD class
@@ -435,32 +431,33 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   FX_A(dev_alloc(c, &b.huge_rings2, (size_t)8 * P.ring_list_cap));
   FX_A(dev_alloc(c, &b.big_merge, B));
   FX_A(dev_alloc(c, &b.huge_merge, B));
-  FX_A(dev_alloc(c, &b.big_desc, L.max_total_keypoints));
   FX_A(dev_alloc(c, &b.list_desc, L.max_total_keypoints));
   FX_A(dev_alloc(c, &b.s_pts, (size_t)L.max_total_keypoints * P.list_cap));
   FX_A(dev_alloc(c, &b.s_cnt, L.max_total_keypoints));
   FX_A(dev_alloc(c, &b.row_map, L.max_total_keypoints));
   FX_A(dev_alloc(c, &b.row_kp, L.max_total_keypoints));
   FX_A(dev_alloc(c, &b.row_xa, L.max_total_keypoints));
-  FX_A(dev_alloc(c, &b.spill_desc, L.max_total_keypoints));
-  FX_A(dev_alloc(c, &b.huge_desc, L.max_total_keypoints));
-  FX_A(dev_alloc(c, &b.exact_desc, L.max_total_keypoints));
   FX_A(dev_alloc(c, &b.wave_desc, L.max_total_keypoints));
-  {
-    // spill tier: a slab of pow2(max_points) entries per workgroup (36 B per entry)
-    uint32_t slab = 1;
-    while (slab < L.max_points) slab <<= 1;
-    c->spill_slab = slab;
-    c->spill_grid = (uint32_t)c->n_cu;
-    if (const char *e = getenv("FX_TAIL_GRID")) c->spill_grid = (uint32_t)atoi(e);  // experiment: grid of the rare descriptor tiers
-    c->tail_grid = c->spill_grid;
-    const size_t n = (size_t)c->spill_grid * slab;
-    FX_A(dev_alloc(c, &b.spill_pts, n));
-    FX_A(dev_alloc(c, &b.spill_d2, n));
-    FX_A(dev_alloc(c, &b.spill_nlist, n));
-    FX_A(dev_alloc(c, &b.spill_key, n));
-    FX_A(dev_alloc(c, &b.spill_w, n));
-  }
+  // dense tier
+  FX_A(dev_alloc(c, &b.dense_rows, P.max_dense_rows));
+  FX_A(dev_alloc(c, &b.dense_order, (size_t)4 * P.max_dense_rows));
+  FX_A(dev_alloc(c, &b.dense_off, P.max_dense_rows));
+  FX_A(dev_alloc(c, &b.dense_koff, P.max_dense_rows));
+  FX_A(dev_alloc(c, &b.dense_nq, P.max_dense_rows));
+  FX_A(dev_alloc(c, &b.dense_nm, P.max_dense_rows));
+  FX_A(dev_alloc(c, &b.dense_cells, (size_t)P.max_dense_rows * fxk_dense_cells()));
+  FX_A(dev_alloc(c, &b.dense_items, (size_t)P.dense_cap / 256 + P.max_dense_rows + 1));
+  FX_A(dev_alloc(c, &b.dense_pts, P.dense_cap));
+  FX_A(dev_alloc(c, &b.dense_q, P.dense_cap));
+  FX_A(dev_alloc(c, &b.dense_key, P.dense_cap));
+  FX_A(dev_alloc(c, &b.dens_cache, B * L.max_points));
+  FX_A(dev_alloc(c, &b.seq, 1));
+  FX_A(dev_alloc(c, &b.ovf_pts, B * P.ovf_cap));
+  FX_A(dev_alloc(c, &b.ovf_kp, B * P.ovf_cap));
+  FX_A(dev_alloc(c, &b.ovf_cnt, B));
+  if (hipMemset(b.dens_cache, 0, B * L.max_points * sizeof(unsigned long long)) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
+  if (hipMemset(b.seq, 0, sizeof(unsigned long long)) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
+  if (hipMemset(b.ovf_cnt, 0, B * sizeof(uint32_t)) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
   FX_A(dev_alloc(c, &b.counters, FX_N_COUNTERS));
   FX_A(dev_alloc(c, &b.clk, 2 * FX_CLK_SLOTS));
   {
@@ -513,7 +510,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   {
     hipError_t ce = fxk_configure(fxk_ring_large_lds_bytes(L.max_ring_points, L.max_ring_points), fxk_merge_lds_bytes(c->merge_big_cap, params->n_rings),
                                   c->merge_big_cap < L.max_candidates ? fxk_merge_huge_lds_bytes(L.max_candidates, c->merge_huge_ccap, params->n_rings) : 0,
-                                  fxk_desc_lds_bytes(L.max_neighbors), fxk_gather_lds_bytes(L.max_keypoints));
+                                  fxk_desc_lds_bytes(P.list_cap < P.dense_min ? P.list_cap : P.dense_min), fxk_gather_lds_bytes(L.max_keypoints));
     if (ce != hipSuccess) return bail(fail(FX_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(ce)));
   }
   if (hipMemset(b.counters, 0, FX_N_COUNTERS * sizeof(uint32_t)) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));

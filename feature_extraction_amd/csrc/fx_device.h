@@ -33,7 +33,12 @@ struct FxDevParams {
       max_ring_points, list_cap, ring_slot_cap;
   uint32_t ring_list_cap;  // entries per XCD class of the deferred-ring lists
   uint32_t near_words;  // words of near bits per scan: one bit per 4 consecutive points = one 64-byte sector (k_prep -> k_gather)
-  uint32_t huge_cap;  // support points k_desc_huge takes (<= its LDS capacity; tests lower it to reach the slab tier)
+  // dense tier (k_dense_*): support sets beyond dense_min points and lists that overflowed list_cap
+  uint32_t dense_min;       // rows with more support points than this take the dense tier (1024)
+  uint32_t ovf_cap;         // entries of a scan's overflow region (list entries beyond list_cap, any row of the scan)
+  uint32_t dense_cap;       // entries of the sorted pool (and of the key pool) per batch
+  uint32_t max_dense_rows;  // rows of the dense-row list / cell tables
+  uint32_t dense_lds_keys;  // binned neighbours k_dense_finish_l sorts in LDS (16384; tests lower it to reach the key pool)
 };
 
 // 3DSC tables in device memory (built on the host by fx_sc3d_tables / fx_sc3d_xaxis).
@@ -90,18 +95,25 @@ struct FxBuffers {
   uint32_t *huge_rings2;  // [B*n_rings]  rings the second run tier hands to the workgroup tier, by XCD class
   uint32_t *big_merge;    // [B]
   uint32_t *huge_merge;   // [B]  scans with more candidates than the LDS merge tiers hold
-  uint32_t *big_desc;     // [max_total_kp]  rows whose support list overflowed list_cap
-  uint32_t *list_desc;    // [max_total_kp]  rows whose list is too long for one wavefront
-  uint32_t *spill_desc;   // [max_total_kp]  rows whose support set does not fit LDS
+  uint32_t *list_desc;    // [max_total_kp]  rows whose list is too long for one wavefront (257 .. dense_min support points)
   uint32_t *wave_desc;    // [max_total_kp]  rows with 65..256 support points (one wavefront each)
-  uint32_t *exact_desc;   // [max_total_kp]  rows with an angle too close to a bin edge for the fp32 pass
-  // spill tier slabs, one per workgroup of k_desc_spill (null when the context has none)
-  uint32_t *huge_desc;    // [max_total_kp]  rows k_desc_huge could not hold either (k_desc_spill takes them)
-  float4 *spill_pts;
-  float *spill_d2;
-  uint32_t *spill_nlist;
-  unsigned long long *spill_key;
-  float *spill_w;
+  // dense tier (k_dense_*)
+  uint32_t *dense_rows;   // [max_dense_rows]  rows of the tier (FX_NONE: no room in the pools, flagged)
+  uint32_t *dense_order;  // [4][max_dense_rows]  slots by size class (largest rows first)
+  uint32_t *dense_off;    // [max_dense_rows]  the row's region of dense_pts / dense_q
+  uint32_t *dense_koff;   // [max_dense_rows]  the row's region of dense_key (rows whose keys do not fit LDS)
+  uint32_t *dense_nq;     // [max_dense_rows]  queries (densities this row computes)
+  uint32_t *dense_nm;     // [max_dense_rows]  binned neighbours (FX_NONE: failed row)
+  uint32_t *dense_cells;  // [max_dense_rows][25 * 25 * 7]  end of every cell in the row's sorted region
+  uint2 *dense_items;     // work items of k_dense_density: (slot, first query)
+  float4 *dense_pts;      // [dense_cap]  support sets sorted by cell (x, y, z rotated, point index as bits)
+  uint32_t *dense_q;      // [dense_cap]  query lists (positions in the row's sorted region, cell order)
+  unsigned long long *dense_key;   // [dense_cap]  (bin, d2, index) keys of rows too large for the LDS sort
+  unsigned long long *dens_cache;  // [B][max_points]  batch tag << 21 | local point density of the point (k_dense_density)
+  unsigned long long *seq;         // [1]  batches processed (device side), the cache's tag
+  float4 *ovf_pts;        // [B][ovf_cap]  list entries beyond list_cap, unordered (k_gather)
+  uint32_t *ovf_kp;       // [B][ovf_cap]  keypoint ordinal of each
+  uint32_t *ovf_cnt;      // [B]
   // per-keypoint support lists written by k_gather
   float4 *s_pts;          // [max_total_kp][list_cap]  (x, y, z rotated, point index as bits)
   uint32_t *s_cnt;        // [max_total_kp]
@@ -110,7 +122,7 @@ struct FxBuffers {
   float2 *row_xa;         //                 per-keypoint kernels fetch everything a row needs in one round trip
   unsigned long long *clk;     // [FX_CLK_SLOTS][2] k_prep's first start / last end on the device's constant-rate clock, by batch
   unsigned long long *stamps;  // [32] diagnostic build only (-DFX_STAMPS)
-  uint32_t *counters;     // [FX_N_COUNTERS]: 24.. rings handed to the workgroup tier per XCD class; 0 -, 1 big_merge, 2 big_desc, 3 -, 4 list_desc, 5 huge_rings, 6 spill_desc, 7 exact_desc, 8 wave_desc, 9 huge_merge, 12 huge_desc
+  uint32_t *counters;     // [FX_N_COUNTERS]: 16.. / 24.. rings handed on per XCD class; 1 big_merge, 4 list_desc, 6 dense rows (2 / 3 / 7 / 10: by size class), 8 wave_desc, 9 huge_merge, 12 key pool used, 13 sorted pool used, 14 density items, 15 / 11 / 5 / 0 tickets of k_dense_density / sort / finish_s / finish_l
 };
 
 #endif

@@ -76,10 +76,14 @@ void fx_limits_default(fx_limits *l, uint32_t max_batch, uint32_t max_points) {
   l->max_candidates = 2048;
   l->max_keypoints = 256;
   // support-list entries per descriptor row (16 B each; the pool is max_total_keypoints rows): VLP-16-sized scans
-  // stay far below 1024 (longer sets take the re-gather / whole-CU tiers); dense many-ring scans get 4096
+  // stay far below 1024; dense many-ring scans get 4096.  Not a cap on the support set: what does not fit a row's list
+  // goes to the scan's overflow region and the row to the dense tier.
   l->max_neighbors = max_points > 65536u ? 4096u : 1024u;
   l->max_total_keypoints = max_batch * 64u;
   l->max_kpc_points = 4096;
+  // dense tier pools: as many entries as the batch has points (16 + 4 + 8 bytes each)
+  const unsigned long long dp = (unsigned long long)max_batch * max_points;
+  l->max_dense_points = dp > 0xfff00000ull ? 0xfff00000u : (uint32_t)dp;
 }
 
 // rotateCloud (ref: node.cpp:159-167): Eigen::AngleAxisf(pitch, Y) * Eigen::AngleAxisf(roll, X).

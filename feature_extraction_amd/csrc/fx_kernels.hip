@@ -2056,6 +2056,7 @@ extern "C" __global__ __launch_bounds__(FX_MSMALL_T) void k_merge_small(FxDevPar
     const uint32_t per = (P.max_total_kp + gridDim.x - 1) / gridDim.x;
     const uint32_t z0 = blockIdx.x * per, z1 = min(z0 + per, P.max_total_kp);
     for (uint32_t t = z0 + threadIdx.x; t < z1; t += FX_MSMALL_T) B.s_cnt[t] = 0u;
+    if (threadIdx.x == 0) B.ovf_cnt[blockIdx.x] = 0u;  // entries in the scan's overflow region (k_gather)
   }
   if (!merge_body<FX_MSMALL_T, true>(P, B, blockIdx.x, cap, cap, smem, false)) {
     if (threadIdx.x == 0) {
@@ -2101,7 +2102,10 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_offsets(FxDevParams P, FxB
     }
     run += tot;
   }
-  if (threadIdx.x == 0) B.kp_offset[batch] = run;
+  if (threadIdx.x == 0) {
+    B.kp_offset[batch] = run;
+    B.seq[0] += 1ull;  // batch tag of the dense tier's density cache (device side: a replayed HIP graph advances it too)
+  }
 }
 
 // ====================================================================== stage 5: descriptors
@@ -2112,14 +2116,16 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_offsets(FxDevParams P, FxB
 //                   (the rows themselves are cleared by k_desc_group, which sees every row once)
 //   k_desc_group    4 keypoints per wavefront: support sets of <= 64 points (the bulk)
 //   k_desc_mid      one launch: one wavefront per keypoint (65..256 support points) and one 256-thread
-//                   workgroup per keypoint (lists of up to 1024 entries); k_desc_wg_xl: longer lists
+//                   workgroup per keypoint (lists of up to 1024 entries)
 //                   -- all three: bins + density + weight per neighbour, sort by (bin, d2, index) ==
-//                      PCL's accumulation order, sequential fp32 sum per bin; angles in fp32 --
-//   k_desc_wg       exact fp64-angle redo of keypoints the fp32 passes flagged (angle near a bin
-//                   edge), and re-gather tier for lists that overflowed list_cap
-//   k_desc_spill    support sets beyond LDS: slabs in HBM
+//                      PCL's accumulation order, sequential fp32 sum per bin; angles in fp32, exact next to a bin edge --
+//   k_dense_*       larger support sets (dense many-ring scans) and overflowed lists: cell-sorted support sets in HBM
+//                   pools, a per-scan density cache shared by the rows, many wavefronts per row
 //   (3DSC's RNG ordinal rule — a keypoint without neighbours draws no x-axis — is applied by k_gather, which knows
 //    which keypoints have one before any descriptor is computed; k_rng_ord when several workgroups share a scan)
+
+__device__ __forceinline__ uint32_t dense_class(uint32_t nS);
+__device__ __forceinline__ uint32_t dense_class_counter(uint32_t cls);
 
 // Which scan does global keypoint row w belong to?  kp_offset is an exclusive prefix.
 __device__ __forceinline__ uint32_t scan_of_row(const uint32_t *kp_offset, uint32_t batch, uint32_t w) {
@@ -2200,14 +2206,10 @@ __device__ __forceinline__ uint32_t sc3d_bin(const float4 kp, float bx, float by
     // edges: phi_div = 30 l, theta_div = l * (180/11) (A.8-2); non-finite angles go the exact way too
     if (!(phi == phi) || !(theta == theta) || near_multiple(phi, 30.0f, 1.0f / 30.0f) ||
         near_multiple(theta, 180.0f / 11.0f, 11.0f / 180.0f)) {
-#ifdef FX_EXACT_PASS
-      amb = true;  // (diagnostic build: hand the keypoint to the exact kernel instead)
-#else
       float pe, te;
       sc3d_angles_exact(cn, xd, tc, &pe, &te);
       phi = cdn < 0.f ? (360.0f - pe) : pe;
       theta = te;
-#endif
     }
   }
 
@@ -2257,7 +2259,7 @@ __host__ __device__ inline uint32_t gather_words(uint32_t mk) {
   uint32_t w = 32 + 4 * mk;                                   // scratch, keypoints
   w += FX_GATHER_CELLS + 4;                                   // cell table (the fill cursors borrow the staging area)
   w += ((9 * mk + 1) / 2 + 3) & ~3u;                          // cell lists (uint16)
-  w += (4 * mk + 3) & ~3u;                                    // staged hits per keypoint, reserved list positions, list lengths, has-a-neighbour flags
+  w += (5 * mk + 3) & ~3u;                                    // staged hits per keypoint, reserved list positions, list lengths, has-a-neighbour flags, overflow slots
   w += FX_GATHER_STAGE + 4 * FX_GATHER_STAGE;                 // staged hits: meta, points
   w += FX_GATHER_NW * FX_GATHER_QUEUE * 5;                    // per-wavefront queues: points, cell info
   return w;
@@ -2275,7 +2277,8 @@ extern "C" __global__ __launch_bounds__(FX_GATHER_T) void k_gather(FxDevParams P
   uint32_t *s_kbase = s_kcnt + MK;                               // [MK] reserved list position
   uint32_t *s_kpos = s_kbase + MK;                               // [MK] list length so far (one workgroup per scan)
   uint32_t *s_knbr = s_kpos + MK;                                // [MK] 1: some point lies within the search radius (one workgroup per scan)
-  uint32_t *s_smeta = s_kcnt + ((4 * MK + 3) & ~3u);             // [STAGE] keypoint << 16 | staged ordinal
+  uint32_t *s_kovf = s_knbr + MK;                                // [MK] overflow-region slot of the keypoint's staged ordinal 0 (entries beyond list_cap)
+  uint32_t *s_smeta = s_kcnt + ((5 * MK + 3) & ~3u);             // [STAGE] keypoint << 16 | staged ordinal
   const bool solo = gridDim.x == 1;
   float4 *s_spt = reinterpret_cast<float4 *>(s_smeta + FX_GATHER_STAGE);
   uint32_t *s_cur = reinterpret_cast<uint32_t *>(s_spt);        // [CELLS] fill cursors while the lists are built (4 STAGE >= CELLS words)
@@ -2294,6 +2297,7 @@ extern "C" __global__ __launch_bounds__(FX_GATHER_T) void k_gather(FxDevParams P
   // keypoints of the scan -> LDS; their bounding box (ordered-uint atomics) for a cheap reject
   if (tid < 6) s_w[tid] = (tid & 1) ? f2ord(-INFINITY) : f2ord(INFINITY);
   if (tid == 0) s_w[8] = 0;  // staged hits
+  if (tid == 0) s_w[9] = 0;  // entries in the scan's overflow region (one workgroup per scan)
   for (uint32_t c = tid; c < FX_GATHER_CELLS; c += FX_GATHER_T) s_cell[c] = 0;
   __syncthreads();
   for (uint32_t k = tid; k < K; k += FX_GATHER_T) {
@@ -2372,16 +2376,27 @@ extern "C" __global__ __launch_bounds__(FX_GATHER_T) void k_gather(FxDevParams P
   const uint32_t hi = lo + chunk < n ? lo + chunk : n;
   const uint32_t *near_bits = B.near_bits + (size_t)scan * P.near_words;
   // called by the whole workgroup, after a barrier: reserve list positions, write the staged hits out
+  // Entries beyond a list's list_cap slots go to the scan's overflow region (B.ovf_pts / B.ovf_kp, ovf_cap entries a
+  // scan, unordered): the dense tier (k_dense_sort) collects a row's entries from there, so no support set is truncated.
+  float4 *ovf_pts = B.ovf_pts + (size_t)scan * P.ovf_cap;
+  uint32_t *ovf_kp = B.ovf_kp + (size_t)scan * P.ovf_cap;
+  auto ovf_reserve = [&](uint32_t n) -> uint32_t { return solo ? atomicAdd(&s_w[9], n) : atomicAdd(&B.ovf_cnt[scan], n); };
   auto flush = [&](uint32_t staged) {
     staged = min(staged, (uint32_t)FX_GATHER_STAGE);
     for (uint32_t k = tid; k < K; k += FX_GATHER_T) {
       const uint32_t c = s_kcnt[k];
       if (c) {
+        uint32_t base;
         if (solo) {  // this workgroup is the only writer of the scan's lists: positions are its own running counts
-          s_kbase[k] = s_kpos[k];
-          s_kpos[k] += c;
+          base = s_kpos[k];
+          s_kpos[k] = base + c;
         } else {
-          s_kbase[k] = atomicAdd(&B.s_cnt[row0 + k], c);
+          base = atomicAdd(&B.s_cnt[row0 + k], c);
+        }
+        s_kbase[k] = base;
+        if (base + c > P.list_cap) {  // ordinals from `first` on overflow the list
+          const uint32_t first = base < P.list_cap ? P.list_cap - base : 0u;
+          s_kovf[k] = ovf_reserve(c - first) - first;  // (wraps below zero for ordinals that stay in the list: unused there)
         }
       }
       s_kcnt[k] = 0;
@@ -2390,7 +2405,15 @@ extern "C" __global__ __launch_bounds__(FX_GATHER_T) void k_gather(FxDevParams P
     for (uint32_t e = tid; e < staged; e += FX_GATHER_T) {
       const uint32_t meta = s_smeta[e], k = meta >> 16;
       const uint32_t pos = s_kbase[k] + (meta & 0xffffu);
-      if (pos < P.list_cap) B.s_pts[(size_t)(row0 + k) * P.list_cap + pos] = s_spt[e];
+      if (pos < P.list_cap) {
+        B.s_pts[(size_t)(row0 + k) * P.list_cap + pos] = s_spt[e];
+      } else {
+        const uint32_t slot = s_kovf[k] + (meta & 0xffffu);
+        if (slot < P.ovf_cap) {
+          ovf_pts[slot] = s_spt[e];
+          ovf_kp[slot] = k;
+        }
+      }
     }
     if (tid == 0) s_w[8] = 0;
     __syncthreads();
@@ -2420,7 +2443,15 @@ extern "C" __global__ __launch_bounds__(FX_GATHER_T) void k_gather(FxDevParams P
             s_smeta[slot] = (k << 16) | atomicAdd(&s_kcnt[k], 1u);
           } else {  // stage full (a burst of hits within one tile): append directly
             const uint32_t pos = solo ? atomicAdd(&s_kpos[k], 1u) : atomicAdd(&B.s_cnt[row0 + k], 1u);
-            if (pos < P.list_cap) B.s_pts[(size_t)(row0 + k) * P.list_cap + pos] = pq;
+            if (pos < P.list_cap) {
+              B.s_pts[(size_t)(row0 + k) * P.list_cap + pos] = pq;
+            } else {
+              const uint32_t os = ovf_reserve(1u);
+              if (os < P.ovf_cap) {
+                ovf_pts[os] = pq;
+                ovf_kp[os] = k;
+              }
+            }
           }
         }
       }
@@ -2487,6 +2518,7 @@ extern "C" __global__ __launch_bounds__(FX_GATHER_T) void k_gather(FxDevParams P
   __syncthreads();
   flush(s_w[8]);
   if (solo) {
+    if (tid == 0) B.ovf_cnt[scan] = s_w[9];
     for (uint32_t k = tid; k < K; k += FX_GATHER_T) B.s_cnt[row0 + k] = s_kpos[k];
     // RNG ordinals: keypoint k takes the x-axis number (keypoints before it that have a neighbour)
     __syncthreads();
@@ -2530,7 +2562,7 @@ __device__ __forceinline__ const FxScTables *tables_to_lds(const FxBuffers &B, u
 
 // One wavefront per keypoint, for the rows in B.wave_desc (support sets of 65..256 points).
 // Angles in fp32; a keypoint with any neighbour whose angle lies within FX_FAST_EPS_DEG of a bin
-// edge is not finished here but handed to the exact workgroup kernel (k_desc_wg, fp64 angles), so
+// edge is evaluated exactly in place (sc3d_bin), so
 // the result is the exact one either way.
 template <bool FAST>
 __device__ __forceinline__ void desc_wave_body(const FxDevParams &P, const FxBuffers &B, uint32_t batch,
@@ -2549,9 +2581,9 @@ __device__ __forceinline__ void desc_wave_body(const FxDevParams &P, const FxBuf
 
   uint32_t total = B.kp_offset[batch];
   if (total > P.max_total_kp) total = P.max_total_kp;
-  const uint32_t n_items = FAST ? B.counters[8] : B.counters[7];
+  const uint32_t n_items = B.counters[8];
   for (uint32_t it = bid * FX_NWAVE + wave; it < n_items; it += nblk * FX_NWAVE) {
-    const uint32_t row = FAST ? B.wave_desc[it] : B.exact_desc[it];
+    const uint32_t row = B.wave_desc[it];
     const uint2 rm = B.row_map[row];
     const uint32_t scan = rm.x, k = rm.y;
     const uint32_t ord = k;
@@ -2564,13 +2596,7 @@ __device__ __forceinline__ void desc_wave_body(const FxDevParams &P, const FxBuf
 #pragma unroll
     for (uint32_t u = 0; u < FX_WAVE_CAP / 64; ++u)
       if (lane + u * 64 < P.list_cap) lv[u] = B.s_pts[(size_t)row * P.list_cap + lane + u * 64];
-    if (nS > FX_WAVE_CAP || nS > P.list_cap) {  // long (or truncated) list: workgroup tiers
-      if (FAST && lane == 0) {  // (k_desc_group sends these rows to their tiers itself; kept for rows listed here by mistake)
-        const uint32_t pos = atomicAdd(&B.counters[nS > P.list_cap ? 2 : 4], 1u);
-        (nS > P.list_cap ? B.big_desc : B.list_desc)[pos] = row;
-      }
-      continue;
-    }
+    if (nS > FX_WAVE_CAP || nS > P.list_cap) continue;  // (never listed here: k_desc_group sends those rows to their tiers)
     float *out = B.desc + (size_t)row * FX_DESC_FLOATS;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -2616,10 +2642,6 @@ __device__ __forceinline__ void desc_wave_body(const FxDevParams &P, const FxBuf
         nw[pos] = w;
       }
       nM += (uint32_t)__popcll(um);
-    }
-    if (FAST && __ballot(amb)) {  // some angle too close to a bin edge for fp32: the exact kernel redoes this keypoint
-      if (lane == 0) B.exact_desc[atomicAdd(&B.counters[7], 1u)] = row;  // the exact workgroup kernel redoes it
-      continue;
     }
     if (lane == 0) B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = nAll;
     if (nAll == 0) {  // no neighbours: NaN descriptor, no RNG draw (A.8-3)
@@ -2719,18 +2741,39 @@ extern "C" __global__ __launch_bounds__(FX_WG, FX_GROUP_OCC) void k_desc_group(F
     // Every descriptor row is cleared here, whichever tier ends up computing it (the keypoint kernels write
     // non-empty bins only): this kernel sees every row once and waits on latencies with its memory pipe idle.
     if (live) desc_zero_row(out, gl, FX_GLANES);
-    if (live) {
-      if (nS > FX_GROUP_CAP || nS > P.list_cap) {  // too long for a group (or truncated): wavefront / workgroup / re-gather tiers
-        if (gl == 0) {
-          // (a support set beyond limits.max_neighbors cannot fit the re-gather tier either: straight to the whole-CU tier)
-          const bool whole_cu = nS > P.list_cap && nS > P.max_neighbors && B.spill_pts != nullptr;
-          const uint32_t c = whole_cu ? 6u : (nS > P.list_cap ? 2u : (nS > FX_WAVE_CAP ? 4u : 8u));
-          uint32_t *list = whole_cu ? B.spill_desc : (nS > P.list_cap ? B.big_desc : (nS > FX_WAVE_CAP ? B.list_desc : B.wave_desc));
-          list[atomicAdd(&B.counters[c], 1u)] = row;
+    // too long for a group: wavefront rows (<= 256 support points), list rows (<= dense_min), and the dense tier beyond
+    // that — also every row whose list overflowed its list_cap slots (the rest of it sits in the scan's overflow region)
+    const bool too_long = live && (nS > FX_GROUP_CAP || nS > P.list_cap);
+    uint32_t dense_fail = 0;
+    if (too_long && gl == 0) {
+      if (nS > P.dense_min || nS > P.list_cap) {
+        // a slot in the dense-row list and nS entries of the sorted pool (k_dense_sort fills them)
+        const uint32_t slot = atomicAdd(&B.counters[6], 1u);
+        const uint32_t off = atomicAdd(&B.counters[13], nS);
+        const bool ok = slot < P.max_dense_rows && off <= P.dense_cap && nS <= P.dense_cap - off;
+        if (slot < P.max_dense_rows) {
+          B.dense_rows[slot] = ok ? row : FX_NONE;
+          B.dense_off[slot] = off;
+          // the tier's kernels take the rows largest first (four size classes), so that the big ones do not end up alone at the tail
+          const uint32_t cls = dense_class(nS);
+          B.dense_order[cls * P.max_dense_rows + atomicAdd(&B.counters[dense_class_counter(cls)], 1u)] = slot;
         }
-        live = false;
+        if (!ok) {  // pools exhausted (limits.max_dense_points): flagged, never silent
+          atomicOr(&B.flags[scan], FX_FLAG_NBR_OVERFLOW);
+          B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = FX_NONE;
+          dense_fail = 1;
+        }
+      } else {
+        const uint32_t c = nS > FX_WAVE_CAP ? 4u : 8u;
+        (nS > FX_WAVE_CAP ? B.list_desc : B.wave_desc)[atomicAdd(&B.counters[c], 1u)] = row;
       }
     }
+    dense_fail = (uint32_t)__shfl((int)dense_fail, (int)(g * FX_GLANES), 64);
+    if (dense_fail) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (the clearing stores first)
+      desc_fill_nan(out, gl, FX_GLANES);
+    }
+    if (too_long) live = false;
     if (!live) nS = 0;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -2755,7 +2798,6 @@ extern "C" __global__ __launch_bounds__(FX_WG, FX_GROUP_OCC) void k_desc_group(F
       float lut;
       bool amb = false;
       const uint32_t bin = sc3d_bin<true>(kp, b.x, b.y, b.z, d2, xa, T, lut, amb);
-      if (amb) cnt[2] = 1u;
       uint32_t dens = 0;  // support points within R/5 of this neighbour (itself included)
 #pragma unroll FX_GROUP_UNROLL
       for (uint32_t q = 0; q < nS; ++q) {
@@ -2771,11 +2813,6 @@ extern "C" __global__ __launch_bounds__(FX_WG, FX_GROUP_OCC) void k_desc_group(F
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const uint32_t nAll = live ? cnt[0] : 0u;
     uint32_t nM = live ? cnt[1] : 0u;
-    if (live && cnt[2]) {  // an angle too close to a bin edge for fp32: the exact kernel redoes this keypoint
-      if (gl == 0) B.exact_desc[atomicAdd(&B.counters[7], 1u)] = row;
-      live = false;
-      nM = 0;
-    }
     // (s_waitcnt vmcnt(0): the clearing stores are acknowledged before anything else is written to the row; a wider
     //  scope would write the whole L2 back)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -2840,7 +2877,6 @@ struct DescLds {
   uint32_t *sidx, *s_w;
 };
 #define FX_DESC_WORDS_PER_POINT 8
-#define FX_DGRID 13  // k_desc_huge's xy density grid, cells per axis: 2 (R + R/5) / (R/5) = 12, + 1
 #define FX_DGRID3 12  // the list tiers' xyz density grid (12^3 cell words + the 3DSC tables fit the image)
 __device__ __forceinline__ DescLds desc_carve(uint32_t *smem, uint32_t cap) {
   DescLds L;
@@ -3041,7 +3077,6 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
       float lut;
       bool amb = false;
       const uint32_t bin = sc3d_bin<FAST>(kp, bq.x, bq.y, bq.z, bq.w, xa, T, lut, amb);
-      if (FAST && amb) L.s_w[3] = 1u;  // some angle too close to a bin edge for fp32
       const uint32_t d = dens[2 * m];
       L.nkey[m] = sc3d_key(bin, bq.w, L.sidx[e]);
       L.nw[m] = (1.0f / (float)d) * lut;
@@ -3055,11 +3090,6 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
     FX_COUNT(12, 1);
     FX_COUNT(13, nS);
     FX_COUNT(14, nM);
-  }
-  if (FAST && L.s_w[3]) {  // hand the keypoint to the exact kernel
-    if (tid == 0) B.exact_desc[atomicAdd(&B.counters[7], 1u)] = row;
-    __syncthreads();
-    return true;
   }
   if (tid == 0) B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = nAll;
   if (nAll == 0) {  // no neighbours: NaN descriptor, no RNG draw (A.8-3)
@@ -3144,47 +3174,24 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
   return true;
 }
 
-// src 0: rows whose list overflowed (big_desc): support set re-gathered from the scan, exact angles
-// src 1: rows whose list is longer than a wavefront handles (list_desc): from the list, fp32 angles
-// src 2: rows with an angle near a bin edge (exact_desc): from the list, exact angles
+// List rows (257 .. cap support points): one keypoint per workgroup at a time, from k_gather's list, fp32 angles
+// (exact in place next to a bin edge).
 template <bool FAST, int NT>
 __device__ __forceinline__ void desc_wg_loop(const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap,
-                                             uint32_t src, uint32_t *smem, uint32_t ns_lo, uint32_t bid, uint32_t nblk) {
-  // a support set that does not fit `cap` goes to the spill tier
-  auto spill = [&](uint32_t row, uint32_t scan, uint32_t k) {
-    if (threadIdx.x == 0) {
-      if (B.spill_pts) {
-        const uint32_t pos = atomicAdd(&B.counters[6], 1u);
-        B.spill_desc[pos] = row;
-      } else {  // context created without a spill slab (limits.max_neighbors is then a hard cap)
-        atomicOr(&B.flags[scan], FX_FLAG_NBR_OVERFLOW);
-        B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = FX_NONE;
-      }
-    }
-    if (!B.spill_pts) desc_fill_nan(B.desc + (size_t)row * FX_DESC_FLOATS, threadIdx.x, NT);
-  };
-  const uint32_t n_items = B.counters[src == 0 ? 2 : (src == 1 ? 4 : 7)];
-  const uint32_t *items = src == 0 ? B.big_desc : (src == 1 ? B.list_desc : B.exact_desc);
+                                             uint32_t *smem, uint32_t bid, uint32_t nblk) {
+  const uint32_t n_items = B.counters[4];
   for (uint32_t i = bid; i < n_items; i += nblk) {
-    const uint32_t row = items[i];
+    const uint32_t row = B.list_desc[i];
     const uint2 rm = B.row_map[row];
-    const uint32_t scan = rm.x, k = rm.y;
     const uint32_t nS = B.s_cnt[row];
-    if (nS > P.list_cap && src != 0) continue;     // (exact_desc rows always fit; list rows too)
-    if (src == 1 && (nS <= ns_lo || nS > cap)) continue;  // list rows are split by length over two launches
-    if (!desc_body<FAST, NT>(P, B, row, scan, k, cap, smem, src != 0)) spill(row, scan, k);
+    if (nS > P.list_cap || nS > cap) continue;  // (never listed here: k_desc_group sends those rows to the dense tier)
+    desc_body<FAST, NT>(P, B, row, rm.x, rm.y, cap, smem, true);
     __syncthreads();
   }
 }
 // The fp32 pass runs 256-thread workgroups, four keypoints per CU at a time (most phases of a keypoint are
-// latency chains that leave lanes idle, so concurrency beats width); the register-heavier exact one 512.
+// latency chains that leave lanes idle, so concurrency beats width).
 #define FX_DESC_WG_FAST_T 256
-#define FX_DESC_WG_EXACT_T 512
-extern "C" __global__ __launch_bounds__(FX_DESC_WG_EXACT_T) void k_desc_wg(FxDevParams P, FxBuffers B, uint32_t batch,
-                                                                            uint32_t cap, uint32_t src) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  desc_wg_loop<false, FX_DESC_WG_EXACT_T>(P, B, batch, cap, src, smem, 0u, blockIdx.x, gridDim.x);
-}
 // Both middle tiers in one launch: the first n_wg workgroups take list rows (257..cap support points, one keypoint per
 // workgroup at a time), the others take wave rows (65..256, one keypoint per wavefront).  Neither tier fills the chip
 // alone (1600 and 900 of the 8192 wave slots on the VLP-16 bench) and neither depends on the other: one after the
@@ -3193,255 +3200,556 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_mid(FxDevParams P, Fx
                                                                 uint32_t n_wg) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   if (blockIdx.x < n_wg)
-    desc_wg_loop<true, FX_DESC_WG_FAST_T>(P, B, batch, cap, 1u, smem, 0u, blockIdx.x, n_wg);
+    desc_wg_loop<true, FX_DESC_WG_FAST_T>(P, B, batch, cap, smem, blockIdx.x, n_wg);
   else
     desc_wave_body<true>(P, B, batch, smem, blockIdx.x - n_wg, gridDim.x - n_wg);
 }
-// the longest lists (beyond FX_LIST_SPLIT entries, up to list_cap): one 1024-thread workgroup per CU
-#define FX_DESC_WG_XL_T 1024
-extern "C" __global__ __launch_bounds__(FX_DESC_WG_XL_T) void k_desc_wg_xl(FxDevParams P, FxBuffers B, uint32_t batch,
-                                                                            uint32_t cap, uint32_t ns_lo) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  desc_wg_loop<true, FX_DESC_WG_XL_T>(P, B, batch, cap, 1u, smem, ns_lo, blockIdx.x, gridDim.x);
+
+// ---------------------------------------------------------------- dense tier
+// Rows with more than P.dense_min support points (dense many-ring scans: thousands of ground returns around a pole
+// next to the sensor), and every row whose list overflowed its slots.  3DSC's local point density — the number of
+// cloud points within R/5 of a neighbour — does not depend on the keypoint: it is a property of
+// the point.  So the tier is built around a per-scan density cache indexed by point:
+//   k_dense_sort     one workgroup per row: the support set (list + the row's entries of the scan's overflow region),
+//                    counting-sorted by a 25 x 25 x 7 cell grid over the support sphere's box (cells half a density
+//                    radius wide in x and y) into the row's region of the sorted pool; the row's cell table; and the
+//                    row's QUERY list: its neighbours whose density no other row of the batch has claimed yet
+//                    (atomic compare-and-swap on the cache), in cell order;
+//   k_dense_density  one workgroup per 1024 consecutive queries, four per lane: the cell rows within reach pass through
+//                    LDS, every lane walks the part its queries can reach (per row a contiguous run, narrowed to the
+//                    sphere's chord) and tests every target against its four queries with packed fp32 arithmetic in
+//                    FLANN's operation order; counts -> the cache;
+//   k_dense_finish   one workgroup per row: (bin, d2, index) keys of the neighbours sorted in LDS — counting sort by
+//                    bin, ranking inside the bin (a bitonic network in the row's region of the key pool beyond 14336
+//                    keys) — weights from the cache, sequential fp32 sum per bin.
+// Many wavefronts share a row, rows share densities, nothing is streamed per row from the scan, and no support set is
+// too large: the pools bound the batch, not the row (FX_FLAG_NBR_OVERFLOW when they are exhausted).
+#define FX_DG 25                    // cells per axis in x and y: 2 (R + R/5) / (R/10) = 24, + 1
+#define FX_DGZ 7                    // layers (at least one density radius high)
+#define FX_DCELLS (FX_DG * FX_DG * FX_DGZ)
+#define FX_DENS_BITS 21             // density count (max_points <= 2^20) in the low bits of a cache word, batch tag above
+#define FX_DENS_MASK ((1ull << FX_DENS_BITS) - 1ull)
+#define FX_DSORT_T 512
+#define FX_DFIN_KS 4096    // binned neighbours the small finishing kernel sorts in LDS
+#define FX_DFIN_KL 14336   // ... the large one (keys + order + bin table: 152 KB of LDS)
+#define FX_DFIN_TS 256
+#define FX_DFIN_TL 1024
+// size classes of the tier's rows and the batch counters that count them (k_desc_group fills the class lists)
+__device__ __forceinline__ uint32_t dense_class(uint32_t nS) { return nS > 8192u ? 0u : (nS > 4096u ? 1u : (nS > 2048u ? 2u : 3u)); }
+__device__ __forceinline__ uint32_t dense_class_counter(uint32_t cls) { return cls == 0u ? 2u : (cls == 1u ? 3u : (cls == 2u ? 7u : 10u)); }
+// i-th row of the tier, largest class first (FX_NONE past the end)
+__device__ __forceinline__ uint32_t dense_nth(const FxDevParams &P, const FxBuffers &B, uint32_t i) {
+#pragma unroll
+  for (uint32_t cls = 0; cls < 4; ++cls) {
+    const uint32_t n = min(B.counters[dense_class_counter(cls)], P.max_dense_rows);
+    if (i < n) return B.dense_order[cls * P.max_dense_rows + i];
+    i -= n;
+  }
+  return FX_NONE;
+}
+// next row of the tier for this workgroup: a ticket from a batch counter, broadcast through LDS (contains two barriers)
+__device__ __forceinline__ uint32_t dense_next(const FxDevParams &P, const FxBuffers &B, uint32_t ticket_counter, uint32_t *s_slot) {
+  __syncthreads();
+  if (threadIdx.x == 0) *s_slot = dense_nth(P, B, atomicAdd(&B.counters[ticket_counter], 1u));
+  __syncthreads();
+  return *s_slot;
+}
+struct DenseGrid {
+  float gx0, gy0, gz0, inv_cw, inv_ch;
+  __device__ __forceinline__ uint32_t cx(float x) const { return (uint32_t)min(max((int)floorf((x - gx0) * inv_cw), 0), FX_DG - 1); }
+  __device__ __forceinline__ uint32_t cy(float y) const { return (uint32_t)min(max((int)floorf((y - gy0) * inv_cw), 0), FX_DG - 1); }
+  __device__ __forceinline__ uint32_t cz(float z) const { return (uint32_t)min(max((int)floorf((z - gz0) * inv_ch), 0), FX_DGZ - 1); }
+  __device__ __forceinline__ uint32_t cell(float x, float y, float z) const { return (cz(z) * FX_DG + cy(y)) * FX_DG + cx(x); }
+};
+// Cells slightly wider than half a density radius: two points closer than the density radius are at most two cells
+// apart in x and in y, and at most one layer apart in z.
+__device__ __forceinline__ DenseGrid dense_grid(const FxDevParams &P, const float4 kp) {
+  const float r_sup = sqrtf(P.r2_support), r_d = sqrtf(P.r2_density);
+  const float cw = fmaxf(0.5f * r_d * 1.001f, 2.0f * r_sup / (float)(FX_DG - 1) * 1.0001f);
+  const float ch = fmaxf(r_d * 1.001f, 2.0f * r_sup / (float)(FX_DGZ - 1) * 1.0001f);
+  DenseGrid g;
+  g.gx0 = kp.x - r_sup, g.gy0 = kp.y - r_sup, g.gz0 = kp.z - r_sup;
+  g.inv_cw = 1.0f / cw, g.inv_ch = 1.0f / ch;
+  return g;
+}
+__device__ __forceinline__ void dense_row_failed(const FxDevParams &P, const FxBuffers &B, uint32_t slot, uint32_t row, uint32_t scan,
+                                                 uint32_t k, uint32_t nt) {
+  if (threadIdx.x == 0) {
+    atomicOr(&B.flags[scan], FX_FLAG_NBR_OVERFLOW);
+    B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = FX_NONE;
+    B.dense_nq[slot] = 0u;
+    B.dense_nm[slot] = FX_NONE;
+  }
+  desc_fill_nan(B.desc + (size_t)row * FX_DESC_FLOATS, threadIdx.x, nt);
 }
 
-// ---------------------------------------------------------------- spill tier
-// Keypoints whose support set does not fit LDS (dense scans: > max_neighbors points within
-// R + R/5).  Same algorithm, with the support set, the neighbour list and the sort in a
-// per-workgroup slab of global memory; the density count streams the support set through LDS
-// tiles.  Slow but exact and without a capacity limit below max_points.
-// ---------------------------------------------------------------- k_desc_huge
-// Support sets beyond the lists (more than list_cap points; up to FX_HUGE_CAP): the whole LDS of a CU
-// goes to one keypoint.  The scan is streamed twice — a cell histogram, then a scatter — so that the
-// support set lands in LDS as xyz triples sorted by density cell (the same 13 x 13 xy cells as the list
-// tiers); indices, distances, keys and weights live in the workgroup's global slab.  The density count
-// of a neighbour then scans three cell rows in LDS instead of the whole set, and the (bin, d2, index)
-// keys are sorted in LDS once the support set is no longer needed.  Angles in fp64 (the exact policy).
-// Anything larger still goes to k_desc_spill.
-#define FX_HUGE_T 1024
-#define FX_HUGE_CAP 12288   // support points (3 floats each)
-#define FX_DGRID_Z 7        // layers of its density grid
-#define FX_HUGE_WORDS (16 + 2 * FX_DGRID * FX_DGRID * FX_DGRID_Z + 2 + FX_TABLE_WORDS + 3 * FX_HUGE_CAP)  // (the image borrows the cell tables)
-extern "C" __global__ __launch_bounds__(FX_HUGE_T) void k_desc_huge(FxDevParams P, FxBuffers B, uint32_t batch,
-                                                                     uint32_t slab_pts) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  constexpr uint32_t G = FX_DGRID, GZ = FX_DGRID_Z, kCells = G * G * GZ;  // x fastest: three x-neighbours are one run of the sorted set
-  uint32_t *s_w = smem;                         // 0 support, 1 binned neighbours, 2 all neighbours
-  uint32_t *cell_start = smem + 16;             // [kCells + 1]
-  uint32_t *cell_fill = cell_start + kCells + 1;  // [kCells]
-  uint32_t *tl = smem + 16 + 2 * kCells + 2;      // (keeps what follows 16-byte aligned)
-  float *xyz = reinterpret_cast<float *>(tl + FX_TABLE_WORDS);  // [3 * FX_HUGE_CAP]; later the sort arrays
-  float *img = reinterpret_cast<float *>(cell_start);  // (the cell tables are done with when the bins are summed)
+extern "C" __global__ __launch_bounds__(FX_DSORT_T) void k_dense_sort(FxDevParams P, FxBuffers B) {
+  __shared__ uint32_t cell_end[FX_DCELLS + 1];
+  __shared__ uint32_t s_w[16];
   const uint32_t tid = threadIdx.x;
-  const uint32_t n_items = B.counters[6];
-  float *sd2 = B.spill_d2 + (size_t)blockIdx.x * slab_pts;                 // squared distance to the keypoint
-  uint32_t *sidx = reinterpret_cast<uint32_t *>(B.spill_w) + (size_t)blockIdx.x * slab_pts;  // point index (weights come later)
-  uint32_t *nlist = B.spill_nlist + (size_t)blockIdx.x * slab_pts;         // support positions of the binned neighbours
-  unsigned long long *nkey = B.spill_key + (size_t)blockIdx.x * slab_pts;
-  float *w_by_idx = reinterpret_cast<float *>(B.spill_pts) + (size_t)blockIdx.x * slab_pts * 4;  // weight of point i (the float4 slab is free here)
-  const FxScTables *T = tables_to_lds(B, tl);
-  const float r_sup = sqrtf(P.r2_support);
-  const float cell_w = fmaxf(sqrtf(P.r2_density) * 1.001f, 2.0f * r_sup / (float)(G - 1) * 1.0001f);
-  const float inv_cw = 1.0f / cell_w;
-  // (layers at least a density radius high: walls and poles put thousands of points into a few xy cells)
-  const float cell_h = fmaxf(sqrtf(P.r2_density) * 1.001f, 2.0f * r_sup / (float)(GZ - 1) * 1.0001f);
-  const float inv_ch = 1.0f / cell_h;
-  FX_STAMP_INIT(B.stamps ? B.stamps + 48 : nullptr);
-  for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
-    const uint32_t row = B.spill_desc[it];
+  __shared__ uint32_t s_slot;
+  const unsigned long long seq = B.seq[0];
+  FX_STAMP_INIT(B.stamps ? B.stamps + 16 : nullptr);
+  while (true) {
+    const uint32_t slot = dense_next(P, B, 11u, &s_slot);
+    if (slot == FX_NONE) break;
+    const uint32_t row = B.dense_rows[slot];
+    if (row == FX_NONE) {  // (no room in the pools: k_desc_group flagged it)
+      if (tid == 0) B.dense_nq[slot] = 0u, B.dense_nm[slot] = FX_NONE;
+      continue;
+    }
     const uint2 rm = B.row_map[row];
     const uint32_t scan = rm.x, k = rm.y;
-    const FxScanMeta M = B.meta[scan];
-    const float4 kp = B.keypoints[(size_t)scan * P.max_keypoints + k];
-    const float2 xa = B.row_xa[row];
-    float *out = B.desc + (size_t)row * FX_DESC_FLOATS;
-    const float gx0 = kp.x - r_sup, gy0 = kp.y - r_sup;
+    const float4 kp = B.row_kp[row];
+    const uint32_t nS = B.s_cnt[row], off = B.dense_off[slot];
+    const uint32_t n_list = min(nS, P.list_cap);
+    const uint32_t n_ovf = nS > P.list_cap ? min(B.ovf_cnt[scan], P.ovf_cap) : 0u;  // entries of the scan's overflow region (any row's)
+    const float4 *lst = B.s_pts + (size_t)row * P.list_cap;
+    const float4 *ovf = B.ovf_pts + (size_t)scan * P.ovf_cap;
+    const uint32_t *ovf_kp = B.ovf_kp + (size_t)scan * P.ovf_cap;
+    const DenseGrid G = dense_grid(P, kp);
+    float4 *dst = B.dense_pts + off;
+    uint32_t *qlist = B.dense_q + off;
+    uint32_t *table = B.dense_cells + (size_t)slot * FX_DCELLS;
+    __syncthreads();
 #ifdef FX_STAMPS
     stamp_prev_ = __builtin_amdgcn_s_memtime();
 #endif
-    const float gz0 = kp.z - r_sup;
-    auto cell_of = [&](float x, float y, float z) {
-      const uint32_t cx = (uint32_t)min(max((int)floorf((x - gx0) * inv_cw), 0), (int)G - 1);
-      const uint32_t cy = (uint32_t)min(max((int)floorf((y - gy0) * inv_cw), 0), (int)G - 1);
-      const uint32_t cz = (uint32_t)min(max((int)floorf((z - gz0) * inv_ch), 0), (int)GZ - 1);
-      return (cz * G + cy) * G + cx;
-    };
+    for (uint32_t t = tid; t < FX_DCELLS + 1; t += FX_DSORT_T) cell_end[t] = 0;
+    if (tid < 16) s_w[tid] = 0;
     __syncthreads();
-    if (tid < 4) s_w[tid] = 0;
-    for (uint32_t t = tid; t < 2 * kCells + 1; t += FX_HUGE_T) cell_start[t] = 0;
-    __syncthreads();
-    // ---- the scan twice: pass 0 counts the support points per cell, pass 1 places them
-    const uint32_t n = M.n;
-    for (int pass = 0; pass < 2; ++pass) {
-      for (uint32_t i0 = 0; i0 < n; i0 += FX_HUGE_T * 4) {
+    // every support point of the row: its list, then its entries of the scan's overflow region; four loads in flight
+    // per lane (a pass is a chain of L2 round trips otherwise)
+    uint32_t mine = 0;
+    auto each_point = [&](auto &&fn) {
+      for (uint32_t e0 = 0; e0 < n_list; e0 += 4u * FX_DSORT_T) {
         float4 v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const uint32_t i = i0 + u * FX_HUGE_T + tid;
-          v[u] = i < n ? *reinterpret_cast<const float4 *>(M.pts + (size_t)i * M.stride_f) : make_float4(NAN, NAN, NAN, 0);
+          const uint32_t e = e0 + (uint32_t)u * FX_DSORT_T + tid;
+          if (e < n_list) v[u] = lst[e];
         }
 #pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (e0 + (uint32_t)u * FX_DSORT_T + tid < n_list) fn(v[u]);
+      }
+      for (uint32_t e0 = 0; e0 < n_ovf; e0 += 4u * FX_DSORT_T) {
+        uint32_t kk[4];
+        float4 v[4];
+#pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const float x = v[u].x, y = v[u].y, z = v[u].z;
-          const float rx = ((M.R[0] * x + M.R[1] * y) + M.R[2] * z) + 0.0f;
-          const float ry = ((M.R[3] * x + M.R[4] * y) + M.R[5] * z) + 0.0f;
-          const float rz = ((M.R[6] * x + M.R[7] * y) + M.R[8] * z) + 0.0f;
-          const float d = dist2(kp.x, kp.y, kp.z, rx, ry, rz);
-          // (the counters every support point bumps are bumped once per wavefront: thousands of LDS atomics on one
-          //  address serialise across the whole workgroup)
-          const bool in = d < P.r2_support && isfinite(rx) && isfinite(ry) && isfinite(rz);
-          const unsigned long long m_in = __ballot(in);
-          if (!m_in) continue;  // (wave-uniform)
-          const uint32_t ce = in ? cell_of(rx, ry, rz) : 0u;
-          if (pass == 0) {
-            if (in) atomicAdd(&cell_fill[ce], 1u);
-            if ((threadIdx.x & 63) == 0) atomicAdd(&s_w[0], (uint32_t)__popcll(m_in));
-          } else {
-            const bool nb = in && d < P.r2_search;
-            const unsigned long long m_nb = __ballot(nb);
-            if ((threadIdx.x & 63) == 0 && m_nb) atomicAdd(&s_w[2], (uint32_t)__popcll(m_nb));
-            if (in) {
-              const uint32_t slot = cell_start[ce] + atomicAdd(&cell_fill[ce], 1u);
-              xyz[3 * slot + 0] = rx;
-              xyz[3 * slot + 1] = ry;
-              xyz[3 * slot + 2] = rz;
-              sd2[slot] = d;
-              sidx[slot] = i0 + u * FX_HUGE_T + tid;
-            }
+          const uint32_t e = e0 + (uint32_t)u * FX_DSORT_T + tid;
+          kk[u] = e < n_ovf ? ovf_kp[e] : FX_NONE;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (kk[u] == k) v[u] = ovf[e0 + (uint32_t)u * FX_DSORT_T + tid];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (kk[u] == k) {
+            fn(v[u]);
+            ++mine;
           }
+      }
+    };
+    // ---- pass 1: support points per cell
+    each_point([&](const float4 &v) { atomicAdd(&cell_end[G.cell(v.x, v.y, v.z)], 1u); });
+    if (mine) atomicAdd(&s_w[8], mine);
+    __syncthreads();
+    FX_STAMP(1);
+    if (n_list + s_w[8] != nS) {  // the scan's overflow region overflowed (workgroup-uniform): entries were lost
+      dense_row_failed(P, B, slot, row, scan, k, FX_DSORT_T);
+      continue;
+    }
+    if (tid < 64) {  // counts -> exclusive starts, in place, by one wavefront
+      constexpr uint32_t per = (FX_DCELLS + 63) / 64;
+      uint32_t sum = 0;
+      for (uint32_t u = 0; u < per; ++u) {
+        const uint32_t ci = tid * per + u;
+        sum += ci < FX_DCELLS ? cell_end[ci] : 0u;
+      }
+      uint32_t incl = sum;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+        if ((int)tid >= d) incl += o;
+      }
+      uint32_t run = incl - sum;
+      for (uint32_t u = 0; u < per; ++u) {
+        const uint32_t ci = tid * per + u;
+        if (ci < FX_DCELLS) {
+          const uint32_t c = cell_end[ci];
+          cell_end[ci] = run;
+          run += c;
+        }
+      }
+    }
+    __syncthreads();
+    FX_STAMP(2);
+    // ---- pass 2: every point to its cell (the fill turns a cell's start into its end = the next cell's start)
+    each_point([&](const float4 &v) { dst[atomicAdd(&cell_end[G.cell(v.x, v.y, v.z)], 1u)] = v; });
+    __threadfence();  // the sorted region is re-read below by other waves of this workgroup
+    __syncthreads();
+    FX_STAMP(3);
+    for (uint32_t t = tid; t < FX_DCELLS; t += FX_DSORT_T) table[t] = cell_end[t];  // cell c = [c ? end[c - 1] : 0, end[c])
+    // ---- pass 3, over the sorted region: neighbours (d2 < R^2; the count 3DSC reports), binned neighbours (not the
+    //      keypoint's own point), and the queries: binned neighbours whose density this row is the first to claim
+    unsigned long long *cache = B.dens_cache + (size_t)scan * P.max_points;
+    const unsigned long long claim = (seq << FX_DENS_BITS) | FX_DENS_MASK;
+    // (every wavefront takes a contiguous share of the region: it claims and counts, then — after one prefix over the
+    //  wavefronts — writes its part of the list; which of its points it won stays in a register bit mask meanwhile)
+    uint32_t n_q = 0;
+    constexpr uint32_t NWS = FX_DSORT_T / 64;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    for (uint32_t r0 = 0; r0 < nS; r0 += NWS * 64u * 64u) {  // (rounds of 32768 points: 64 trips of 64 lanes per wavefront)
+      const uint32_t span = min(nS - r0, NWS * 64u * 64u);
+      const uint32_t chunk = ((span + NWS - 1u) / NWS + 63u) / 64u * 64u;
+      const uint32_t w0 = r0 + wave * chunk, w1 = min(w0 + chunk, r0 + span);
+      unsigned long long won_bits = 0;
+      uint32_t n_won = 0, n_nb = 0, n_use = 0;
+      for (uint32_t p0 = w0, trip = 0; p0 < w1; p0 += 64u, ++trip) {
+        const uint32_t p = p0 + lane;
+        bool nb = false, use = false, won = false;
+        if (p < w1) {
+          const float4 v = dst[p];
+          const float d2 = dist2(kp.x, kp.y, kp.z, v.x, v.y, v.z);
+          nb = d2 < P.r2_search;
+          use = nb && !sc3d_is_origin(d2);
+          if (use) {
+            // batch tags only grow and a claim is the largest word of its batch: one atomic max both tests and claims
+            won = (atomicMax(cache + __float_as_uint(v.w), claim) >> FX_DENS_BITS) != seq;
+          }
+        }
+        const unsigned long long m_won = __ballot(won);
+        if (lane == trip) won_bits = m_won;  // lane `trip` keeps the trip's mask
+        n_won += (uint32_t)__popcll(m_won);
+        n_nb += (uint32_t)__popcll(__ballot(nb));
+        n_use += (uint32_t)__popcll(__ballot(use));
+      }
+      if (lane == 0) {
+        s_w[wave] = n_won;
+        if (n_nb) atomicAdd(&s_w[9], n_nb);
+        if (n_use) atomicAdd(&s_w[10], n_use);
+      }
+      __syncthreads();
+      uint32_t before = n_q, total = 0;
+#pragma unroll
+      for (uint32_t w = 0; w < NWS; ++w) {
+        const uint32_t c = s_w[w];
+        before += w < wave ? c : 0u;
+        total += c;
+      }
+      __syncthreads();
+      for (uint32_t p0 = w0, trip = 0; p0 < w1; p0 += 64u, ++trip) {
+        const unsigned long long m = __shfl(won_bits, (int)trip, 64);
+        if ((m >> lane) & 1ull) qlist[before + lanes_below(m)] = p0 + lane;
+        before += (uint32_t)__popcll(m);
+      }
+      n_q += total;
+    }
+    __syncthreads();
+    FX_STAMP(4);
+    if (tid == 0) {
+      FX_COUNT(6, 1);
+      FX_COUNT(7, nS);
+      FX_COUNT(8, n_ovf);
+      B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = s_w[9];
+      B.dense_nq[slot] = n_q;
+      B.dense_nm[slot] = s_w[10];
+      if (s_w[10] > min(P.dense_lds_keys, (uint32_t)FX_DFIN_KL)) {  // keys beyond the finishing kernel's LDS array: a region of the key pool
+        uint32_t p2 = 1;
+        while (p2 < s_w[10]) p2 <<= 1;
+        const uint32_t koff = atomicAdd(&B.counters[12], p2);
+        if (koff <= P.dense_cap && p2 <= P.dense_cap - koff) {
+          B.dense_koff[slot] = koff;
+        } else {  // key pool exhausted
+          atomicOr(&B.flags[scan], FX_FLAG_NBR_OVERFLOW);
+          B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = FX_NONE;
+          B.dense_nm[slot] = FX_NONE;
+          s_w[11] = 1u;
+        }
+      }
+      // one work item per 1024 queries (FX_DDENS_Q of k_dense_density)
+      const uint32_t n_items = (n_q + 1023u) / 1024u;
+      const uint32_t base = n_items ? atomicAdd(&B.counters[14], n_items) : 0u;
+      for (uint32_t i = 0; i < n_items; ++i) B.dense_items[base + i] = make_uint2(slot, i * 1024u);
+    }
+    __syncthreads();
+    FX_STAMP(5);
+    if (s_w[11]) desc_fill_nan(B.desc + (size_t)row * FX_DESC_FLOATS, tid, FX_DSORT_T);  // (the claimed densities are still computed: other rows read them)
+  }
+}
+
+// Density of up to 1024 consecutive queries of a row by one workgroup, four per lane (consecutive in cell order, so
+// almost always in one cell).  The cell rows within reach of any of the workgroup's queries — per row one contiguous
+// run of the sorted region — pass through LDS in windows of FX_DDENS_C targets; every lane walks, per row, the part
+// of the window that the density spheres of ITS queries can reach (the row narrowed to the sphere's chord) and tests
+// each target against its four queries with packed fp32 arithmetic in FLANN's operation order.
+// (Per-lane walks straight from global memory were measured: 64 scattered 16-byte loads per instruction keep the
+//  texture unit busier than the 24 arithmetic instructions they feed — 3.8 ms against 2.1 ms for a wave-uniform
+//  stream of the whole box, which tests 2-3 times as many targets as a lane needs.)
+typedef float fx_f2 __attribute__((ext_vector_type(2)));
+#define FX_DDENS_T 256
+#define FX_DDENS_Q (4 * FX_DDENS_T)  // queries per work item
+#define FX_DDENS_C 2048              // targets per window
+extern "C" __global__ __launch_bounds__(FX_DDENS_T) void k_dense_density(FxDevParams P, FxBuffers B) {
+  __shared__ uint32_t s_tab[FX_DCELLS + 1];     // s_tab[c] = start of cell c, s_tab[c + 1] = its end
+  __shared__ float4 s_t[FX_DDENS_C];
+  __shared__ uint32_t s_cat[FX_DG * FX_DGZ + 1];  // start of every row of the box in the concatenation of the rows' runs
+  __shared__ uint32_t s_w[16];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t n_items = B.counters[14];
+  const unsigned long long tag = B.seq[0] << FX_DENS_BITS;
+  const float r2d = P.r2_density;
+  const float r_d = sqrtf(r2d);
+  while (true) {
+    __syncthreads();
+    if (tid == 0) s_w[0] = atomicAdd(&B.counters[15], 1u);
+    if (tid >= 4 && tid < 10) s_w[tid] = (tid & 1u) ? 0u : FX_NONE;  // the box: 4 ylo 5 yhi 6 zlo 7 zhi 8 xlo 9 xhi
+    __syncthreads();
+    const uint32_t it = s_w[0];
+    if (it >= n_items) break;
+    const uint2 item = B.dense_items[it];
+    const uint32_t slot = item.x, qb = item.y;
+    const uint32_t row = B.dense_rows[slot], off = B.dense_off[slot], n_q = B.dense_nq[slot];
+    const uint32_t scan = B.row_map[row].x;
+    const DenseGrid G = dense_grid(P, B.row_kp[row]);
+    const float cw = 1.0f / G.inv_cw, ch = 1.0f / G.inv_ch;
+    const float4 *pts = B.dense_pts + off;
+    const uint32_t *qlist = B.dense_q + off;
+    const uint32_t *table = B.dense_cells + (size_t)slot * FX_DCELLS;
+    for (uint32_t t = tid; t < FX_DCELLS; t += FX_DDENS_T) s_tab[t + 1] = table[t];
+    if (tid == 0) s_tab[0] = 0u;
+    // ---- this lane's four queries and their box (coordinates)
+    float4 q[4];
+    float bx0 = INFINITY, bx1 = -INFINITY, by0 = INFINITY, by1 = -INFINITY, bz0 = INFINITY, bz1 = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t qi = qb + 4u * tid + (uint32_t)u;
+      q[u] = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.0f);  // (no query: its differences overflow to infinity, never below the radius)
+      if (qi < n_q) {
+        q[u] = pts[qlist[qi]];
+        bx0 = fminf(bx0, q[u].x), bx1 = fmaxf(bx1, q[u].x);
+        by0 = fminf(by0, q[u].y), by1 = fmaxf(by1, q[u].y);
+        bz0 = fminf(bz0, q[u].z), bz1 = fmaxf(bz1, q[u].z);
+      }
+    }
+    const bool any_q = bx0 <= bx1;
+    // Margins: a point's cell comes from a rounded product, so cell borders are taken a thousandth of a cell wide.
+    const float eps_w = 1e-3f * cw, eps_h = 1e-3f * ch;
+    const float rr = r_d * 1.0001f;
+    // rows (cy, cz) the lane walks: two cells either side in y, one layer either side in z (dense_grid)
+    uint32_t ylo = 0, ny = 0, zlo = 0, n_rows = 0;
+    if (any_q) {
+      const uint32_t cy0 = G.cy(by0), cy1 = G.cy(by1), cz0 = G.cz(bz0), cz1 = G.cz(bz1);
+      ylo = cy0 >= 2u ? cy0 - 2u : 0u;
+      const uint32_t yhi = min(cy1 + 2u, (uint32_t)FX_DG - 1u);
+      zlo = cz0 >= 1u ? cz0 - 1u : 0u;
+      const uint32_t zhi = min(cz1 + 1u, (uint32_t)FX_DGZ - 1u);
+      ny = yhi - ylo + 1u;
+      n_rows = ny * (zhi - zlo + 1u);
+      const float hmax = rr * 1.0001f + eps_w;
+      atomicMin(&s_w[4], ylo), atomicMax(&s_w[5], yhi), atomicMin(&s_w[6], zlo), atomicMax(&s_w[7], zhi);
+      atomicMin(&s_w[8], G.cx(bx0 - hmax)), atomicMax(&s_w[9], G.cx(bx1 + hmax));
+    }
+    __syncthreads();
+    const uint32_t UY0 = s_w[4], UY1 = s_w[5], UZ0 = s_w[6], UZ1 = s_w[7], UX0 = s_w[8], UX1 = s_w[9];
+    if (UY0 > UY1) continue;  // (an item without queries: never emitted)
+    const uint32_t uny = UY1 - UY0 + 1u, unr = uny * (UZ1 - UZ0 + 1u);
+    // ---- the rows of the box laid end to end: s_cat[r] = start of row r in that concatenation
+    if (tid < 64) {
+      const uint32_t per = (unr + 63u) / 64u;
+      uint32_t sum = 0;
+      for (uint32_t u = 0; u < per; ++u) {
+        const uint32_t r = tid * per + u;
+        if (r < unr) {
+          const uint32_t base = ((UZ0 + r / uny) * FX_DG + UY0 + r % uny) * FX_DG;
+          sum += s_tab[base + UX1 + 1u] - s_tab[base + UX0];
+        }
+      }
+      uint32_t incl = sum;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+        if ((int)tid >= d) incl += o;
+      }
+      uint32_t run = incl - sum;
+      for (uint32_t u = 0; u < per; ++u) {
+        const uint32_t r = tid * per + u;
+        if (r < unr) {
+          const uint32_t base = ((UZ0 + r / uny) * FX_DG + UY0 + r % uny) * FX_DG;
+          s_cat[r] = run;
+          run += s_tab[base + UX1 + 1u] - s_tab[base + UX0];
+        }
+      }
+      if (tid == 63) s_cat[unr] = incl;
+    }
+    __syncthreads();
+    const uint32_t t_tot = s_cat[unr];
+    const fx_f2 ax = {q[0].x, q[1].x}, ay = {q[0].y, q[1].y}, az = {q[0].z, q[1].z};
+    const fx_f2 bx = {q[2].x, q[3].x}, by = {q[2].y, q[3].y}, bz = {q[2].z, q[3].z};
+    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    for (uint32_t w = 0; w < t_tot; w += FX_DDENS_C) {
+      const uint32_t wn = min((uint32_t)FX_DDENS_C, t_tot - w);
+      // ---- the window: concatenation position -> row (binary search) -> sorted-region position
+      for (uint32_t f = tid; f < wn; f += FX_DDENS_T) {
+        const uint32_t g = w + f;
+        uint32_t lo = 0, hi = unr;  // invariant: s_cat[lo] <= g < s_cat[hi]
+        while (hi - lo > 1u) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (s_cat[mid] <= g)
+            lo = mid;
+          else
+            hi = mid;
+        }
+        const uint32_t base = ((UZ0 + lo / uny) * FX_DG + UY0 + lo % uny) * FX_DG;
+        s_t[f] = pts[s_tab[base + UX0] + (g - s_cat[lo])];
+      }
+      __syncthreads();
+      // ---- every lane: its rows, each narrowed to the chord of the density sphere, as far as they lie in the window
+      for (uint32_t r = 0; r < n_rows; ++r) {
+        const uint32_t cz = zlo + r / ny, cy = ylo + r % ny;
+        const float y0 = G.gy0 + (float)cy * cw - eps_w, y1 = G.gy0 + (float)(cy + 1u) * cw + eps_w;
+        const float z0 = G.gz0 + (float)cz * ch - eps_h, z1 = G.gz0 + (float)(cz + 1u) * ch + eps_h;
+        // (edge cells also hold what the clamp put there: they extend outwards without limit)
+        const float dy = fmaxf(fmaxf(cy == 0u ? 0.0f : y0 - by1, cy == FX_DG - 1u ? 0.0f : by0 - y1), 0.0f);
+        const float dz = fmaxf(fmaxf(cz == 0u ? 0.0f : z0 - bz1, cz == FX_DGZ - 1u ? 0.0f : bz0 - z1), 0.0f);
+        const float h2 = rr * rr - (dy * dy + dz * dz);
+        if (!(h2 > 0.0f)) continue;  // the row is out of reach
+        const float h = sqrtf(h2) * 1.0001f + eps_w;
+        const uint32_t base = (cz * FX_DG + cy) * FX_DG;
+        const uint32_t ur = (cz - UZ0) * uny + (cy - UY0);
+        // window-relative positions of the run [start(cxl), end(cxh)) of this row
+        const uint32_t shift = s_cat[ur] - s_tab[base + UX0];  // sorted-region position -> concatenation position (mod 2^32)
+        const uint32_t g0 = s_tab[base + G.cx(bx0 - h)] + shift, g1 = s_tab[base + G.cx(bx1 + h) + 1u] + shift;
+        const uint32_t i0 = g0 > w ? g0 - w : 0u, i1 = g1 > w ? min(g1 - w, wn) : 0u;
+#pragma unroll 2
+        for (uint32_t i = i0; i < i1; ++i) {
+          const float4 t = s_t[i];
+          // FLANN L2_Simple, query - point, ((dx dx) + dy dy) + dz dz: two queries per packed instruction
+          const fx_f2 dxa = ax - t.x, dya = ay - t.y, dza = az - t.z;
+          const fx_f2 dxb = bx - t.x, dyb = by - t.y, dzb = bz - t.z;
+          fx_f2 ra = dxa * dxa, rb2 = dxb * dxb;
+          ra = ra + dya * dya, rb2 = rb2 + dyb * dyb;
+          ra = ra + dza * dza, rb2 = rb2 + dzb * dzb;
+          c0 += ra.x < r2d ? 1u : 0u;
+          c1 += ra.y < r2d ? 1u : 0u;
+          c2 += rb2.x < r2d ? 1u : 0u;
+          c3 += rb2.y < r2d ? 1u : 0u;
         }
       }
       __syncthreads();
-      if (pass == 0) {
-        if (s_w[0] > P.huge_cap) break;  // (workgroup-uniform)
-        if (tid < 64) {  // exclusive prefix over the cells by one wavefront
-          constexpr uint32_t per = (kCells + 63) / 64;
-          uint32_t c[per], sum = 0;
+    }
+    // ---- counts -> the scan's density cache (k_dense_finish of every row that has the point as a neighbour reads them)
+    unsigned long long *cache = B.dens_cache + (size_t)scan * P.max_points;
+    const uint32_t cnt[4] = {c0, c1, c2, c3};
 #pragma unroll
-          for (uint32_t u = 0; u < per; ++u) {
-            const uint32_t ci = tid * per + u;
-            c[u] = ci < kCells ? cell_fill[ci] : 0u;
-            sum += c[u];
+    for (int u = 0; u < 4; ++u)
+      if (qb + 4u * tid + (uint32_t)u < n_q) cache[__float_as_uint(q[u].w)] = tag | (unsigned long long)cnt[u];
+  }
+}
+
+// Bitonic sort of p2 (a power of two) keys in global memory by NT threads (rows whose keys do not fit LDS).
+template <int NT>
+__device__ __forceinline__ void dense_bitonic_global(unsigned long long *sk, uint32_t p2) {
+  for (uint32_t kb = 2; kb <= p2; kb <<= 1) {
+    for (uint32_t jb = kb >> 1; jb > 0; jb >>= 1) {
+      for (uint32_t t = threadIdx.x; t < p2; t += NT) {
+        const uint32_t x = t ^ jb;
+        if (x > t) {
+          const unsigned long long a = sk[t], c = sk[x];
+          const bool up = (t & kb) == 0;
+          if ((a > c) == up) {
+            sk[t] = c;
+            sk[x] = a;
           }
-          uint32_t incl = sum;
-#pragma unroll
-          for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
-            if ((int)tid >= d) incl += o;
-          }
-          uint32_t run = incl - sum;
-#pragma unroll
-          for (uint32_t u = 0; u < per; ++u) {
-            const uint32_t ci = tid * per + u;
-            if (ci < kCells) {
-              cell_start[ci] = run;
-              cell_fill[ci] = 0;
-            }
-            run += c[u];
-          }
-          if (tid == 63) cell_start[kCells] = incl;
         }
-        __syncthreads();
       }
-    }
-    FX_STAMP(1);
-    const uint32_t nS = s_w[0];
-    if (nS > P.huge_cap) {  // does not fit even here: the slab tier
-      if (tid == 0) B.huge_desc[atomicAdd(&B.counters[12], 1u)] = row;
-      continue;
-    }
-    __threadfence();  // the slab arrays are re-read by other waves of this workgroup
-    __syncthreads();
-    {
-      // the binned neighbours in cell order (a stable compaction over the cell-sorted support set): the lanes of a
-      // wavefront then hold neighbours of the same few cells, whose density queries read the same LDS words — one
-      // broadcast per instruction instead of 64 scattered reads (the scan is LDS-bandwidth bound)
-      uint32_t n_use = 0;
-      for (uint32_t q0 = 0; q0 < nS; q0 += FX_HUGE_T) {
-        const uint32_t q = q0 + tid;
-        const float d = q < nS ? sd2[q] : INFINITY;
-        const bool use = d < P.r2_search && !sc3d_is_origin(d);
-        uint32_t tot;
-        const uint32_t r = block_rank<FX_HUGE_T>(use, cell_fill, tot);  // (the fill cursors are done with: scratch)
-        if (use) nlist[n_use + r] = q;
-        n_use += tot;
-      }
-      if (tid == 0) s_w[1] = n_use;
       __threadfence();
       __syncthreads();
     }
-    const uint32_t nM = s_w[1], nAll = s_w[2];
-    if (tid == 0) B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = nAll;
-    if (nAll == 0) {
-      desc_fill_nan(out, tid, FX_HUGE_T);
-      continue;
-    }
-    // ---- one neighbour per lane at a time: density from three cell rows of the LDS copy, bin, weight
-    for (uint32_t m = tid; m < nM; m += FX_HUGE_T) {
-      const uint32_t e = nlist[m];
-      const float bx = xyz[3 * e], by = xyz[3 * e + 1], bz = xyz[3 * e + 2];
-      const float d2 = sd2[e];
-      const uint32_t cx = (uint32_t)min(max((int)floorf((bx - gx0) * inv_cw), 0), (int)G - 1);
-      const uint32_t cy = (uint32_t)min(max((int)floorf((by - gy0) * inv_cw), 0), (int)G - 1);
-      const uint32_t cz = (uint32_t)min(max((int)floorf((bz - gz0) * inv_ch), 0), (int)GZ - 1);
-      const uint32_t xa0 = cx > 0 ? cx - 1 : 0, xa1 = min(cx + 1, G - 1);
-      uint32_t dens = 0;
-      for (uint32_t rowi = 0; rowi < 9; ++rowi) {  // three z layers of three y rows of three x cells
-        const uint32_t yy = cy + rowi % 3u - 1u, zz = cz + rowi / 3u - 1u;
-        if (yy >= G || zz >= GZ) continue;
-        const uint32_t q0 = cell_start[(zz * G + yy) * G + xa0], q1 = cell_start[(zz * G + yy) * G + xa1 + 1];
-#pragma unroll 8
-        for (uint32_t q = q0; q < q1; ++q)
-          dens += (dist2(bx, by, bz, xyz[3 * q], xyz[3 * q + 1], xyz[3 * q + 2]) < P.r2_density) ? 1u : 0u;
+  }
+}
+// The (bin, d2, index) key of every binned neighbour of the row -> sk[0 .. nM), in any order; HIST: also a histogram of
+// the bins (LDS, cleared by the caller).
+template <int NT, bool HIST>
+__device__ __forceinline__ void dense_keys(const FxDevParams &P, const float4 *pts, uint32_t nS, const float4 kp, const float2 xa,
+                                           const FxScTables *T, unsigned long long *sk, uint32_t *hist, uint32_t *s_w) {
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t p0 = 0; p0 < nS; p0 += NT) {
+    const uint32_t p = p0 + tid;
+    bool use = false;
+    unsigned long long key = 0;
+    if (p < nS) {
+      const float4 v = pts[p];
+      const float d2 = dist2(kp.x, kp.y, kp.z, v.x, v.y, v.z);
+      use = d2 < P.r2_search && !sc3d_is_origin(d2);
+      if (use) {
+        float lut;
+        bool amb = false;
+        const uint32_t bin = sc3d_bin<true>(kp, v.x, v.y, v.z, d2, xa, T, lut, amb);
+        key = sc3d_key(bin, d2, __float_as_uint(v.w));
+        if (HIST) atomicAdd(&hist[bin], 1u);
       }
-      float lut;
-      bool amb_unused = false;
-      const uint32_t bin = sc3d_bin<false>(kp, bx, by, bz, d2, xa, T, lut, amb_unused);
-      const uint32_t idx = sidx[e];
-      nkey[m] = sc3d_key(bin, d2, idx);
-      w_by_idx[idx] = (1.0f / (float)dens) * lut;
+    }
+    const unsigned long long m = __ballot(use);
+    if (m) {  // (wave-uniform)
+      uint32_t base = 0;
+      if ((tid & 63u) == 0) base = atomicAdd(&s_w[0], (uint32_t)__popcll(m));
+      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+      if (use) sk[base + lanes_below(m)] = key;
+    }
+  }
+}
+__device__ __forceinline__ float dense_weight(unsigned long long key, const unsigned long long *cache, unsigned long long seq,
+                                              const FxScTables *T) {
+  const unsigned long long cw = cache[(uint32_t)(key & 0xfffffull)];
+  // (a word of another batch or a bare claim cannot be here: every binned neighbour of a dense row was claimed by some
+  //  row of this batch and k_dense_density has run; a zero density would show as an infinite weight)
+  const uint32_t dens = (cw >> FX_DENS_BITS) == seq ? (uint32_t)(cw & FX_DENS_MASK) : 0u;
+  return (1.0f / (float)dens) * T->lut[(uint32_t)(key >> 52) % 165u];
+}
+// One row.  PCL adds a bin's contributions in the order of its sorted radius search, (d2, index) ascending, so the keys
+// are sorted by (bin, d2, index) — here as a counting sort by bin (1980 of them) followed by a ranking inside each bin
+// (a bitonic network over 16384 keys took 0.28 ms of a CU) — and one lane per bin then adds the bin's weights in order.
+// LDS: keys [KMAX] u64 (later the sorted weights), ord [KMAX] u16, bin table [1984].
+template <int KMAX, int NT>
+__device__ __forceinline__ void dense_finish_row(const FxDevParams &P, const FxBuffers &B, uint32_t slot, uint32_t *smem,
+                                                 const FxScTables *T, unsigned long long seq) {
+  constexpr int PER = (KMAX + NT - 1) / NT;
+  unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);
+  uint16_t *ord = reinterpret_cast<uint16_t *>(smem + 2 * KMAX);
+  uint32_t *bin_end = smem + 2 * KMAX + KMAX / 2;  // [1984]
+  uint32_t *s_w = bin_end + 1984 + FX_TABLE_WORDS;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t row = B.dense_rows[slot], off = B.dense_off[slot], nM = B.dense_nm[slot];
+  const uint32_t scan = B.row_map[row].x;
+  const uint32_t nS = B.s_cnt[row];
+  const float4 kp = B.row_kp[row];
+  const float2 xa = B.row_xa[row];
+  float *out = B.desc + (size_t)row * FX_DESC_FLOATS;
+  const float4 *pts = B.dense_pts + off;
+  const unsigned long long *cache = B.dens_cache + (size_t)scan * P.max_points;
+  __syncthreads();
+  if (tid == 0) s_w[0] = 0;
+  if (nM > (uint32_t)KMAX || nM > P.dense_lds_keys) {
+    // ---- more keys than LDS holds: a bitonic network over the row's region of the key pool
+    unsigned long long *sk = B.dense_key + B.dense_koff[slot];
+    uint32_t p2 = 1;
+    while (p2 < nM) p2 <<= 1;
+    __syncthreads();
+    dense_keys<NT, false>(P, pts, nS, kp, xa, T, sk, nullptr, s_w);
+    for (uint32_t t = nM + tid; t < p2; t += NT) sk[t] = ~0ull;
+    __threadfence();
+    __syncthreads();
+    dense_bitonic_global<NT>(sk, p2);
+    for (uint32_t t = tid; t < nM; t += NT) {  // every sorted key becomes (bin, weight) in place
+      const unsigned long long key = sk[t];
+      sk[t] = ((key >> 52) << 32) | (unsigned long long)__float_as_uint(dense_weight(key, cache, seq, T));
     }
     __threadfence();
     __syncthreads();
-    FX_STAMP(7);
-    if (tid == 0) {
-      FX_COUNT(12, 1);
-      FX_COUNT(13, nS);
-      FX_COUNT(14, nM);
-    }
-    // ---- sort the keys (bin, d2, index) in LDS: the support copy is done with, and 2^14 keys fit where it
-    //      was; the weights stay in the slab, addressed by point index (the low bits of a key)
-    uint32_t p2 = 1;
-    while (p2 < nM) p2 <<= 1;
-    unsigned long long *sk = reinterpret_cast<unsigned long long *>(xyz);
-    for (uint32_t t = tid; t < p2; t += FX_HUGE_T) sk[t] = t < nM ? nkey[t] : ~0ull;
-    __syncthreads();
-    for (uint32_t kb = 2; kb <= p2; kb <<= 1) {
-      for (uint32_t jb = kb >> 1; jb > 0; jb >>= 1) {
-        for (uint32_t t = tid; t < p2; t += FX_HUGE_T) {
-          const uint32_t x = t ^ jb;
-          if (x > t) {
-            const unsigned long long a = sk[t], c = sk[x];
-            const bool up = (t & kb) == 0;
-            if ((a > c) == up) {
-              sk[t] = c;
-              sk[x] = a;
-            }
-          }
-        }
-        __syncthreads();
-      }
-    }
-    FX_STAMP(3);
-    // ---- every sorted key fetches its weight (in parallel) and becomes (bin, weight) in place
-    for (uint32_t t = tid; t < nM; t += FX_HUGE_T) {
-      const unsigned long long key = sk[t];
-      sk[t] = ((key >> 52) << 32) | (unsigned long long)__float_as_uint(w_by_idx[(uint32_t)(key & 0xfffffull)]);
-    }
-    // ---- the image: one lane per bin run adds its weights in sorted order; then the row
-    for (uint32_t t = tid; t < FX_DESC_BINS; t += FX_HUGE_T) img[t] = 0.0f;
-    __syncthreads();
-    for (uint32_t t = tid; t < nM; t += FX_HUGE_T) {
+    for (uint32_t t = tid; t < nM; t += NT) {  // one lane per bin run
       const uint32_t bin = (uint32_t)(sk[t] >> 32);
       if (t > 0 && (uint32_t)(sk[t - 1] >> 32) == bin) continue;
       float acc = 0.0f;
@@ -3450,148 +3758,103 @@ extern "C" __global__ __launch_bounds__(FX_HUGE_T) void k_desc_huge(FxDevParams 
         acc += __uint_as_float((uint32_t)sk[e]);
         ++e;
       } while (e < nM && (uint32_t)(sk[e] >> 32) == bin);
-      img[bin] = acc;
-    }
-    __syncthreads();
-    for (uint32_t t = tid; t < FX_DESC_FLOATS; t += FX_HUGE_T) out[t] = t < FX_DESC_BINS ? img[t] : 0.0f;  // rf = 0
-    FX_STAMP(4);
-  }
-}
-
-#define FX_SPILL_TILE 1024
-extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_spill(FxDevParams P, FxBuffers B, uint32_t batch,
-                                                                  uint32_t slab_pts) {
-  __shared__ float t_x[FX_SPILL_TILE], t_y[FX_SPILL_TILE], t_z[FX_SPILL_TILE];
-  __shared__ uint32_t s_cnt[4];
-  const uint32_t tid = threadIdx.x;
-  const uint32_t n_items = B.counters[12];  // what k_desc_huge could not hold
-  float4 *sp = B.spill_pts + (size_t)blockIdx.x * slab_pts;              // support set (x, y, z, index bits)
-  float *sd2 = B.spill_d2 + (size_t)blockIdx.x * slab_pts;               // its squared distances
-  uint32_t *nlist = B.spill_nlist + (size_t)blockIdx.x * slab_pts;       // support positions of the binned neighbours
-  unsigned long long *nkey = B.spill_key + (size_t)blockIdx.x * slab_pts;  // slab_pts is a power of two
-  float *nw = B.spill_w + (size_t)blockIdx.x * slab_pts;
-  const FxScTables *T = B.tables;
-  for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
-    const uint32_t row = B.huge_desc[it];
-    const uint2 rm = B.row_map[row];
-    const uint32_t scan = rm.x, k = rm.y;
-    const FxScanMeta M = B.meta[scan];
-    const float4 kp = B.keypoints[(size_t)scan * P.max_keypoints + k];
-    const float2 xa = B.row_xa[row];
-    float *out = B.desc + (size_t)row * FX_DESC_FLOATS;
-    if (tid < 4) s_cnt[tid] = 0;
-    __syncthreads();
-    // ---- gather into the slab
-    const uint32_t n = M.n;
-    for (uint32_t i0 = 0; i0 < n; i0 += FX_WG * 4) {
-      float4 v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const uint32_t i = i0 + u * FX_WG + tid;
-        v[u] = i < n ? *reinterpret_cast<const float4 *>(M.pts + (size_t)i * M.stride_f) : make_float4(NAN, NAN, NAN, 0);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float x = v[u].x, y = v[u].y, z = v[u].z;
-        const float rx = ((M.R[0] * x + M.R[1] * y) + M.R[2] * z) + 0.0f;
-        const float ry = ((M.R[3] * x + M.R[4] * y) + M.R[5] * z) + 0.0f;
-        const float rz = ((M.R[6] * x + M.R[7] * y) + M.R[8] * z) + 0.0f;
-        const float d = dist2(kp.x, kp.y, kp.z, rx, ry, rz);
-        if (d < P.r2_support && isfinite(rx) && isfinite(ry) && isfinite(rz)) {
-          const uint32_t pos = atomicAdd(&s_cnt[0], 1u);
-          sp[pos] = make_float4(rx, ry, rz, __uint_as_float(i0 + u * FX_WG + tid));
-          sd2[pos] = d;
-          if (d < P.r2_search) {
-            atomicAdd(&s_cnt[2], 1u);
-            if (!sc3d_is_origin(d)) nlist[atomicAdd(&s_cnt[1], 1u)] = pos;
-          }
-        }
-      }
-    }
-    __threadfence();  // the slab is re-read by other waves of this workgroup: release + L1 invalidate
-    __syncthreads();
-    const uint32_t nS = s_cnt[0], nM = s_cnt[1], nAll = s_cnt[2];
-    if (tid == 0) B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = nAll;
-    if (nAll == 0) {
-      desc_fill_nan(out, tid, FX_WG);
-      __syncthreads();
-      continue;
-    }
-    // ---- neighbours in batches of one per thread; density = support points within R/5, counted
-    //      while the support set streams through LDS tiles
-    for (uint32_t m0 = 0; m0 < nM; m0 += FX_WG) {
-      const uint32_t m = m0 + tid;
-      const bool live = m < nM;
-      const uint32_t e = live ? nlist[m] : 0u;
-      const float4 b = live ? sp[e] : make_float4(0, 0, 0, 0);
-      uint32_t dens = 0;
-      for (uint32_t q0 = 0; q0 < nS; q0 += FX_SPILL_TILE) {
-        __syncthreads();
-        for (uint32_t q = tid; q < FX_SPILL_TILE; q += FX_WG) {
-          const float4 v = q0 + q < nS ? sp[q0 + q] : make_float4(INFINITY, INFINITY, INFINITY, 0);
-          t_x[q] = v.x;
-          t_y[q] = v.y;
-          t_z[q] = v.z;
-        }
-        __syncthreads();
-        const uint32_t lim = min((uint32_t)FX_SPILL_TILE, nS - q0);
-        for (uint32_t q = 0; q < lim; ++q) dens += (dist2(b.x, b.y, b.z, t_x[q], t_y[q], t_z[q]) < P.r2_density) ? 1u : 0u;
-      }
-      if (live) {
-        const float d2 = sd2[e];
-        float lut;
-        bool amb_unused = false;
-        const uint32_t bin = sc3d_bin<false>(kp, b.x, b.y, b.z, d2, xa, T, lut, amb_unused);
-        nkey[m] = sc3d_key(bin, d2, __float_as_uint(b.w));
-        nw[m] = (1.0f / (float)dens) * lut;
-      }
-    }
-    // ---- bitonic sort by (bin, d2, index) in the slab
-    uint32_t p2 = 1;
-    while (p2 < nM) p2 <<= 1;
-    for (uint32_t t = nM + tid; t < p2; t += FX_WG) nkey[t] = ~0ull;
-    __threadfence();
-    __syncthreads();
-    for (uint32_t kb = 2; kb <= p2; kb <<= 1) {
-      for (uint32_t jb = kb >> 1; jb > 0; jb >>= 1) {
-        for (uint32_t t = tid; t < p2; t += FX_WG) {
-          const uint32_t x = t ^ jb;
-          if (x > t) {
-            const unsigned long long a = nkey[t], c = nkey[x];
-            const bool up = (t & kb) == 0;
-            if ((a > c) == up) {
-              nkey[t] = c;
-              nkey[x] = a;
-              const float wa = nw[t];
-              nw[t] = nw[x];
-              nw[x] = wa;
-            }
-          }
-        }
-        __threadfence();
-        __syncthreads();
-      }
-    }
-    // ---- zero the row, then one lane per bin run adds its weights in order
-    for (uint32_t t = tid; t < FX_DESC_FLOATS; t += FX_WG) out[t] = 0.0f;
-    __threadfence();
-    __syncthreads();
-    for (uint32_t t = tid; t < nM; t += FX_WG) {
-      const uint32_t bin = (uint32_t)(nkey[t] >> 52);
-      if (t > 0 && (uint32_t)(nkey[t - 1] >> 52) == bin) continue;
-      float acc = 0.0f;
-      uint32_t e = t;
-      do {
-        acc += nw[e];
-        ++e;
-      } while (e < nM && (uint32_t)(nkey[e] >> 52) == bin);
       out[bin] = acc;
     }
-    __threadfence();
     __syncthreads();
+    return;
+  }
+  for (uint32_t t = tid; t < 1984; t += NT) bin_end[t] = 0;
+  __syncthreads();
+  dense_keys<NT, true>(P, pts, nS, kp, xa, T, keys, bin_end, s_w);
+  __syncthreads();
+  if (tid < 64) {  // counts -> exclusive starts, in place, by one wavefront
+    constexpr uint32_t per = 1984 / 64;
+    uint32_t sum = 0;
+    for (uint32_t u = 0; u < per; ++u) sum += bin_end[tid * per + u];
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+      if ((int)tid >= d) incl += o;
+    }
+    uint32_t run = incl - sum;
+    for (uint32_t u = 0; u < per; ++u) {
+      const uint32_t c = bin_end[tid * per + u];
+      bin_end[tid * per + u] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  // every key's index to its bin's segment (the fill turns a bin's start into its end = the next bin's start)
+  for (uint32_t e = tid; e < nM; e += NT) ord[atomicAdd(&bin_end[(uint32_t)(keys[e] >> 52)], 1u)] = (uint16_t)e;
+  __syncthreads();
+  // rank inside the bin (keys are unique: they end in the point index), and the weight
+  uint32_t dst[PER];
+  float wgt[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const uint32_t p = tid + (uint32_t)u * NT;
+    dst[u] = FX_NONE;
+    if (p < nM) {
+      const unsigned long long key = keys[ord[p]];
+      const uint32_t bin = (uint32_t)(key >> 52);
+      const uint32_t s0 = bin ? bin_end[bin - 1u] : 0u, s1 = bin_end[bin];
+      uint32_t rank = 0;
+#pragma unroll 4
+      for (uint32_t qq = s0; qq < s1; ++qq) rank += keys[ord[qq]] < key ? 1u : 0u;
+      dst[u] = s0 + rank;
+      wgt[u] = dense_weight(key, cache, seq, T);
+    }
+  }
+  __syncthreads();  // (the keys are done with: their storage takes the weights, in sorted order)
+  float *sw = reinterpret_cast<float *>(keys);
+#pragma unroll
+  for (int u = 0; u < PER; ++u)
+    if (dst[u] != FX_NONE) sw[dst[u]] = wgt[u];
+  __syncthreads();
+  // one lane per bin adds the bin's weights in order (the row was cleared by k_desc_group)
+  for (uint32_t bin = tid; bin < FX_DESC_BINS; bin += NT) {
+    const uint32_t s0 = bin ? bin_end[bin - 1u] : 0u, s1 = bin_end[bin];
+    if (s0 == s1) continue;
+    float acc = 0.0f;
+#pragma unroll 4
+    for (uint32_t qq = s0; qq < s1; ++qq) acc += sw[qq];
+    out[bin] = acc;
+  }
+  __syncthreads();
+}
+// rows of up to KS binned neighbours: 256-thread workgroups, several per CU; larger: one 1024-thread workgroup per CU
+template <int KMAX, int NT, bool LARGE>
+__device__ __forceinline__ void dense_finish_loop(const FxDevParams &P, const FxBuffers &B) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  uint32_t *tl = smem + 2 * KMAX + KMAX / 2 + 1984;
+  const FxScTables *T = tables_to_lds(B, tl);
+  uint32_t *s_slot = tl + FX_TABLE_WORDS + 8;
+  const unsigned long long seq = B.seq[0];
+  while (true) {
+    const uint32_t slot = dense_next(P, B, LARGE ? 0u : 5u, s_slot);
+    if (slot == FX_NONE) break;
+    const uint32_t nM = B.dense_nm[slot];
+    if (nM == FX_NONE) continue;  // failed row (flagged)
+    // (P.dense_lds_keys: tests lower it to reach the global-memory sort)
+    const bool large = nM > (uint32_t)FX_DFIN_KS || nM > P.dense_lds_keys;
+    if (large != LARGE) continue;
+    const uint32_t row = B.dense_rows[slot];
+    const uint2 rm = B.row_map[row];
+    if (B.kp_nbrs[(size_t)rm.x * P.max_keypoints + rm.y] == 0u) {  // no point within R: NaN descriptor, no RNG draw (A.8-3)
+      desc_fill_nan(B.desc + (size_t)row * FX_DESC_FLOATS, threadIdx.x, NT);
+      continue;
+    }
+    if (nM == 0) continue;  // (only the keypoint's own point: the cleared row is the descriptor)
+    dense_finish_row<KMAX, NT>(P, B, slot, smem, T, seq);
   }
 }
-
+extern "C" __global__ __launch_bounds__(FX_DFIN_TS) void k_dense_finish_s(FxDevParams P, FxBuffers B) {
+  dense_finish_loop<FX_DFIN_KS, FX_DFIN_TS, false>(P, B);
+}
+extern "C" __global__ __launch_bounds__(FX_DFIN_TL) void k_dense_finish_l(FxDevParams P, FxBuffers B) {
+  dense_finish_loop<FX_DFIN_KL, FX_DFIN_TL, true>(P, B);
+}
 
 // RNG ordinals when several workgroups of k_gather shared a scan (small batches): 3DSC draws its three numbers only for
 // keypoints that have neighbours; k_gather left a flag per keypoint in kp_nbrs (the descriptor kernels then store the counts).
@@ -3721,8 +3984,12 @@ void fxk_rings_large(hipStream_t s, const FxDevParams &P, const FxBuffers &B, ui
 }
 size_t fxk_merge_lds_bytes(uint32_t cap, uint32_t n_rings) { return merge_words(cap, cap, n_rings, true) * 4; }
 size_t fxk_merge_huge_lds_bytes(uint32_t cap, uint32_t ccap, uint32_t n_rings) { return merge_words(cap, ccap, n_rings, false) * 4; }
-uint32_t fxk_huge_cap(void) { return FX_HUGE_CAP; }
 size_t fxk_gather_lds_bytes(uint32_t max_keypoints) { return (size_t)gather_words(max_keypoints) * 4; }
+size_t fxk_dense_finish_lds_bytes(int large) {
+  const size_t k = large ? FX_DFIN_KL : FX_DFIN_KS;
+  return (2 * k + k / 2 + 1984 + FX_TABLE_WORDS + 16) * 4;
+}
+uint32_t fxk_dense_cells(void) { return FX_DCELLS; }
 size_t fxk_desc_lds_bytes(uint32_t cap) { return (size_t)(16 + FX_DESC_WORDS_PER_POINT * cap + FX_DESC_BINS) * 4; }
 
 hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t merge_huge, size_t desc_big, size_t gather) {
@@ -3735,13 +4002,9 @@ hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t merge_huge, s
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void *)k_merge_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)merge_big);
   if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void *)k_desc_wg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)desc_big);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void *)k_desc_wg_xl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)desc_big);
-  if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void *)k_desc_mid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)desc_big);
   if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void *)k_desc_huge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FX_HUGE_WORDS * 4));
+  e = hipFuncSetAttribute((const void *)k_dense_finish_l, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fxk_dense_finish_lds_bytes(1));
   return e;
 }
 
@@ -3791,24 +4054,16 @@ void fxk_gather(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_
 void fxk_desc_group(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid) {
   hipLaunchKernelGGL(k_desc_group, dim3(grid), dim3(FX_WG), (size_t)(FX_NWAVE * FX_GROUPS * FX_GROUP_WORDS + FX_TABLE_WORDS) * 4, s, P, B, batch);
 }
-void fxk_desc_wg(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t grid,
-                 uint32_t src) {
-  hipLaunchKernelGGL(k_desc_wg, dim3(grid), dim3(FX_DESC_WG_EXACT_T), fxk_desc_lds_bytes(cap), s, P, B, batch, cap, src);
-}
-void fxk_desc_wg_xl(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t ns_lo,
-                    uint32_t grid) {
-  hipLaunchKernelGGL(k_desc_wg_xl, dim3(grid), dim3(FX_DESC_WG_XL_T), fxk_desc_lds_bytes(cap), s, P, B, batch, cap, ns_lo);
-}
 void fxk_desc_mid(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t n_wg,
                   uint32_t n_wave) {
   const size_t lds_wave = (size_t)(FX_NWAVE * FX_WAVE_WORDS + FX_TABLE_WORDS) * 4, lds_wg = fxk_desc_lds_bytes(cap);
   hipLaunchKernelGGL(k_desc_mid, dim3(n_wg + n_wave), dim3(FX_WG), lds_wave > lds_wg ? lds_wave : lds_wg, s, P, B, batch, cap, n_wg);
 }
-void fxk_desc_huge(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t slab_pts) {
-  hipLaunchKernelGGL(k_desc_huge, dim3(grid), dim3(FX_HUGE_T), (size_t)FX_HUGE_WORDS * 4, s, P, B, batch, slab_pts);
-}
-void fxk_desc_spill(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid, uint32_t slab_pts) {
-  hipLaunchKernelGGL(k_desc_spill, dim3(grid), dim3(FX_WG), 0, s, P, B, batch, slab_pts);
+void fxk_dense(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t n_cu) {
+  hipLaunchKernelGGL(k_dense_sort, dim3(n_cu * 4), dim3(FX_DSORT_T), 0, s, P, B);
+  hipLaunchKernelGGL(k_dense_density, dim3(n_cu * 3), dim3(FX_DDENS_T), 0, s, P, B);
+  hipLaunchKernelGGL(k_dense_finish_s, dim3(n_cu * 4), dim3(FX_DFIN_TS), fxk_dense_finish_lds_bytes(0), s, P, B);
+  hipLaunchKernelGGL(k_dense_finish_l, dim3(n_cu), dim3(FX_DFIN_TL), fxk_dense_finish_lds_bytes(1), s, P, B);
 }
 void fxk_test_sort_replay(hipStream_t s, const uint32_t *sizes, uint32_t n_seq, uint32_t n, uint32_t *perm) {
   hipLaunchKernelGGL(k_test_sort_replay, dim3(n_seq), dim3(64), 0, s, sizes, n, perm);

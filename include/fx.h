@@ -22,7 +22,7 @@ extern "C" {
 #endif
 
 #define FX_VERSION_MAJOR 0
-#define FX_VERSION_MINOR 3
+#define FX_VERSION_MINOR 4
 
 /* pcl::ShapeContext1980: 12 azimuth x 11 elevation x 15 radius bins + rf[9]
  * (ref: include/feature_extraction/feature_extraction_node.h:35-53,75). */
@@ -47,7 +47,8 @@ typedef enum fx_status {
 #define FX_FLAG_RING_OVERFLOW 0x1u      /* a ring held more points than limits.max_ring_points */
 #define FX_FLAG_CAND_OVERFLOW 0x2u      /* more per-ring candidates than limits.max_candidates */
 #define FX_FLAG_KP_OVERFLOW 0x4u        /* more keypoints than limits.max_keypoints */
-#define FX_FLAG_NBR_OVERFLOW 0x8u       /* support set too large and the context has no spill slab (not raised by default) */
+#define FX_FLAG_NBR_OVERFLOW 0x8u       /* the dense descriptor tier's pools are exhausted (limits.max_dense_points; the scan's
+                                         * overflow region holds max_points entries): the keypoint's descriptor is NaN */
 #define FX_FLAG_TOTAL_KP_OVERFLOW 0x10u /* batch-wide keypoint pool exhausted */
 #define FX_FLAG_KPC_OVERFLOW 0x20u      /* keypoint_cloud exceeded its pool */
 
@@ -84,11 +85,13 @@ typedef struct fx_limits {
   uint32_t max_candidates;      /* per-ring candidates per scan, all rings (def 2048; <= ~3800 live in LDS as points,
                                  * beyond that — up to ~16000 — the large merge tier keeps the coordinates in HBM) */
   uint32_t max_keypoints;       /* keypoints per scan                    (def 256)  */
-  uint32_t max_neighbors;       /* support-set points per keypoint the list tiers hold (def 1024, 4096 for scans of more
-                                 * than 65536 points; 16 B of list per entry and descriptor row); larger sets take the
-                                 * re-gather / whole-CU tiers (<= 12288) or HBM slabs */
+  uint32_t max_neighbors;       /* support-list slots per keypoint row (def 1024, 4096 for scans of more than 65536
+                                 * points; 16 B each, capped at 4096).  Not a cap on the support set: larger sets overflow
+                                 * into a per-scan region and take the dense tier */
   uint32_t max_total_keypoints; /* keypoints per batch (descriptor pool) (def max_batch*64) */
   uint32_t max_kpc_points;      /* keypoint_cloud points per scan        (def 4096) */
+  uint32_t max_dense_points;    /* support points per batch the dense descriptor tier sorts (rows of more than 1024
+                                 * support points; def max_batch*max_points; 28 B each).  New in 0.4 */
 } fx_limits;
 
 /* One scan = what cloudCallback receives after fromPCLPointCloud2

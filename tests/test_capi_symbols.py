@@ -29,13 +29,13 @@ def test_header_symbols_exported(fxlib):
 def test_struct_sizes_match_header(fxlib):
     # fx_params: int32 + 6 doubles + double + 2 int32 + double + int32 + int32 + double + int32 + 2 doubles + int32
     assert C.sizeof(capi.FxParams) == 128
-    assert C.sizeof(capi.FxLimits) == 9 * 4
+    assert C.sizeof(capi.FxLimits) == 10 * 4
     assert C.sizeof(capi.FxScanDesc) == 32
     assert C.sizeof(capi.FxTimings) == (capi.FX_N_STAGES + 2) * 4
 
 
 def test_version_and_status_strings(fxlib):
-    assert fxlib.fx_version() == (0 << 16) | 3  # FX_VERSION_MAJOR << 16 | FX_VERSION_MINOR (include/fx.h)
+    assert fxlib.fx_version() == (0 << 16) | 4  # FX_VERSION_MAJOR << 16 | FX_VERSION_MINOR (include/fx.h)
     for code in range(6):
         assert fxlib.fx_status_str(code)
     assert b"no CPU fallback" in fxlib.fx_status_str(capi.FX_ERR_NO_DEVICE)

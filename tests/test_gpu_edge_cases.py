@@ -167,24 +167,49 @@ def test_capacity_overflow_is_flagged_never_silent(fxlib, oracle):
     ctx.close()
 
 
-def test_support_sets_beyond_lds_use_the_spill_tier(fxlib, oracle):
-    """max_neighbors only sizes the LDS tiers: larger support sets go through global-memory slabs."""
+def test_overflowed_lists_take_the_dense_tier(fxlib, oracle):
+    """max_neighbors only sizes the per-row lists: what does not fit goes to the scan's overflow region and the row to
+    the dense tier (cell-sorted pools, per-scan density cache), whose results are the same."""
     s = util.vlp16_scan(1000)
     p = capi.params("launch")
-    _cmp(oracle, p, capi.limits(1, 28800, max_neighbors=64), [s], 0.02, -0.015, "spill tier (tiny LDS cap)")
-    _cmp(oracle, capi.params("default"), capi.limits(1, 28800, max_neighbors=128), [s], 0.02, -0.015, "spill tier default")
+    _cmp(oracle, p, capi.limits(1, 28800, max_neighbors=64), [s], 0.02, -0.015, "dense tier (64-entry lists)")
+    _cmp(oracle, p, capi.limits(1, 28800, max_neighbors=16), [s], 0.02, -0.015, "dense tier (16-entry lists)")
+    _cmp(oracle, capi.params("default"), capi.limits(1, 28800, max_neighbors=128), [s], 0.02, -0.015, "dense tier, default preset")
+    # several scans share nothing: each has its own overflow region and density cache
+    scans = [util.vlp16_scan(1000 + b) for b in range(3)]
+    _cmp(oracle, p, capi.limits(3, 28800, max_neighbors=32), scans, 0.02, -0.015, "dense tier, batch of 3")
 
 
-def test_support_sets_beyond_the_whole_cu_tier_use_global_slabs(fxlib, oracle, monkeypatch):
-    """k_desc_huge keeps up to 12288 support points in LDS; the slab tier behind it is reached here by
-    lowering that capacity (FX_HUGE_CAP is read at fx_create)."""
+def test_dense_tier_key_sort_in_global_memory(fxlib, oracle, monkeypatch):
+    """k_dense_finish_l sorts up to 16384 keys in LDS; rows beyond that sort in their region of the key pool. Reached
+    here by lowering the LDS capacity (FX_DENSE_LDS_KEYS is read at fx_create; it can only lower it)."""
     s = util.vlp16_scan(1000)
-    monkeypatch.setenv("FX_HUGE_CAP", "100")
-    _cmp(oracle, capi.params("launch"), capi.limits(1, 28800, max_neighbors=64), [s], 0.02, -0.015, "slab tier")
+    monkeypatch.setenv("FX_DENSE_LDS_KEYS", "20")
+    _cmp(oracle, capi.params("launch"), capi.limits(1, 28800, max_neighbors=64), [s], 0.02, -0.015, "dense tier, global key sort")
+
+
+def test_dense_tier_pool_exhaustion_is_flagged(fxlib, oracle):
+    """A sorted pool too small for the batch's dense rows: FX_FLAG_NBR_OVERFLOW on the scan, NaN descriptors for the rows
+    that did not fit, every other row still exact."""
+    s = util.vlp16_scan(1000, n_poles=8, x_lo=3.0, x_hi=8.0, y_lo=-4.0, y_hi=4.0)
+    p = capi.params("default", descriptor_radius=4.0)
+    ora = oracle.run(p, s)
+    assert ora["kp_neighbors"].max() > 1100
+    ctx = capi.Context(p, capi.limits(1, 28800, max_dense_points=4096))
+    got = ctx.process_host([s])[0]
+    ctx.close()
+    assert got["flags"] & 0x8
+    K = ora["n_keypoints"]
+    assert got["n_keypoints"] == K
+    bad = [k for k in range(K) if np.isnan(got["descriptors"][k, :1980]).all() and not np.isnan(ora["descriptors"][k, :1980]).all()]
+    assert bad, "a 4096-entry pool cannot hold this scan's dense rows"
+    for k in range(K):
+        if k not in bad:
+            np.testing.assert_allclose(got["descriptors"][k], ora["descriptors"][k], rtol=0, atol=util.DESC_TOL)
 
 
 def test_long_support_lists_use_the_workgroup_tiers(fxlib, oracle):
-    """Keypoints with > 256 and > 1024 support points (list tier and re-gather tier)."""
+    """Keypoints with > 256 and > 1024 support points (list tier and dense tier)."""
     s = util.vlp16_scan(1000, n_poles=8, x_lo=3.0, x_hi=8.0, y_lo=-4.0, y_hi=4.0)
     p = capi.params("default", descriptor_radius=4.0)
     ora = oracle.run(p, s)

@@ -68,7 +68,8 @@ def test_synthetic_generator_shape(fxlib):
 def test_limits_defaults(fxlib):
     l = capi.limits(1024, 28800)
     assert (l.max_batch, l.max_points, l.max_ring_points, l.max_ring_candidates, l.max_candidates, l.max_keypoints,
-            l.max_neighbors, l.max_total_keypoints, l.max_kpc_points) == (1024, 28800, 2048, 256, 2048, 256, 1024, 65536, 4096)
+            l.max_neighbors, l.max_total_keypoints, l.max_kpc_points, l.max_dense_points) == (
+                1024, 28800, 2048, 256, 2048, 256, 1024, 65536, 4096, 1024 * 28800)
     assert capi.limits(64, 128 * 2048).max_neighbors == 4096  # dense many-ring scans: longer support lists
 
 

@@ -51,8 +51,9 @@ out = (C.c_uint32 * 16)()
 lib = capi.load()
 lib.fx_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
 capi.check(lib.fx_debug_counters(ctx.handle, out))
-names = ["rings -> second run tier", "scans -> big merge", "rows -> re-gather tier", "-", "rows -> list tier",
-         "rings -> workgroup tier", "rows -> spill tier", "rows -> exact angle pass", "rows -> wavefront tier", "-", "-", "-", "rows -> slab tier"]
+names = ["rings -> second run tier", "scans -> big merge", "-", "-", "rows -> list tier",
+         "rings -> workgroup tier", "rows -> dense tier", "-", "rows -> wavefront tier", "scans -> huge merge", "-", "-",
+         "key-pool entries", "sorted-pool entries", "density work items", "-"]
 print("  " + ", ".join(f"{n}: {c}" for n, c in zip(names, out)) + f", rows total {int(nk.sum())}")
 nb = np.ctypeslib.as_array(v.h_kp_neighbors, shape=(B, lim.max_keypoints)) if v.h_kp_neighbors else None
 if nb is not None:

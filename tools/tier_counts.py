@@ -13,8 +13,9 @@ v = ctx.process_raw(descs, B, capi.FX_OUT_HOST)
 out = (C.c_uint32 * 16)()
 lib.fx_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
 capi.check(lib.fx_debug_counters(ctx.handle, out))
-names = ["rings -> second run tier", "scans -> big merge", "rows -> re-gather tier", "-", "rows -> list tier",
-         "rings -> workgroup tier", "rows -> spill tier", "rows -> exact angle pass", "rows -> wavefront tier", "-", "-", "-", "rows -> slab tier"]
+names = ["rings -> second run tier", "scans -> big merge", "-", "-", "rows -> list tier",
+         "rings -> workgroup tier", "rows -> dense tier", "-", "rows -> wavefront tier", "scans -> huge merge", "-", "-",
+         "key-pool entries", "sorted-pool entries", "density work items", "-"]
 print(f"batch {B} scans, {v.total_keypoints} keypoint rows, {B * 16} rings")
 for n, c in zip(names, out):
     print(f"  {n:28s} {c}")
