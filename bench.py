@@ -180,7 +180,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    build.build()
+    # one rank builds (a stale library would otherwise be rewritten by every rank at once); the others wait for it
+    if local_rank == 0:
+        build.build()
+    else:
+        t_wait = time.time()
+        while build.stale() and time.time() - t_wait < 900:
+            time.sleep(0.5)
     capi.load()  # raises if the HIP library is missing
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
@@ -195,7 +201,6 @@ def main():
             print(f"[bench] torch.distributed backend {dist.get_backend()} (RCCL), world {dist.get_world_size()}", file=sys.stderr)
 
     B, N = args.batch, N_RINGS * N_AZ
-    REC_KP = sharding.REC_KP
     roll, pitch = 0.02, -0.015
     threads = os.cpu_count() or 1
     # ---- synthetic input (SURVEY.md Appendix C / BASELINE.md config 2), seed 1000 + global scan index
@@ -210,6 +215,7 @@ def main():
     K = max(1, args.contexts)
     ctxs = [capi.Context(params, capi.limits(B, N), device=local_rank) for _ in range(K)]
     ctx = ctxs[0]
+    REC_KP = int(ctx.limits.max_keypoints)  # record stride = the context's keypoint capacity: a gathered record is never truncated
     # the contexts' own HIP streams, wrapped for torch (streams from torch's pool can share a hardware queue: two such
     # contexts then do not overlap at all; FX_BENCH_TORCH_STREAMS=1 brings them back)
     if os.environ.get("FX_BENCH_TORCH_STREAMS") == "1":
@@ -231,18 +237,18 @@ def main():
     # function the gloo test runs)
     rccl = None
     if use_dist and os.environ.get("FX_BENCH_TORCH_GATHER") != "1":
-        ok = 1
-        try:
-            rccl = sharding.RcclGather(world, rank, dev, n_comms=K)
-        except Exception as e:  # noqa: BLE001  (e.g. a torch build without its own librccl.so): torch.distributed's gather then
-            print(f"[bench] rank {rank}: direct RCCL gather unavailable ({e}); using torch.distributed", file=sys.stderr)
-            ok = 0
-        if world > 1:  # every rank takes the same path
+        # ONE communicator for all contexts: its collectives are issued in step order on every rank, which is RCCL's
+        # ordering contract (one communicator per context could interleave differently on two ranks and deadlock when the
+        # streams share a hardware queue).  Every rank first proves it can load RCCL's C API; only then are ids exchanged.
+        ok = 1 if sharding.RcclGather.available() else 0
+        if world > 1:
             t = torch.tensor([ok], dtype=torch.int64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            if int(t.item()) == 0 and rccl is not None:
-                rccl.close()
-                rccl = None
+            ok = int(t.item())
+        if ok:
+            rccl = sharding.RcclGather(world, rank, dev, n_comms=1)
+        elif rank == 0:
+            print("[bench] direct RCCL gather unavailable on some rank; using torch.distributed's all_gather", file=sys.stderr)
     torch.cuda.synchronize(dev)  # inputs and zeroed buffers are in place before any side stream starts
 
     def step():
@@ -255,7 +261,7 @@ def main():
             ctxs[j].process_raw(descs, B, capi.FX_IN_DEVICE)
             ctxs[j].pack_keypoint_records(recs[j].data_ptr(), REC_KP)
             if rccl is not None:  # the path's one collective, an ordinary kernel of this context's stream
-                rccl.all_gather(recs[j], gathered[j], streams[j].cuda_stream, comm=j)
+                rccl.all_gather(recs[j], gathered[j], streams[j].cuda_stream, comm=0)
             elif use_dist:
                 _tab, pending[j] = sharding.all_gather_records(recs[j], world, out=gathered[j], async_op=True)
 
@@ -304,20 +310,12 @@ def main():
     drain()
     torch.cuda.synchronize(dev)
     stage_ms = mean_timings(n_sel)
-    # The roofline line is about ONE kernel: among the stages that are a single launch (a HIP-event span around several
-    # launches is mostly queueing when other batches are in flight), the longest — or the kernel the committed rocprofv3
-    # summary of this command names (profiles/dominant.json: its top AverageNs row), as long as it is within a quarter of it.
+    # The roofline line is about ONE kernel: the longest of the stages that are a single launch (a HIP-event span around
+    # several launches is mostly queueing when other batches are in flight).
     singles = {k: stage_ms[k] for k in capi.SINGLE_LAUNCH_STAGES}
     dom = max(singles, key=singles.get)
-    dom_rule = f"longest single-launch stage over {n_sel} profiled steps per context before the timed region"
-    try:
-        hint = json.load(open(os.path.join(ROOT, "profiles", "dominant.json")))["kernel"]
-        if hint in singles and singles[hint] >= 0.75 * singles[dom]:
-            dom = hint
-            dom_rule = ("top AverageNs kernel of the committed rocprofv3 summary (profiles/dominant.json), confirmed within 25 % of the "
-                        f"longest single-launch stage over {n_sel} profiled steps per context before the timed region")
-    except Exception:
-        pass
+    dom_rule = (f"longest single-launch stage (HIP-event mean over {n_sel} profiled steps per context, {K} batches in flight) "
+                "measured in this run before the timed region")
     if use_dist:  # every rank times the same kernel
         names = list(capi.STAGE_NAMES)
         t = torch.tensor([names.index(dom)], dtype=torch.int64, device=dev)
@@ -350,6 +348,7 @@ def main():
     v = ctx.process_raw(descs, B, capi.FX_IN_DEVICE | capi.FX_OUT_HOST)
     k_total = int(v.total_keypoints)
     flags_or = int(np.bitwise_or.reduce(np.ctypeslib.as_array(v.h_flags, shape=(B,)))) if B else 0
+    stage_bytes = ctx.stage_bytes()  # algorithmic bytes (read, written) of every stage of that batch, from its own counts
     n_chk = min(args.check, B) if rank == 0 else 0
     res = []
     if n_chk:
@@ -384,10 +383,13 @@ def main():
                 kchk += st["K"]
             parity = {"scans_checked": n_chk, "keypoints_checked": kchk, "keypoint_f1_vs_oracle": 1.0,
                       "cluster_membership": "exact", "descriptor_max_abs_diff": worst}
-        # algorithmic bytes per launch of the dominant kernel = B_alg per scan x scans per launch
-        # (16 N read + 16 K + 7956 K written per scan; K measured, this rank's batch)
-        alg_bytes = 16.0 * N * B + (16.0 + 7956.0) * k_total
-        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+        # Whole path: 16 N read + 16 K + 7956 K written per scan; K measured, this rank's batch.
+        path_bytes = 16.0 * N * B + (16.0 + 7956.0) * k_total
+        # The named kernel's OWN algorithmic bytes per launch (fx_get_stage_bytes: what it must read of its inputs and write
+        # of its outputs, once each, from the batch's counts): the bandwidth statement about that kernel.
+        own_r, own_w = stage_bytes[dom]
+        own_bytes = own_r + own_w
+        achieved = own_bytes / (dom_ms * 1e-3) / 1e9
         ms_per_step = elapsed / args.steps * 1e3
         traffic = traffic_total = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -399,6 +401,12 @@ def main():
                 traffic_total = sum(x for k, x in tj.items() if k.startswith("k_"))
             except Exception:
                 traffic = traffic_total = None
+        flag_msg = None
+        if use_dist:  # the gathered records carry every scan's flags: a truncated record (more keypoints than the stride) shows here
+            last = (counter[0] - 1) % K
+            hdr = gathered[last].view(torch.int32)[:, 0, :2].cpu().numpy()
+            flag_msg = int(np.bitwise_or.reduce(hdr[:, 1])) if len(hdr) else 0
+            assert flag_msg == 0, f"gathered keypoint records carry flags 0x{flag_msg:x} (0x4: more keypoints than the record stride)"
         out = {
             "metric": "VLP-16 scans/sec (16x1800 pts), detector+descriptor", "value": world * B * args.steps / elapsed,
             "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -408,21 +416,35 @@ def main():
                                    f"device-resident, preset '{args.preset}', roll/pitch 0.02/-0.015",
                        "scans_per_gpu": B, "points_per_scan": N, "preset": args.preset,
                        "parallelism": f"frame-sharded x{world}" + (", all-gather of keypoint records (RCCL)" if world > 1 else ""),
-                       "keypoints_per_scan": k_all / (world * B), "flags_or": flags_or, "batches_in_flight": K},
+                       "keypoints_per_scan": k_all / (world * B), "flags_or": flags_or, "batches_in_flight": K,
+                       "gathered_record_flags_or": flag_msg},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "alg_bytes_per_launch": alg_bytes, "kernel_ms": dom_ms,
-                         "timed": "HIP events around this kernel on the launch stream, inside the timed region",
+                         "definition": "achieved = this kernel's own algorithmic bytes per launch (alg_bytes_read + alg_bytes_written, "
+                                       "fx_get_stage_bytes) / kernel_ms; path_frac = the whole path's algorithmic bytes per step "
+                                       "(SURVEY.md 8d) / ms_per_step / peak: the figure to hold against north_star's 0.40",
+                         "alg_bytes_per_launch": own_bytes, "alg_bytes_read": own_r, "alg_bytes_written": own_w,
+                         "kernel_ms": dom_ms,
+                         "kernel_ms_source": f"HIP events around this kernel on the launch stream, inside the timed region, {K} batches in flight "
+                                             "(also counts the launch's wait for free CUs behind the other batches)",
                          "selected_by": dom_rule,
                          "longest_stage": max(stage_ms, key=stage_ms.get),
-                         # the kernel's own measured HBM bytes over its duration, and the whole path against the peak
-                         # the kernel's execution span on the device clock (what rocprofv3 calls its duration; the HIP-event
-                         # span above also counts the launch's wait for free CUs behind the other batches in flight)
+                         # the kernel's execution span on the device clock (what rocprofv3 calls its duration)
                          "kernel_exec_ms": dom_exec_ms,
-                         "frac_exec": (alg_bytes / (dom_exec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if dom_exec_ms else None,
+                         "kernel_exec_ms_source": "device clock, first workgroup's start to last workgroup's end (k_prep only): what rocprofv3 reports",
+                         "frac_exec": (own_bytes / (dom_exec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if dom_exec_ms else None,
                          "kernel_traffic_gbs": (traffic / (dom_ms * 1e-3) / 1e9) if traffic else None,
-                         "path_frac": alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "traffic_total": traffic_total},
+                         "path_alg_bytes_per_step": path_bytes,
+                         "path_frac": path_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         # the task statement's literal reading (the per-scan figure x scans / ONE kernel's time): kept for
+                         # comparison with earlier rounds, not a bandwidth statement about any kernel
+                         "path_bytes_over_kernel_ms_frac": path_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "traffic_total": traffic_total,
+                         "traffic_over_path_alg_bytes": (traffic_total / path_bytes) if traffic_total else None,
+                         # every stage's own bytes and the fraction they make of the peak over the stage's pre-pass duration
+                         "stage_alg_bytes": {k: [r, w] for k, (r, w) in stage_bytes.items()},
+                         "stage_frac": {k: ((r + w) / (stage_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS if stage_ms.get(k) else None)
+                                        for k, (r, w) in stage_bytes.items()}},
             "kernel_ms": stage_ms,
             "kernel_ms_source": f"all stages: {n_sel * K} profiled steps before the timed region, {K} batches in flight",
             "parity": parity,

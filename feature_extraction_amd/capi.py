@@ -85,6 +85,10 @@ class FxTimings(C.Structure):
     _fields_ = [("ms", C.c_float * FX_N_STAGES), ("total_ms", C.c_float), ("k_prep_exec_ms", C.c_float)]
 
 
+class FxStageBytes(C.Structure):
+    _fields_ = [("read", C.c_double * FX_N_STAGES), ("written", C.c_double * FX_N_STAGES)]
+
+
 class FxSynthCfg(C.Structure):
     _fields_ = [("n_rings", C.c_uint32), ("n_az", C.c_uint32), ("el0_deg", C.c_double), ("el_step_deg", C.c_double),
                 ("n_poles", C.c_uint32), ("pole_radius", C.c_double), ("pole_height", C.c_double),
@@ -95,7 +99,7 @@ class FxSynthCfg(C.Structure):
 # every symbol include/fx.h declares (tests/test_capi_symbols.py checks the list against the header)
 EXPORTS = ("fx_version", "fx_status_str", "fx_last_error", "fx_params_default", "fx_params_launch",
            "fx_limits_default", "fx_create", "fx_destroy", "fx_set_stream", "fx_get_stream", "fx_set_graph_batch", "fx_set_profiling", "fx_set_profiling_stages", "fx_get_timings",
-           "fx_get_limits", "fx_process_batch", "fx_synchronize", "fx_pack_features", "fx_pack_keypoint_records",
+           "fx_get_stage_bytes", "fx_get_limits", "fx_process_batch", "fx_synchronize", "fx_pack_features", "fx_pack_keypoint_records",
            "fx_rotation_from_roll_pitch", "fx_sc3d_tables", "fx_sc3d_xaxis", "fx_synth_cfg_vlp16",
            "fx_synth_scan", "fx_test_sort_replay", "fx_test_sort_replay_ranked", "fx_test_sort_replay_lists", "fx_test_sort_replay_device", "fx_unpack_pointcloud2",
            "fx_pack_pointxyzi")
@@ -139,6 +143,7 @@ def load():
     lib.fx_get_stream.restype = C.c_int
     lib.fx_get_timings.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(FxTimings)]
     lib.fx_get_limits.argtypes = [C.c_void_p, C.POINTER(FxLimits)]
+    lib.fx_get_stage_bytes.argtypes = [C.c_void_p, C.POINTER(FxStageBytes)]
     lib.fx_process_batch.argtypes = [C.c_void_p, C.POINTER(FxScanDesc), C.c_uint32, C.c_uint32,
                                      C.POINTER(FxBatchView)]
     lib.fx_process_batch.restype = C.c_int
@@ -277,6 +282,12 @@ class Context:
         check(self.lib.fx_get_timings(self.handle, back, C.byref(t)))
         self.last_k_prep_exec_ms = t.k_prep_exec_ms
         return {STAGE_NAMES[i]: t.ms[i] for i in range(FX_N_STAGES)}, t.total_ms
+
+    def stage_bytes(self):
+        """Algorithmic bytes (read, written) per stage of the last batch: {stage: (read, written)}."""
+        sb = FxStageBytes()
+        check(self.lib.fx_get_stage_bytes(self.handle, C.byref(sb)))
+        return {STAGE_NAMES[i]: (sb.read[i], sb.written[i]) for i in range(FX_N_STAGES)}
 
     def pack_keypoint_records(self, dst_device_ptr, rec_keypoints):
         check(self.lib.fx_pack_keypoint_records(self.handle, C.c_void_p(dst_device_ptr), rec_keypoints))

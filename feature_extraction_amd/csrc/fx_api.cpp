@@ -599,6 +599,69 @@ fx_status fx_get_timings(fx_ctx *c, uint32_t back, fx_timings *t) {
   }
   return FX_OK;
 }
+// Algorithmic bytes per stage of the last batch, from the batch's own counts (diagnostic: small device-to-host copies).
+fx_status fx_get_stage_bytes(fx_ctx *c, fx_stage_bytes *out) {
+  if (!c || !out) return fail(FX_ERR_INVALID_ARG, "null argument");
+  std::memset(out, 0, sizeof(*out));
+  const uint32_t B = c->last_batch;
+  if (!B) return FX_OK;
+  FX_HIP(hipSetDevice(c->device));
+  FX_HIP(hipStreamSynchronize(c->stream));
+  const fx_limits &L = c->lim;
+  const FxBuffers &b = c->buf;
+  const size_t R = (size_t)c->params.n_rings;
+  auto fetch = [&](const uint32_t *src, size_t n, std::vector<uint32_t> &v) -> hipError_t {
+    v.resize(n);
+    return n ? hipMemcpy(v.data(), src, n * 4, hipMemcpyDeviceToHost) : hipSuccess;
+  };
+  std::vector<uint32_t> n_filt, ring_cnt, ring_cand, kpc_ring, n_cand, n_kp, n_kpc, kp_off, s_cnt, near;
+  std::vector<FxScanMeta> meta(B);
+  FX_HIP(hipMemcpy(meta.data(), c->d_meta, (size_t)B * sizeof(FxScanMeta), hipMemcpyDeviceToHost));
+  FX_HIP(fetch(b.n_filt, B, n_filt));
+  FX_HIP(fetch(b.ring_cnt, B * R, ring_cnt));
+  FX_HIP(fetch(b.ring_cand_cnt, B * R, ring_cand));
+  FX_HIP(fetch(b.kpc_ring_cnt, B * R, kpc_ring));
+  FX_HIP(fetch(b.n_cand, B, n_cand));
+  FX_HIP(fetch(b.n_kp, B, n_kp));
+  FX_HIP(fetch(b.n_kpc, B, n_kpc));
+  FX_HIP(fetch(b.kp_offset, B + 1, kp_off));
+  uint32_t total_kp = kp_off[B] < L.max_total_keypoints ? kp_off[B] : L.max_total_keypoints;
+  FX_HIP(fetch(b.s_cnt, total_kp, s_cnt));
+  FX_HIP(fetch(b.near_bits, (size_t)B * c->dp.near_words, near));
+  double n_pts = 0, nf = 0, n_ring = 0, n_rc = 0, n_mem = 0, nc = 0, nk = 0, nkpc = 0, near_pts = 0;
+  for (uint32_t i = 0; i < B; ++i) {
+    n_pts += meta[i].n, nf += n_filt[i], nc += n_cand[i], nk += n_kp[i], nkpc += n_kpc[i];
+    for (size_t r = 0; r < R; ++r) n_ring += ring_cnt[i * R + r], n_rc += ring_cand[i * R + r], n_mem += kpc_ring[i * R + r];
+    if (n_kp[i]) {  // (k_gather does not touch a scan without keypoints)
+      const uint32_t words = (meta[i].n + 127u) / 128u;  // one bit per four points
+      for (uint32_t w = 0; w < words && w < c->dp.near_words; ++w) near_pts += 4.0 * __builtin_popcount(near[(size_t)i * c->dp.near_words + w]);
+    }
+  }
+  double s_small = 0, s_mid = 0, s_dense = 0, rows_mid = 0, rows_dense = 0;
+  for (uint32_t r = 0; r < total_kp; ++r) {
+    const double n = s_cnt[r];
+    if (s_cnt[r] > c->dp.dense_min || s_cnt[r] > c->dp.list_cap)
+      s_dense += n, rows_dense += 1;
+    else if (s_cnt[r] > 64u)
+      s_mid += n, rows_mid += 1;
+    else
+      s_small += n;
+  }
+  const bool desc = c->params.estimate_descriptors != 0;
+  double *rd = out->read, *wr = out->written;
+  rd[0] = 16.0 * n_pts, wr[0] = 16.0 * nf + n_pts / 32.0 + 4.0 * R * B;      // k_prep: the scan; ~cloud, near-sector bits, ring counts
+  rd[1] = 16.0 * nf, wr[1] = 16.0 * n_ring;                                     // k_bucket: ~cloud; ring-major copy
+  rd[2] = 16.0 * n_ring, wr[2] = 20.0 * n_rc + 20.0 * n_mem;                   // ring tiers: ring points; candidates + sizes, members + their candidate
+  rd[3] = 0, wr[3] = 0;                                                         // (the larger ring tiers' share is counted with the first)
+  rd[4] = 20.0 * n_rc + 20.0 * n_mem, wr[4] = 24.0 * nc + 20.0 * nk + 20.0 * nkpc;  // merge: candidates, members; keypoints_full + maps, keypoints, keypoint_cloud
+  if (desc) {
+    rd[5] = 16.0 * near_pts + 16.0 * nk, wr[5] = 16.0 * (s_small + s_mid + s_dense) + 40.0 * nk;  // k_gather: near sectors; support lists + row tables
+    rd[6] = 16.0 * s_small + 44.0 * total_kp, wr[6] = 7956.0 * total_kp;       // k_desc_group: short lists; every row (cleared here)
+    rd[7] = 16.0 * s_mid, wr[7] = 0.0 * rows_mid;                               // k_desc_mid: lists; (non-empty bins of rows already counted)
+    rd[8] = 16.0 * s_dense, wr[8] = 0.0 * rows_dense;                           // dense tier: lists
+  }
+  return FX_OK;
+}
 fx_status fx_synchronize(fx_ctx *c) {
   if (!c) return fail(FX_ERR_INVALID_ARG, "null ctx");
   FX_HIP(hipStreamSynchronize(c->stream));

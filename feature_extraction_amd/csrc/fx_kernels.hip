@@ -3288,6 +3288,7 @@ extern "C" __global__ __launch_bounds__(FX_DSORT_T) void k_dense_sort(FxDevParam
   __shared__ uint32_t s_w[16];
   const uint32_t tid = threadIdx.x;
   __shared__ uint32_t s_slot;
+  if (B.counters[6] == 0u) return;  // no dense rows in this batch (sparse scans): not even a ticket is drawn
   const unsigned long long seq = B.seq[0];
   FX_STAMP_INIT(B.stamps ? B.stamps + 16 : nullptr);
   while (true) {
@@ -3499,6 +3500,7 @@ extern "C" __global__ __launch_bounds__(FX_DDENS_T) void k_dense_density(FxDevPa
   __shared__ uint32_t s_w[16];
   const uint32_t tid = threadIdx.x;
   const uint32_t n_items = B.counters[14];
+  if (n_items == 0u) return;
   const unsigned long long tag = B.seq[0] << FX_DENS_BITS;
   const float r2d = P.r2_density;
   const float r_d = sqrtf(r2d);
@@ -3827,6 +3829,7 @@ __device__ __forceinline__ void dense_finish_row(const FxDevParams &P, const FxB
 template <int KMAX, int NT, bool LARGE>
 __device__ __forceinline__ void dense_finish_loop(const FxDevParams &P, const FxBuffers &B) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  if (B.counters[6] == 0u) return;  // no dense rows in this batch
   uint32_t *tl = smem + 2 * KMAX + KMAX / 2 + 1984;
   const FxScTables *T = tables_to_lds(B, tl);
   uint32_t *s_slot = tl + FX_TABLE_WORDS + 8;
@@ -4060,9 +4063,9 @@ void fxk_desc_mid(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint3
   hipLaunchKernelGGL(k_desc_mid, dim3(n_wg + n_wave), dim3(FX_WG), lds_wave > lds_wg ? lds_wave : lds_wg, s, P, B, batch, cap, n_wg);
 }
 void fxk_dense(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t n_cu) {
-  hipLaunchKernelGGL(k_dense_sort, dim3(n_cu * 4), dim3(FX_DSORT_T), 0, s, P, B);
+  hipLaunchKernelGGL(k_dense_sort, dim3(n_cu * 2), dim3(FX_DSORT_T), 0, s, P, B);  // (what is resident at once: the rows are taken by ticket)
   hipLaunchKernelGGL(k_dense_density, dim3(n_cu * 3), dim3(FX_DDENS_T), 0, s, P, B);
-  hipLaunchKernelGGL(k_dense_finish_s, dim3(n_cu * 4), dim3(FX_DFIN_TS), fxk_dense_finish_lds_bytes(0), s, P, B);
+  hipLaunchKernelGGL(k_dense_finish_s, dim3(n_cu * 3), dim3(FX_DFIN_TS), fxk_dense_finish_lds_bytes(0), s, P, B);
   hipLaunchKernelGGL(k_dense_finish_l, dim3(n_cu), dim3(FX_DFIN_TL), fxk_dense_finish_lds_bytes(1), s, P, B);
 }
 void fxk_test_sort_replay(hipStream_t s, const uint32_t *sizes, uint32_t n_seq, uint32_t n, uint32_t *perm) {

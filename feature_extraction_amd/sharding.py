@@ -72,16 +72,37 @@ class RcclGather:
     (the librccl.so torch ships, so the process keeps ONE RCCL).  torch.distributed brings the ranks up and carries the
     unique ids; the collective itself is then an ordinary kernel of the context's own stream — no side stream, no
     cross-stream events (through torch.distributed's stream juggling the same gather cost 19 % of the throughput with
-    three batches in flight, this way 2 %).  One communicator per context in flight, so that the contexts' streams
-    are not tied to each other through a shared communicator's ordering.  csrc/fx_multi.hpp does the same from C++."""
+    three batches in flight, this way 2 %).  bench.py uses ONE communicator for all contexts in flight and issues the
+    gathers in step order on every rank — RCCL's ordering contract; several communicators per device (n_comms > 1) are
+    only safe when their kernels can always run side by side.  csrc/fx_multi.hpp does the same from C++."""
 
-    def __init__(self, world, rank, device, n_comms=1):
+    @staticmethod
+    def _load():
         import ctypes as C
         import os
         import torch
+        lib = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+        for sym in ("ncclGetUniqueId", "ncclCommInitRank", "ncclAllGather", "ncclCommDestroy", "ncclGetErrorString"):
+            getattr(lib, sym)
+        return lib
+
+    @staticmethod
+    def available():
+        """True when RCCL's C API can be loaded in this process.  Every rank checks this (and the ranks agree on the
+        answer through a collective) BEFORE any communicator is created: a rank that failed later would leave the
+        others waiting inside ncclCommInitRank."""
+        try:
+            RcclGather._load()
+            return True
+        except (OSError, AttributeError):
+            return False
+
+    def __init__(self, world, rank, device, n_comms=1):
+        import ctypes as C
+        import torch
         import torch.distributed as dist
         self.C, self.world, self.rank = C, world, rank
-        self.lib = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+        self.lib = self._load()
         self.lib.ncclGetErrorString.restype = C.c_char_p
 
         class _Uid(C.Structure):  # ncclUniqueId is passed by value

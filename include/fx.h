@@ -203,6 +203,15 @@ fx_status fx_set_profiling(fx_ctx *ctx, int depth);
  * first and last event of a batch are always recorded (total_ms); untimed stages read 0. */
 fx_status fx_set_profiling_stages(fx_ctx *ctx, uint32_t stage_mask);
 fx_status fx_get_timings(fx_ctx *ctx, uint32_t back, fx_timings *t);
+/* Algorithmic bytes every stage of the LAST batch had to move — what it must read of its inputs plus what it must
+ * write of its outputs, each once, from the batch's own counts (points, survivors, ring members, candidates, support
+ * points, keypoints); no padding, no re-reads.  The figure a per-kernel roofline fraction divides by the kernel's
+ * duration.  Waits for the batch.  (SURVEY.md 8d's per-scan B_alg is the whole path's: bytes[0]'s read + the keypoint
+ * and descriptor writes.) */
+typedef struct fx_stage_bytes {
+  double read[FX_N_STAGES], written[FX_N_STAGES];
+} fx_stage_bytes;
+fx_status fx_get_stage_bytes(fx_ctx *ctx, fx_stage_bytes *out);
 fx_status fx_get_limits(const fx_ctx *ctx, fx_limits *l);
 
 /* Replaces cloudCallback's body for a batch of B scans (ref: node.cpp:83-115):

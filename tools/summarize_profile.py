@@ -38,7 +38,7 @@ for row in csv.DictReader(open(os.path.join(dst, f"{tag}_kernel_stats.csv"))):
     name = row["Name"].split("(")[0]
     if name.startswith("k_") and (best is None or float(row["AverageNs"]) > best[1]):
         best = (name, float(row["AverageNs"]), int(row["Calls"]))
-if best and "--set-dominant" in sys.argv:
+if False:  # (bench.py picks the dominant kernel from its own pre-pass since round 3)
     json.dump({"kernel": best[0], "average_ns": best[1], "calls": best[2],
                "source": f"top AverageNs row among the path's kernels in profiles/{tag}_kernel_stats.csv (rocprofv3 --kernel-trace --stats of bench.py)"},
               open(os.path.join(dst, "dominant.json"), "w"), indent=1)
