@@ -76,6 +76,26 @@ def build_multi(force=False, verbose=False):
     return MULTI
 
 
+ROS_MOCK_NODE = os.path.join(HERE, "bin", "fx_ros_mock_node")
+
+
+def build_ros_mock(force=False, verbose=False):
+    """The ROS1 shell (ros/feature_extraction_node.cpp) compiled against the stand-in headers of tests/ros_mock — test
+    infrastructure, NOT roscpp (ROS is not installable here); the real build goes through ros/CMakeLists.txt."""
+    root = os.path.dirname(HERE)
+    mock = os.path.join(root, "tests", "ros_mock")
+    src = os.path.join(root, "ros", "feature_extraction_node.cpp")
+    deps = [src, os.path.join(CSRC, "fx_node.hpp"), LIB] + [os.path.join(d, f) for d, _, fs in os.walk(mock) for f in fs]
+    if force or not _newer(ROS_MOCK_NODE, deps):
+        os.makedirs(os.path.dirname(ROS_MOCK_NODE), exist_ok=True)
+        cmd = ["g++", "-O1", "-std=c++17", "-Wall", "-I", mock, "-o", ROS_MOCK_NODE, src, "-L" + os.path.dirname(LIB), "-lfx_hip",
+               "-Wl,-rpath," + os.path.dirname(LIB)]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return ROS_MOCK_NODE
+
+
 def build(force=False, verbose=False):
     if force or stale():
         os.makedirs(os.path.dirname(LIB), exist_ok=True)

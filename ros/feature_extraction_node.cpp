@@ -6,9 +6,11 @@
 // sensor_msgs and tf only: no PCL, pcl_ros or pcl_conversions — it reads and writes the PointCloud2
 // byte layouts those libraries would produce.
 //
-// NOT BUILT IN THE DEVELOPMENT IMAGE: ROS is not installed there (no network).  ros/CMakeLists.txt
-// builds it where catkin, roscpp, sensor_msgs and tf exist; everything below the message handling
-// (fx_node.hpp, include/fx.h) is what the test-suite exercises.
+// ROS is not installable in the development image (no network), so this file has never been built against roscpp:
+// the test-suite compiles it against the stand-in headers of tests/ros_mock (a mock, clearly not ROS) and drives
+// imuCallback / cloudCallback with a driver-style PointCloud2 and an Imu (tests/test_ros_shell.py: the four published
+// byte buffers against the oracle and against fx_pack_features / fx_pack_pointxyzi).  ros/CMakeLists.txt builds it
+// where catkin, roscpp, sensor_msgs and tf exist.
 #include <ros/ros.h>
 #include <sensor_msgs/Imu.h>
 #include <sensor_msgs/PointCloud2.h>
