@@ -76,6 +76,23 @@ def build_multi(force=False, verbose=False):
     return MULTI
 
 
+BATCHER = os.path.join(HERE, "bin", "fx_batcher_cli")
+
+
+def build_batcher(force=False, verbose=False):
+    """Streaming front end (csrc/fx_batcher.hpp: producers push scans, one consumer batches whatever has arrived) and its
+    simulated-sensors driver."""
+    deps = [os.path.join(CSRC, s) for s in ("fx_batcher_cli.cpp", "fx_batcher.hpp", "fx_node.hpp")] + [LIB]
+    if force or not _newer(BATCHER, deps):
+        os.makedirs(os.path.dirname(BATCHER), exist_ok=True)
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-pthread", "-o", BATCHER, os.path.join(CSRC, "fx_batcher_cli.cpp"),
+               "-L" + os.path.dirname(LIB), "-lfx_hip", "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath," + os.path.dirname(LIB)]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return BATCHER
+
+
 ROS_MOCK_NODE = os.path.join(HERE, "bin", "fx_ros_mock_node")
 
 
@@ -104,7 +121,11 @@ def build(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd)
     build_cli(force, verbose)
-    build_multi(force, verbose)
+    build_batcher(force, verbose)
+    try:  # the multi-GPU driver needs RCCL's development files: without them the library and everything else still build
+        build_multi(force, verbose)
+    except (subprocess.CalledProcessError, OSError) as e:
+        print(f"[fx build] fx_multi_cli not built ({e}); tests/test_gpu_multi.py and tests/test_cpp_sharding.py build it on demand")
     return LIB
 
 

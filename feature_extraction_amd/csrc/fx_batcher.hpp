@@ -1,0 +1,184 @@
+// fx_batcher.hpp — streaming front end for nodes that fan in several sensors.
+//
+// The reference node handles one scan per callback, single-threaded, with subscriber queues of size 0 = unbounded
+// (ref: src/feature_extraction_node.cpp:47-48, 386): a scan that arrives while another is being processed waits in
+// the queue, and N sensors cost N callbacks in a row.  On the GPU a batch of a few scans costs barely more than one
+// scan (0.38 ms for one, 0.63 ms for eight), so the policy here is: never wait for a batch to fill —
+// whenever the GPU is free, take WHATEVER HAS ARRIVED (up to max_batch scans) as one batch.  Under light load that is
+// one scan at a time at the single-scan latency; when scans arrive faster than batches finish, the batches grow by
+// themselves and the throughput follows.  Small batch sizes are replayed as one HIP graph each (fx_set_graph_batch).
+//
+// Threads: any number of producers call push() (the scan is copied: the caller's buffer is free on return); one
+// consumer thread owns the fx_ctx (a context is not thread-safe), runs the batches and hands every scan's result to
+// the callback, in arrival order.  No CPU fallback: construction fails without a GPU.
+#ifndef FX_BATCHER_HPP_
+#define FX_BATCHER_HPP_
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/fx.h"
+#include "fx_node.hpp"
+
+namespace fx {
+
+class StreamBatcher {
+ public:
+  struct Result {
+    uint64_t id = 0;        // what push() returned
+    uint32_t sensor = 0;
+    uint32_t flags = 0;     // FX_FLAG_* of the scan
+    uint32_t batch = 0;     // scans in the batch it rode in
+    double latency_ms = 0;  // push() to callback
+    PointCloud keypoints;         // ~keypoints (ref: node.cpp:129-131)
+    DescriptorCloud descriptors;  // ~features payload (ref: node.cpp:113-124)
+  };
+  using Callback = std::function<void(Result &&)>;
+  struct Stats {
+    uint64_t scans = 0, batches = 0;
+    uint32_t largest_batch = 0;
+  };
+
+  StreamBatcher(const fx_params &params, uint32_t max_batch, uint32_t max_points, int device, Callback cb)
+      : cb_(std::move(cb)), max_batch_(max_batch), max_points_(max_points) {
+    fx_limits lim;
+    fx_limits_default(&lim, max_batch, max_points);
+    if (fx_create(&params, &lim, device, &ctx_) != FX_OK) throw std::runtime_error(std::string("fx_create: ") + fx_last_error());
+    fx_set_graph_batch(ctx_, max_batch < 16u ? max_batch : 16u);  // the launch-bound sizes: one graph per batch size
+    estimate_descriptors_ = params.estimate_descriptors != 0;
+    consumer_ = std::thread([this] { run(); });
+  }
+  ~StreamBatcher() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    if (consumer_.joinable()) consumer_.join();
+    if (ctx_) fx_destroy(ctx_);
+  }
+  StreamBatcher(const StreamBatcher &) = delete;
+  StreamBatcher &operator=(const StreamBatcher &) = delete;
+
+  // One scan of one sensor: n_points records of stride_bytes (16: packed x y z i; 32: pcl::PointXYZI in memory), with the
+  // attitude that goes with it (ref: node.h:116).  Thread-safe; returns the scan's id.
+  uint64_t push(uint32_t sensor, const void *points, uint32_t n_points, uint32_t stride_bytes, double roll, double pitch) {
+    if (n_points > max_points_) throw std::invalid_argument("fx::StreamBatcher::push: scan larger than max_points");
+    if (stride_bytes < 16 || stride_bytes % 16) throw std::invalid_argument("fx::StreamBatcher::push: stride_bytes must be a multiple of 16");
+    Pending p;
+    p.sensor = sensor;
+    p.n = n_points;
+    p.roll = roll, p.pitch = pitch;
+    p.xyzi.resize((size_t)n_points * 4);
+    const uint8_t *src = static_cast<const uint8_t *>(points);
+    if (stride_bytes == 16) {
+      if (n_points) std::memcpy(p.xyzi.data(), src, (size_t)n_points * 16);
+    } else {
+      for (uint32_t i = 0; i < n_points; ++i) std::memcpy(&p.xyzi[(size_t)i * 4], src + (size_t)i * stride_bytes, 16);
+    }
+    p.t0 = std::chrono::steady_clock::now();
+    uint64_t id;
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      if (!error_.empty()) throw std::runtime_error(error_);
+      id = p.id = next_id_++;
+      queue_.push_back(std::move(p));
+    }
+    cv_.notify_all();
+    return id;
+  }
+  // Returns when every scan pushed so far has been delivered (or throws what stopped the consumer).
+  void flush() {
+    std::unique_lock<std::mutex> lk(m_);
+    const uint64_t upto = next_id_;
+    cv_.wait(lk, [&] { return delivered_ >= upto || !error_.empty(); });
+    if (!error_.empty()) throw std::runtime_error(error_);
+  }
+  Stats stats() const {
+    std::lock_guard<std::mutex> lk(m_);
+    return stats_;
+  }
+
+ private:
+  struct Pending {
+    uint64_t id = 0;
+    uint32_t sensor = 0, n = 0;
+    double roll = 0, pitch = 0;
+    std::vector<float> xyzi;
+    std::chrono::steady_clock::time_point t0;
+  };
+  void run() {
+    std::vector<Pending> batch;
+    std::vector<fx_scan_desc> descs;
+    while (true) {
+      batch.clear();
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return stop_ || !queue_.empty(); });
+        if (queue_.empty()) return;  // (stop, and everything delivered)
+        // whatever has arrived, up to the context's batch capacity; nothing is waited for
+        while (!queue_.empty() && batch.size() < max_batch_) {
+          batch.push_back(std::move(queue_.front()));
+          queue_.pop_front();
+        }
+      }
+      descs.resize(batch.size());
+      for (size_t i = 0; i < batch.size(); ++i)
+        descs[i] = fx_scan_desc{batch[i].xyzi.data(), batch[i].n, 16, batch[i].roll, batch[i].pitch};
+      fx_batch_view v;
+      if (fx_process_batch(ctx_, descs.data(), (uint32_t)batch.size(), FX_OUT_HOST, &v) != FX_OK) {
+        std::lock_guard<std::mutex> lk(m_);
+        error_ = std::string("fx_process_batch: ") + fx_last_error();
+        cv_.notify_all();
+        return;
+      }
+      for (size_t i = 0; i < batch.size(); ++i) {
+        Result r;
+        r.id = batch[i].id;
+        r.sensor = batch[i].sensor;
+        r.flags = v.h_flags[i];
+        r.batch = (uint32_t)batch.size();
+        const uint32_t K = v.h_n_keypoints[i];
+        r.keypoints.resize(K);
+        if (K) std::memcpy(r.keypoints.data(), v.h_keypoints + (size_t)i * v.max_keypoints * 4, (size_t)K * sizeof(Point));
+        if (estimate_descriptors_ && K) {
+          r.descriptors.resize(K);
+          std::memcpy(r.descriptors.data(), v.h_descriptors + (size_t)v.h_kp_offset[i] * FX_DESC_FLOATS, (size_t)K * sizeof(Descriptor));
+        }
+        r.latency_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - batch[i].t0).count();
+        cb_(std::move(r));
+      }
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        delivered_ += batch.size();
+        stats_.scans += batch.size();
+        stats_.batches += 1;
+        if (batch.size() > stats_.largest_batch) stats_.largest_batch = (uint32_t)batch.size();
+      }
+      cv_.notify_all();
+    }
+  }
+
+  Callback cb_;
+  uint32_t max_batch_, max_points_;
+  bool estimate_descriptors_ = true;
+  fx_ctx *ctx_ = nullptr;
+  mutable std::mutex m_;
+  std::condition_variable cv_;
+  std::deque<Pending> queue_;
+  std::thread consumer_;
+  bool stop_ = false;
+  uint64_t next_id_ = 0, delivered_ = 0;
+  std::string error_;
+  Stats stats_;
+};
+
+}  // namespace fx
+#endif

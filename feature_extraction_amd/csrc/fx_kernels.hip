@@ -2252,6 +2252,9 @@ __device__ __forceinline__ unsigned long long sc3d_key(uint32_t bin, float d2, u
 #ifndef FX_GATHER_STAGE
 #define FX_GATHER_STAGE 384  // hits one workgroup stages between flushes (a larger stage costs more in occupancy than it saves in flushes)
 #endif
+#ifndef FX_GATHER_DIRECT
+#define FX_GATHER_DIRECT 1   // one workgroup per scan: hits go straight to their list slots (positions are LDS counters)
+#endif
 #ifndef FX_GATHER_QUEUE
 #define FX_GATHER_QUEUE 80   // points one wavefront parks before it drains them (drained once more than 16 are waiting)
 #endif
@@ -2437,11 +2440,14 @@ extern "C" __global__ __launch_bounds__(FX_GATHER_T) void k_gather(FxDevParams P
             else
               B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = 1u;  // (cleared by the merge stage; k_rng_ord reads it)
           }
-          const uint32_t slot = atomicAdd(&s_w[8], 1u);
+          // One workgroup per scan: the list position is the workgroup's own LDS counter, so the hit goes straight to
+          // its slot (no staging, no flush, no workgroup barrier in the tile loop).  Several workgroups per scan
+          // (small batches): hits are staged and a flush reserves positions with one global atomic per keypoint.
+          const uint32_t slot = (FX_GATHER_DIRECT && solo) ? FX_GATHER_STAGE : atomicAdd(&s_w[8], 1u);
           if (slot < FX_GATHER_STAGE) {
             s_spt[slot] = pq;
             s_smeta[slot] = (k << 16) | atomicAdd(&s_kcnt[k], 1u);
-          } else {  // stage full (a burst of hits within one tile): append directly
+          } else {  // (also: stage full — a burst of hits within one tile)
             const uint32_t pos = solo ? atomicAdd(&s_kpos[k], 1u) : atomicAdd(&B.s_cnt[row0 + k], 1u);
             if (pos < P.list_cap) {
               B.s_pts[(size_t)(row0 + k) * P.list_cap + pos] = pq;
@@ -2480,7 +2486,7 @@ extern "C" __global__ __launch_bounds__(FX_GATHER_T) void k_gather(FxDevParams P
   for (uint32_t i0 = lo; i0 < hi; i0 += kTile) {
     nnib = near_sectors(i0 + kTile);
     load_tile(i0 + kTile, nnib, nv);  // the next tile's loads are in flight while this one is tested
-    if (i0 != lo) {  // flush when the next tile might not fit any more (workgroup-uniform decision)
+    if (i0 != lo && !(FX_GATHER_DIRECT && solo)) {  // flush when the next tile might not fit any more (workgroup-uniform decision)
       __syncthreads();
       const uint32_t staged = s_w[8];
       __syncthreads();

@@ -1,20 +1,32 @@
-// fx_multi.hpp — C++ host driver that frame-shards a batch of scans over the GPUs of one node and gathers the
+// fx_multi.hpp — C++ host driver that frame-shards batches of scans over the GPUs of one node and gathers the
 // keypoint records with one RCCL collective per batch (north star: "host side stays C++ ... scans are
 // batched and frame-sharded across the 8 GPUs of one node with an RCCL gather of keypoints over xGMI").
 //
-// One process, one host thread + one fx_ctx + one stream per device.  The reference is a single-threaded ROS node with
-// one scan in flight (ref: src/feature_extraction_node.cpp:386 ros::spin, :47 queue size 0); this is what replaces its
-// cloudCallback loop when a node has several GPUs and the scans of several sensors / a recorded stream to chew through.
+// The reference is a single-threaded ROS node with one scan in flight (ref: src/feature_extraction_node.cpp:386
+// ros::spin, :47 queue size 0); this is what replaces its cloudCallback loop when a node has several GPUs and the
+// scans of several sensors / a recorded stream to chew through.
 //   * scan b of a batch of B goes to rank floor(b G / B) (contiguous blocks, fx_shard.hpp): output order is trivial;
 //   * every rank runs the unchanged single-GPU pipeline (fx_process_batch) on its block;
-//   * fx_pack_keypoint_records writes the block's fixed-stride records, ncclAllGather assembles the table on every GPU
-//     (2 KiB per scan: latency bound, not xGMI-bandwidth bound); descriptors stay on the producing GPU.
+//   * fx_pack_keypoint_records writes the block's fixed-stride records (stride = the context's keypoint capacity, so a
+//     record is never truncated), ncclAllGather assembles the table on every GPU (latency bound, not xGMI-bandwidth
+//     bound); descriptors stay on the producing GPU.
+// Threads: ONE persistent worker per device, fed through a queue — no thread is created per batch.  Every device has
+// `in_flight` contexts, each on its own stream: submit() returns at once with a ticket, batch t runs on context
+// t % in_flight, and nothing in the worker waits for the GPU except the reuse of a context (the stage kernels of one
+// batch leave most of the GPU idle; the next batch fills it).  Ticket::wait() is where the caller synchronises.
+// Errors: a rank that fails before the collective would leave the others waiting inside it for ever, so the workers
+// meet at a barrier after the local part of a batch and issue the collective only when every rank got that far;
+// otherwise the batch fails as a whole and the error is reported by wait().
 // Links against libfx_hip.so, librccl and libamdhip64.  No CPU fallback.
 #ifndef FX_MULTI_HPP_
 #define FX_MULTI_HPP_
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -25,105 +37,153 @@
 
 namespace fx {
 
+struct MultiGpuOptions {
+  uint32_t in_flight = 2;  // contexts (batches in flight) per device
+  uint32_t rec_kp = 0;     // keypoints per gathered record; 0 = the contexts' limits.max_keypoints
+  fx_limits limits{};      // non-zero fields override fx_limits_default(scans per rank, max_points)
+};
+// What one batch produced.  Valid until `in_flight` more batches have been submitted (the contexts own the memory).
+struct MultiGpuBatch {
+  uint32_t batch = 0;
+  std::vector<fx_batch_view> views;    // per rank: that rank's block
+  std::vector<const float *> tables;   // per rank: the gathered table on that device (world * scans_per_rank records)
+  std::string error;                   // empty = ok
+};
+class MultiGpu;
+struct MultiGpuJob {
+  MultiGpu *owner = nullptr;
+  const fx_scan_desc *scans = nullptr;
+  uint32_t flags = 0, slot = 0;
+  MultiGpuBatch out;
+  std::vector<std::string> local_error;  // per rank: what failed before the collective
+  std::mutex m;
+  std::condition_variable cv;
+  uint32_t arrived = 0;    // ranks that finished the local part (the barrier before the collective)
+  uint32_t enqueued = 0;   // ranks that finished enqueuing (or gave up): wait() may look at the events
+};
+
+
 class MultiGpu {
  public:
-  // devices: HIP device ids, one rank each; max_batch: scans of one call over all devices together
-  MultiGpu(const fx_params &params, const std::vector<int> &devices, uint32_t max_batch, uint32_t max_points,
-           uint32_t rec_kp = kRecKeypoints)
-      : devices_(devices), rec_kp_(rec_kp), max_batch_(max_batch) {
+  using Options = MultiGpuOptions;
+  using Batch = MultiGpuBatch;
+  class Ticket {
+   public:
+    Ticket() = default;
+    // Waits for the batch on every device; throws what went wrong.  table_host (optional): rank 0's gathered table.
+    const Batch &wait(std::vector<float> *table_host = nullptr);
+
+   private:
+    friend class MultiGpu;
+    std::shared_ptr<MultiGpuJob> job_;
+  };
+
+  // devices: HIP device ids, one rank each; max_batch: scans of one batch over all devices together
+  MultiGpu(const fx_params &params, const std::vector<int> &devices, uint32_t max_batch, uint32_t max_points, const Options &opt = Options())
+      : devices_(devices), max_batch_(max_batch), in_flight_(opt.in_flight ? opt.in_flight : 1u) {
     const uint32_t G = (uint32_t)devices.size();
     if (!G) throw std::invalid_argument("fx::MultiGpu: no devices");
     per_rank_ = (max_batch + G - 1) / G;
-    ranks_.resize(G);
-    comms_.resize(G);
-    // one communicator per device of this process (ncclCommInitAll: single-process, multi-device)
-    nccl(ncclCommInitAll(comms_.data(), (int)G, devices_.data()), "ncclCommInitAll");
-    for (uint32_t r = 0; r < G; ++r) {
-      Rank &R = ranks_[r];
-      hip(hipSetDevice(devices_[r]), "hipSetDevice");
-      fx_limits lim;
-      fx_limits_default(&lim, per_rank_, max_points);
-      const fx_status st = fx_create(&params, &lim, devices_[r], &R.ctx);
-      if (st != FX_OK) throw std::runtime_error(std::string("fx_create: ") + fx_last_error());
-      hip(hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking), "hipStreamCreate");
-      fx_set_stream(R.ctx, R.stream);
-      hip(hipMalloc((void **)&R.rec, (size_t)per_rank_ * record_floats(rec_kp_) * sizeof(float)), "hipMalloc records");
-      hip(hipMalloc((void **)&R.table, (size_t)per_rank_ * G * record_floats(rec_kp_) * sizeof(float)), "hipMalloc table");
-      hip(hipMemset(R.rec, 0, (size_t)per_rank_ * record_floats(rec_kp_) * sizeof(float)), "hipMemset");
+    for (uint32_t r = 0; r < G; ++r) ranks_.emplace_back(new Rank());
+    comms_.assign(G, nullptr);
+    try {
+      // one communicator per device of this process (ncclCommInitAll: single-process, multi-device); the slots of a device
+      // share it and issue their collectives in ticket order, which is RCCL's ordering contract
+      nccl(ncclCommInitAll(comms_.data(), (int)G, devices_.data()), "ncclCommInitAll");
+      for (uint32_t r = 0; r < G; ++r) {
+        Rank &R = *ranks_[r];
+        hip(hipSetDevice(devices_[r]), "hipSetDevice");
+        R.slots.resize(in_flight_);
+        for (Slot &S : R.slots) {
+          fx_limits lim;
+          fx_limits_default(&lim, per_rank_, max_points);
+          const uint32_t *ov = reinterpret_cast<const uint32_t *>(&opt.limits);
+          uint32_t *dst = reinterpret_cast<uint32_t *>(&lim);
+          for (size_t i = 2; i < sizeof(fx_limits) / 4; ++i)  // (max_batch / max_points are the constructor's)
+            if (ov[i]) dst[i] = ov[i];
+          if (fx_create(&params, &lim, devices_[r], &S.ctx) != FX_OK) throw std::runtime_error(std::string("fx_create: ") + fx_last_error());
+          fx_limits got;
+          fx_get_limits(S.ctx, &got);
+          rec_kp_ = opt.rec_kp ? opt.rec_kp : got.max_keypoints;
+          hip(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking), "hipStreamCreate");
+          fx_set_stream(S.ctx, S.stream);
+          hip(hipEventCreateWithFlags(&S.done, hipEventDisableTiming), "hipEventCreate");
+          const size_t rec_bytes = (size_t)per_rank_ * record_floats(rec_kp_) * sizeof(float);
+          hip(hipMalloc((void **)&S.rec, rec_bytes), "hipMalloc records");
+          hip(hipMalloc((void **)&S.table, rec_bytes * G), "hipMalloc table");
+          hip(hipMemset(S.rec, 0, rec_bytes), "hipMemset");
+        }
+      }
+      for (uint32_t r = 0; r < G; ++r) ranks_[r]->worker = std::thread([this, r] { work(r); });
+    } catch (...) {
+      shutdown();
+      throw;
     }
   }
-  ~MultiGpu() {
-    for (size_t r = 0; r < ranks_.size(); ++r) {
-      (void)hipSetDevice(devices_[r]);
-      if (ranks_[r].ctx) fx_destroy(ranks_[r].ctx);
-      if (ranks_[r].rec) (void)hipFree(ranks_[r].rec);
-      if (ranks_[r].table) (void)hipFree(ranks_[r].table);
-      if (ranks_[r].stream) (void)hipStreamDestroy(ranks_[r].stream);
-      if (comms_[r]) (void)ncclCommDestroy(comms_[r]);
-    }
-  }
+  ~MultiGpu() { shutdown(); }
   MultiGpu(const MultiGpu &) = delete;
   MultiGpu &operator=(const MultiGpu &) = delete;
 
   uint32_t world() const { return (uint32_t)devices_.size(); }
   uint32_t scans_per_rank() const { return per_rank_; }
+  uint32_t in_flight() const { return in_flight_; }
+  uint32_t record_keypoints() const { return rec_kp_; }
 
-  // Runs the hot path on `batch` scans (host or device pointers per `flags`, as fx_process_batch takes them), block r
-  // of the stream on device r, then gathers the keypoint records.  table_host (optional): the gathered table as
-  // world * scans_per_rank records — rank r's block starts at record r * scans_per_rank; its first
-  // shard_range(batch, world, r) records are live, the rest zero.  views (optional): every rank's fx_batch_view.
+  // Enqueues the hot path on `batch` scans (host or device pointers per `flags`, as fx_process_batch takes them; block r
+  // of the batch must be readable by device r) and the gather of the keypoint records.  Returns at once; `scans` and
+  // what they point to must stay valid until the ticket has been waited for.  Call from one thread.
+  Ticket submit(const fx_scan_desc *scans, uint32_t batch, uint32_t flags) {
+    if (batch > max_batch_) throw std::invalid_argument("fx::MultiGpu::submit: batch > max_batch");
+    auto job = std::make_shared<MultiGpuJob>();
+    job->owner = this;
+    job->scans = scans;
+    job->flags = flags;
+    job->slot = (uint32_t)(next_ticket_++ % in_flight_);
+    job->out.batch = batch;
+    job->out.views.resize(world());
+    job->out.tables.resize(world());
+    job->local_error.resize(world());
+    for (auto &rp : ranks_) {
+      Rank &R = *rp;
+      {
+        std::lock_guard<std::mutex> lk(R.m);
+        R.queue.push_back(job);
+      }
+      R.cv.notify_one();
+    }
+    Ticket t;
+    t.job_ = job;
+    return t;
+  }
+  // submit + wait: one batch at a time (table_host: rank 0's gathered table; views: every rank's fx_batch_view)
   void process(const fx_scan_desc *scans, uint32_t batch, uint32_t flags, std::vector<float> *table_host,
                std::vector<fx_batch_view> *views = nullptr) {
-    if (batch > max_batch_) throw std::invalid_argument("fx::MultiGpu::process: batch > max_batch");
-    const uint32_t G = world();
-    std::vector<std::string> errors(G);
-    std::vector<fx_batch_view> local(G);
-    std::vector<std::thread> threads;
-    for (uint32_t r = 0; r < G; ++r)
-      threads.emplace_back([&, r]() {
-        try {
-          Rank &R = ranks_[r];
-          hip(hipSetDevice(devices_[r]), "hipSetDevice");
-          const auto span = shard_range(batch, G, r);
-          const uint32_t n = (uint32_t)(span.second - span.first);
-          if (fx_process_batch(R.ctx, scans + span.first, n, flags, &local[r]) != FX_OK)
-            throw std::runtime_error(std::string("fx_process_batch: ") + fx_last_error());
-          // the whole block is rewritten every batch: ranks with fewer scans than scans_per_rank leave zero records behind
-          hip(hipMemsetAsync(R.rec, 0, (size_t)per_rank_ * record_floats(rec_kp_) * sizeof(float), R.stream), "hipMemsetAsync");
-          if (n && fx_pack_keypoint_records(R.ctx, R.rec, rec_kp_) != FX_OK)
-            throw std::runtime_error(std::string("fx_pack_keypoint_records: ") + fx_last_error());
-          // the path's one collective
-          nccl(ncclAllGather(R.rec, R.table, (size_t)per_rank_ * record_floats(rec_kp_), ncclFloat, comms_[r], R.stream),
-               "ncclAllGather");
-          hip(hipStreamSynchronize(R.stream), "hipStreamSynchronize");
-        } catch (const std::exception &e) {
-          errors[r] = e.what();
-        }
-      });
-    for (auto &t : threads) t.join();
-    for (const auto &e : errors)
-      if (!e.empty()) throw std::runtime_error(e);
-    if (views) *views = local;
-    if (table_host) {
-      table_host->resize((size_t)per_rank_ * G * record_floats(rec_kp_));
-      hip(hipSetDevice(devices_[0]), "hipSetDevice");
-      hip(hipMemcpy(table_host->data(), ranks_[0].table, table_host->size() * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy table");
-    }
+    Ticket t = submit(scans, batch, flags);
+    const Batch &b = t.wait(table_host);
+    if (views) *views = b.views;
   }
-  // record of stream position `scan` of the last batch of `batch` scans inside a gathered table
+  // record of stream position `scan` of a batch of `batch` scans inside a gathered table
   KeypointRecordView record(const std::vector<float> &table, uint64_t scan, uint64_t batch) const {
     const uint32_t r = owner_of(scan, batch, world());
     const uint64_t local = scan - shard_range(batch, world(), r).first;
     return record_of(table.data(), (uint64_t)r * per_rank_ + local, rec_kp_);
   }
-  // the gathered table as rank `r` holds it (device memory), for a check that every rank got the same bytes
-  const float *device_table(uint32_t r) const { return ranks_[r].table; }
 
  private:
-  struct Rank {
+  struct Slot {
     fx_ctx *ctx = nullptr;
     hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
     float *rec = nullptr, *table = nullptr;
+    bool used = false;
+  };
+  struct Rank {
+    std::vector<Slot> slots;
+    std::thread worker;
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<std::shared_ptr<MultiGpuJob>> queue;
+    bool stop = false;
   };
   static void hip(hipError_t e, const char *what) {
     if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
@@ -131,11 +191,124 @@ class MultiGpu {
   static void nccl(ncclResult_t e, const char *what) {
     if (e != ncclSuccess) throw std::runtime_error(std::string(what) + ": " + ncclGetErrorString(e));
   }
+
+  // the worker of rank r: jobs in ticket order (the same order on every rank: the collectives match up)
+  void work(uint32_t r);
+  void shutdown() {
+    for (auto &rp : ranks_) {
+      Rank &R = *rp;
+      {
+        std::lock_guard<std::mutex> lk(R.m);
+        R.stop = true;
+      }
+      R.cv.notify_one();
+    }
+    for (auto &rp : ranks_)
+      if (rp->worker.joinable()) rp->worker.join();
+    for (size_t r = 0; r < ranks_.size(); ++r) {
+      (void)hipSetDevice(devices_[r]);
+      for (Slot &S : ranks_[r]->slots) {
+        if (S.stream) (void)hipStreamSynchronize(S.stream);
+        if (S.ctx) fx_destroy(S.ctx);
+        if (S.rec) (void)hipFree(S.rec);
+        if (S.table) (void)hipFree(S.table);
+        if (S.done) (void)hipEventDestroy(S.done);
+        if (S.stream) (void)hipStreamDestroy(S.stream);
+        S = Slot();
+      }
+      if (r < comms_.size() && comms_[r]) {
+        (void)ncclCommDestroy(comms_[r]);
+        comms_[r] = nullptr;
+      }
+    }
+  }
+
   std::vector<int> devices_;
-  std::vector<Rank> ranks_;
+  std::vector<std::unique_ptr<Rank>> ranks_;  // (a Rank holds a mutex: it never moves)
   std::vector<ncclComm_t> comms_;
-  uint32_t rec_kp_, max_batch_, per_rank_ = 0;
+  uint32_t rec_kp_ = kRecKeypoints, max_batch_, per_rank_ = 0, in_flight_;
+  uint64_t next_ticket_ = 0;
 };
+
+inline const MultiGpu::Batch &MultiGpu::Ticket::wait(std::vector<float> *table_host) {
+    if (!job_) throw std::logic_error("fx::MultiGpu::Ticket: empty");
+    {
+      std::unique_lock<std::mutex> lk(job_->m);
+      job_->cv.wait(lk, [&] { return job_->enqueued == job_->owner->world(); });
+    }
+    if (!job_->out.error.empty()) throw std::runtime_error(job_->out.error);
+    for (uint32_t r = 0; r < job_->owner->world(); ++r) {
+      hip(hipSetDevice(job_->owner->devices_[r]), "hipSetDevice");
+      hip(hipEventSynchronize(job_->owner->ranks_[r]->slots[job_->slot].done), "hipEventSynchronize");
+    }
+    if (table_host) {
+      const MultiGpu &o = *job_->owner;
+      table_host->resize((size_t)o.per_rank_ * o.world() * record_floats(o.rec_kp_));
+      hip(hipSetDevice(o.devices_[0]), "hipSetDevice");
+      hip(hipMemcpy(table_host->data(), job_->out.tables[0], table_host->size() * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy table");
+    }
+    return job_->out;
+  }
+
+inline void MultiGpu::work(uint32_t r) {
+  Rank &R = *ranks_[r];
+  const uint32_t G = world();
+  (void)hipSetDevice(devices_[r]);
+  while (true) {
+    std::shared_ptr<MultiGpuJob> job;
+    {
+      std::unique_lock<std::mutex> lk(R.m);
+      R.cv.wait(lk, [&] { return R.stop || !R.queue.empty(); });
+      if (R.queue.empty()) return;  // (stop, and nothing left to run)
+      job = R.queue.front();
+      R.queue.pop_front();
+    }
+    Slot &S = R.slots[job->slot];
+    // ---- the local part: this rank's block through the unchanged single-GPU pipeline, then its records
+    try {
+      if (S.used) hip(hipEventSynchronize(S.done), "hipEventSynchronize");  // the context's previous batch (in_flight tickets ago)
+      const auto span = shard_range(job->out.batch, G, r);
+      const uint32_t n = (uint32_t)(span.second - span.first);
+      if (fx_process_batch(S.ctx, job->scans + span.first, n, job->flags, &job->out.views[r]) != FX_OK)
+        throw std::runtime_error(std::string("fx_process_batch: ") + fx_last_error());
+      // the whole block is rewritten every batch: ranks with fewer scans than scans_per_rank leave zero records behind
+      hip(hipMemsetAsync(S.rec, 0, (size_t)per_rank_ * record_floats(rec_kp_) * sizeof(float), S.stream), "hipMemsetAsync");
+      if (n && fx_pack_keypoint_records(S.ctx, S.rec, rec_kp_) != FX_OK)
+        throw std::runtime_error(std::string("fx_pack_keypoint_records: ") + fx_last_error());
+    } catch (const std::exception &e) {
+      job->local_error[r] = std::string("rank ") + std::to_string(r) + ": " + e.what();
+    }
+    // ---- every rank got this far?  (a rank missing from the collective would hang the others inside it)
+    bool all_ok = true;
+    {
+      std::unique_lock<std::mutex> lk(job->m);
+      ++job->arrived;
+      job->cv.notify_all();
+      job->cv.wait(lk, [&] { return job->arrived == G; });
+      for (const std::string &e : job->local_error)
+        if (!e.empty()) {
+          all_ok = false;
+          if (job->out.error.empty()) job->out.error = e;
+        }
+    }
+    std::string late;
+    if (all_ok) {
+      // the path's one collective, an ordinary kernel of the slot's stream
+      const ncclResult_t ce = ncclAllGather(S.rec, S.table, (size_t)per_rank_ * record_floats(rec_kp_), ncclFloat, comms_[r], S.stream);
+      if (ce != ncclSuccess) late = std::string("rank ") + std::to_string(r) + ": ncclAllGather: " + ncclGetErrorString(ce);
+    }
+    const hipError_t he = hipEventRecord(S.done, S.stream);
+    if (he != hipSuccess && late.empty()) late = std::string("rank ") + std::to_string(r) + ": hipEventRecord: " + hipGetErrorString(he);
+    S.used = true;
+    job->out.tables[r] = S.table;
+    {
+      std::lock_guard<std::mutex> lk(job->m);
+      if (!late.empty() && job->out.error.empty()) job->out.error = late;
+      ++job->enqueued;
+    }
+    job->cv.notify_all();
+  }
+}
 
 }  // namespace fx
 #endif

@@ -1,11 +1,13 @@
-// fx_multi_cli — the C++ multi-GPU driver (fx_multi.hpp) on synthetic VLP-16 scans: frame-shards a batch over the
+// fx_multi_cli — the C++ multi-GPU driver (fx_multi.hpp) on synthetic VLP-16 scans: frame-shards batches over the
 // visible GPUs (or --devices N of them), gathers the keypoint records over RCCL, checks the gathered table against the
-// per-rank results and prints scans/s.  On a 1-GPU box it runs with one rank: RCCL initialises and the collective runs.
-//   fx_multi_cli [--devices N] [--batch B] [--steps K] [--launch]
+// per-rank results and prints scans/s with the inputs resident in device memory (--host-input: handed over as host
+// buffers).  On a 1-GPU box it runs with one rank: RCCL initialises and the collective runs.
+//   fx_multi_cli [--devices N] [--batch B] [--steps K] [--inflight F] [--default] [--host-input]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 
 #include "fx_multi.hpp"
 
@@ -17,13 +19,15 @@ int main(int argc, char **argv) {
       return 3;
     }
     int want = n_dev;
-    uint32_t batch = 256, steps = 5;
-    bool launch = true;
+    uint32_t batch = 256, steps = 20, in_flight = 3;
+    bool launch = true, host_input = false;
     for (int i = 1; i < argc; ++i) {
       if (!std::strcmp(argv[i], "--devices") && i + 1 < argc) want = std::atoi(argv[++i]);
       else if (!std::strcmp(argv[i], "--batch") && i + 1 < argc) batch = (uint32_t)std::atoi(argv[++i]);
       else if (!std::strcmp(argv[i], "--steps") && i + 1 < argc) steps = (uint32_t)std::atoi(argv[++i]);
+      else if (!std::strcmp(argv[i], "--inflight") && i + 1 < argc) in_flight = (uint32_t)std::atoi(argv[++i]);
       else if (!std::strcmp(argv[i], "--default")) launch = false;
+      else if (!std::strcmp(argv[i], "--host-input")) host_input = true;
     }
     if (want < 1 || want > n_dev) want = n_dev;
     std::vector<int> devices;
@@ -40,40 +44,81 @@ int main(int argc, char **argv) {
       fx_synth_scan(&cfg, &host[(size_t)b * N * 4], N);
       scans[b] = fx_scan_desc{&host[(size_t)b * N * 4], N, 16, 0.02, -0.015};
     }
-    fx::MultiGpu multi(p, devices, batch, N);
-    std::printf("fx_multi_cli: %d device(s) visible, %u rank(s), %u scans per batch (%u per rank), RCCL communicators up\n", n_dev,
-                multi.world(), batch, multi.scans_per_rank());
+    fx::MultiGpu::Options opt;
+    opt.in_flight = in_flight;
+    fx::MultiGpu multi(p, devices, batch, N, opt);
+    const uint32_t G = multi.world(), rec_kp = multi.record_keypoints();
+    std::printf("fx_multi_cli: %d device(s) visible, %u rank(s), %u scans per batch (%u per rank), %u batches in flight per device, "
+                "records of %u keypoints, RCCL communicators up\n", n_dev, G, batch, multi.scans_per_rank(), multi.in_flight(), rec_kp);
+    // ---- a checked batch (host input, results back on the host): the gathered table against every rank's own results
     std::vector<float> table;
     std::vector<fx_batch_view> views;
-    multi.process(scans.data(), batch, FX_OUT_HOST, &table, &views);  // warm-up + the checked batch
-    // the gathered table against every rank's own results
+    multi.process(scans.data(), batch, FX_OUT_HOST, &table, &views);
     uint64_t kp_total = 0;
     for (uint32_t b = 0; b < batch; ++b) {
-      const uint32_t r = fx::owner_of(b, batch, multi.world());
-      const uint32_t local = (uint32_t)(b - fx::shard_range(batch, multi.world(), r).first);
+      const uint32_t r = fx::owner_of(b, batch, G);
+      const uint32_t local = (uint32_t)(b - fx::shard_range(batch, G, r).first);
       const fx_batch_view &v = views[r];
       const fx::KeypointRecordView rec = multi.record(table, b, batch);
       const uint32_t K = v.h_n_keypoints[local];
-      const uint32_t Kr = K < fx::kRecKeypoints ? K : fx::kRecKeypoints;
-      if (rec.n_keypoints() != Kr) throw std::runtime_error("gathered keypoint count differs from the producing rank's");
-      if (std::memcmp(rec.keypoint(0), v.h_keypoints + (size_t)local * v.max_keypoints * 4, (size_t)Kr * 16) != 0)
+      if (rec.n_keypoints() != K || rec.flags() != v.h_flags[local])
+        throw std::runtime_error("gathered keypoint count / flags differ from the producing rank's");
+      if (std::memcmp(rec.keypoint(0), v.h_keypoints + (size_t)local * v.max_keypoints * 4, (size_t)K * 16) != 0)
         throw std::runtime_error("gathered keypoints differ from the producing rank's");
       kp_total += K;
     }
-    // every rank holds the same table
-    std::vector<float> other(table.size());
-    for (uint32_t r = 1; r < multi.world(); ++r) {
-      if (hipSetDevice(devices[r]) != hipSuccess ||
-          hipMemcpy(other.data(), multi.device_table(r), other.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
-        throw std::runtime_error("hipMemcpy of a rank's table failed");
-      if (std::memcmp(other.data(), table.data(), table.size() * sizeof(float)) != 0)
-        throw std::runtime_error("ranks hold different gathered tables");
+    {  // every rank holds the same table
+      fx::MultiGpu::Ticket t = multi.submit(scans.data(), batch, 0);
+      std::vector<float> t0;
+      const fx::MultiGpu::Batch &res = t.wait(&t0);
+      std::vector<float> other(t0.size());
+      for (uint32_t r = 1; r < G; ++r) {
+        if (hipSetDevice(devices[r]) != hipSuccess ||
+            hipMemcpy(other.data(), res.tables[r], other.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+          throw std::runtime_error("hipMemcpy of a rank's table failed");
+        if (std::memcmp(other.data(), t0.data(), t0.size() * sizeof(float)) != 0) throw std::runtime_error("ranks hold different gathered tables");
+      }
+      if (std::memcmp(t0.data(), table.data(), table.size() * sizeof(float)) != 0)
+        throw std::runtime_error("the same batch gave a different table the second time");
     }
+    // ---- throughput: tickets kept in flight; inputs resident on the devices unless --host-input
+    std::vector<void *> d_in(G, nullptr);
+    std::vector<fx_scan_desc> dscans = scans;
+    uint32_t flags = 0;
+    if (!host_input) {
+      flags = FX_IN_DEVICE;
+      for (uint32_t r = 0; r < G; ++r) {
+        const auto span = fx::shard_range(batch, G, r);
+        const size_t n = (size_t)(span.second - span.first);
+        if (!n) continue;
+        if (hipSetDevice(devices[r]) != hipSuccess || hipMalloc(&d_in[r], n * N * 16) != hipSuccess ||
+            hipMemcpy(d_in[r], &host[(size_t)span.first * N * 4], n * N * 16, hipMemcpyHostToDevice) != hipSuccess)
+          throw std::runtime_error("upload of a rank's block failed");
+        for (size_t i = 0; i < n; ++i) dscans[span.first + i].points = (const char *)d_in[r] + i * N * 16;
+      }
+    }
+    std::deque<fx::MultiGpu::Ticket> pending;
+    for (uint32_t s = 0; s < in_flight; ++s) multi.submit(dscans.data(), batch, flags).wait();  // warm-up
     const auto t0 = std::chrono::steady_clock::now();
-    for (uint32_t s = 0; s < steps; ++s) multi.process(scans.data(), batch, 0, nullptr);
+    for (uint32_t s = 0; s < steps; ++s) {
+      if (pending.size() >= in_flight) {
+        pending.front().wait();
+        pending.pop_front();
+      }
+      pending.push_back(multi.submit(dscans.data(), batch, flags));
+    }
+    while (!pending.empty()) {
+      pending.front().wait();
+      pending.pop_front();
+    }
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    std::printf("fx_multi_cli: gathered table == per-rank results (%llu keypoints in %u scans); host-input batches: %.0f scans/s over %u rank(s)\n",
-                (unsigned long long)kp_total, batch, (double)batch * steps / dt, multi.world());
+    for (uint32_t r = 0; r < G; ++r)
+      if (d_in[r]) {
+        (void)hipSetDevice(devices[r]);
+        (void)hipFree(d_in[r]);
+      }
+    std::printf("fx_multi_cli: gathered table == per-rank results (%llu keypoints in %u scans); %s batches, %u in flight: %.0f scans/s over %u rank(s)\n",
+                (unsigned long long)kp_total, batch, host_input ? "host-input" : "device-resident", in_flight, (double)batch * steps / dt, G);
     return 0;
   } catch (const std::exception &e) {
     std::fprintf(stderr, "fx_multi_cli: %s\n", e.what());

@@ -1,5 +1,5 @@
 // fx_shard_selftest — CPU check of the C++ sharding plan and record layout (fx_shard.hpp), run as one process per rank
-// by tests/test_cpp_sharding.py:  fx_shard_selftest TOTAL WORLD RANK IN.bin OUT.bin
+// by tests/test_cpp_sharding.py:  fx_shard_selftest TOTAL WORLD RANK IN.bin OUT.bin [REC_KP]
 // IN.bin: TOTAL records of keypoints as the test wrote them ({u32 n, n x float4} per scan); the rank packs the records of
 // its block exactly as fx_pack_keypoint_records lays them out and writes them to OUT.bin; stdout: "first last".
 #include <cstdio>
@@ -9,7 +9,8 @@
 #include "fx_shard.hpp"
 
 int main(int argc, char **argv) {
-  if (argc != 6) return 2;
+  if (argc != 6 && argc != 7) return 2;
+  const uint32_t rec_kp = argc == 7 ? (uint32_t)std::atoi(argv[6]) : fx::kRecKeypoints;  // record stride (fx::MultiGpu: the contexts' max_keypoints)
   const uint64_t total = std::strtoull(argv[1], nullptr, 10);
   const uint32_t world = (uint32_t)std::atoi(argv[2]), rank = (uint32_t)std::atoi(argv[3]);
   const auto span = fx::shard_range(total, world, rank);
@@ -20,16 +21,16 @@ int main(int argc, char **argv) {
   }
   FILE *in = std::fopen(argv[4], "rb"), *out = std::fopen(argv[5], "wb");
   if (!in || !out) return 4;
-  std::vector<float> rec(fx::record_floats(fx::kRecKeypoints));
+  std::vector<float> rec(fx::record_floats(rec_kp));
   for (uint64_t s = 0; s < total; ++s) {
     uint32_t n = 0;
     if (std::fread(&n, 4, 1, in) != 1) return 5;
     std::vector<float> kp((size_t)n * 4);
     if (n && std::fread(kp.data(), 16, n, in) != n) return 5;
     if (s < span.first || s >= span.second) continue;
-    fx::pack_record(rec.data(), kp.data(), n, 0u);
-    const fx::KeypointRecordView v = fx::record_of(rec.data(), 0);
-    if (v.n_keypoints() != (n < fx::kRecKeypoints ? n : fx::kRecKeypoints)) return 6;
+    fx::pack_record(rec.data(), kp.data(), n, 0u, rec_kp);
+    const fx::KeypointRecordView v = fx::record_of(rec.data(), 0, rec_kp);
+    if (v.n_keypoints() != (n < rec_kp ? n : rec_kp)) return 6;
     std::fwrite(rec.data(), sizeof(float), rec.size(), out);
   }
   std::fclose(in);

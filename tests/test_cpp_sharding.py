@@ -11,8 +11,8 @@ import pytest
 from feature_extraction_amd import build, sharding
 
 
-@pytest.mark.parametrize("total,world", [(6, 2), (7, 2), (5, 3), (3, 4)])
-def test_ranks_tile_the_stream_and_records_match(tmp_path, total, world):
+@pytest.mark.parametrize("total,world,rec_kp", [(6, 2, 127), (7, 2, 256), (5, 3, 256), (3, 4, 64)])
+def test_ranks_tile_the_stream_and_records_match(tmp_path, total, world, rec_kp):
     build.build_multi()
     exe = build.SELFTEST
     rng = np.random.default_rng(total * 10 + world)
@@ -24,7 +24,7 @@ def test_ranks_tile_the_stream_and_records_match(tmp_path, total, world):
             f.write(kp.tobytes())
     procs = []
     for r in range(world):  # one process per rank, as on a node with `world` GPUs
-        procs.append(subprocess.Popen([exe, str(total), str(world), str(r), str(src), str(tmp_path / f"out{r}.bin")],
+        procs.append(subprocess.Popen([exe, str(total), str(world), str(r), str(src), str(tmp_path / f"out{r}.bin"), str(rec_kp)],
                                       stdout=subprocess.PIPE, text=True))
     spans = []
     for r, pr in enumerate(procs):
@@ -34,7 +34,7 @@ def test_ranks_tile_the_stream_and_records_match(tmp_path, total, world):
     assert spans == [sharding.shard_range(total, world, r) for r in range(world)]
     assert spans[0][0] == 0 and spans[-1][1] == total and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
     got = np.concatenate([np.fromfile(tmp_path / f"out{r}.bin", np.float32) for r in range(world)])
-    want = sharding.pack_records(kps, [0] * total)
+    want = sharding.pack_records(kps, [0] * total, rec_kp=rec_kp)  # (a stride below a scan's count truncates and flags it)
     assert np.array_equal(got.view(np.uint32), want.reshape(-1).view(np.uint32))
     for s in range(total):
         o = sharding.owner_of(s, total, world)

@@ -14,6 +14,7 @@ from oracle import oracle_py
 from tests import util
 
 TOTAL = 6
+REC_KP = 256  # bench.py's record stride: the contexts' keypoint capacity (limits.max_keypoints), never truncating
 
 
 def _free_port():
@@ -31,7 +32,7 @@ def _records_for(span):
         r = oracle_py.run(p, util.vlp16_scan(1000 + b, n_az=450), roll=0.02, pitch=-0.015)
         kps.append(r["keypoints"])
         flags.append(0)
-    return sharding.pack_records(kps, flags)
+    return sharding.pack_records(kps, flags, rec_kp=REC_KP)
 
 
 def _worker(rank, world, port, out_path):
@@ -42,7 +43,7 @@ def _worker(rank, world, port, out_path):
     rec = torch.from_numpy(_records_for(span))
     gathered = sharding.all_gather_records(rec, world)
     # the form bench.py uses: preallocated table, collective left in flight, waited for later
-    table = torch.zeros((TOTAL, 1 + sharding.REC_KP, 4), dtype=torch.float32)
+    table = torch.zeros((TOTAL, 1 + REC_KP, 4), dtype=torch.float32)
     same, work = sharding.all_gather_records(rec, world, out=table, async_op=True)
     work.wait()
     assert same is table and torch.equal(table, gathered)
@@ -61,7 +62,7 @@ def test_two_rank_gather_equals_unsharded(tmp_path):
     mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     got = np.load(out)
     want = _records_for((0, TOTAL))
-    assert got.shape == want.shape == (TOTAL, 1 + sharding.REC_KP, 4)
+    assert got.shape == want.shape == (TOTAL, 1 + REC_KP, 4)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     per_scan = sharding.unpack_records(got)
     assert sum(k for k, _, _ in per_scan) > 0 and all(f == 0 for _, f, _ in per_scan)
