@@ -235,18 +235,23 @@ def main():
     # the collective goes straight on the context's stream through RCCL's C API (sharding.RcclGather);
     # FX_BENCH_TORCH_GATHER=1 takes torch.distributed's all_gather_into_tensor instead (sharding.all_gather_records, the
     # function the gloo test runs)
-    rccl = None
+    rccl, rccl_comms = None, 1
     if use_dist and os.environ.get("FX_BENCH_TORCH_GATHER") != "1":
-        # ONE communicator for all contexts: its collectives are issued in step order on every rank, which is RCCL's
-        # ordering contract (one communicator per context could interleave differently on two ranks and deadlock when the
-        # streams share a hardware queue).  Every rank first proves it can load RCCL's C API; only then are ids exchanged.
+        # ONE communicator for all contexts, its collectives issued in step order on every rank: RCCL's ordering contract,
+        # whatever the streams do.  Measured on one rank with the collective forced: 1.50 million scans/s against 1.68
+        # without a collective — the shared communicator orders the contexts' streams against each other.  One
+        # communicator per context (FX_BENCH_MULTI_COMM=1: 1.68; every rank issues them in the same host order, so no two
+        # ranks can hold each other's kernels back, but that has never run on more than one GPU) and a dedicated gather
+        # stream fed through events (1.30: cross-stream waits are dear on this stack) were measured too.
+        # Every rank first proves it can load RCCL's C API; only then are ids exchanged.
         ok = 1 if sharding.RcclGather.available() else 0
         if world > 1:
             t = torch.tensor([ok], dtype=torch.int64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             ok = int(t.item())
         if ok:
-            rccl = sharding.RcclGather(world, rank, dev, n_comms=1)
+            rccl_comms = K if os.environ.get("FX_BENCH_MULTI_COMM") == "1" else 1
+            rccl = sharding.RcclGather(world, rank, dev, n_comms=rccl_comms)
         elif rank == 0:
             print("[bench] direct RCCL gather unavailable on some rank; using torch.distributed's all_gather", file=sys.stderr)
     torch.cuda.synchronize(dev)  # inputs and zeroed buffers are in place before any side stream starts
@@ -261,7 +266,7 @@ def main():
             ctxs[j].process_raw(descs, B, capi.FX_IN_DEVICE)
             ctxs[j].pack_keypoint_records(recs[j].data_ptr(), REC_KP)
             if rccl is not None:  # the path's one collective, an ordinary kernel of this context's stream
-                rccl.all_gather(recs[j], gathered[j], streams[j].cuda_stream, comm=0)
+                rccl.all_gather(recs[j], gathered[j], streams[j].cuda_stream, comm=j % rccl_comms)
             elif use_dist:
                 _tab, pending[j] = sharding.all_gather_records(recs[j], world, out=gathered[j], async_op=True)
 

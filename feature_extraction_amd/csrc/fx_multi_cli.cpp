@@ -19,7 +19,7 @@ int main(int argc, char **argv) {
       return 3;
     }
     int want = n_dev;
-    uint32_t batch = 256, steps = 20, in_flight = 3;
+    uint32_t batch = 256, steps = 20, in_flight = 2;
     bool launch = true, host_input = false;
     for (int i = 1; i < argc; ++i) {
       if (!std::strcmp(argv[i], "--devices") && i + 1 < argc) want = std::atoi(argv[++i]);
