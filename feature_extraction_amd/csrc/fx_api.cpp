@@ -365,7 +365,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   P.ovf_cap = L.max_points;
   {
     const unsigned long long want = L.max_dense_points ? L.max_dense_points : (unsigned long long)L.max_batch * L.max_points;
-    P.dense_cap = (uint32_t)(want > 0xfff00000ull ? 0xfff00000ull : (want < 4096ull ? 4096ull : want));
+    P.dense_cap = (uint32_t)(want > 0xfff00000ull ? 0xfff00000ull : (want < 4096ull ? 4096ull : want));  // (a row takes its support points + 700 entries of it)
     const uint32_t per_row = P.list_cap < P.dense_min ? P.list_cap : P.dense_min;  // a dense row has more support points than this
     const unsigned long long rows = (unsigned long long)P.dense_cap / (per_row ? per_row : 1u) + 1ull;
     P.max_dense_rows = (uint32_t)(rows < L.max_total_keypoints ? rows : L.max_total_keypoints);

@@ -89,6 +89,15 @@ __device__ __forceinline__ float dist2(float qx, float qy, float qz, float px, f
   return r;
 }
 
+// Global memory written by one wavefront of a workgroup and re-read by another: __syncthreads() orders the stores (they
+// are written through to the L2 and acknowledged before the barrier), and an ACQUIRE at agent scope drops the lines this
+// CU's L1 may still hold from an earlier read.  (__threadfence() would also RELEASE at agent scope: on gfx950 that writes
+// the whole L2 back — paid by every wavefront that executes it; the dense tier spent half its sorting time there.)
+__device__ __forceinline__ void wg_global_sync() {
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
 // ------------------------------------------------------------------ union-find in LDS
 // Links always go from the larger root to the smaller one, so a component's root is its
 // smallest member index — PCL's "indices[0]" and its discovery order.
@@ -1864,8 +1873,8 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
     parent[idx] = idx;
     atomicAdd(&bin[bin_of(cell_x(v.x), cell_y(v.y))], 1u);
   }
-  if (!LDS_PTS) __threadfence();  // `cand` is re-read below by other waves of this workgroup
   __syncthreads();
+  if (!LDS_PTS) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // `cand` is re-read below by other waves of this workgroup (see wg_global_sync)
   FX_STAMP(1);
   uint32_t n_c = 0;
   if (C > 0) {  // ref: node.cpp:209-210
@@ -1963,8 +1972,8 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
       if (pos == 0) continue;
       unord[mbase[pos - 1u] + atomicAdd(&mfill[pos - 1u], 1u)] = (uint16_t)i;
     }
-    if (!LDS_PTS) __threadfence();
     __syncthreads();
+    if (!LDS_PTS) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     for (uint32_t i = tid; i < C; i += NT) {  // rank within the cluster = members with a smaller index
       const uint32_t pos = csize[parent[i]] >> 16;
       if (pos == 0) continue;
@@ -1973,8 +1982,8 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
       for (uint32_t m = 0; m < sz; ++m) rank += (uint32_t)unord[m0 + m] < i ? 1u : 0u;
       ord[m0 + rank] = (uint16_t)i;
     }
-    if (!LDS_PTS) __threadfence();
     __syncthreads();
+    if (!LDS_PTS) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     float4 *kp = B.keypoints + (size_t)scan * P.max_keypoints;
     uint32_t *kps = B.kp_size + (size_t)scan * P.max_keypoints;
     for (uint32_t s = tid; s < K; s += NT) {
@@ -2124,6 +2133,9 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_offsets(FxDevParams P, FxB
 //   (3DSC's RNG ordinal rule — a keypoint without neighbours draws no x-axis — is applied by k_gather, which knows
 //    which keypoints have one before any descriptor is computed; k_rng_ord when several workgroups share a scan)
 
+// a dense row reserves this many pool entries beyond its support points: room for the padding of its query list (every
+// one of the 25 x 7 cell rows of its grid to a multiple of four entries)
+#define FX_DQ_PAD (4 * 25 * 7)
 __device__ __forceinline__ uint32_t dense_class(uint32_t nS);
 __device__ __forceinline__ uint32_t dense_class_counter(uint32_t cls);
 
@@ -2755,8 +2767,8 @@ extern "C" __global__ __launch_bounds__(FX_WG, FX_GROUP_OCC) void k_desc_group(F
       if (nS > P.dense_min || nS > P.list_cap) {
         // a slot in the dense-row list and nS entries of the sorted pool (k_dense_sort fills them)
         const uint32_t slot = atomicAdd(&B.counters[6], 1u);
-        const uint32_t off = atomicAdd(&B.counters[13], nS);
-        const bool ok = slot < P.max_dense_rows && off <= P.dense_cap && nS <= P.dense_cap - off;
+        const uint32_t off = atomicAdd(&B.counters[13], nS + FX_DQ_PAD);
+        const bool ok = slot < P.max_dense_rows && off <= P.dense_cap && nS + FX_DQ_PAD <= P.dense_cap - off;
         if (slot < P.max_dense_rows) {
           B.dense_rows[slot] = ok ? row : FX_NONE;
           B.dense_off[slot] = off;
@@ -3236,6 +3248,8 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_mid(FxDevParams P, Fx
 #define FX_DENS_BITS 21             // density count (max_points <= 2^20) in the low bits of a cache word, batch tag above
 #define FX_DENS_MASK ((1ull << FX_DENS_BITS) - 1ull)
 #define FX_DSORT_T 512
+#define FX_DSORT_WONW 2048     // words of k_dense_sort's winners bit map
+#define FX_DQ_WON 0x80000000u  // sorted region, index word: the row computes this point's density (set by k_dense_sort)
 #define FX_DFIN_KS 4096    // binned neighbours the small finishing kernel sorts in LDS
 #define FX_DFIN_KL 14336   // ... the large one (keys + order + bin table: 152 KB of LDS)
 #define FX_DFIN_TS 256
@@ -3294,6 +3308,8 @@ extern "C" __global__ __launch_bounds__(FX_DSORT_T) void k_dense_sort(FxDevParam
   __shared__ uint32_t s_w[16];
   const uint32_t tid = threadIdx.x;
   __shared__ uint32_t s_slot;
+  __shared__ uint32_t won_bits[FX_DSORT_WONW];
+  __shared__ uint32_t row_n[FX_DG * FX_DGZ], row_at[FX_DG * FX_DGZ];  // queries per cell row, start of the row's part of the query list
   if (B.counters[6] == 0u) return;  // no dense rows in this batch (sparse scans): not even a ticket is drawn
   const unsigned long long seq = B.seq[0];
   FX_STAMP_INIT(B.stamps ? B.stamps + 16 : nullptr);
@@ -3395,64 +3411,114 @@ extern "C" __global__ __launch_bounds__(FX_DSORT_T) void k_dense_sort(FxDevParam
     FX_STAMP(2);
     // ---- pass 2: every point to its cell (the fill turns a cell's start into its end = the next cell's start)
     each_point([&](const float4 &v) { dst[atomicAdd(&cell_end[G.cell(v.x, v.y, v.z)], 1u)] = v; });
-    __threadfence();  // the sorted region is re-read below by other waves of this workgroup
-    __syncthreads();
+    // (the sorted region is re-read below by other waves of this workgroup: they share the CU's L1, and the barrier's
+    //  workgroup-scope fences order the stores — an agent-scope __threadfence() would write the L2 back each time)
+    wg_global_sync();
     FX_STAMP(3);
     for (uint32_t t = tid; t < FX_DCELLS; t += FX_DSORT_T) table[t] = cell_end[t];  // cell c = [c ? end[c - 1] : 0, end[c])
     // ---- pass 3, over the sorted region: neighbours (d2 < R^2; the count 3DSC reports), binned neighbours (not the
     //      keypoint's own point), and the queries: binned neighbours whose density this row is the first to claim
     unsigned long long *cache = B.dens_cache + (size_t)scan * P.max_points;
     const unsigned long long claim = (seq << FX_DENS_BITS) | FX_DENS_MASK;
-    // (every wavefront takes a contiguous share of the region: it claims and counts, then — after one prefix over the
-    //  wavefronts — writes its part of the list; which of its points it won stays in a register bit mask meanwhile)
-    uint32_t n_q = 0;
-    constexpr uint32_t NWS = FX_DSORT_T / 64;
+    // The list is built x-row by x-row of cells (a row = 25 consecutive cells = one contiguous run of the sorted region),
+    // every row's part padded to a multiple of four entries: k_dense_density gives a lane four consecutive queries, and
+    // four queries of ONE row have a small box — across a row boundary the box would span the whole grid and the lane
+    // (and with it its wavefront) would walk whole rows.  Pass a: rows dealt to the wavefronts; claim, count, and mark
+    // the winners in the sorted region (top bit of the index word).  Then a padded prefix over the rows.  Pass b: the
+    // same walk writes the list.
+    constexpr uint32_t NWS = FX_DSORT_T / 64, kRows = FX_DG * FX_DGZ;
     const uint32_t lane = tid & 63u, wave = tid >> 6;
-    for (uint32_t r0 = 0; r0 < nS; r0 += NWS * 64u * 64u) {  // (rounds of 32768 points: 64 trips of 64 lanes per wavefront)
-      const uint32_t span = min(nS - r0, NWS * 64u * 64u);
-      const uint32_t chunk = ((span + NWS - 1u) / NWS + 63u) / 64u * 64u;
-      const uint32_t w0 = r0 + wave * chunk, w1 = min(w0 + chunk, r0 + span);
-      unsigned long long won_bits = 0;
-      uint32_t n_won = 0, n_nb = 0, n_use = 0;
-      for (uint32_t p0 = w0, trip = 0; p0 < w1; p0 += 64u, ++trip) {
-        const uint32_t p = p0 + lane;
-        bool nb = false, use = false, won = false;
-        if (p < w1) {
-          const float4 v = dst[p];
-          const float d2 = dist2(kp.x, kp.y, kp.z, v.x, v.y, v.z);
-          nb = d2 < P.r2_search;
-          use = nb && !sc3d_is_origin(d2);
-          if (use) {
-            // batch tags only grow and a claim is the largest word of its batch: one atomic max both tests and claims
-            won = (atomicMax(cache + __float_as_uint(v.w), claim) >> FX_DENS_BITS) != seq;
-          }
-        }
-        const unsigned long long m_won = __ballot(won);
-        if (lane == trip) won_bits = m_won;  // lane `trip` keeps the trip's mask
-        n_won += (uint32_t)__popcll(m_won);
-        n_nb += (uint32_t)__popcll(__ballot(nb));
-        n_use += (uint32_t)__popcll(__ballot(use));
-      }
-      if (lane == 0) {
-        s_w[wave] = n_won;
-        if (n_nb) atomicAdd(&s_w[9], n_nb);
-        if (n_use) atomicAdd(&s_w[10], n_use);
-      }
-      __syncthreads();
-      uint32_t before = n_q, total = 0;
+    // which points the row won: a bit map in LDS (rows of up to 65536 support points), else the top bit of the point's
+    // index word in the sorted region
+    const bool in_lds = nS <= 32u * FX_DSORT_WONW;
+    if (in_lds)
+      for (uint32_t t = tid; t < (nS + 31u) / 32u; t += FX_DSORT_T) won_bits[t] = 0u;
+    __syncthreads();
+    uint32_t n_nb = 0, n_use = 0;
+    auto row_start = [&](uint32_t R) { return R ? cell_end[R * FX_DG - 1u] : 0u; };  // (cell_end[c]: end of cell c, still in LDS)
+    auto row_end = [&](uint32_t R) { return cell_end[R * FX_DG + FX_DG - 1u]; };
+    for (uint32_t R = wave; R < kRows; R += NWS) {
+      const uint32_t rs = row_start(R), re = row_end(R);
+      uint32_t cnt = 0;
+      // (four trips of 64 points at a time: their loads, then their claims, are in flight together — a row is a chain of
+      //  L2 round trips otherwise)
+      for (uint32_t p0 = rs; p0 < re; p0 += 256u) {
+        float4 v[4];
+        bool use[4];
 #pragma unroll
-      for (uint32_t w = 0; w < NWS; ++w) {
-        const uint32_t c = s_w[w];
-        before += w < wave ? c : 0u;
-        total += c;
+        for (uint32_t u = 0; u < 4; ++u) {
+          const uint32_t p = p0 + u * 64u + lane;
+          v[u] = p < re ? dst[p] : make_float4(INFINITY, INFINITY, INFINITY, 0.0f);
+        }
+        unsigned long long old[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+          const float d2 = dist2(kp.x, kp.y, kp.z, v[u].x, v[u].y, v[u].z);  // (no point: infinite)
+          const bool nb = d2 < P.r2_search;
+          use[u] = nb && !sc3d_is_origin(d2);
+          n_nb += (uint32_t)__popcll(__ballot(nb));
+          n_use += (uint32_t)__popcll(__ballot(use[u]));
+          // batch tags only grow and a claim is the largest word of its batch: one atomic max both tests and claims
+          old[u] = use[u] ? atomicMax(cache + __float_as_uint(v[u].w), claim) : claim;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+          const bool won = use[u] && (old[u] >> FX_DENS_BITS) != seq;
+          if (won) {
+            const uint32_t p = p0 + u * 64u + lane;
+            if (in_lds)
+              atomicOr(&won_bits[p >> 5], 1u << (p & 31u));
+            else
+              reinterpret_cast<uint32_t *>(dst + p)[3] = __float_as_uint(v[u].w) | FX_DQ_WON;
+          }
+          cnt += (uint32_t)__popcll(__ballot(won));
+        }
       }
-      __syncthreads();
-      for (uint32_t p0 = w0, trip = 0; p0 < w1; p0 += 64u, ++trip) {
-        const unsigned long long m = __shfl(won_bits, (int)trip, 64);
-        if ((m >> lane) & 1ull) qlist[before + lanes_below(m)] = p0 + lane;
-        before += (uint32_t)__popcll(m);
+      if (lane == 0) row_n[R] = cnt;
+    }
+    if (lane == 0) {
+      if (n_nb) atomicAdd(&s_w[9], n_nb);
+      if (n_use) atomicAdd(&s_w[10], n_use);
+    }
+    wg_global_sync();  // (the marks in the sorted region are re-read below when the bit map is too small)
+    if (tid < 64) {  // padded counts -> row starts, by one wavefront
+      constexpr uint32_t per = (kRows + 63) / 64;
+      uint32_t sum = 0;
+      for (uint32_t u = 0; u < per; ++u) {
+        const uint32_t R = tid * per + u;
+        sum += R < kRows ? (row_n[R] + 3u) & ~3u : 0u;
       }
-      n_q += total;
+      uint32_t incl = sum;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+        if ((int)tid >= d) incl += o;
+      }
+      uint32_t run = incl - sum;
+      for (uint32_t u = 0; u < per; ++u) {
+        const uint32_t R = tid * per + u;
+        if (R < kRows) {
+          row_at[R] = run;
+          run += (row_n[R] + 3u) & ~3u;
+        }
+      }
+      if (tid == 63) s_w[12] = incl;
+    }
+    __syncthreads();
+    const uint32_t n_q = s_w[12];  // (with the padding)
+    for (uint32_t R = wave; R < kRows; R += NWS) {
+      const uint32_t rs = row_start(R), re = row_end(R);
+      uint32_t at = row_at[R];
+      for (uint32_t p0 = rs; p0 < re; p0 += 64u) {
+        const uint32_t p = p0 + lane;
+        const bool won = p < re && (in_lds ? ((won_bits[p >> 5] >> (p & 31u)) & 1u) != 0u
+                                           : (reinterpret_cast<const uint32_t *>(dst + p)[3] & FX_DQ_WON) != 0u);
+        const unsigned long long m = __ballot(won);
+        if (won) qlist[at + lanes_below(m)] = p;
+        at += (uint32_t)__popcll(m);
+      }
+      const uint32_t cnt = row_n[R], pad = ((cnt + 3u) & ~3u) - cnt;
+      if (lane < pad) qlist[at + lane] = FX_NONE;  // (no query: k_dense_density skips it)
     }
     __syncthreads();
     FX_STAMP(4);
@@ -3535,8 +3601,10 @@ extern "C" __global__ __launch_bounds__(FX_DDENS_T) void k_dense_density(FxDevPa
     for (int u = 0; u < 4; ++u) {
       const uint32_t qi = qb + 4u * tid + (uint32_t)u;
       q[u] = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.0f);  // (no query: its differences overflow to infinity, never below the radius)
-      if (qi < n_q) {
-        q[u] = pts[qlist[qi]];
+      const uint32_t qp = qi < n_q ? qlist[qi] : FX_NONE;  // (FX_NONE: padding at the end of a cell row)
+      if (qp != FX_NONE) {
+        q[u] = pts[qp];
+        q[u].w = __uint_as_float(__float_as_uint(q[u].w) & ~FX_DQ_WON);
         bx0 = fminf(bx0, q[u].x), bx1 = fmaxf(bx1, q[u].x);
         by0 = fminf(by0, q[u].y), by1 = fmaxf(by1, q[u].y);
         bz0 = fminf(bz0, q[u].z), bz1 = fmaxf(bz1, q[u].z);
@@ -3615,8 +3683,7 @@ extern "C" __global__ __launch_bounds__(FX_DDENS_T) void k_dense_density(FxDevPa
       }
       __syncthreads();
       // ---- every lane: its rows, each narrowed to the chord of the density sphere, as far as they lie in the window
-      for (uint32_t r = 0; r < n_rows; ++r) {
-        const uint32_t cz = zlo + r / ny, cy = ylo + r % ny;
+      for (uint32_t r = 0, cy = ylo, cz = zlo; r < n_rows; ++r, cz += (cy + 1u == ylo + ny) ? 1u : 0u, cy = (cy + 1u == ylo + ny) ? ylo : cy + 1u) {
         const float y0 = G.gy0 + (float)cy * cw - eps_w, y1 = G.gy0 + (float)(cy + 1u) * cw + eps_w;
         const float z0 = G.gz0 + (float)cz * ch - eps_h, z1 = G.gz0 + (float)(cz + 1u) * ch + eps_h;
         // (edge cells also hold what the clamp put there: they extend outwards without limit)
@@ -3653,7 +3720,7 @@ extern "C" __global__ __launch_bounds__(FX_DDENS_T) void k_dense_density(FxDevPa
     const uint32_t cnt[4] = {c0, c1, c2, c3};
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      if (qb + 4u * tid + (uint32_t)u < n_q) cache[__float_as_uint(q[u].w)] = tag | (unsigned long long)cnt[u];
+      if (q[u].x < 1.0e38f) cache[__float_as_uint(q[u].w)] = tag | (unsigned long long)cnt[u];
   }
 }
 
@@ -3673,8 +3740,7 @@ __device__ __forceinline__ void dense_bitonic_global(unsigned long long *sk, uin
           }
         }
       }
-      __threadfence();
-      __syncthreads();
+      wg_global_sync();
     }
   }
 }
@@ -3696,7 +3762,7 @@ __device__ __forceinline__ void dense_keys(const FxDevParams &P, const float4 *p
         float lut;
         bool amb = false;
         const uint32_t bin = sc3d_bin<true>(kp, v.x, v.y, v.z, d2, xa, T, lut, amb);
-        key = sc3d_key(bin, d2, __float_as_uint(v.w));
+        key = sc3d_key(bin, d2, __float_as_uint(v.w) & ~FX_DQ_WON);
         if (HIST) atomicAdd(&hist[bin], 1u);
       }
     }
@@ -3748,15 +3814,13 @@ __device__ __forceinline__ void dense_finish_row(const FxDevParams &P, const FxB
     __syncthreads();
     dense_keys<NT, false>(P, pts, nS, kp, xa, T, sk, nullptr, s_w);
     for (uint32_t t = nM + tid; t < p2; t += NT) sk[t] = ~0ull;
-    __threadfence();
-    __syncthreads();
+    wg_global_sync();
     dense_bitonic_global<NT>(sk, p2);
     for (uint32_t t = tid; t < nM; t += NT) {  // every sorted key becomes (bin, weight) in place
       const unsigned long long key = sk[t];
       sk[t] = ((key >> 52) << 32) | (unsigned long long)__float_as_uint(dense_weight(key, cache, seq, T));
     }
-    __threadfence();
-    __syncthreads();
+    wg_global_sync();
     for (uint32_t t = tid; t < nM; t += NT) {  // one lane per bin run
       const uint32_t bin = (uint32_t)(sk[t] >> 32);
       if (t > 0 && (uint32_t)(sk[t - 1] >> 32) == bin) continue;

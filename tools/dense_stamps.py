@@ -36,3 +36,8 @@ rows = max(v[base + 6], 1)
 print(f"{name}: k_dense_sort rows {rows:.0f} (stamped workgroups only), support {v[base + 7] / rows:.0f}, overflow region {v[base + 8] / rows:.0f}")
 for k, nm in {1: "clear + pass 1 (histogram)", 2: "prefix", 3: "pass 2 (scatter)", 4: "pass 3 (claims, query list)", 5: "items"}.items():
     print(f"   {nm:32s} {v[base + k] / rows:10.0f} cycles per row (100 MHz clock x ?)")
+# k_dense_density's diagnostic counters (columns 44..48: free of the ring / merge / descriptor kernels' stamps)
+t, d, q, box, items = v[44], v[45], v[46], v[47], v[48]
+if q:
+    print(f"k_dense_density: {items:.0f} items, {q:.0f} queries; targets walked per query {t / (q / 4) :.0f} (a lane's walk serves its 4 queries), "
+          f"true density per query {d / q:.0f}, box targets per item {box / max(items, 1):.0f}")
