@@ -2258,7 +2258,7 @@ __device__ __forceinline__ unsigned long long sc3d_key(uint32_t bin, float d2, u
 #ifndef FX_GATHER_T
 #define FX_GATHER_T 256  // (384 and 512 threads measured: see DESIGN.md)
 #endif
-#define FX_GATHER_NW (FX_GATHER_T / 64)
+#define FX_GATHER_WIDE_T 1024  // one workgroup per scan for batches that do not fill the GPU with 256-thread ones
 #define FX_GATHER_G 32  // cells per axis at most
 #define FX_GATHER_CELLS (FX_GATHER_G * FX_GATHER_G)
 #ifndef FX_GATHER_STAGE
@@ -2270,17 +2270,18 @@ __device__ __forceinline__ unsigned long long sc3d_key(uint32_t bin, float d2, u
 #ifndef FX_GATHER_QUEUE
 #define FX_GATHER_QUEUE 80   // points one wavefront parks before it drains them (drained once more than 16 are waiting)
 #endif
-__host__ __device__ inline uint32_t gather_words(uint32_t mk) {
+__host__ __device__ inline uint32_t gather_words(uint32_t mk, uint32_t nt) {
   uint32_t w = 32 + 4 * mk;                                   // scratch, keypoints
   w += FX_GATHER_CELLS + 4;                                   // cell table (the fill cursors borrow the staging area)
   w += ((9 * mk + 1) / 2 + 3) & ~3u;                          // cell lists (uint16)
   w += (5 * mk + 3) & ~3u;                                    // staged hits per keypoint, reserved list positions, list lengths, has-a-neighbour flags, overflow slots
   w += FX_GATHER_STAGE + 4 * FX_GATHER_STAGE;                 // staged hits: meta, points
-  w += FX_GATHER_NW * FX_GATHER_QUEUE * 5;                    // per-wavefront queues: points, cell info
+  w += (nt / 64) * FX_GATHER_QUEUE * 5;                       // per-wavefront queues: points, cell info
   return w;
 }
-extern "C" __global__ __launch_bounds__(FX_GATHER_T) void k_gather(FxDevParams P, FxBuffers B, float box_margin) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+template <int NT>
+__device__ __forceinline__ void gather_body(const FxDevParams &P, const FxBuffers &B, float box_margin, uint32_t *smem) {
+  constexpr uint32_t FX_GATHER_NW = NT / 64;
   const uint32_t MK = P.max_keypoints;
   uint32_t *s_w = smem;                                          // 0..5 keypoint box, 8 staged hits
   float4 *s_kp = reinterpret_cast<float4 *>(smem + 32);          // 16-byte aligned
@@ -2308,14 +2309,14 @@ extern "C" __global__ __launch_bounds__(FX_GATHER_T) void k_gather(FxDevParams P
   const FxScanMeta M = B.meta[scan];
   // row -> (scan, keypoint) map for the per-keypoint kernels (one load instead of a binary search)
   if (slice == 0)
-    for (uint32_t k = tid; k < K; k += FX_GATHER_T) B.row_map[row0 + k] = make_uint2(scan, k);
+    for (uint32_t k = tid; k < K; k += NT) B.row_map[row0 + k] = make_uint2(scan, k);
   // keypoints of the scan -> LDS; their bounding box (ordered-uint atomics) for a cheap reject
   if (tid < 6) s_w[tid] = (tid & 1) ? f2ord(-INFINITY) : f2ord(INFINITY);
   if (tid == 0) s_w[8] = 0;  // staged hits
   if (tid == 0) s_w[9] = 0;  // entries in the scan's overflow region (one workgroup per scan)
-  for (uint32_t c = tid; c < FX_GATHER_CELLS; c += FX_GATHER_T) s_cell[c] = 0;
+  for (uint32_t c = tid; c < FX_GATHER_CELLS; c += NT) s_cell[c] = 0;
   __syncthreads();
-  for (uint32_t k = tid; k < K; k += FX_GATHER_T) {
+  for (uint32_t k = tid; k < K; k += NT) {
     const float4 kp = B.keypoints[(size_t)scan * P.max_keypoints + k];
     s_kp[k] = kp;
     s_kcnt[k] = 0;
@@ -2342,7 +2343,7 @@ extern "C" __global__ __launch_bounds__(FX_GATHER_T) void k_gather(FxDevParams P
   const int ncx = min((int)((bx1 - bx0) * inv_wx) + 1, FX_GATHER_G), ncy = min((int)((by1 - by0) * inv_wy) + 1, FX_GATHER_G);
   auto cell_x = [&](float x) { return min(max((int)floorf((x - bx0) * inv_wx), 0), ncx - 1); };
   auto cell_y = [&](float y) { return min(max((int)floorf((y - by0) * inv_wy), 0), ncy - 1); };
-  for (uint32_t k = tid; k < K; k += FX_GATHER_T) {
+  for (uint32_t k = tid; k < K; k += NT) {
     const int cx = cell_x(s_kp[k].x), cy = cell_y(s_kp[k].y);
     for (int dy = -1; dy <= 1; ++dy)
       for (int dx = -1; dx <= 1; ++dx)
@@ -2374,7 +2375,7 @@ extern "C" __global__ __launch_bounds__(FX_GATHER_T) void k_gather(FxDevParams P
     }
   }
   __syncthreads();
-  for (uint32_t k = tid; k < K; k += FX_GATHER_T) {
+  for (uint32_t k = tid; k < K; k += NT) {
     const int cx = cell_x(s_kp[k].x), cy = cell_y(s_kp[k].y);
     for (int dy = -1; dy <= 1; ++dy)
       for (int dx = -1; dx <= 1; ++dx)
@@ -2383,7 +2384,7 @@ extern "C" __global__ __launch_bounds__(FX_GATHER_T) void k_gather(FxDevParams P
   }
   __syncthreads();
 
-  constexpr uint32_t kTile = FX_GATHER_T * 4;  // 1024 points: wave w owns [256 w, 256 w + 256), 64 consecutive points per load
+  constexpr uint32_t kTile = NT * 4;  // 1024 points: wave w owns [256 w, 256 w + 256), 64 consecutive points per load
   const uint32_t n = M.n;
   uint32_t chunk = (n + gridDim.x - 1) / gridDim.x;
   chunk = (chunk + kTile - 1) / kTile * kTile;
@@ -2398,7 +2399,7 @@ extern "C" __global__ __launch_bounds__(FX_GATHER_T) void k_gather(FxDevParams P
   auto ovf_reserve = [&](uint32_t n) -> uint32_t { return solo ? atomicAdd(&s_w[9], n) : atomicAdd(&B.ovf_cnt[scan], n); };
   auto flush = [&](uint32_t staged) {
     staged = min(staged, (uint32_t)FX_GATHER_STAGE);
-    for (uint32_t k = tid; k < K; k += FX_GATHER_T) {
+    for (uint32_t k = tid; k < K; k += NT) {
       const uint32_t c = s_kcnt[k];
       if (c) {
         uint32_t base;
@@ -2417,7 +2418,7 @@ extern "C" __global__ __launch_bounds__(FX_GATHER_T) void k_gather(FxDevParams P
       s_kcnt[k] = 0;
     }
     __syncthreads();
-    for (uint32_t e = tid; e < staged; e += FX_GATHER_T) {
+    for (uint32_t e = tid; e < staged; e += NT) {
       const uint32_t meta = s_smeta[e], k = meta >> 16;
       const uint32_t pos = s_kbase[k] + (meta & 0xffffu);
       if (pos < P.list_cap) {
@@ -2454,7 +2455,10 @@ extern "C" __global__ __launch_bounds__(FX_GATHER_T) void k_gather(FxDevParams P
           }
           // One workgroup per scan: the list position is the workgroup's own LDS counter, so the hit goes straight to
           // its slot (no staging, no flush, no workgroup barrier in the tile loop).  Several workgroups per scan
-          // (small batches): hits are staged and a flush reserves positions with one global atomic per keypoint.
+          // (small batches): hits are staged and a flush reserves positions with one global atomic per keypoint —
+          // fine for a handful of sparse scans, hopeless for dense ones (hundreds of flushes: BASELINE config 3 with four
+          // workgroups per scan 5.4 ms against 0.66 with one; a global atomic per hit: 7.3 ms, the hot keypoints' counters
+          // serialise), which is why dense scans get one WIDE workgroup instead (k_gather_wide).
           const uint32_t slot = (FX_GATHER_DIRECT && solo) ? FX_GATHER_STAGE : atomicAdd(&s_w[8], 1u);
           if (slot < FX_GATHER_STAGE) {
             s_spt[slot] = pq;
@@ -2537,7 +2541,7 @@ extern "C" __global__ __launch_bounds__(FX_GATHER_T) void k_gather(FxDevParams P
   flush(s_w[8]);
   if (solo) {
     if (tid == 0) B.ovf_cnt[scan] = s_w[9];
-    for (uint32_t k = tid; k < K; k += FX_GATHER_T) B.s_cnt[row0 + k] = s_kpos[k];
+    for (uint32_t k = tid; k < K; k += NT) B.s_cnt[row0 + k] = s_kpos[k];
     // RNG ordinals: keypoint k takes the x-axis number (keypoints before it that have a neighbour)
     __syncthreads();
     if (wave == 0) {
@@ -2550,6 +2554,14 @@ extern "C" __global__ __launch_bounds__(FX_GATHER_T) void k_gather(FxDevParams P
       }
     }
   }
+}
+extern "C" __global__ __launch_bounds__(FX_GATHER_T) void k_gather(FxDevParams P, FxBuffers B, float box_margin) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  gather_body<FX_GATHER_T>(P, B, box_margin, smem);
+}
+extern "C" __global__ __launch_bounds__(FX_GATHER_WIDE_T) void k_gather_wide(FxDevParams P, FxBuffers B, float box_margin) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  gather_body<FX_GATHER_WIDE_T>(P, B, box_margin, smem);
 }
 
 // ---------------------------------------------------------------- wavefront tier (runs inside k_desc_mid)
@@ -4057,7 +4069,7 @@ void fxk_rings_large(hipStream_t s, const FxDevParams &P, const FxBuffers &B, ui
 }
 size_t fxk_merge_lds_bytes(uint32_t cap, uint32_t n_rings) { return merge_words(cap, cap, n_rings, true) * 4; }
 size_t fxk_merge_huge_lds_bytes(uint32_t cap, uint32_t ccap, uint32_t n_rings) { return merge_words(cap, ccap, n_rings, false) * 4; }
-size_t fxk_gather_lds_bytes(uint32_t max_keypoints) { return (size_t)gather_words(max_keypoints) * 4; }
+size_t fxk_gather_lds_bytes(uint32_t max_keypoints) { return (size_t)gather_words(max_keypoints, FX_GATHER_WIDE_T) * 4; }
 size_t fxk_dense_finish_lds_bytes(int large) {
   const size_t k = large ? FX_DFIN_KL : FX_DFIN_KS;
   return (2 * k + k / 2 + 1984 + FX_TABLE_WORDS + 16) * 4;
@@ -4070,6 +4082,8 @@ hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t merge_huge, s
   e = hipFuncSetAttribute((const void *)k_merge_huge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)merge_huge);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void *)k_gather, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gather);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void *)k_gather_wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gather);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void *)k_rings_large, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_big);
   if (e != hipSuccess) return e;
@@ -4118,11 +4132,16 @@ void fxk_offsets(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32
 #ifndef FX_GATHER_SLICES
 #define FX_GATHER_SLICES 1u
 #endif
-uint32_t fxk_gather_slices(uint32_t batch) { return batch >= 128 ? FX_GATHER_SLICES : (batch >= 16 ? 4u : 16u); }
+// One workgroup per scan (the sole writer of the scan's lists: no global atomics) from 64 scans on — 256 threads when
+// the batch alone fills the GPU, 1024 (k_gather_wide) when it does not; only a handful of scans (streaming) is split
+// over several workgroups per scan.
+uint32_t fxk_gather_slices(uint32_t batch) { return batch >= 64u ? FX_GATHER_SLICES : (batch >= 16u ? 4u : 16u); }
 void fxk_gather(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float box_margin) {
   const uint32_t slices = fxk_gather_slices(batch);
-  hipLaunchKernelGGL(k_gather, dim3(slices, batch), dim3(FX_GATHER_T),
-                     fxk_gather_lds_bytes(P.max_keypoints), s, P, B, box_margin);
+  if (slices == 1 && batch < 1024u)
+    hipLaunchKernelGGL(k_gather_wide, dim3(1, batch), dim3(FX_GATHER_WIDE_T), (size_t)gather_words(P.max_keypoints, FX_GATHER_WIDE_T) * 4, s, P, B, box_margin);
+  else
+    hipLaunchKernelGGL(k_gather, dim3(slices, batch), dim3(FX_GATHER_T), (size_t)gather_words(P.max_keypoints, FX_GATHER_T) * 4, s, P, B, box_margin);
 }
 void fxk_desc_group(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid) {
   hipLaunchKernelGGL(k_desc_group, dim3(grid), dim3(FX_WG), (size_t)(FX_NWAVE * FX_GROUPS * FX_GROUP_WORDS + FX_TABLE_WORDS) * 4, s, P, B, batch);
