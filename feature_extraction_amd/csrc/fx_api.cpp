@@ -370,6 +370,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
     const unsigned long long rows = (unsigned long long)P.dense_cap / (per_row ? per_row : 1u) + 1ull;
     P.max_dense_rows = (uint32_t)(rows < L.max_total_keypoints ? rows : L.max_total_keypoints);
   }
+  P.dense_qcap = P.dense_cap > 0x7ff00000u ? 0xfff00000u : 2u * P.dense_cap;  // (cells' queries padded to four: typically 1.2 entries per query)
   P.dense_lds_keys = 14336u;  // FX_DFIN_KL of fx_kernels.hip
   if (const char *e = getenv("FX_DENSE_LDS_KEYS")) {  // test hook: push rows on to the global-memory key sort (can only lower the cap)
     const int v = atoi(e);
@@ -448,7 +449,8 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   FX_A(dev_alloc(c, &b.dense_cells, (size_t)P.max_dense_rows * fxk_dense_cells()));
   FX_A(dev_alloc(c, &b.dense_items, (size_t)P.dense_cap / 256 + P.max_dense_rows + 1));
   FX_A(dev_alloc(c, &b.dense_pts, P.dense_cap));
-  FX_A(dev_alloc(c, &b.dense_q, P.dense_cap));
+  FX_A(dev_alloc(c, &b.dense_q, P.dense_qcap));
+  FX_A(dev_alloc(c, &b.dense_qoff, P.max_dense_rows));
   FX_A(dev_alloc(c, &b.dense_key, P.dense_cap));
   FX_A(dev_alloc(c, &b.dens_cache, B * L.max_points));
   FX_A(dev_alloc(c, &b.seq, 1));
@@ -892,6 +894,15 @@ fx_status fx_debug_stamps(fx_ctx *c, unsigned long long *out32 /* 64 words */) {
     out32[k] = 0;
     for (int w = 0; w < 64; ++w) out32[k] += all[(size_t)w * 64 + k];
   }
+  return FX_OK;
+}
+
+// Diagnostic (-DFX_STAMPS builds): the raw stamp words (64 x 64).
+fx_status fx_debug_stamps_raw(fx_ctx *c, unsigned long long *out4096) {
+  if (!c || !out4096) return fail(FX_ERR_INVALID_ARG, "null argument");
+  FX_HIP(hipSetDevice(c->device));
+  FX_HIP(hipStreamSynchronize(c->stream));
+  FX_HIP(hipMemcpy(out4096, c->buf.stamps, 64 * 64 * 8, hipMemcpyDeviceToHost));
   return FX_OK;
 }
 

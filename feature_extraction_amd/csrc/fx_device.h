@@ -38,6 +38,7 @@ struct FxDevParams {
   uint32_t ovf_cap;         // entries of a scan's overflow region (list entries beyond list_cap, any row of the scan)
   uint32_t dense_cap;       // entries of the sorted pool (and of the key pool) per batch
   uint32_t max_dense_rows;  // rows of the dense-row list / cell tables
+  uint32_t dense_qcap;      // entries of the query pool (every cell's queries padded to four: up to 4 per support point)
   uint32_t dense_lds_keys;  // binned neighbours k_dense_finish_l sorts in LDS (16384; tests lower it to reach the key pool)
 };
 
@@ -51,7 +52,8 @@ struct FxScTables {
 
 // Every device buffer of a context.
 #define FX_CLK_SLOTS 64
-#define FX_N_COUNTERS 32
+#define FX_N_COUNTERS 40
+#define FX_CNT_QPOOL 32   // counters[32]: entries of the dense tier's query pool in use
 #define FX_CNT_LARGE2 16  // counters[16 + c]: rings of XCD class c the second run tier hands to the workgroup tier
 #define FX_CNT_LARGE 24  // counters[24 + c]: ... to the large tier
 struct FxBuffers {
@@ -102,12 +104,13 @@ struct FxBuffers {
   uint32_t *dense_order;  // [4][max_dense_rows]  slots by size class (largest rows first)
   uint32_t *dense_off;    // [max_dense_rows]  the row's region of dense_pts / dense_q
   uint32_t *dense_koff;   // [max_dense_rows]  the row's region of dense_key (rows whose keys do not fit LDS)
+  uint32_t *dense_qoff;   // [max_dense_rows]  the row's region of dense_q
   uint32_t *dense_nq;     // [max_dense_rows]  queries (densities this row computes)
   uint32_t *dense_nm;     // [max_dense_rows]  binned neighbours (FX_NONE: failed row)
   uint32_t *dense_cells;  // [max_dense_rows][25 * 25 * 7]  end of every cell in the row's sorted region
   uint2 *dense_items;     // work items of k_dense_density: (slot, first query)
   float4 *dense_pts;      // [dense_cap]  support sets sorted by cell (x, y, z rotated, point index as bits)
-  uint32_t *dense_q;      // [dense_cap]  query lists (positions in the row's sorted region, cell order)
+  uint32_t *dense_q;      // [dense_qcap]  query lists (positions in the row's sorted region, cell by cell, padded to four)
   unsigned long long *dense_key;   // [dense_cap]  (bin, d2, index) keys of rows too large for the LDS sort
   unsigned long long *dens_cache;  // [B][max_points]  batch tag << 21 | local point density of the point (k_dense_density)
   unsigned long long *seq;         // [1]  batches processed (device side), the cache's tag

@@ -2133,9 +2133,6 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_offsets(FxDevParams P, FxB
 //   (3DSC's RNG ordinal rule — a keypoint without neighbours draws no x-axis — is applied by k_gather, which knows
 //    which keypoints have one before any descriptor is computed; k_rng_ord when several workgroups share a scan)
 
-// a dense row reserves this many pool entries beyond its support points: room for the padding of its query list (every
-// one of the 25 x 7 cell rows of its grid to a multiple of four entries)
-#define FX_DQ_PAD (4 * 25 * 7)
 __device__ __forceinline__ uint32_t dense_class(uint32_t nS);
 __device__ __forceinline__ uint32_t dense_class_counter(uint32_t cls);
 
@@ -2779,8 +2776,8 @@ extern "C" __global__ __launch_bounds__(FX_WG, FX_GROUP_OCC) void k_desc_group(F
       if (nS > P.dense_min || nS > P.list_cap) {
         // a slot in the dense-row list and nS entries of the sorted pool (k_dense_sort fills them)
         const uint32_t slot = atomicAdd(&B.counters[6], 1u);
-        const uint32_t off = atomicAdd(&B.counters[13], nS + FX_DQ_PAD);
-        const bool ok = slot < P.max_dense_rows && off <= P.dense_cap && nS + FX_DQ_PAD <= P.dense_cap - off;
+        const uint32_t off = atomicAdd(&B.counters[13], nS);
+        const bool ok = slot < P.max_dense_rows && off <= P.dense_cap && nS <= P.dense_cap - off;
         if (slot < P.max_dense_rows) {
           B.dense_rows[slot] = ok ? row : FX_NONE;
           B.dense_off[slot] = off;
@@ -3321,7 +3318,7 @@ extern "C" __global__ __launch_bounds__(FX_DSORT_T) void k_dense_sort(FxDevParam
   const uint32_t tid = threadIdx.x;
   __shared__ uint32_t s_slot;
   __shared__ uint32_t won_bits[FX_DSORT_WONW];
-  __shared__ uint32_t row_n[FX_DG * FX_DGZ], row_at[FX_DG * FX_DGZ];  // queries per cell row, start of the row's part of the query list
+  __shared__ uint32_t cell_q[FX_DCELLS + 1];  // queries per cell, then the cell's part of the query list
   if (B.counters[6] == 0u) return;  // no dense rows in this batch (sparse scans): not even a ticket is drawn
   const unsigned long long seq = B.seq[0];
   FX_STAMP_INIT(B.stamps ? B.stamps + 16 : nullptr);
@@ -3344,7 +3341,6 @@ extern "C" __global__ __launch_bounds__(FX_DSORT_T) void k_dense_sort(FxDevParam
     const uint32_t *ovf_kp = B.ovf_kp + (size_t)scan * P.ovf_cap;
     const DenseGrid G = dense_grid(P, kp);
     float4 *dst = B.dense_pts + off;
-    uint32_t *qlist = B.dense_q + off;
     uint32_t *table = B.dense_cells + (size_t)slot * FX_DCELLS;
     __syncthreads();
 #ifdef FX_STAMPS
@@ -3432,73 +3428,69 @@ extern "C" __global__ __launch_bounds__(FX_DSORT_T) void k_dense_sort(FxDevParam
     //      keypoint's own point), and the queries: binned neighbours whose density this row is the first to claim
     unsigned long long *cache = B.dens_cache + (size_t)scan * P.max_points;
     const unsigned long long claim = (seq << FX_DENS_BITS) | FX_DENS_MASK;
-    // The list is built x-row by x-row of cells (a row = 25 consecutive cells = one contiguous run of the sorted region),
-    // every row's part padded to a multiple of four entries: k_dense_density gives a lane four consecutive queries, and
-    // four queries of ONE row have a small box — across a row boundary the box would span the whole grid and the lane
-    // (and with it its wavefront) would walk whole rows.  Pass a: rows dealt to the wavefronts; claim, count, and mark
-    // the winners in the sorted region (top bit of the index word).  Then a padded prefix over the rows.  Pass b: the
-    // same walk writes the list.
-    constexpr uint32_t NWS = FX_DSORT_T / 64, kRows = FX_DG * FX_DGZ;
-    const uint32_t lane = tid & 63u, wave = tid >> 6;
-    // which points the row won: a bit map in LDS (rows of up to 65536 support points), else the top bit of the point's
-    // index word in the sorted region
+    // The list is built cell by cell, every cell's part padded to a multiple of four entries: k_dense_density gives a lane
+    // four consecutive queries, and four queries of ONE cell have a box no larger than the cell.  (Unpadded, 4 % of the
+    // lanes held queries of three or more cells — the sparse stretches of a row, the edges of what other rows had
+    // claimed — walked twice as far as the others, and nearly every wavefront had one: 974 trips a wavefront against
+    // 509 a lane.)  Pass a: claim, count per cell, remember the winners (a bit map in LDS; the top bit of the point's
+    // index word in the sorted region for rows beyond 65536 support points).  Then a padded prefix over the cells and
+    // the row's share of the query pool.  Pass b: every winner to its cell's part of the list.
     const bool in_lds = nS <= 32u * FX_DSORT_WONW;
+    for (uint32_t t = tid; t < FX_DCELLS + 1; t += FX_DSORT_T) cell_q[t] = 0u;
     if (in_lds)
       for (uint32_t t = tid; t < (nS + 31u) / 32u; t += FX_DSORT_T) won_bits[t] = 0u;
     __syncthreads();
+    const uint32_t lane = tid & 63u;
     uint32_t n_nb = 0, n_use = 0;
-    auto row_start = [&](uint32_t R) { return R ? cell_end[R * FX_DG - 1u] : 0u; };  // (cell_end[c]: end of cell c, still in LDS)
-    auto row_end = [&](uint32_t R) { return cell_end[R * FX_DG + FX_DG - 1u]; };
-    for (uint32_t R = wave; R < kRows; R += NWS) {
-      const uint32_t rs = row_start(R), re = row_end(R);
-      uint32_t cnt = 0;
-      // (four trips of 64 points at a time: their loads, then their claims, are in flight together — a row is a chain of
-      //  L2 round trips otherwise)
-      for (uint32_t p0 = rs; p0 < re; p0 += 256u) {
-        float4 v[4];
-        bool use[4];
+    // (four points per lane at a time: their loads, then their claims, are in flight together — the pass is a chain of L2
+    //  round trips otherwise)
+    for (uint32_t p0 = 0; p0 < nS; p0 += 4u * FX_DSORT_T) {
+      float4 v[4];
+      bool use[4];
 #pragma unroll
-        for (uint32_t u = 0; u < 4; ++u) {
-          const uint32_t p = p0 + u * 64u + lane;
-          v[u] = p < re ? dst[p] : make_float4(INFINITY, INFINITY, INFINITY, 0.0f);
-        }
-        unsigned long long old[4];
+      for (uint32_t u = 0; u < 4; ++u) {
+        const uint32_t p = p0 + u * FX_DSORT_T + tid;
+        v[u] = p < nS ? dst[p] : make_float4(INFINITY, INFINITY, INFINITY, 0.0f);
+      }
+      unsigned long long old[4];
 #pragma unroll
-        for (uint32_t u = 0; u < 4; ++u) {
-          const float d2 = dist2(kp.x, kp.y, kp.z, v[u].x, v[u].y, v[u].z);  // (no point: infinite)
-          const bool nb = d2 < P.r2_search;
-          use[u] = nb && !sc3d_is_origin(d2);
-          n_nb += (uint32_t)__popcll(__ballot(nb));
-          n_use += (uint32_t)__popcll(__ballot(use[u]));
-          // batch tags only grow and a claim is the largest word of its batch: one atomic max both tests and claims
-          old[u] = use[u] ? atomicMax(cache + __float_as_uint(v[u].w), claim) : claim;
-        }
+      for (uint32_t u = 0; u < 4; ++u) {
+        const float d2 = dist2(kp.x, kp.y, kp.z, v[u].x, v[u].y, v[u].z);  // (no point: infinite)
+        const bool nb = d2 < P.r2_search;
+        use[u] = nb && !sc3d_is_origin(d2);
+        n_nb += (uint32_t)__popcll(__ballot(nb));
+        n_use += (uint32_t)__popcll(__ballot(use[u]));
+        // batch tags only grow and a claim is the largest word of its batch: one atomic max both tests and claims
+#ifdef FX_NO_DEDUPE  // (diagnostic: every row computes all its neighbours' densities itself)
+        old[u] = 0ull;
+        if (use[u]) atomicMax(cache + __float_as_uint(v[u].w), claim);
+#else
+        old[u] = use[u] ? atomicMax(cache + __float_as_uint(v[u].w), claim) : claim;
+#endif
+      }
 #pragma unroll
-        for (uint32_t u = 0; u < 4; ++u) {
-          const bool won = use[u] && (old[u] >> FX_DENS_BITS) != seq;
-          if (won) {
-            const uint32_t p = p0 + u * 64u + lane;
-            if (in_lds)
-              atomicOr(&won_bits[p >> 5], 1u << (p & 31u));
-            else
-              reinterpret_cast<uint32_t *>(dst + p)[3] = __float_as_uint(v[u].w) | FX_DQ_WON;
-          }
-          cnt += (uint32_t)__popcll(__ballot(won));
+      for (uint32_t u = 0; u < 4; ++u) {
+        if (use[u] && (old[u] >> FX_DENS_BITS) != seq) {  // won: this row computes the point's density
+          const uint32_t p = p0 + u * FX_DSORT_T + tid;
+          atomicAdd(&cell_q[G.cell(v[u].x, v[u].y, v[u].z)], 1u);
+          if (in_lds)
+            atomicOr(&won_bits[p >> 5], 1u << (p & 31u));
+          else
+            reinterpret_cast<uint32_t *>(dst + p)[3] = __float_as_uint(v[u].w) | FX_DQ_WON;
         }
       }
-      if (lane == 0) row_n[R] = cnt;
     }
-    if (lane == 0) {
+    if (lane == 0) {  // (the ballots above are wave-wide: one lane reports them)
       if (n_nb) atomicAdd(&s_w[9], n_nb);
       if (n_use) atomicAdd(&s_w[10], n_use);
     }
     wg_global_sync();  // (the marks in the sorted region are re-read below when the bit map is too small)
-    if (tid < 64) {  // padded counts -> row starts, by one wavefront
-      constexpr uint32_t per = (kRows + 63) / 64;
+    if (tid < 64) {  // padded counts -> cell starts, in place, by one wavefront
+      constexpr uint32_t per = (FX_DCELLS + 63) / 64;
       uint32_t sum = 0;
       for (uint32_t u = 0; u < per; ++u) {
-        const uint32_t R = tid * per + u;
-        sum += R < kRows ? (row_n[R] + 3u) & ~3u : 0u;
+        const uint32_t ci = tid * per + u;
+        sum += ci < FX_DCELLS ? (cell_q[ci] + 3u) & ~3u : 0u;
       }
       uint32_t incl = sum;
 #pragma unroll
@@ -3508,29 +3500,50 @@ extern "C" __global__ __launch_bounds__(FX_DSORT_T) void k_dense_sort(FxDevParam
       }
       uint32_t run = incl - sum;
       for (uint32_t u = 0; u < per; ++u) {
-        const uint32_t R = tid * per + u;
-        if (R < kRows) {
-          row_at[R] = run;
-          run += (row_n[R] + 3u) & ~3u;
+        const uint32_t ci = tid * per + u;
+        if (ci < FX_DCELLS) {
+          const uint32_t c = (cell_q[ci] + 3u) & ~3u;
+          cell_q[ci] = run;
+          run += c;
         }
       }
-      if (tid == 63) s_w[12] = incl;
+      if (tid == 63) {  // the row's share of the query pool
+        s_w[12] = incl;
+        const uint32_t qo = atomicAdd(&B.counters[FX_CNT_QPOOL], incl);
+        s_w[13] = qo;
+        s_w[14] = (qo <= P.dense_qcap && incl <= P.dense_qcap - qo) ? 1u : 0u;
+      }
     }
     __syncthreads();
-    const uint32_t n_q = s_w[12];  // (with the padding)
-    for (uint32_t R = wave; R < kRows; R += NWS) {
-      const uint32_t rs = row_start(R), re = row_end(R);
-      uint32_t at = row_at[R];
-      for (uint32_t p0 = rs; p0 < re; p0 += 64u) {
-        const uint32_t p = p0 + lane;
-        const bool won = p < re && (in_lds ? ((won_bits[p >> 5] >> (p & 31u)) & 1u) != 0u
-                                           : (reinterpret_cast<const uint32_t *>(dst + p)[3] & FX_DQ_WON) != 0u);
-        const unsigned long long m = __ballot(won);
-        if (won) qlist[at + lanes_below(m)] = p;
-        at += (uint32_t)__popcll(m);
+    const uint32_t n_q = s_w[12], qoff = s_w[13];  // (with the padding)
+    if (!s_w[14]) {  // query pool exhausted (workgroup-uniform).  What the row claimed is never computed: rows that share
+                     // those points fail with it — flagged below by k_dense_finish (a density of zero is not a weight).
+      dense_row_failed(P, B, slot, row, scan, k, FX_DSORT_T);
+      continue;
+    }
+    uint32_t *qlist = B.dense_q + qoff;
+    for (uint32_t p0 = 0; p0 < nS; p0 += 4u * FX_DSORT_T) {
+      float4 v[4];
+      bool won[4];
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u) {
+        const uint32_t p = p0 + u * FX_DSORT_T + tid;
+        won[u] = false;
+        if (p < nS && in_lds && !((won_bits[p >> 5] >> (p & 31u)) & 1u)) continue;  // (most points: no load)
+        if (p < nS) {
+          v[u] = dst[p];
+          won[u] = in_lds || (__float_as_uint(v[u].w) & FX_DQ_WON) != 0u;
+        }
       }
-      const uint32_t cnt = row_n[R], pad = ((cnt + 3u) & ~3u) - cnt;
-      if (lane < pad) qlist[at + lane] = FX_NONE;  // (no query: k_dense_density skips it)
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u)
+        if (won[u]) qlist[atomicAdd(&cell_q[G.cell(v[u].x, v[u].y, v[u].z)], 1u)] = p0 + u * FX_DSORT_T + tid;
+    }
+    __syncthreads();
+    // the padding behind every cell's queries (cell_q[c] is now the end of what cell c wrote; its part ends at the next multiple of four)
+    for (uint32_t c = tid; c < FX_DCELLS; c += FX_DSORT_T) {
+      const uint32_t e = cell_q[c];
+      for (uint32_t t = e; t < ((e + 3u) & ~3u); ++t) qlist[t] = FX_NONE;  // (no query: k_dense_density skips it)
     }
     __syncthreads();
     FX_STAMP(4);
@@ -3540,6 +3553,7 @@ extern "C" __global__ __launch_bounds__(FX_DSORT_T) void k_dense_sort(FxDevParam
       FX_COUNT(8, n_ovf);
       B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = s_w[9];
       B.dense_nq[slot] = n_q;
+      B.dense_qoff[slot] = qoff;
       B.dense_nm[slot] = s_w[10];
       if (s_w[10] > min(P.dense_lds_keys, (uint32_t)FX_DFIN_KL)) {  // keys beyond the finishing kernel's LDS array: a region of the key pool
         uint32_t p2 = 1;
@@ -3580,7 +3594,7 @@ typedef float fx_f2 __attribute__((ext_vector_type(2)));
 extern "C" __global__ __launch_bounds__(FX_DDENS_T) void k_dense_density(FxDevParams P, FxBuffers B) {
   __shared__ uint32_t s_tab[FX_DCELLS + 1];     // s_tab[c] = start of cell c, s_tab[c + 1] = its end
   __shared__ float4 s_t[FX_DDENS_C];
-  __shared__ uint32_t s_cat[FX_DG * FX_DGZ + 1];  // start of every row of the box in the concatenation of the rows' runs
+  __shared__ uint32_t s_cat[FX_DDENS_T];  // start of every row of the box (<= 176) in the concatenation of the rows' runs; before that: the quads' weights
   __shared__ uint32_t s_w[16];
   const uint32_t tid = threadIdx.x;
   const uint32_t n_items = B.counters[14];
@@ -3602,16 +3616,18 @@ extern "C" __global__ __launch_bounds__(FX_DDENS_T) void k_dense_density(FxDevPa
     const DenseGrid G = dense_grid(P, B.row_kp[row]);
     const float cw = 1.0f / G.inv_cw, ch = 1.0f / G.inv_ch;
     const float4 *pts = B.dense_pts + off;
-    const uint32_t *qlist = B.dense_q + off;
+    const uint32_t *qlist = B.dense_q + B.dense_qoff[slot];
     const uint32_t *table = B.dense_cells + (size_t)slot * FX_DCELLS;
     for (uint32_t t = tid; t < FX_DCELLS; t += FX_DDENS_T) s_tab[t + 1] = table[t];
     if (tid == 0) s_tab[0] = 0u;
+    const uint32_t my_quad = tid;  // (dealing the quads to the lanes by the number of targets around them was measured: 951 trips a
+                                   //  wavefront against 856 — lanes that are not neighbours in space walk different rows at the same time)
     // ---- this lane's four queries and their box (coordinates)
     float4 q[4];
     float bx0 = INFINITY, bx1 = -INFINITY, by0 = INFINITY, by1 = -INFINITY, bz0 = INFINITY, bz1 = -INFINITY;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const uint32_t qi = qb + 4u * tid + (uint32_t)u;
+      const uint32_t qi = qb + 4u * my_quad + (uint32_t)u;
       q[u] = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.0f);  // (no query: its differences overflow to infinity, never below the radius)
       const uint32_t qp = qi < n_q ? qlist[qi] : FX_NONE;  // (FX_NONE: padding at the end of a cell row)
       if (qp != FX_NONE) {
@@ -3677,6 +3693,9 @@ extern "C" __global__ __launch_bounds__(FX_DDENS_T) void k_dense_density(FxDevPa
     const fx_f2 ax = {q[0].x, q[1].x}, ay = {q[0].y, q[1].y}, az = {q[0].z, q[1].z};
     const fx_f2 bx = {q[2].x, q[3].x}, by = {q[2].y, q[3].y}, bz = {q[2].z, q[3].z};
     uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+#ifdef FX_STAMPS
+    unsigned long long n_tests = 0, n_wave = 0;
+#endif
     for (uint32_t w = 0; w < t_tot; w += FX_DDENS_C) {
       const uint32_t wn = min((uint32_t)FX_DDENS_C, t_tot - w);
       // ---- the window: concatenation position -> row (binary search) -> sorted-region position
@@ -3710,6 +3729,14 @@ extern "C" __global__ __launch_bounds__(FX_DDENS_T) void k_dense_density(FxDevPa
         const uint32_t shift = s_cat[ur] - s_tab[base + UX0];  // sorted-region position -> concatenation position (mod 2^32)
         const uint32_t g0 = s_tab[base + G.cx(bx0 - h)] + shift, g1 = s_tab[base + G.cx(bx1 + h) + 1u] + shift;
         const uint32_t i0 = g0 > w ? g0 - w : 0u, i1 = g1 > w ? min(g1 - w, wn) : 0u;
+#ifdef FX_STAMPS
+        if (i1 > i0) n_tests += i1 - i0;
+        {
+          uint32_t mx = i1 > i0 ? i1 - i0 : 0u;
+          for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+          n_wave += mx;
+        }
+#endif
 #pragma unroll 2
         for (uint32_t i = i0; i < i1; ++i) {
           const float4 t = s_t[i];
@@ -3727,6 +3754,21 @@ extern "C" __global__ __launch_bounds__(FX_DDENS_T) void k_dense_density(FxDevPa
       }
       __syncthreads();
     }
+#ifdef FX_STAMPS
+    if (B.stamps) {  // diagnostic: targets walked per lane, per wavefront (row by row: the longest lane), true densities, queries
+      unsigned long long nq = 0, dsum = 0;
+      const uint32_t cc[4] = {c0, c1, c2, c3};
+      for (int u = 0; u < 4; ++u)
+        if (q[u].x < 1.0e38f) nq += 1, dsum += cc[u];
+      const bool wide = any_q && G.cx(bx1) - G.cx(bx0) > 1u;
+      atomicAdd(&B.stamps[44 + 0], n_tests);
+      atomicAdd(&B.stamps[44 + 1], dsum);
+      atomicAdd(&B.stamps[44 + 2], nq);
+      if ((tid & 63u) == 0) atomicAdd(&B.stamps[44 + 3], n_wave);
+      if (any_q) atomicAdd(&B.stamps[44 + 4], 1ull);
+      if (wide) atomicAdd(&B.stamps[63], 1ull);
+    }
+#endif
     // ---- counts -> the scan's density cache (k_dense_finish of every row that has the point as a neighbour reads them)
     unsigned long long *cache = B.dens_cache + (size_t)scan * P.max_points;
     const uint32_t cnt[4] = {c0, c1, c2, c3};
@@ -3787,12 +3829,14 @@ __device__ __forceinline__ void dense_keys(const FxDevParams &P, const float4 *p
     }
   }
 }
+// weight of one binned neighbour: (1 / local point density) x the bin's volume normalisation.  The
+// density comes from the scan's cache; a word of another batch or a bare claim means the row that claimed the point did
+// not get to compute it (its share of the query pool was refused): *missing is set and the row fails, flagged.
 __device__ __forceinline__ float dense_weight(unsigned long long key, const unsigned long long *cache, unsigned long long seq,
-                                              const FxScTables *T) {
+                                              const FxScTables *T, uint32_t *missing) {
   const unsigned long long cw = cache[(uint32_t)(key & 0xfffffull)];
-  // (a word of another batch or a bare claim cannot be here: every binned neighbour of a dense row was claimed by some
-  //  row of this batch and k_dense_density has run; a zero density would show as an infinite weight)
   const uint32_t dens = (cw >> FX_DENS_BITS) == seq ? (uint32_t)(cw & FX_DENS_MASK) : 0u;
+  if (dens == 0u || dens == (uint32_t)FX_DENS_MASK) *missing = 1u;
   return (1.0f / (float)dens) * T->lut[(uint32_t)(key >> 52) % 165u];
 }
 // One row.  PCL adds a bin's contributions in the order of its sorted radius search, (d2, index) ascending, so the keys
@@ -3817,7 +3861,7 @@ __device__ __forceinline__ void dense_finish_row(const FxDevParams &P, const FxB
   const float4 *pts = B.dense_pts + off;
   const unsigned long long *cache = B.dens_cache + (size_t)scan * P.max_points;
   __syncthreads();
-  if (tid == 0) s_w[0] = 0;
+  if (tid == 0) s_w[0] = 0, s_w[1] = 0;
   if (nM > (uint32_t)KMAX || nM > P.dense_lds_keys) {
     // ---- more keys than LDS holds: a bitonic network over the row's region of the key pool
     unsigned long long *sk = B.dense_key + B.dense_koff[slot];
@@ -3830,9 +3874,18 @@ __device__ __forceinline__ void dense_finish_row(const FxDevParams &P, const FxB
     dense_bitonic_global<NT>(sk, p2);
     for (uint32_t t = tid; t < nM; t += NT) {  // every sorted key becomes (bin, weight) in place
       const unsigned long long key = sk[t];
-      sk[t] = ((key >> 52) << 32) | (unsigned long long)__float_as_uint(dense_weight(key, cache, seq, T));
+      sk[t] = ((key >> 52) << 32) | (unsigned long long)__float_as_uint(dense_weight(key, cache, seq, T, &s_w[1]));
     }
     wg_global_sync();
+    if (s_w[1]) {  // a density this row needs was never computed (workgroup-uniform)
+      if (tid == 0) {
+        atomicOr(&B.flags[scan], FX_FLAG_NBR_OVERFLOW);
+        B.kp_nbrs[(size_t)scan * P.max_keypoints + B.row_map[row].y] = FX_NONE;
+      }
+      desc_fill_nan(out, tid, NT);
+      __syncthreads();
+      return;
+    }
     for (uint32_t t = tid; t < nM; t += NT) {  // one lane per bin run
       const uint32_t bin = (uint32_t)(sk[t] >> 32);
       if (t > 0 && (uint32_t)(sk[t - 1] >> 32) == bin) continue;
@@ -3887,10 +3940,19 @@ __device__ __forceinline__ void dense_finish_row(const FxDevParams &P, const FxB
 #pragma unroll 4
       for (uint32_t qq = s0; qq < s1; ++qq) rank += keys[ord[qq]] < key ? 1u : 0u;
       dst[u] = s0 + rank;
-      wgt[u] = dense_weight(key, cache, seq, T);
+      wgt[u] = dense_weight(key, cache, seq, T, &s_w[1]);
     }
   }
   __syncthreads();  // (the keys are done with: their storage takes the weights, in sorted order)
+  if (s_w[1]) {  // a density this row needs was never computed (workgroup-uniform)
+    if (tid == 0) {
+      atomicOr(&B.flags[scan], FX_FLAG_NBR_OVERFLOW);
+      B.kp_nbrs[(size_t)scan * P.max_keypoints + B.row_map[row].y] = FX_NONE;
+    }
+    desc_fill_nan(out, tid, NT);
+    __syncthreads();
+    return;
+  }
   float *sw = reinterpret_cast<float *>(keys);
 #pragma unroll
   for (int u = 0; u < PER; ++u)

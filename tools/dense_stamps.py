@@ -9,7 +9,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from feature_extraction_amd import capi
 
-capi.LIB_PATH = os.path.join(os.path.dirname(capi.LIB_PATH), "libfx_hip_stamps.so")
+capi.LIB_PATH = os.path.join(os.path.dirname(capi.LIB_PATH), os.environ.get("FX_STAMPS_LIB", "libfx_hip_stamps.so"))
 lib = capi.load()
 import bench
 import torch
@@ -36,8 +36,8 @@ rows = max(v[base + 6], 1)
 print(f"{name}: k_dense_sort rows {rows:.0f} (stamped workgroups only), support {v[base + 7] / rows:.0f}, overflow region {v[base + 8] / rows:.0f}")
 for k, nm in {1: "clear + pass 1 (histogram)", 2: "prefix", 3: "pass 2 (scatter)", 4: "pass 3 (claims, query list)", 5: "items"}.items():
     print(f"   {nm:32s} {v[base + k] / rows:10.0f} cycles per row (100 MHz clock x ?)")
-# k_dense_density's diagnostic counters (columns 44..48: free of the ring / merge / descriptor kernels' stamps)
-t, d, q, box, items = v[44], v[45], v[46], v[47], v[48]
+# k_dense_density's diagnostic counters (columns 44..48, 63: free of the ring / merge / descriptor kernels' stamps)
+t, d, q, wv, lanes, wide = v[44], v[45], v[46], v[47], v[48], v[63]
 if q:
-    print(f"k_dense_density: {items:.0f} items, {q:.0f} queries; targets walked per query {t / (q / 4) :.0f} (a lane's walk serves its 4 queries), "
-          f"true density per query {d / q:.0f}, box targets per item {box / max(items, 1):.0f}")
+    print(f"k_dense_density: {q:.0f} queries on {lanes:.0f} lanes ({q / lanes:.2f} per lane; {wide / lanes * 100:.1f} % of the lanes span more than two cells); "
+          f"targets walked per lane {t / lanes:.0f}, per wavefront (sum over rows of the longest lane) {wv / (lanes / 64):.0f} per 64 lanes; true density per query {d / q:.0f}")
