@@ -3256,7 +3256,9 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_mid(FxDevParams P, Fx
 #define FX_DCELLS (FX_DG * FX_DG * FX_DGZ)
 #define FX_DENS_BITS 21             // density count (max_points <= 2^20) in the low bits of a cache word, batch tag above
 #define FX_DENS_MASK ((1ull << FX_DENS_BITS) - 1ull)
+#ifndef FX_DSORT_T
 #define FX_DSORT_T 512
+#endif
 #define FX_DSORT_WONW 2048     // words of k_dense_sort's winners bit map
 #define FX_DQ_WON 0x80000000u  // sorted region, index word: the row computes this point's density (set by k_dense_sort)
 #define FX_DFIN_KS 4096    // binned neighbours the small finishing kernel sorts in LDS
@@ -4214,7 +4216,7 @@ void fxk_desc_mid(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint3
   hipLaunchKernelGGL(k_desc_mid, dim3(n_wg + n_wave), dim3(FX_WG), lds_wave > lds_wg ? lds_wave : lds_wg, s, P, B, batch, cap, n_wg);
 }
 void fxk_dense(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t n_cu) {
-  hipLaunchKernelGGL(k_dense_sort, dim3(n_cu * 2), dim3(FX_DSORT_T), 0, s, P, B);  // (what is resident at once: the rows are taken by ticket)
+  hipLaunchKernelGGL(k_dense_sort, dim3(n_cu * (1024 / FX_DSORT_T)), dim3(FX_DSORT_T), 0, s, P, B);  // (what is resident at once: the rows are taken by ticket)
   hipLaunchKernelGGL(k_dense_density, dim3(n_cu * 3), dim3(FX_DDENS_T), 0, s, P, B);
   hipLaunchKernelGGL(k_dense_finish_s, dim3(n_cu * 3), dim3(FX_DFIN_TS), fxk_dense_finish_lds_bytes(0), s, P, B);
   hipLaunchKernelGGL(k_dense_finish_l, dim3(n_cu), dim3(FX_DFIN_TL), fxk_dense_finish_lds_bytes(1), s, P, B);
