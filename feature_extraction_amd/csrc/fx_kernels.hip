@@ -2211,6 +2211,8 @@ __device__ __forceinline__ uint32_t sc3d_bin(const float4 kp, float bx, float by
   const float mx = (-1.0f < theta) ? theta : -1.0f;  // std::max(-1.0f, theta)
   const float tc = (mx < 1.0f) ? mx : 1.0f;          // std::min(1.0f, .)
   theta = (FAST ? acosf(tc) : (float)acos((double)tc)) * 57.29578f;
+#ifndef FX_TRIG_LITERAL_F32  // (diagnostic build: PCL's literal atan2f / acosf — this device's — with no exact re-evaluation;
+                             //  tools/trig_policy.py counts the bins that moves)
   if (FAST) {
     // edges: phi_div = 30 l, theta_div = l * (180/11) (A.8-2); non-finite angles go the exact way too
     if (!(phi == phi) || !(theta == theta) || near_multiple(phi, 30.0f, 1.0f / 30.0f) ||
@@ -2221,6 +2223,7 @@ __device__ __forceinline__ uint32_t sc3d_bin(const float4 kp, float bx, float by
       theta = te;
     }
   }
+#endif
 
   // PCL scans each edge table for the first edge >= the value and falls back to bin 0 when there is
   // none (A.8-9).  The edges ascend, so "first edge >= v" is the number of edges below v: counted

@@ -64,10 +64,8 @@ def test_golden_fixtures(fxlib, path):
     """Committed fixtures (inputs + oracle outputs): the comparison needs neither the oracle library
     nor /root/reference on the GPU box."""
     g = np.load(path)
-    preset = "default" if "default" in os.path.basename(path) else "launch"
-    _, roll, pitch = g["meta"]
-    pts = np.concatenate([g["points_xyz"], np.zeros((len(g["points_xyz"]), 1), np.float32)], axis=1)
-    ctx = capi.Context(capi.params(preset), capi.limits(2, 28800))
+    p, lim, pts, roll, pitch = util.golden_case(g, os.path.basename(path))
+    ctx = capi.Context(p, lim)
     got = ctx.process_host([pts], roll=float(roll), pitch=float(pitch))[0]
     ora = {k: g[k] for k in g.files}
     ora["n_keypoints"] = len(g["keypoints"])

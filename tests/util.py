@@ -10,6 +10,21 @@ def vlp16_scan(seed, **over):
     return capi.synth_scan(capi.synth_cfg(seed, **over))
 
 
+def golden_case(g, name):
+    """(params, limits, scan, roll, pitch) of a tests/golden fixture.  The VLP-16 fixtures store their input; the
+    64- and 128-ring ones store the generator's configuration ("spec") and a checksum of the scan it makes."""
+    import json
+    if "spec" in g.files:
+        c = json.loads(bytes(g["spec"]).decode())
+        pts = capi.synth_scan(capi.synth_cfg(c["seed"], **c["synth"]))
+        assert int(pts.view(np.uint32).astype(np.uint64).sum()) == int(g["points_checksum"][0]), "the generator no longer makes the fixture's scan"
+        return capi.params(c["preset"], **c["params"]), capi.limits(1, len(pts), **c["limits"]), pts, c["roll"], c["pitch"]
+    preset = "default" if "default" in name else "launch"
+    _, roll, pitch = g["meta"]
+    pts = np.concatenate([g["points_xyz"], np.zeros((len(g["points_xyz"]), 1), np.float32)], axis=1)
+    return capi.params(preset), capi.limits(2, 28800), pts, float(roll), float(pitch)
+
+
 def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
