@@ -56,6 +56,20 @@ def test_dense_128_ring_scan_radius_2m(fxlib, oracle, preset):
     ctx.close()
 
 
+def test_128_rings_by_4096_azimuths(fxlib, oracle):
+    """A sensor beyond BASELINE's largest: 128 x 4096 = 524 288 points a scan, R = 2 m, launch preset (≈ 5000 per-ring
+    candidates, support sets of more than 11 000 points).  Must run unflagged and match the oracle."""
+    s = capi.synth_scan(capi.synth_cfg(10, n_rings=128, n_az=4096, el0_deg=-25.0, el_step_deg=40.0 / 127, n_poles=256))
+    p = _dense_params("launch")
+    ctx = capi.Context(p, capi.limits(1, len(s), max_ring_points=2400, max_ring_candidates=512, max_candidates=16000, max_kpc_points=131072,
+                                      max_keypoints=1024, max_total_keypoints=1024))
+    got = ctx.process_host([s], roll=0.02, pitch=-0.015)[0]
+    ora = oracle.run(p, s, roll=0.02, pitch=-0.015)
+    st = util.compare_scan(got, ora, tag="128 x 4096")
+    assert st["K"] > 100 and int(ora["kp_neighbors"].max()) > 10000
+    ctx.close()
+
+
 def test_large_merge_tier_on_vlp16_scans(fxlib, oracle, monkeypatch):
     """The large merge tier (cell-sorted ids + union-find in LDS, coordinates in HBM) on ordinary scans: the test
     hook lowers the LDS tier's capacity so that every scan with more than 16 candidates takes it."""
