@@ -300,8 +300,8 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   if (merge_big_cap < L.max_candidates &&
       (L.max_candidates > 65535 || fxk_merge_huge_lds_bytes(L.max_candidates, merge_huge_ccap, params->n_rings) > kLds))
     return fail(FX_ERR_INVALID_ARG, "max_candidates (with max_keypoints) exceeds the LDS budget of the large merge tier (<= ~16000)");
-  if (fxk_gather_lds_bytes(L.max_keypoints) > 96 * 1024)
-    return fail(FX_ERR_INVALID_ARG, "max_keypoints exceeds the LDS budget of the support gather (<= ~1700)");
+  if (fxk_gather_lds_bytes(L.max_keypoints) > kLds)
+    return fail(FX_ERR_INVALID_ARG, "max_keypoints exceeds the LDS budget of the support gather (<= ~2300)");
   if (L.max_keypoints > 65535 || L.max_candidates > 32768 || L.max_ring_points > 32768)
     return fail(FX_ERR_INVALID_ARG, "limit exceeds the 16-bit packing of the order replay");
 
@@ -312,9 +312,15 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   c->device = device_id;
   c->merge_big_cap = merge_big_cap;
   c->merge_huge_ccap = merge_huge_ccap;
-  if (const char *e = getenv("FX_DESC_WGS_PER_CU")) c->desc_wgs_per_cu = (uint32_t)atoi(e);
+  if (const char *e = getenv("FX_DESC_WGS_PER_CU")) {  // experiment hook: ignored outside 1..32
+    const int v = atoi(e);
+    if (v >= 1 && v <= 32) c->desc_wgs_per_cu = (uint32_t)v;
+  }
   if (const char *e = getenv("FX_DEBUG_SYNC")) c->debug_sync = atoi(e) != 0;
-  if (const char *e = getenv("FX_GRAPH_MAX_BATCH")) c->graph_max_batch = (uint32_t)atoi(e);
+  if (const char *e = getenv("FX_GRAPH_MAX_BATCH")) {
+    const int v = atoi(e);
+    if (v >= 0) c->graph_max_batch = (uint32_t)v;
+  }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->n_cu = prop.multiProcessorCount;
 

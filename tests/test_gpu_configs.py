@@ -183,6 +183,26 @@ def test_stage_timings_are_reported(fxlib):
     ctx.close()
 
 
+def test_stage_bytes_follow_the_batch_counts(fxlib, oracle):
+    """fx_get_stage_bytes: every stage's own algorithmic bytes (the per-kernel roofline's numerator) from the batch's counts."""
+    B = 3
+    scans = [util.vlp16_scan(1000 + b) for b in range(B)]
+    p = capi.params("launch")
+    ctx = capi.Context(p, capi.limits(B, 28800))
+    got = ctx.process_host(scans, roll=0.02, pitch=-0.015)
+    sb = ctx.stage_bytes()
+    n_f = sum(len(g["filtered"]) for g in got)
+    K = sum(g["n_keypoints"] for g in got)
+    assert sb["k_prep"][0] == 16.0 * 28800 * B
+    assert abs(sb["k_prep"][1] - (16.0 * n_f + 28800 * B / 32.0 + 4.0 * 16 * B)) < 1e-6
+    assert sb["k_bucket"][0] == 16.0 * n_f and sb["k_bucket"][1] >= 16.0 * n_f  # (a window-boundary point is in two rings)
+    assert sb["k_desc_group"][1] == 7956.0 * K
+    support = sum(int(x) for g in got for x in g["kp_neighbors"])  # neighbours <= support points
+    assert sb["k_gather"][1] >= 16.0 * support and sb["k_gather"][0] > 0
+    assert all(r >= 0 and w >= 0 for r, w in sb.values())
+    ctx.close()
+
+
 def test_graph_replay_matches_plain_launches(fxlib, oracle):
     """Streaming mode: small batches replayed as one HIP graph per batch size give
     the same bits as separate launches, across changing inputs and batch sizes."""
