@@ -3127,79 +3127,68 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
     __syncthreads();
     return true;
   }
-  // ---- sort by (bin, d2, index).  Up to 512 neighbours: ranking (every key counts the smaller
-  //      ones, the count split over lanes like the density above; keys are unique); beyond that a
-  //      bitonic network.  Either way sk / sv end up holding the sorted keys and weights.
-  const unsigned long long *sk = L.nkey;
-  const float *sv = L.nw;
-  if (nM <= 512) {
-    unsigned long long *skey = reinterpret_cast<unsigned long long *>(L.sp);  // the support set is done with
-    float *sw = reinterpret_cast<float *>(L.sp) + 2 * cap;
-    uint32_t *rank = L.sidx;
-    for (uint32_t m = tid; m < nM; m += NT) rank[m] = 0;
-    __syncthreads();
-    uint32_t parts = 1;
-    while (parts < 32 && nM * parts * 2 <= (uint32_t)NT) parts <<= 1;
-    const uint32_t chunk = (nM + parts - 1) / parts;
-    for (uint32_t t = tid; t < nM * parts; t += NT) {
-      const uint32_t m = t / parts, part = t % parts;
-      const unsigned long long key = L.nkey[m];
-      const uint32_t q0 = part * chunk, q1 = min(q0 + chunk, nM);
-      uint32_t c = 0;
-#pragma unroll 8
-      for (uint32_t q = q0; q < q1; ++q) c += (L.nkey[q] < key) ? 1u : 0u;
-      if (c) atomicAdd(&rank[m], c);
+  // ---- PCL adds a bin's contributions in the order of its sorted radius search, (d2, index) ascending: counting sort by
+  //      bin (the image doubles as the bin table), ranking inside the bin (keys are unique: they end in the point index),
+  //      then one lane per bin adds the bin's weights in order.  (A ranking of all keys against all keys — 160 000
+  //      comparisons for 400 neighbours — was most of a list row's instructions; a bitonic network beyond 512.)
+  uint32_t *bin_end = reinterpret_cast<uint32_t *>(L.img);  // [1980], zero (cleared above)
+  unsigned long long *skey = reinterpret_cast<unsigned long long *>(L.sp);  // the support set is done with: [cap] keys by bin,
+  float *sw = reinterpret_cast<float *>(L.sp) + 2 * cap;                    // [cap] their weights,
+  float *sorted_w = reinterpret_cast<float *>(L.sp) + 3 * cap;              // [cap] the weights in (bin, d2, index) order
+  __syncthreads();
+  for (uint32_t m = tid; m < nM; m += NT) atomicAdd(&bin_end[(uint32_t)(L.nkey[m] >> 52)], 1u);
+  __syncthreads();
+  if (tid < 64) {  // counts -> exclusive starts, in place, by one wavefront
+    constexpr uint32_t per = (FX_DESC_BINS + 63) / 64;
+    uint32_t sum = 0;
+    for (uint32_t u = 0; u < per; ++u) {
+      const uint32_t bi = tid * per + u;
+      sum += bi < FX_DESC_BINS ? bin_end[bi] : 0u;
     }
-    __syncthreads();
-    for (uint32_t m = tid; m < nM; m += NT) {
-      skey[rank[m]] = L.nkey[m];
-      sw[rank[m]] = L.nw[m];
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+      if ((int)tid >= d) incl += o;
     }
-    __syncthreads();
-    sk = skey;
-    sv = sw;
-  } else {
-    uint32_t p2 = 1;
-    while (p2 < nM) p2 <<= 1;
-    for (uint32_t t = nM + tid; t < p2; t += NT) L.nkey[t] = ~0ull;
-    __syncthreads();
-    for (uint32_t kb = 2; kb <= p2; kb <<= 1) {
-      for (uint32_t jb = kb >> 1; jb > 0; jb >>= 1) {
-        for (uint32_t t = tid; t < p2; t += NT) {
-          const uint32_t x = t ^ jb;
-          if (x > t) {
-            const unsigned long long a = L.nkey[t], b = L.nkey[x];
-            const bool up = (t & kb) == 0;
-            if ((a > b) == up) {
-              L.nkey[t] = b;
-              L.nkey[x] = a;
-              const float wa = L.nw[t];
-              L.nw[t] = L.nw[x];
-              L.nw[x] = wa;
-            }
-          }
-        }
-        __syncthreads();
+    uint32_t run = incl - sum;
+    for (uint32_t u = 0; u < per; ++u) {
+      const uint32_t bi = tid * per + u;
+      if (bi < FX_DESC_BINS) {
+        const uint32_t c = bin_end[bi];
+        bin_end[bi] = run;
+        run += c;
       }
     }
   }
+  __syncthreads();
+  for (uint32_t m = tid; m < nM; m += NT) {  // (the fill turns a bin's start into its end = the next bin's start)
+    const unsigned long long key = L.nkey[m];
+    const uint32_t pos = atomicAdd(&bin_end[(uint32_t)(key >> 52)], 1u);
+    skey[pos] = key;
+    sw[pos] = L.nw[m];
+  }
+  __syncthreads();
+  for (uint32_t p = tid; p < nM; p += NT) {
+    const unsigned long long key = skey[p];
+    const uint32_t bin = (uint32_t)(key >> 52);
+    const uint32_t s0 = bin ? bin_end[bin - 1u] : 0u, s1 = bin_end[bin];
+    uint32_t rank = 0;
+    for (uint32_t q = s0; q < s1; ++q) rank += skey[q] < key ? 1u : 0u;
+    sorted_w[s0 + rank] = sw[p];
+  }
+  __syncthreads();
   FX_STAMP(3);
-  // ---- sequential fp32 accumulation per bin, in sorted order
-  for (uint32_t t = tid; t < nM; t += NT) {
-    const uint32_t bin = (uint32_t)(sk[t] >> 52);
-    if (t > 0 && (uint32_t)(sk[t - 1] >> 52) == bin) continue;
+  // ---- sequential fp32 accumulation per bin, in sorted order; the row was cleared by k_desc_group (rf stays zero)
+  for (uint32_t bin = tid; bin < FX_DESC_BINS; bin += NT) {
+    const uint32_t s0 = bin ? bin_end[bin - 1u] : 0u, s1 = bin_end[bin];
+    if (s0 == s1) continue;
     float acc = 0.0f;
-    uint32_t e = t;
-    do {
-      acc += sv[e];
-      ++e;
-    } while (e < nM && (uint32_t)(sk[e] >> 52) == bin);
-    L.img[bin] = acc;
+    for (uint32_t q = s0; q < s1; ++q) acc += sorted_w[q];
+    out[bin] = acc;
   }
   __syncthreads();
   FX_STAMP(4);
-  for (uint32_t t = tid; t < FX_DESC_FLOATS; t += NT) out[t] = t < FX_DESC_BINS ? L.img[t] : 0.0f;  // rf = 0
-  __syncthreads();
   FX_STAMP(5);
   return true;
 }
