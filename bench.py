@@ -25,7 +25,12 @@ import sys
 import threading
 import time
 
-import numpy as np
+# HIP streams beyond the runtime's default of 4 hardware queues share queues (and then run one after the other): the batches
+# in flight each need their own, next to torch's and RCCL's.  Read by the HIP runtime when it starts, so set before
+# anything loads it; an explicit setting in the environment wins.  (a host application does the same.)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -179,7 +184,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="scans per GPU per step")
     ap.add_argument("--preset", default="launch", choices=["default", "launch"])
-    ap.add_argument("--contexts", type=int, default=3,
+    ap.add_argument("--contexts", type=int, default=4,
                     help="batches in flight per GPU: contexts (each on its own HIP stream) taking the steps in turn")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip other_configs and the host-to-host measurement")

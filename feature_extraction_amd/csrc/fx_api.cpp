@@ -26,7 +26,7 @@ size_t fxk_merge_lds_bytes(uint32_t cap, uint32_t n_rings);
 size_t fxk_desc_lds_bytes(uint32_t cap);
 size_t fxk_gather_lds_bytes(uint32_t max_keypoints);
 uint32_t fxk_dense_cells(void);
-void fxk_dense(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t n_cu);
+void fxk_dense(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t n_cu, uint32_t rows, uint32_t items);
 size_t fxk_merge_huge_lds_bytes(uint32_t cap, uint32_t ccap, uint32_t n_rings);
 hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t merge_huge, size_t desc_big, size_t gather);
 uint32_t fxk_near_words(uint32_t max_points);
@@ -47,6 +47,7 @@ void fxk_pack_kp_records(hipStream_t s, const FxDevParams &P, const FxBuffers &B
                          uint32_t rec_kp);
 void fxk_rng_ord(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
 void fxk_test_sort_replay(hipStream_t s, const uint32_t *sizes, uint32_t n_seq, uint32_t n, uint32_t *perm);
+void fxk_test_elevation(hipStream_t s, const float *xyz, uint32_t n, const double *tab, float *fast, uint8_t *ok, float *exact);
 void fxk_unpack_pc2(hipStream_t s, const void *src, uint32_t n, uint32_t point_step, uint32_t ox, uint32_t oy, uint32_t oz,
                     uint32_t oi, uint32_t big_endian, void *dst, uint32_t grid);
 void fxk_pack_xyzi32(hipStream_t s, const void *src, uint32_t n, void *dst, uint32_t grid);
@@ -118,6 +119,9 @@ struct fx_ctx {
   std::vector<std::pair<uint32_t, hipGraphExec_t>> graphs;
   uint32_t graph_max_batch = 0;
   bool debug_sync = false;
+  // the previous batch's work for the rarely used tiers (pinned; written by the device: FxBuffers::tier_hint)
+  volatile uint32_t *tier_hint = nullptr;
+  uint32_t tier_min_grid = 8;  // FX_TIER_MIN_GRID: workgroups those tiers get at least (0: always the full grids)
 };
 
 namespace {
@@ -152,13 +156,43 @@ fx_status host_alloc(fx_ctx *c, T **p, size_t count) {
 }  // namespace
 
 namespace {
+// k_prep's arctangent (elevation_fast): atan(c + d) = sum_k a_k d^k about c = i / FX_ATAN_N, a_0 = atan(c),
+// a_k = (-1)^(k-1) sin^k(th) sin(k th) / k with th = pi/2 - atan(c) (the k-th derivative of the arctangent in closed form);
+// evaluated in long double: the entries are good to the last bit or two of double.
+std::vector<double> atan_table() {
+  std::vector<double> at((FX_ATAN_N + 1) * (FX_ATAN_DEG + 1));
+  for (int i = 0; i <= FX_ATAN_N; ++i) {
+    const long double cpt = (long double)i / FX_ATAN_N, a0 = atanl(cpt), th = atan2l(1.0L, cpt), st = sinl(th);
+    long double pw = 1.0L;
+    at[(size_t)i * (FX_ATAN_DEG + 1)] = (double)a0;
+    for (int kk = 1; kk <= FX_ATAN_DEG; ++kk) {
+      pw *= st;
+      at[(size_t)i * (FX_ATAN_DEG + 1) + kk] = (double)(((kk & 1) ? 1.0L : -1.0L) * pw * sinl(kk * th) / kk);
+    }
+  }
+  return at;
+}
+
 // Enqueues the stage kernels of one batch on stream s (the whole device-side pipeline between the
 // scan-table upload and the result copies).  Also what a HIP graph of the batch is captured from.
-fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof) {
+fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof, bool capture = false) {
   const fx_limits &L = c->lim;
   const FxDevParams &P = c->dp;
   const FxBuffers &B = c->buf;
   const uint32_t big_grid = (uint32_t)c->n_cu;
+  // The tiers behind the common ones (workgroup-per-ring, LDS-sized merges, the dense descriptor tier) take their work from
+  // lists by stride or ticket, so any grid computes the same; a launch that finds its list empty still has to place every
+  // workgroup, and these want most of a CU each.  Their grids follow what the context's previous batch handed them (twice
+  // that, at least tier_min_grid, at most the full grid; the full grid while nothing is known): a sparse batch costs
+  // eight workgroups a tier instead of 256, and a batch that is suddenly dense runs its tiers narrow once.
+  uint32_t hint[FX_N_HINTS];
+  for (int i = 0; i < FX_N_HINTS; ++i) hint[i] = (capture || !c->tier_min_grid) ? 0xffffffffu : c->tier_hint[i];
+  auto tier_grid = [&](uint32_t work, uint32_t full, uint32_t bound, uint32_t per = 1) -> uint32_t {
+    uint32_t g = work > full / 2 ? full : 2 * work;  // (also: unknown)
+    if (g < (c->tier_min_grid + per - 1) / per) g = (c->tier_min_grid + per - 1) / per;
+    if (g > bound) g = bound ? bound : 1;            // never more workgroups than the batch could have items for
+    return g < full ? g : full;
+  };
   if (prof) {
     c->ev = &c->ev_ring[(size_t)(c->ev_count % c->ev_depth) * (FX_N_STAGES + 1)];
     c->ev_mask[c->ev_count % c->ev_depth] = c->prof_mask;
@@ -192,12 +226,16 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof) {
     FX_HIP(mark(3));
     // sensors of more than the reference's 16 rings: dense rings, many of which need longer run tables than the first tier's
     const bool runs2 = c->params.n_rings > 16;
-    if (runs2) fxk_rings_runs2(s, P, B, L.max_ring_points, (big_grid * 6 + 7) / 8 * 8);
-    fxk_rings_large(s, P, B, L.max_ring_points, L.max_ring_points, (big_grid + 7) / 8 * 8, runs2 ? 1u : 0u);
+    // (these two take the list of XCD class blockIdx % 8: grids are multiples of 8, the hints the longest class list)
+    const uint32_t n_items = batch * (uint32_t)c->params.n_rings;
+    if (runs2) fxk_rings_runs2(s, P, B, L.max_ring_points, 8 * tier_grid(hint[0], (big_grid * 6 + 7) / 8, (n_items + 7) / 8, 8));
+    fxk_rings_large(s, P, B, L.max_ring_points, L.max_ring_points, 8 * tier_grid(hint[runs2 ? 1 : 0], (big_grid + 7) / 8, (n_items + 7) / 8, 8),
+                    runs2 ? 1u : 0u);
     FX_HIP(mark(4));
     fxk_merge_small(s, P, B, batch, merge_small);
-    fxk_merge_big(s, P, B, c->merge_big_cap, big_grid, c->merge_big_cap >= L.max_candidates);
-    if (c->merge_big_cap < L.max_candidates) fxk_merge_huge(s, P, B, L.max_candidates, c->merge_huge_ccap, big_grid);
+    fxk_merge_big(s, P, B, c->merge_big_cap, tier_grid(hint[2], big_grid, batch), c->merge_big_cap >= L.max_candidates);
+    if (c->merge_big_cap < L.max_candidates)
+      fxk_merge_huge(s, P, B, L.max_candidates, c->merge_huge_ccap, tier_grid(hint[3], big_grid, batch));
     fxk_offsets(s, P, B, batch);
     FX_HIP(mark(5));
     if (P.estimate_descriptors) {
@@ -210,7 +248,13 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof) {
       fxk_desc_mid(s, P, B, batch, P.list_cap < P.dense_min ? P.list_cap : P.dense_min, big_grid * 4, big_grid * 4);
       FX_HIP(mark(8));
       // the dense tier: larger support sets and overflowed lists (empty launches on sparse scans)
-      fxk_dense(s, P, B, big_grid);
+      {
+        const uint32_t max_rows = batch * L.max_keypoints < L.max_total_keypoints ? batch * L.max_keypoints : L.max_total_keypoints;
+        const uint32_t rows = tier_grid(hint[4], 3 * big_grid, max_rows);
+        // density items: 1024 queries each, at most one a row more than the support points fill
+        const uint32_t items = hint[5] == 0xffffffffu ? 3 * big_grid : tier_grid(hint[4] + hint[5] / 1024u, 3 * big_grid, 0xffffffffu);
+        fxk_dense(s, P, B, big_grid, rows, items);
+      }
     } else {
       for (int i = 6; i <= 8; ++i) FX_HIP(mark(i));
     }
@@ -232,7 +276,7 @@ fx_status launch_graph(fx_ctx *c, hipStream_t s, uint32_t batch) {
   if (!exec) {
     hipGraph_t graph = nullptr;
     FX_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    fx_status st = enqueue_stages(c, s, batch, false);
+    fx_status st = enqueue_stages(c, s, batch, false, true);  // (a graph's grids are fixed: the full ones, bounded by the batch)
     hipError_t e = hipStreamEndCapture(s, &graph);
     if (st != FX_OK) {
       if (graph) (void)hipGraphDestroy(graph);
@@ -402,6 +446,9 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   float2 *d_win = nullptr;
   FX_A(dev_alloc(c, &d_win, R));
   b.ring_win = d_win;
+  double *d_atan = nullptr;
+  FX_A(dev_alloc(c, &d_atan, (size_t)(FX_ATAN_N + 1) * (FX_ATAN_DEG + 1)));
+  b.atan_tab = d_atan;
   FxScTables *d_tab = nullptr;
   FX_A(dev_alloc(c, &d_tab, 1));
   b.tables = d_tab;
@@ -467,6 +514,16 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   if (hipMemset(b.seq, 0, sizeof(unsigned long long)) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
   if (hipMemset(b.ovf_cnt, 0, B * sizeof(uint32_t)) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
   FX_A(dev_alloc(c, &b.counters, FX_N_COUNTERS));
+  {
+    uint32_t *h = nullptr;
+    FX_A(host_alloc(c, &h, FX_N_HINTS));
+    for (int i = 0; i < FX_N_HINTS; ++i) h[i] = 0xffffffffu;  // nothing known yet: full grids
+    void *dv = nullptr;
+    if (hipHostGetDevicePointer(&dv, h, 0) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipHostGetDevicePointer"));
+    b.tier_hint = (uint32_t *)dv;
+    c->tier_hint = h;
+    if (const char *e = getenv("FX_TIER_MIN_GRID")) c->tier_min_grid = (uint32_t)std::max(0, atoi(e));
+  }
   FX_A(dev_alloc(c, &b.clk, 2 * FX_CLK_SLOTS));
   {
     std::vector<unsigned long long> init(2 * FX_CLK_SLOTS);
@@ -490,6 +547,11 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
     }
     if (hipMemcpy(d_win, win.data(), R * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess)
       return bail(fail(FX_ERR_HIP, "upload ring windows"));
+    {
+      const std::vector<double> at = atan_table();
+      if (hipMemcpy(d_atan, at.data(), at.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+        return bail(fail(FX_ERR_HIP, "upload arctangent table"));
+    }
     FxScTables T;
     std::vector<float> lut(FX_DESC_BINS);
     fx_sc3d_tables(params->descriptor_radius, T.radii, T.theta, T.phi, lut.data());
@@ -850,6 +912,29 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
   return FX_OK;
 }
 
+// Test hook: k_prep's two elevation paths on caller-supplied points.
+fx_status fx_test_elevation_device(int device, const float *xyz, uint32_t n, float *fast_out, uint8_t *fast_ok_out, float *exact_out) {
+  if (!xyz || !fast_out || !fast_ok_out || !exact_out) return fail(FX_ERR_INVALID_ARG, "null argument");
+  if (!n) return FX_OK;
+  FX_HIP(hipSetDevice(device));
+  const std::vector<double> at = atan_table();
+  char *d = nullptr;
+  const size_t o_tab = (size_t)n * 12, o_fast = o_tab + at.size() * 8, o_exact = o_fast + (size_t)n * 4, o_ok = o_exact + (size_t)n * 4;
+  FX_HIP(hipMalloc((void **)&d, o_ok + n));
+  hipError_t e = hipMemcpy(d, xyz, (size_t)n * 12, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d + o_tab, at.data(), at.size() * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    fxk_test_elevation(nullptr, (const float *)d, n, (const double *)(d + o_tab), (float *)(d + o_fast), (uint8_t *)(d + o_ok), (float *)(d + o_exact));
+    e = hipDeviceSynchronize();
+  }
+  if (e == hipSuccess) e = hipMemcpy(fast_out, d + o_fast, (size_t)n * 4, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(exact_out, d + o_exact, (size_t)n * 4, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(fast_ok_out, d + o_ok, n, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  FX_HIP(e);
+  return FX_OK;
+}
+
 // Test hook: the device build of the cluster-order replay on caller-supplied size sequences.
 fx_status fx_test_sort_replay_device(int device, const uint32_t *sizes, uint32_t n_seq, uint32_t n, uint32_t *perm_out) {
   if (!sizes || !perm_out) return fail(FX_ERR_INVALID_ARG, "null argument");
@@ -872,6 +957,14 @@ fx_status fx_test_sort_replay_device(int device, const uint32_t *sizes, uint32_t
   return FX_OK;
 }
 
+// Diagnostic: what the last completed batch left for the next one's tier grids (FxBuffers::tier_hint).
+fx_status fx_debug_tier_hints(fx_ctx *c, uint32_t *out /* FX_N_HINTS = 8 words */) {
+  if (!c || !out) return fail(FX_ERR_INVALID_ARG, "null argument");
+  FX_HIP(hipSetDevice(c->device));
+  FX_HIP(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < FX_N_HINTS; ++i) out[i] = c->tier_hint[i];
+  return FX_OK;
+}
 // Diagnostic: the work-list counters of the last batch (rings / scans / keypoint rows deferred to larger tiers).
 fx_status fx_debug_counters(fx_ctx *c, uint32_t *out8 /* 16 words */) {
   if (!c || !out8) return fail(FX_ERR_INVALID_ARG, "null argument");

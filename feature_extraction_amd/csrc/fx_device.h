@@ -53,12 +53,16 @@ struct FxScTables {
 // Every device buffer of a context.
 #define FX_CLK_SLOTS 64
 #define FX_N_COUNTERS 40
+#define FX_ATAN_N 64      // table step of k_prep's arctangent: 1 / 64 over [0, 1]
+#define FX_ATAN_DEG 6     // degree of the expansion about a table point (|offset| <= 1 / 128: truncation below 2^-51)
+#define FX_N_HINTS 8      // tier_hint[]: 0 / 1 rings handed to the second run tier / the workgroup tier (largest XCD class), 2 big merges, 3 huge merges, 4 dense rows, 5 dense support points
 #define FX_CNT_QPOOL 32   // counters[32]: entries of the dense tier's query pool in use
 #define FX_CNT_LARGE2 16  // counters[16 + c]: rings of XCD class c the second run tier hands to the workgroup tier
 #define FX_CNT_LARGE 24  // counters[24 + c]: ... to the large tier
 struct FxBuffers {
   const FxScanMeta *meta;
   const float2 *ring_win;  // [n_rings] (lo, hi) as float, inclusive
+  const double *atan_tab;  // [FX_ATAN_N + 1][FX_ATAN_DEG + 1]: Taylor coefficients of atan about i / FX_ATAN_N (k_prep's elevation)
   const FxScTables *tables;
   const float2 *xaxis;  // [max_keypoints]
   // stage 1
@@ -125,6 +129,7 @@ struct FxBuffers {
   float2 *row_xa;         //                 per-keypoint kernels fetch everything a row needs in one round trip
   unsigned long long *clk;     // [FX_CLK_SLOTS][2] k_prep's first start / last end on the device's constant-rate clock, by batch
   unsigned long long *stamps;  // [32] diagnostic build only (-DFX_STAMPS)
+  uint32_t *tier_hint;    // [FX_N_HINTS], pinned HOST memory: the batch's counts of work for the rarely used tiers, which the host sizes the next batch's launches of those tiers by (k_offsets, k_desc_mid write them; grid sizes only — never what is computed)
   uint32_t *counters;     // [FX_N_COUNTERS]: 16.. / 24.. rings handed on per XCD class; 1 big_merge, 4 list_desc, 6 dense rows (2 / 3 / 7 / 10: by size class), 8 wave_desc, 9 huge_merge, 12 key pool used, 13 sorted pool used, 14 density items, 15 / 11 / 5 / 0 tickets of k_dense_density / sort / finish_s / finish_l
 };
 

@@ -741,6 +741,9 @@ typedef float __attribute__((address_space(1))) gfloat;
 // (out of line: the fp64 atan2 / sin / cos code then costs k_prep 86 registers instead of 128 — the same speed alone,
 //  3 % more throughput with four batches in flight, where the registers go to other batches' kernels)
 __device__ __noinline__ float elevation_deg(float xf, float yf, float zf) {
+#ifdef FX_EXPERIMENT_CHEAP_EL
+  return atan2f(zf, sqrtf(xf * xf + yf * yf)) * 57.29578f;
+#endif
   const double x = xf, y = yf, z = zf;
   const double e = atan2(z, sqrt(x * x + y * y)) * 180 / M_PI;
   const float f = (float)e;
@@ -752,6 +755,44 @@ __device__ __noinline__ float elevation_deg(float xf, float yf, float zf) {
   const double az = atan2(y, x);
   const double xp = cos(az) * x + sin(az) * y;
   return (float)(atan2(z, xp) * 180 / M_PI);
+}
+
+// The same value for all but one point in ten thousand at a fifth of the instructions (the library's fp64 atan2 was 4 % of the
+// whole batch's vector instructions, at the half rate of fp64): t = z / |xy| from a refined fp32 reciprocal square root,
+// atan(|t|) from the degree-6 expansion about the nearest multiple of 1/64 (tab: FxBuffers::atan_tab in LDS), good to
+// 2^-44 relative (expansion 2^-51.8 absolute on values >= 2^-7; the root and the quotient a few ulp of double) where the
+// reference's own double, evaluated by the host's libm, is within a few ulp of the true value.  The float it rounds to
+// is therefore the reference's unless the double lies within 2^14 of its ulps (2^-39 relative: a margin of 32) of the
+// midpoint of two floats — the only place where round-to-nearest changes; such points, and whatever the expansion
+// does not cover (|t| > 1, a denormal or huge |xy|^2, results below the normal floats), return false and take
+// elevation_deg.  (tests/test_gpu_elevation.py compares the two paths on 10^7 points.)
+__device__ __forceinline__ bool elevation_fast(float xf, float yf, float zf, const double *tab, float &out) {
+  const double x = xf, y = yf, z = zf;
+  const double s = x * x + y * y;  // (the products are exact)
+  const float sf = (float)s;
+  if (!(sf > 1e-30f && sf < 1e30f)) return false;
+  const double y0 = (double)__builtin_amdgcn_rsqf(sf);  // 2^-22
+  const double e = fma(-s, y0 * y0, 1.0);               // 1 - s y0^2, |e| < 2^-20
+  const double y1 = fma(y0 * e, fma(0.375, e, 0.5), y0);  // y0 (1 + e/2 + 3 e^2/8): 1/sqrt(s) to 5/16 e^3
+  const double t = z * y1;
+  const double ta = fabs(t);
+  if (!(ta <= 1.0)) return false;  // (also a NaN z)
+  const float ti = rintf((float)ta * (float)FX_ATAN_N);
+  const double d = ta - (double)ti * (1.0 / FX_ATAN_N);
+  const double *a = tab + (FX_ATAN_DEG + 1) * (int)ti;
+  double r = a[FX_ATAN_DEG];
+#pragma unroll
+  for (int kk = FX_ATAN_DEG - 1; kk >= 0; --kk) r = fma(r, d, a[kk]);
+  const double deg = copysign(r, t) * 57.295779513082320876798154814105;
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(deg);
+  if (((bits >> 52) & 0x7ffu) < 1023u - 100u) {  // |deg| < 2^-100: z = +-0 gives the reference's +-0; the rest is the exact path's
+    out = (float)deg;
+    return deg == 0.0;
+  }
+  const uint32_t dropped = (uint32_t)bits & 0x1fffffffu;  // the 29 bits the conversion rounds away; the midpoint is 2^28
+  const uint32_t dist = dropped > 0x10000000u ? dropped - 0x10000000u : 0x10000000u - dropped;
+  out = (float)deg;
+  return dist > (1u << 14);
 }
 
 // rings a point belongs to (ref: node.cpp:200-201): used by k_prep (counts) and k_bucket (the split)
@@ -788,6 +829,7 @@ __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, 
   __shared__ uint32_t s_cnt[2][NW];                  // per wave: survivors of the tile; by tile parity
   __shared__ float s_keep[3 * kKeep];                // un-rotated survivors (x, y, z) waiting for the elevation sweep
   __shared__ uint32_t s_ring[FX_MAX_RINGS];          // survivors per ring (a window-boundary point counts in both rings)
+  __shared__ double s_atan[(FX_ATAN_N + 1) * (FX_ATAN_DEG + 1)];  // elevation_fast's table
   float4 *out = B.filt + (size_t)scan * P.max_points;
   uint32_t *near_bits = B.near_bits + (size_t)scan * P.near_words;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -810,6 +852,7 @@ __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, 
     return;
   }
   for (uint32_t r = tid; r < R; r += FX_PREP_T) s_ring[r] = 0u;  // (ordered before the first sweep by the tile barriers)
+  for (uint32_t r = tid; r < (FX_ATAN_N + 1) * (FX_ATAN_DEG + 1); r += FX_PREP_T) s_atan[r] = B.atan_tab[r];
   // the loads of the next tile are issued before this tile's barrier, so the memory pipe stays full
   // while the tile is compacted
   auto load_tile = [&](uint32_t t0, float4 (&v)[FX_PREP_U]) {
@@ -819,8 +862,8 @@ __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, 
       const gfloat *q = gpts + (size_t)min(i, n - 1u) * M.stride_f;  // clamped: no branch around the load
       // (the record's fourth word is never used and the compiler narrows the load to 12 bytes a lane — measured faster
       //  than the full 16-byte load: 0.17 against 0.20 ms)
-      const float4 w = make_float4(q[0], q[1], q[2], q[3]);
-      v[u] = i < n ? w : make_float4(NAN, NAN, NAN, 0.f);
+      // past the end: a NaN x makes all three rotated coordinates NaN, which fail every range test below
+      v[u] = make_float4(i < n ? q[0] : NAN, q[1], q[2], 0.f);
     }
   };
   // The fp64 elevation is a long dependent chain: it runs over the buffered survivors only when the buffer could
@@ -832,7 +875,8 @@ __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, 
       const float rx = ((M.R[0] * x + M.R[1] * y) + M.R[2] * z) + 0.0f;
       const float ry = ((M.R[3] * x + M.R[4] * y) + M.R[5] * z) + 0.0f;
       const float rz = ((M.R[6] * x + M.R[7] * y) + M.R[8] * z) + 0.0f;
-      const float el = elevation_deg(x, y, z);
+      float el;
+      if (!elevation_fast(x, y, z, s_atan, el)) el = elevation_deg(x, y, z);
       out[base + j] = make_float4(rx, ry, rz, el);
       // ring counts for k_bucket's split (it then reads the filtered cloud once, not twice)
       int r_first;
@@ -844,8 +888,15 @@ __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, 
     base += buffered;
     buffered = 0;
   };
-  const float nx0 = P.x_min - near_margin, nx1 = P.x_max + near_margin, ny0 = P.y_min - near_margin,
-              ny1 = P.y_max + near_margin, nz0 = P.z_min - near_margin, nz1 = P.z_max + near_margin;
+  // Range tests with both ends clamped to the finite floats: a NaN or an infinite coordinate fails them (PassThrough drops
+  // non-finite points first, ref: SURVEY.md A.2), a finite one compares as in PCL's !(v < min || v > max); an infinite or
+  // NaN limit (no limit on that side; a NaN limit compares false in PCL too) becomes +-FLT_MAX.
+  auto lo_lim = [](float v) { return fmaxf(v, -FLT_MAX); };
+  auto hi_lim = [](float v) { return fminf(v, FLT_MAX); };
+  const float nx0 = lo_lim(P.x_min - near_margin), nx1 = hi_lim(P.x_max + near_margin), ny0 = lo_lim(P.y_min - near_margin),
+              ny1 = hi_lim(P.y_max + near_margin), nz0 = lo_lim(P.z_min - near_margin), nz1 = hi_lim(P.z_max + near_margin);
+  const float fx0 = lo_lim(P.x_min), fx1 = hi_lim(P.x_max), fy0 = lo_lim(P.y_min), fy1 = hi_lim(P.y_max), fz0 = lo_lim(P.z_min),
+              fz1 = hi_lim(P.z_max);
   float4 v[FX_PREP_U], nv[FX_PREP_U];
   load_tile(0, v);
   for (uint32_t t0 = 0; t0 < n; t0 += kTile) {
@@ -861,12 +912,8 @@ __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, 
       const float rx = ((M.R[0] * x + M.R[1] * y) + M.R[2] * z) + 0.0f;
       const float ry = ((M.R[3] * x + M.R[4] * y) + M.R[5] * z) + 0.0f;
       const float rz = ((M.R[6] * x + M.R[7] * y) + M.R[8] * z) + 0.0f;
-      // (a NaN or an infinity fails one of the range tests of the wider box)
       const bool near = rx >= nx0 && rx <= nx1 && ry >= ny0 && ry <= ny1 && rz >= nz0 && rz <= nz1;
-      bool k = near && isfinite(rx) && isfinite(ry) && isfinite(rz);
-      k = k && !(rz < P.z_min || rz > P.z_max);
-      k = k && !(ry < P.y_min || ry > P.y_max);
-      k = k && !(rx < P.x_min || rx > P.x_max);
+      const bool k = rx >= fx0 && rx <= fx1 && ry >= fy0 && ry <= fy1 && rz >= fz0 && rz <= fz1;
       keep[u] = k;
       mask[u] = __ballot(k);
       wave_cnt += (uint32_t)__popcll(mask[u]);
@@ -1680,7 +1727,10 @@ __device__ __forceinline__ bool ring_runs_body(const FxDevParams &P, const FxBuf
   FX_STAMP(11);
   return true;
 }
-extern "C" __global__ __launch_bounds__(64) void k_rings_runs(FxDevParams P, FxBuffers B, uint32_t max_pts, uint32_t n_items) {
+#ifndef FX_RUNS_OCC
+#define FX_RUNS_OCC 1
+#endif
+extern "C" __global__ __launch_bounds__(64, FX_RUNS_OCC) void k_rings_runs(FxDevParams P, FxBuffers B, uint32_t max_pts, uint32_t n_items) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   // persistent wavefronts over the (scan, ring) items, dealt by XCD class
   const uint32_t R = (uint32_t)P.n_rings, n_scans = n_items / R;
@@ -2112,6 +2162,15 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_offsets(FxDevParams P, FxB
     run += tot;
   }
   if (threadIdx.x == 0) {
+    // what the rarely used tiers had to do in this batch (every kernel that adds to these lists has completed): the host
+    // sizes the next batch's launches of those tiers by it — an empty 256-workgroup launch of a kernel that takes a whole
+    // CU's LDS waits for 256 CUs to drain, in the way of the other batches in flight
+    uint32_t l1 = 0, l2 = 0;
+    for (uint32_t c = 0; c < 8u; ++c) l1 = max(l1, B.counters[FX_CNT_LARGE + c]), l2 = max(l2, B.counters[FX_CNT_LARGE2 + c]);
+    B.tier_hint[0] = l1;
+    B.tier_hint[1] = l2;
+    B.tier_hint[2] = B.counters[1];
+    B.tier_hint[3] = B.counters[9];
     B.kp_offset[batch] = run;
     B.seq[0] += 1ull;  // batch tag of the dense tier's density cache (device side: a replayed HIP graph advances it too)
   }
@@ -3217,6 +3276,10 @@ __device__ __forceinline__ void desc_wg_loop(const FxDevParams &P, const FxBuffe
 // other they cost 0.135 + 0.075 ms, together about the longer of the two.
 extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_mid(FxDevParams P, FxBuffers B, uint32_t batch, uint32_t cap,
                                                                 uint32_t n_wg) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // (k_desc_group, which fills the dense tier's row list, has completed)
+    B.tier_hint[4] = B.counters[6];
+    B.tier_hint[5] = B.counters[13];
+  }
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   if (blockIdx.x < n_wg)
     desc_wg_loop<true, FX_DESC_WG_FAST_T>(P, B, batch, cap, smem, blockIdx.x, n_wg);
@@ -4207,11 +4270,29 @@ void fxk_desc_mid(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint3
   const size_t lds_wave = (size_t)(FX_NWAVE * FX_WAVE_WORDS + FX_TABLE_WORDS) * 4, lds_wg = fxk_desc_lds_bytes(cap);
   hipLaunchKernelGGL(k_desc_mid, dim3(n_wg + n_wave), dim3(FX_WG), lds_wave > lds_wg ? lds_wave : lds_wg, s, P, B, batch, cap, n_wg);
 }
-void fxk_dense(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t n_cu) {
-  hipLaunchKernelGGL(k_dense_sort, dim3(n_cu * (1024 / FX_DSORT_T)), dim3(FX_DSORT_T), 0, s, P, B);  // (what is resident at once: the rows are taken by ticket)
-  hipLaunchKernelGGL(k_dense_density, dim3(n_cu * 3), dim3(FX_DDENS_T), 0, s, P, B);
-  hipLaunchKernelGGL(k_dense_finish_s, dim3(n_cu * 3), dim3(FX_DFIN_TS), fxk_dense_finish_lds_bytes(0), s, P, B);
-  hipLaunchKernelGGL(k_dense_finish_l, dim3(n_cu), dim3(FX_DFIN_TL), fxk_dense_finish_lds_bytes(1), s, P, B);
+// (rows and items are taken by ticket: any grid is correct; the full ones are what is resident at once)
+void fxk_dense(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t n_cu, uint32_t rows, uint32_t items) {
+  auto grid = [](uint32_t want, uint32_t full) { return want < full ? (want ? want : 1u) : full; };
+  hipLaunchKernelGGL(k_dense_sort, dim3(grid(rows, n_cu * (1024 / FX_DSORT_T))), dim3(FX_DSORT_T), 0, s, P, B);
+  hipLaunchKernelGGL(k_dense_density, dim3(grid(items, n_cu * 3)), dim3(FX_DDENS_T), 0, s, P, B);
+  hipLaunchKernelGGL(k_dense_finish_s, dim3(grid(rows, n_cu * 3)), dim3(FX_DFIN_TS), fxk_dense_finish_lds_bytes(0), s, P, B);
+  hipLaunchKernelGGL(k_dense_finish_l, dim3(grid(rows, n_cu)), dim3(FX_DFIN_TL), fxk_dense_finish_lds_bytes(1), s, P, B);
+}
+extern "C" __global__ __launch_bounds__(FX_WG) void k_test_elevation(const float *xyz, uint32_t n, const double *tab, float *fast, uint8_t *ok,
+                                                                     float *exact) {
+  __shared__ double s_atan[(FX_ATAN_N + 1) * (FX_ATAN_DEG + 1)];
+  for (uint32_t r = threadIdx.x; r < (FX_ATAN_N + 1) * (FX_ATAN_DEG + 1); r += FX_WG) s_atan[r] = tab[r];
+  __syncthreads();
+  for (uint32_t i = blockIdx.x * FX_WG + threadIdx.x; i < n; i += gridDim.x * FX_WG) {
+    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    float f = 0.f;
+    ok[i] = elevation_fast(x, y, z, s_atan, f) ? 1 : 0;
+    fast[i] = f;
+    exact[i] = elevation_deg(x, y, z);
+  }
+}
+void fxk_test_elevation(hipStream_t s, const float *xyz, uint32_t n, const double *tab, float *fast, uint8_t *ok, float *exact) {
+  hipLaunchKernelGGL(k_test_elevation, dim3(1024), dim3(FX_WG), 0, s, xyz, n, tab, fast, ok, exact);
 }
 void fxk_test_sort_replay(hipStream_t s, const uint32_t *sizes, uint32_t n_seq, uint32_t n, uint32_t *perm) {
   hipLaunchKernelGGL(k_test_sort_replay, dim3(n_seq), dim3(64), 0, s, sizes, n, perm);

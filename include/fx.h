@@ -291,6 +291,10 @@ void fx_test_sort_replay_lists(const uint32_t *sizes, uint32_t n, uint32_t *perm
 /* Test hook: the replay as the kernels run it (wavefront partition phase + ranking) on device `device`,
  * one workgroup per sequence; n <= 192 per sequence.  sizes / perm_out: host arrays [n_seq][n]. */
 fx_status fx_test_sort_replay_device(int device, const uint32_t *sizes, uint32_t n_seq, uint32_t n, uint32_t *perm_out);
+/* Test hook: the two evaluations of a point's elevation angle the filter stage has (ref: node.cpp:147-156) on host
+ * points xyz[n][3]: the table-driven one (fast_out, and whether it vouches for its value: fast_ok_out) and the one
+ * through the library's fp64 atan2 that takes the points it does not vouch for (exact_out). */
+fx_status fx_test_elevation_device(int device, const float *xyz, uint32_t n, float *fast_out, uint8_t *fast_ok_out, float *exact_out);
 
 #ifdef __cplusplus
 }

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from feature_extraction_amd import capi
 lib = capi.load()
 preset = sys.argv[1] if len(sys.argv) > 1 else "launch"
-B = 256
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 scans = [capi.synth_scan(capi.synth_cfg(1000 + b)) for b in range(B)]
 ctx = capi.Context(capi.params(preset), capi.limits(B, 28800))
 descs = ctx.make_descs([s.ctypes.data for s in scans], [len(s) for s in scans], 16, 0.02, -0.015)
@@ -19,3 +19,7 @@ names = ["rings -> second run tier", "scans -> big merge", "-", "-", "rows -> li
 print(f"batch {B} scans, {v.total_keypoints} keypoint rows, {B * 16} rings")
 for n, c in zip(names, out):
     print(f"  {n:28s} {c}")
+hints = (C.c_uint32 * 8)()
+lib.fx_debug_tier_hints.argtypes = [C.c_void_p, C.c_void_p]
+capi.check(lib.fx_debug_tier_hints(ctx.handle, hints))
+print("tier hints (second run tier, workgroup ring tier [largest XCD class], big merges, huge merges, dense rows, dense points):", list(hints)[:6])
