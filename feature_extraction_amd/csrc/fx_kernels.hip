@@ -830,6 +830,9 @@ __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, 
   __shared__ float s_keep[3 * kKeep];                // un-rotated survivors (x, y, z) waiting for the elevation sweep
   __shared__ uint32_t s_ring[FX_MAX_RINGS];          // survivors per ring (a window-boundary point counts in both rings)
   __shared__ double s_atan[(FX_ATAN_N + 1) * (FX_ATAN_DEG + 1)];  // elevation_fast's table
+  // the ring windows (a sweep then loads nothing from global memory: the wait for such a load would also be one for the
+  // acknowledgement of the sweep's earlier stores — vmcnt counts loads and stores in issue order)
+  __shared__ float2 s_win[FX_MAX_RINGS];
   float4 *out = B.filt + (size_t)scan * P.max_points;
   uint32_t *near_bits = B.near_bits + (size_t)scan * P.near_words;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -853,6 +856,7 @@ __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, 
   }
   for (uint32_t r = tid; r < R; r += FX_PREP_T) s_ring[r] = 0u;  // (ordered before the first sweep by the tile barriers)
   for (uint32_t r = tid; r < (FX_ATAN_N + 1) * (FX_ATAN_DEG + 1); r += FX_PREP_T) s_atan[r] = B.atan_tab[r];
+  for (uint32_t r = tid; r < R; r += FX_PREP_T) s_win[r] = B.ring_win[r];
   // the loads of the next tile are issued before this tile's barrier, so the memory pipe stays full
   // while the tile is compacted
   auto load_tile = [&](uint32_t t0, float4 (&v)[FX_PREP_U]) {
@@ -880,7 +884,7 @@ __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, 
       out[base + j] = make_float4(rx, ry, rz, el);
       // ring counts for k_bucket's split (it then reads the filtered cloud once, not twice)
       int r_first;
-      const uint32_t mask = isfinite(el) ? ring_membership(el, B.ring_win, P.n_rings, el0, inv_step, r_first) : 0u;
+      const uint32_t mask = isfinite(el) ? ring_membership(el, s_win, P.n_rings, el0, inv_step, r_first) : 0u;
 #pragma unroll
       for (int d = 0; d < 3; ++d)
         if (mask & (1u << d)) atomicAdd(&s_ring[r_first + d], 1u);
