@@ -1315,6 +1315,9 @@ __device__ __forceinline__ bool ring_body(const FxDevParams &P, const FxBuffers 
 // granules —, and 384 / 256 (24 KB) behind it for the rings of dense many-ring sensors, which otherwise need a 1024-thread
 // workgroup each.
 #define FX_RR_QUEUE 96
+#ifndef FX_RR_U
+#define FX_RR_U 8  // LDS / L2 reads in flight in the run tier's pair loops
+#endif
 #define FX_RR_CACHE 170
 template <uint32_t S, uint32_t RN>
 __host__ __device__ constexpr uint32_t rr_words() {
@@ -1476,13 +1479,13 @@ __device__ __forceinline__ bool ring_runs_body(const FxDevParams &P, const FxBuf
     for (uint32_t a0 = 0; a0 + 1u < n_runs; a0 += 64) {
       const uint32_t a = a0 + lane;
       const float4 ba = rbox4[min(a, n_runs - 1u)];
-      for (uint32_t b0 = a0 + 1u; b0 < n_runs; b0 += 8) {  // (eight reads in flight: the wavefront has little company on its SIMD)
-        float4 bx[8];
+      for (uint32_t b0 = a0 + 1u; b0 < n_runs; b0 += FX_RR_U) {  // (FX_RR_U reads in flight: the wavefront has little company on its SIMD)
+        float4 bx[FX_RR_U];
 #pragma unroll
-        for (uint32_t u = 0; u < 8; ++u) bx[u] = rbox4[min(b0 + u, n_runs - 1u)];
+        for (uint32_t u = 0; u < FX_RR_U; ++u) bx[u] = rbox4[min(b0 + u, n_runs - 1u)];
         uint32_t near = 0;
 #pragma unroll
-        for (uint32_t u = 0; u < 8; ++u) {
+        for (uint32_t u = 0; u < FX_RR_U; ++u) {
           const float dx = fmaxf(fmaxf(bx[u].x - ba.y, ba.x - bx[u].y), 0.0f);
           const float dy = fmaxf(fmaxf(bx[u].z - ba.w, ba.z - bx[u].w), 0.0f);
           near |= (b0 + u < n_runs && b0 + u > a && !(dx * dx + dy * dy > r2_pad)) ? (1u << u) : 0u;
@@ -1517,11 +1520,11 @@ __device__ __forceinline__ bool ring_runs_body(const FxDevParams &P, const FxBuf
           const float dy = fmaxf(fmaxf(sb.z - q.y, q.y - sb.w), 0.0f);
           if (dx * dx + dy * dy > r2_pad) continue;
           const uint32_t j1 = sst(sg + 1);
-          for (uint32_t j = sst(sg); j < j1 && !linked; j += 8) {
-            float jx[8], jy[8], jz[8];
-            fetch(std::integral_constant<uint32_t, 8>{}, j, j1 - 1u, jx, jy, jz);
+          for (uint32_t j = sst(sg); j < j1 && !linked; j += FX_RR_U) {
+            float jx[FX_RR_U], jy[FX_RR_U], jz[FX_RR_U];
+            fetch(std::integral_constant<uint32_t, FX_RR_U>{}, j, j1 - 1u, jx, jy, jz);
 #pragma unroll
-            for (uint32_t u = 0; u < 8; ++u) linked |= dist2(q.x, q.y, q.z, jx[u], jy[u], jz[u]) < r2;
+            for (uint32_t u = 0; u < FX_RR_U; ++u) linked |= dist2(q.x, q.y, q.z, jx[u], jy[u], jz[u]) < r2;
           }
           if (linked) uf_union(rparent, b, a);  // the two runs are one component now; more edges add nothing
         }
