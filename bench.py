@@ -132,16 +132,19 @@ def run_other_config(name, cfg, capi, torch, dev, threads, roll, pitch, steps=6,
     ctxs = [capi.Context(p, capi.limits(B, N, **cfg["limits"]), device=dev.index) for _ in range(in_flight)]
     ctx = ctxs[0]
     descs = ctx.make_descs([d_in.data_ptr() + b * N * 16 for b in range(B)], [N] * B, 16, roll, pitch)
+    # the same scans one place on: the steps alternate between the two orders, so that a context never gets the batch it
+    # had last time (its descriptor rows keep their content between batches)
+    descs_b = ctx.make_descs([d_in.data_ptr() + ((b + 1) % B) * N * 16 for b in range(B)], [N] * B, 16, roll, pitch)
     torch.cuda.synchronize(dev)
 
     def timed(cs, n_steps):
         for j in range(2 * len(cs)):
-            cs[j % len(cs)].process_raw(descs, B, capi.FX_IN_DEVICE)
+            cs[j % len(cs)].process_raw(descs_b if (j // len(cs)) % 2 else descs, B, capi.FX_IN_DEVICE)
         for c in cs:
             c.synchronize()
         t0 = time.perf_counter()
         for j in range(n_steps):
-            cs[j % len(cs)].process_raw(descs, B, capi.FX_IN_DEVICE)
+            cs[j % len(cs)].process_raw(descs_b if (j // len(cs)) % 2 else descs, B, capi.FX_IN_DEVICE)
         for c in cs:
             c.synchronize()
         return (time.perf_counter() - t0) / n_steps
@@ -246,6 +249,13 @@ def main():
         c.set_stream(st.cuda_stream)
     base = d_in.data_ptr()
     descs = ctx.make_descs([base + b * N * 16 for b in range(B)], [N] * B, 16, roll, pitch)
+    # A second batch of different scans: the steps alternate between the two, so no context ever sees the batch it
+    # processed last time (descriptor rows keep their content between batches — k_desc_group clears a row by un-writing
+    # what it wrote — and a repeated batch would clear and rewrite the very same bins).
+    scans_b = make_scans(capi, [1000 + (world + rank) * B + b for b in range(B)], max(1, threads // max(1, min(world, 8))))
+    d_in_b = torch.from_numpy(np.stack(scans_b)).to(dev)
+    descs_b = ctx.make_descs([d_in_b.data_ptr() + b * N * 16 for b in range(B)], [N] * B, 16, roll, pitch)
+    del scans_b
     # keypoint records, one buffer per context: the gather of a batch (RCCL, its own stream) overlaps the
     # kernels of the batches behind it; a buffer is reused only after its collective has completed
     recs = [torch.zeros((B, 1 + REC_KP, 4), dtype=torch.float32, device=dev) for _ in range(K)]
@@ -278,12 +288,13 @@ def main():
 
     def step():
         j = counter[0] % K
+        batch_descs = descs_b if (counter[0] // K) % 2 else descs
         counter[0] += 1
         with torch.cuda.stream(streams[j]):
             if pending[j] is not None:
                 pending[j].wait()  # stream-level wait: rec[j] / gathered[j] are free again
                 pending[j] = None
-            ctxs[j].process_raw(descs, B, capi.FX_IN_DEVICE)
+            ctxs[j].process_raw(batch_descs, B, capi.FX_IN_DEVICE)
             ctxs[j].pack_keypoint_records(recs[j].data_ptr(), REC_KP)
             if rccl is not None:  # the path's one collective, an ordinary kernel of this context's stream
                 rccl.all_gather(recs[j], gathered[j], streams[j].cuda_stream, comm=j % rccl_comms)
@@ -370,9 +381,12 @@ def main():
     profile_all(0)
 
     # ---- what the batch produced (for the algorithmic byte count) + a parity spot check
-    v = ctx.process_raw(descs, B, capi.FX_IN_DEVICE | capi.FX_OUT_HOST)
-    k_total = int(v.total_keypoints)
+    v = ctx.process_raw(descs_b, B, capi.FX_IN_DEVICE | capi.FX_OUT_HOST)
+    k_total_b = int(v.total_keypoints)
     flags_or = int(np.bitwise_or.reduce(np.ctypeslib.as_array(v.h_flags, shape=(B,)))) if B else 0
+    v = ctx.process_raw(descs, B, capi.FX_IN_DEVICE | capi.FX_OUT_HOST)
+    k_total = (int(v.total_keypoints) + k_total_b) / 2.0  # keypoints per step: the two alternating batches' mean
+    flags_or |= int(np.bitwise_or.reduce(np.ctypeslib.as_array(v.h_flags, shape=(B,)))) if B else 0
     stage_bytes = ctx.stage_bytes()  # algorithmic bytes (read, written) of every stage of that batch, from its own counts
     n_chk = min(args.check, B) if rank == 0 else 0
     res = []
@@ -380,9 +394,9 @@ def main():
         v2 = ctx.process_raw(descs, n_chk, capi.FX_IN_DEVICE | capi.FX_OUT_HOST | capi.FX_OUT_CLOUDS | capi.FX_OUT_DEBUG)
         res = ctx.unpack(v2)
     if world > 1:
-        kt = torch.tensor([k_total], dtype=torch.int64, device=dev)
+        kt = torch.tensor([k_total], dtype=torch.float64, device=dev)
         dist.all_reduce(kt)
-        k_all = int(kt.item())
+        k_all = float(kt.item())
     else:
         k_all = k_total
     if use_dist and rank == 0:

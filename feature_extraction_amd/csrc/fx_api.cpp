@@ -480,6 +480,12 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   FX_A(dev_alloc(c, &b.kpc_cand, B * L.max_kpc_points));
   FX_A(dev_alloc(c, &b.n_kpc, B));
   FX_A(dev_alloc(c, &b.desc, (size_t)L.max_total_keypoints * FX_DESC_FLOATS + 4));
+  FX_A(dev_alloc(c, &b.desc_nbins, (size_t)L.max_total_keypoints));
+  FX_A(dev_alloc(c, &b.desc_bins, (size_t)L.max_total_keypoints * 64));  // (FX_GROUP_CAP of fx_kernels.hip)
+  // rows start out zero with nothing recorded in them: k_desc_group then clears a row by un-writing what it wrote last time
+  if (hipMemset(b.desc, 0, ((size_t)L.max_total_keypoints * FX_DESC_FLOATS + 4) * sizeof(float)) != hipSuccess ||
+      hipMemset(b.desc_nbins, 0, (size_t)L.max_total_keypoints * sizeof(uint32_t)) != hipSuccess)
+    return bail(fail(FX_ERR_HIP, "hipMemset"));
   FX_A(dev_alloc(c, &b.flags, B));
   FX_A(dev_alloc(c, &b.huge_rings, (size_t)8 * P.ring_list_cap));
   FX_A(dev_alloc(c, &b.huge_rings2, (size_t)8 * P.ring_list_cap));

@@ -55,6 +55,7 @@ struct FxScTables {
 #define FX_N_COUNTERS 40
 #define FX_ATAN_N 64      // table step of k_prep's arctangent: 1 / 64 over [0, 1]
 #define FX_ATAN_DEG 6     // degree of the expansion about a table point (|offset| <= 1 / 128: truncation below 2^-51)
+#define FX_ROW_DIRTY 0xffffffffu
 #define FX_N_HINTS 8      // tier_hint[]: 0 / 1 rings handed to the second run tier / the workgroup tier (largest XCD class), 2 big merges, 3 huge merges, 4 dense rows, 5 dense support points
 #define FX_CNT_QPOOL 32   // counters[32]: entries of the dense tier's query pool in use
 #define FX_CNT_LARGE2 16  // counters[16 + c]: rings of XCD class c the second run tier hands to the workgroup tier
@@ -95,6 +96,11 @@ struct FxBuffers {
   uint32_t *n_kpc;        // [B]
   // stage 5
   float *desc;            // [max_total_kp][1989]
+  // What the previous batches left in each descriptor row (rows outlive a batch: the buffer is zeroed when the context is
+  // made, and a row is cleared by un-writing what was written to it): the number of non-zero bins k_desc_group wrote, or
+  // FX_ROW_DIRTY when another tier (or a NaN fill) wrote the row — such a row is cleared whole.
+  uint32_t *desc_nbins;   // [max_total_kp]
+  uint16_t *desc_bins;    // [max_total_kp][FX_GROUP_CAP]: those bins
   uint32_t *flags;        // [B]
   // work lists for the large-capacity tiers
   uint32_t *huge_rings;   // [B*n_rings]  rings for the workgroup tier (k_rings_large), by XCD class

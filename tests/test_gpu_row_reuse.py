@@ -1,0 +1,70 @@
+"""Descriptor rows outlive a batch: k_desc_group clears a row by un-writing the bins it wrote to it last time (rows another
+tier or a NaN fill wrote are cleared whole).  One context, different batches one after another — every row must come out as
+if it had been cleared in full: compared with the oracle, and with a fresh context, bit for bit."""
+import numpy as np
+import pytest
+
+from feature_extraction_amd import capi
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(ctx, oracle, p, scans, tag, roll=0.02, pitch=-0.015):
+    got = ctx.process_host(scans, roll=roll, pitch=pitch)
+    for b, s in enumerate(scans):
+        util.compare_scan(got[b], oracle.run(p, s, roll=roll, pitch=pitch), tag=f"{tag} scan {b}")
+    return got
+
+
+def test_rows_are_clean_across_batches_of_different_scenes(fxlib, oracle):
+    p = capi.params("launch")
+    ctx = capi.Context(p, capi.limits(6, 28800, max_total_keypoints=6 * 256))
+    sparse = [util.vlp16_scan(3000 + b) for b in range(6)]
+    dense = [util.vlp16_scan(3100 + b, n_poles=256) for b in range(4)]      # more rows, more bins per row
+    lonely = [util.vlp16_scan(3200 + b, n_poles=8) for b in range(3)]       # few rows
+    _check(ctx, oracle, p, dense, "dense first")
+    _check(ctx, oracle, p, sparse, "sparse after dense")      # rows that held many bins now hold few
+    _check(ctx, oracle, p, lonely, "few rows after many")     # most rows of the last batch are not touched at all ...
+    _check(ctx, oracle, p, dense[::-1], "dense again")        # ... and are reused here with their old lists
+    _check(ctx, oracle, p, [sparse[0]], "one scan")
+    ctx.close()
+
+
+def test_rows_written_by_the_other_tiers_and_nan_rows_are_cleared_whole(fxlib, oracle):
+    # descriptor radius 1.2 m: most keypoints leave the 64-point tier (wavefront and list tiers write their rows); support
+    # radius 0.05 m: most keypoints have no neighbour at all (NaN rows); then the launch preset on the same rows
+    base = capi.params("launch")
+    big = capi.params("launch", descriptor_radius=1.2)
+    tiny = capi.params("launch", descriptor_radius=0.05)
+    scans = [util.vlp16_scan(3300 + b, n_poles=128) for b in range(3)]
+    lim = capi.limits(3, 28800, max_total_keypoints=3 * 256)
+    # (a context has one parameter set: the rows' history is made with three contexts' worth of batches on one device
+    #  buffer only within a context, so each parameter set gets its own context and runs dense -> plain -> dense)
+    for p, tag in ((big, "R 1.2 m"), (tiny, "R 0.05 m"), (base, "launch")):
+        ctx = capi.Context(p, lim)
+        first = _check(ctx, oracle, p, scans, tag + " a")
+        _check(ctx, oracle, p, scans[::-1], tag + " b")
+        again = _check(ctx, oracle, p, scans, tag + " c")
+        for a, b in zip(first, again):
+            assert np.array_equal(a["descriptors"].view(np.uint32), b["descriptors"].view(np.uint32))
+        ctx.close()
+
+
+def test_row_history_with_a_changing_batch_size_matches_a_fresh_context(fxlib):
+    p = capi.params("launch")
+    lim = capi.limits(8, 28800, max_total_keypoints=8 * 256)
+    ctx = capi.Context(p, lim)
+    rng = np.random.default_rng(5)
+    pool = [util.vlp16_scan(3400 + b, n_poles=int(rng.integers(8, 256))) for b in range(10)]
+    for step in range(12):
+        pick = [pool[i] for i in rng.choice(len(pool), size=int(rng.integers(1, 9)), replace=False)]
+        got = ctx.process_host(pick, roll=0.01, pitch=0.0)
+        fresh_ctx = capi.Context(p, lim)
+        want = fresh_ctx.process_host(pick, roll=0.01, pitch=0.0)
+        fresh_ctx.close()
+        for b, (g, w) in enumerate(zip(got, want)):
+            assert g["flags"] == 0 and w["flags"] == 0
+            assert g["n_keypoints"] == w["n_keypoints"]
+            assert np.array_equal(g["descriptors"].view(np.uint32), w["descriptors"].view(np.uint32)), f"step {step} scan {b}"
+    ctx.close()
