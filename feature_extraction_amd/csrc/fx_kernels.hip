@@ -1318,7 +1318,15 @@ __device__ __forceinline__ bool ring_body(const FxDevParams &P, const FxBuffers 
 #ifndef FX_RR_U
 #define FX_RR_U 8  // LDS / L2 reads in flight in the run tier's pair loops
 #endif
+#ifndef FX_RR_CACHE
 #define FX_RR_CACHE 170
+#endif
+#ifndef FX_RR_S
+#define FX_RR_S 128   // first run tier: segments
+#endif
+#ifndef FX_RR_RN
+#define FX_RR_RN 128  // first run tier: runs and clusters
+#endif
 template <uint32_t S, uint32_t RN>
 __host__ __device__ constexpr uint32_t rr_words() {
   return 152 + 4 * RN + FX_RR_QUEUE + (S + 4) + 4 * S + (RN + 1) + 4 * RN + 4 * RN + 3 * FX_RR_CACHE;
@@ -1370,7 +1378,7 @@ __device__ __forceinline__ bool ring_runs_body(const FxDevParams &P, const FxBuf
   wave_sync_lds();
   FX_STAMP(1);
   // ---- run labelling: a point starts a run when it is not closer than the tolerance to its predecessor
-  const uint32_t seg_len = max(8u, (n + 95u) / 96u);
+  const uint32_t seg_len = max(8u, (n + (S * 3u / 4u) - 1u) / (S * 3u / 4u));  // (at most 3/4 S segments by length; runs start the others)
   const unsigned long long le_mask = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
   uint32_t n_runs = 0, n_segs = 0, head_carry = 0;
   float4 prev_last = make_float4(0, 0, 0, 0);
@@ -1746,7 +1754,7 @@ extern "C" __global__ __launch_bounds__(64, FX_RUNS_OCC) void k_rings_runs(FxDev
   for (uint32_t q = slot; q < cls_items; q += per_cls) {
     const uint32_t scan = cls + 8u * (q / R), ring = q % R;
     const uint32_t item = scan * R + ring;
-    if (!ring_runs_body<128, 128>(P, B, scan, ring, max_pts, smem)) {
+    if (!ring_runs_body<FX_RR_S, FX_RR_RN>(P, B, scan, ring, max_pts, smem)) {
       if (threadIdx.x == 0) {  // the next tier's list of this XCD class (it too then finds the ring's points in its own L2)
         const uint32_t pos = atomicAdd(&B.counters[FX_CNT_LARGE + cls], 1u);
         B.huge_rings[(size_t)cls * P.ring_list_cap + pos] = item;
@@ -4249,7 +4257,7 @@ void fxk_bucket(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_
   const size_t lds = (48 + (size_t)P.n_rings * (2 + FX_BUCKET_NW) + 1) * 4;
   hipLaunchKernelGGL(k_bucket, dim3(batch), dim3(FX_BUCKET_T), lds, s, P, B, el0, inv_step, clk_next);
 }
-size_t fxk_ring_runs_lds_bytes(void) { return (size_t)rr_words<128, 128>() * 4; }
+size_t fxk_ring_runs_lds_bytes(void) { return (size_t)rr_words<FX_RR_S, FX_RR_RN>() * 4; }
 void fxk_rings_runs2(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t max_pts, uint32_t grid) {
   constexpr size_t lds = (size_t)rr_words<384, 256>() * 4;
   hipLaunchKernelGGL(k_rings_runs2, dim3(grid), dim3(64), lds, s, P, B, max_pts);

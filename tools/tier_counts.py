@@ -3,6 +3,8 @@ import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from feature_extraction_amd import capi
+if len(sys.argv) > 3:  # an alternative build under feature_extraction_amd/lib
+    capi.LIB_PATH = os.path.join(os.path.dirname(capi.LIB_PATH), sys.argv[3])
 lib = capi.load()
 preset = sys.argv[1] if len(sys.argv) > 1 else "launch"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
