@@ -68,3 +68,32 @@ def test_row_history_with_a_changing_batch_size_matches_a_fresh_context(fxlib):
             assert g["n_keypoints"] == w["n_keypoints"]
             assert np.array_equal(g["descriptors"].view(np.uint32), w["descriptors"].view(np.uint32)), f"step {step} scan {b}"
     ctx.close()
+
+
+def test_tier_grids_follow_the_previous_batch_without_changing_results(fxlib, oracle, monkeypatch):
+    """The grids of the rarely used tiers follow the context's previous batch (FxBuffers::tier_hint): a dense batch right
+    after sparse ones runs its dense tier on the smallest grids, a sparse one after it on wide ones — same results either
+    way, and with FX_TIER_MIN_GRID=0 (always the full grids)."""
+    import ctypes as C
+    p = capi.params("default", descriptor_radius=4.0)
+    dense = util.vlp16_scan(1000, n_poles=8, x_lo=3.0, x_hi=8.0, y_lo=-4.0, y_hi=4.0)  # rows of > 1024 support points
+    sparse = util.vlp16_scan(1001, n_poles=4)
+    ora_d, ora_s = oracle.run(p, dense), oracle.run(p, sparse)
+    assert ora_d["kp_neighbors"].max() > 1100
+    lib = capi.load()
+    lib.fx_debug_tier_hints.argtypes = [C.c_void_p, C.c_void_p]
+    for min_grid in ("8", "1", "0"):
+        monkeypatch.setenv("FX_TIER_MIN_GRID", min_grid)
+        ctx = capi.Context(p, capi.limits(2, 28800))
+        seen = []
+        for scans, oras, tag in (([sparse], [ora_s], "sparse"), ([sparse, sparse], [ora_s, ora_s], "sparse x2"),
+                                 ([dense, sparse], [ora_d, ora_s], "dense after sparse"), ([dense, dense], [ora_d, ora_d], "dense x2"),
+                                 ([sparse], [ora_s], "sparse after dense"), ([dense], [ora_d], "dense again")):
+            got = ctx.process_host(scans)
+            for b, o in enumerate(oras):
+                util.compare_scan(got[b], o, tag=f"min grid {min_grid}: {tag} scan {b}")
+            hints = (C.c_uint32 * 8)()
+            capi.check(lib.fx_debug_tier_hints(ctx.handle, hints))
+            seen.append(int(hints[4]))
+        ctx.close()
+        assert seen[0] == 0 and seen[2] > 0 and seen[3] > seen[2] and seen[4] == 0, seen  # dense rows of each batch
