@@ -12,6 +12,9 @@
 #include "fx_multi.hpp"
 
 int main(int argc, char **argv) {
+  // every batch in flight wants a hardware queue of its own (the HIP runtime's default is 4 per device for all streams of
+  // the process: more streams than that share queues and run one after the other); read when the runtime starts
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);
   try {
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
@@ -19,7 +22,7 @@ int main(int argc, char **argv) {
       return 3;
     }
     int want = n_dev;
-    uint32_t batch = 256, steps = 20, in_flight = 2;
+    uint32_t batch = 256, steps = 20, in_flight = 4;
     bool launch = true, host_input = false;
     for (int i = 1; i < argc; ++i) {
       if (!std::strcmp(argv[i], "--devices") && i + 1 < argc) want = std::atoi(argv[++i]);
