@@ -183,7 +183,7 @@ def run_other_config(name, cfg, capi, torch, dev, threads, roll, pitch, steps=6,
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="scans per GPU per step")
     ap.add_argument("--preset", default="launch", choices=["default", "launch"])
