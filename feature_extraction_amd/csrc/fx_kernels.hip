@@ -1750,6 +1750,18 @@ extern "C" __global__ __launch_bounds__(64, FX_RUNS_OCC) void k_rings_runs(FxDev
   // persistent wavefronts over the (scan, ring) items, dealt by XCD class
   const uint32_t R = (uint32_t)P.n_rings, n_scans = n_items / R;
   const uint32_t cls = blockIdx.x & 7u, slot = blockIdx.x >> 3, per_cls = gridDim.x >> 3;  // (grid is a multiple of 8)
+  if (n_scans < 64u) {
+    // a handful of scans (streaming): a ring per wavefront, whatever its XCD — dealt by class, one scan's sixteen rings were
+    // two wavefronts' work, eight rings one after the other (0.117 ms of a 0.37 ms host-to-host call)
+    const uint32_t item = blockIdx.x;  // (the launcher's grid covers the items)
+    if (item < n_items && !ring_runs_body<FX_RR_S, FX_RR_RN>(P, B, item / R, item % R, max_pts, smem)) {
+      if (threadIdx.x == 0) {
+        const uint32_t pos = atomicAdd(&B.counters[FX_CNT_LARGE + cls], 1u);
+        B.huge_rings[(size_t)cls * P.ring_list_cap + pos] = item;
+      }
+    }
+    return;
+  }
   const uint32_t cls_items = ((n_scans + 7u - cls) / 8u) * R;
   for (uint32_t q = slot; q < cls_items; q += per_cls) {
     const uint32_t scan = cls + 8u * (q / R), ring = q % R;
