@@ -741,9 +741,6 @@ typedef float __attribute__((address_space(1))) gfloat;
 // (out of line: the fp64 atan2 / sin / cos code then costs k_prep 86 registers instead of 128 — the same speed alone,
 //  3 % more throughput with four batches in flight, where the registers go to other batches' kernels)
 __device__ __noinline__ float elevation_deg(float xf, float yf, float zf) {
-#ifdef FX_EXPERIMENT_CHEAP_EL
-  return atan2f(zf, sqrtf(xf * xf + yf * yf)) * 57.29578f;
-#endif
   const double x = xf, y = yf, z = zf;
   const double e = atan2(z, sqrt(x * x + y * y)) * 180 / M_PI;
   const float f = (float)e;
@@ -757,8 +754,8 @@ __device__ __noinline__ float elevation_deg(float xf, float yf, float zf) {
   return (float)(atan2(z, xp) * 180 / M_PI);
 }
 
-// The same value for all but one point in ten thousand at a fifth of the instructions (the library's fp64 atan2 was 4 % of the
-// whole batch's vector instructions, at the half rate of fp64): t = z / |xy| from a refined fp32 reciprocal square root,
+// The same value for all but one point in sixteen thousand at a fifth of the instructions (the library's fp64 atan2 was 4 % of
+// the whole batch's vector instructions): t = z / |xy| from a refined fp32 reciprocal square root,
 // atan(|t|) from the degree-6 expansion about the nearest multiple of 1/64 (tab: FxBuffers::atan_tab in LDS), good to
 // 2^-44 relative (expansion 2^-51.8 absolute on values >= 2^-7; the root and the quotient a few ulp of double) where the
 // reference's own double, evaluated by the host's libm, is within a few ulp of the true value.  The float it rounds to
