@@ -118,7 +118,7 @@ def host_to_host(ctxs, capi, torch, host, B, N, roll, pitch, steps=4):
     return B * steps * len(ctxs) / dt
 
 
-def run_other_config(name, cfg, capi, torch, dev, threads, roll, pitch, steps=6, in_flight=3):
+def run_other_config(name, cfg, capi, torch, dev, threads, roll, pitch, steps=6, in_flight=4):
     """One of BASELINE.json's other configurations at its stated batch size: scans/s with inputs resident in HBM,
     capacity flags, keypoints per scan.  `in_flight` contexts take the steps in turn, each on its own HIP stream — the
     way the headline number is measured (a batch of these configurations is a few hundred workgroups per kernel: one

@@ -491,6 +491,8 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   FX_A(dev_alloc(c, &b.huge_rings2, (size_t)8 * P.ring_list_cap));
   FX_A(dev_alloc(c, &b.big_merge, B));
   FX_A(dev_alloc(c, &b.huge_merge, B));
+  b.merge_sorted = nullptr;
+  if (c->merge_big_cap < L.max_candidates) FX_A(dev_alloc(c, &b.merge_sorted, (size_t)B * L.max_candidates));
   FX_A(dev_alloc(c, &b.list_desc, L.max_total_keypoints));
   FX_A(dev_alloc(c, &b.s_pts, (size_t)L.max_total_keypoints * P.list_cap));
   FX_A(dev_alloc(c, &b.s_cnt, L.max_total_keypoints));

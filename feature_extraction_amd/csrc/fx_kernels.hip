@@ -1970,17 +1970,42 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
       }
     }
     __syncthreads();
+    // (coordinates left in HBM: a copy of the merge points in bin order, id in .w, so that the pair tests below read a bin's
+    //  entries from consecutive addresses instead of one dependent L2 load per id — 86 % of k_merge_huge was that loop)
+    float4 *msort = LDS_PTS ? nullptr : B.merge_sorted + (size_t)scan * P.max_candidates;
     for (uint32_t idx = tid; idx < C; idx += NT) {  // each id to its bin: a start becomes the bin's end
       const float4 v = merge_pt(idx);
-      sorted[atomicAdd(&bin[bin_of(cell_x(v.x), cell_y(v.y))], 1u)] = (uint16_t)idx;
+      const uint32_t pos = atomicAdd(&bin[bin_of(cell_x(v.x), cell_y(v.y))], 1u);
+      sorted[pos] = (uint16_t)idx;
+      if (!LDS_PTS) msort[pos] = make_float4(v.x, v.y, v.z, __uint_as_float(idx));
     }
     __syncthreads();
+    if (!LDS_PTS) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (msort is read below by other waves of this workgroup)
     FX_STAMP(2);
     // ---- pcl::EuclideanClusterExtraction on (x, y, pseudo z) (ref: node.cpp:222-229)
     // (one work item per (candidate, neighbouring bin): a wavefront's trip count is then the longest single bin of its
     //  lanes, not the sum over nine bins of the longest; two entries per trip, loaded before either is used; the
     //  distance test comes before any union-find lookup — one LDS round trip against several dependent ones)
-    for (uint32_t t = tid; t < 9u * C; t += NT) {
+    if (!LDS_PTS) {
+      for (uint32_t t = tid; t < 9u * C; t += NT) {
+        const uint32_t p = t / 9u, d = t - 9u * p;
+        const float4 v = msort[p];
+        const uint32_t i = __float_as_uint(v.w);
+        const uint32_t b = bin_of(cell_x(v.x) + (int)(d % 3u) - 1, cell_y(v.y) + (int)(d / 3u) - 1);
+        const uint32_t q0 = b ? bin[b - 1] : 0u, q1 = bin[b];
+        for (uint32_t q = q0; q < q1; q += 4) {
+          float4 u[4];
+#pragma unroll
+          for (uint32_t e = 0; e < 4; ++e) u[e] = msort[min(q + e, q1 - 1u)];
+#pragma unroll
+          for (uint32_t e = 0; e < 4; ++e) {
+            const uint32_t j = __float_as_uint(u[e].w);
+            if (q + e < q1 && j > i && dist2(v.x, v.y, v.z, u[e].x, u[e].y, u[e].z) < P.r2_merge) uf_union(parent, j, i);
+          }
+        }
+      }
+    }
+    for (uint32_t t = tid; LDS_PTS && t < 9u * C; t += NT) {
       const uint32_t i = t / 9u, d = t - 9u * i;
       const float4 v = merge_pt(i);
       const uint32_t b = bin_of(cell_x(v.x) + (int)(d % 3u) - 1, cell_y(v.y) + (int)(d / 3u) - 1);
