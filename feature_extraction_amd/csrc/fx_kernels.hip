@@ -1057,12 +1057,44 @@ extern "C" __global__ __launch_bounds__(FX_BUCKET_T) void k_bucket(FxDevParams P
     lo = max(lo, 0);
     hi = min(hi, (int)R);
     uint32_t my_rank[3] = {0, 0, 0};
-    for (int r = lo; r < hi; ++r) {
-      const int d = r - r_first;
-      const bool in = mask && d >= 0 && d < 3 && (mask & (1u << d));
-      const unsigned long long m = __ballot(in);
-      if (in) my_rank[d] = lanes_below(m);
-      if (lane == 0) cw[wave * R + r] = (uint32_t)__popcll(m);
+    // Rank of every point among the points of its ring in this wavefront's 64, and the wavefront's count per ring.
+    // Few rings in the chunk: one ballot per ring.  Many (a 64- or 128-ring sensor in firing order: every ring, every chunk):
+    // the lanes sort (ring, lane) keys — a bitonic network over the wavefront, 21 exchanges whatever the number of rings —,
+    // a ring's points are then neighbours in lane order, and a point's rank is its distance from the ring's first.
+    // (Only for wavefronts without a point on a window boundary — such a point is in two rings; those take the ballots.)
+    const bool by_sort = hi - lo > 24 && !__ballot(mask & (mask - 1u));
+    if (by_sort) {
+      for (int r = lo + (int)lane; r < hi; r += 64) cw[wave * R + r] = 0u;
+      const uint32_t d0 = mask ? (uint32_t)__ffs((int)mask) - 1u : 0u;
+      // (lanes without a point sort behind every ring and keep their lane number: the way back below is a permutation)
+      uint32_t key = ((mask ? (uint32_t)(r_first + (int)d0) : 0x3ffffffu) << 6) | lane;
+#pragma unroll
+      for (uint32_t kk = 2; kk <= 64; kk <<= 1) {
+#pragma unroll
+        for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+          const uint32_t other = (uint32_t)__shfl_xor((int)key, (int)j, 64);
+          const bool up = (lane & kk) == 0u, low = (lane & j) == 0u;  // ascending block / lower lane of the pair
+          key = (up == low) ? min(key, other) : max(key, other);
+        }
+      }
+      const uint32_t ring_s = key >> 6, prev = (uint32_t)__shfl_up((int)key, 1, 64), next = (uint32_t)__shfl_down((int)key, 1, 64);
+      const bool valid = ring_s != 0x3ffffffu;
+      const bool first = valid && (lane == 0 || (prev >> 6) != ring_s);
+      const unsigned long long starts = __ballot(first);
+      const unsigned long long below = starts & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+      const uint32_t rank = valid ? lane - (63u - (uint32_t)__clzll((long long)below)) : 0u;
+      if (valid && (lane == 63 || (next >> 6) != ring_s)) cw[wave * R + ring_s] = rank + 1u;  // (the ring's last point here)
+      // back to the lane the point came from
+      const uint32_t mine = (uint32_t)__builtin_amdgcn_ds_permute((int)((key & 63u) << 2), (int)rank);
+      if (mask) my_rank[d0] = mine;
+    } else {
+      for (int r = lo; r < hi; ++r) {
+        const int d = r - r_first;
+        const bool in = mask && d >= 0 && d < 3 && (mask & (1u << d));
+        const unsigned long long m = __ballot(in);
+        if (in) my_rank[d] = lanes_below(m);
+        if (lane == 0) cw[wave * R + r] = (uint32_t)__popcll(m);
+      }
     }
     __syncthreads();
 #pragma unroll

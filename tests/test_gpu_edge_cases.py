@@ -74,6 +74,21 @@ def test_points_on_window_boundaries_belong_to_two_rings(fxlib, oracle):
     assert got[0]["n_keypoints"] > 0
 
 
+def test_boundary_points_among_many_rings(fxlib, oracle):
+    """A 64-ring sensor in firing order has every ring in every 512-point chunk: k_bucket then ranks a wavefront's points by
+    sorting (ring, lane) keys — except in wavefronts that hold a point on a window boundary (two rings), which take the
+    per-ring ballots; both kinds share the chunk's per-ring offsets."""
+    over = dict(n_rings=64, n_az=256, el0_deg=-31.5, el_step_deg=1.0)
+    s = util.vlp16_scan(4100, **over)
+    s[::53, 2] = 0.0  # elevation exactly 0: the boundary of rings 31 and 32 (windows [-1, 0] and [0, 1])
+    p = capi.params("default", z_min=-3.0, secondary_max=64, **{k: over[k] for k in ("n_rings", "el0_deg", "el_step_deg")})
+    lim = capi.limits(1, len(s), max_candidates=4096, max_kpc_points=32768, max_keypoints=512, max_total_keypoints=512)
+    got = _cmp(oracle, p, lim, [s], tag="64 rings, boundary points")
+    ora = oracle.run(p, s, want_labels=True)
+    assert ((ora["ring_labels"] >= 0).sum(axis=0) == 2).sum() > 50  # points really are in two rings
+    assert len(got[0]["filtered"]) > 4000
+
+
 def test_unordered_input_takes_the_all_pairs_path(fxlib, oracle):
     """Shuffled points: no azimuth order, one run per point — exactness must not depend on order."""
     rng = np.random.default_rng(4)
