@@ -26,7 +26,8 @@ STAGE_NAMES = ("k_prep", "k_bucket", "k_rings_runs", "k_rings_large", "k_merge",
 # stages that are one kernel launch (eligible as the roofline line's dominant kernel: their HIP-event span is that kernel)
 SINGLE_LAUNCH_STAGES = ("k_prep", "k_bucket", "k_rings_runs", "k_gather", "k_desc_group", "k_desc_mid")
 # kernels launched inside each timed stage (rocprofv3 / PMC rows are per kernel name)
-STAGE_KERNELS = {"k_rings_large": ("k_rings_runs2", "k_rings_large"),  # (k_rings_runs2: sensors of more than 16 rings)
+STAGE_KERNELS = {"k_bucket": ("k_bucket", "k_bucket_many"),  # (k_bucket_many: sensors of more than 24 rings)
+                 "k_rings_large": ("k_rings_runs2", "k_rings_large"),  # (k_rings_runs2: sensors of more than 16 rings)
                  "k_merge": ("k_merge_small", "k_merge_big", "k_merge_huge", "k_offsets"),
                  "k_desc_mid": ("k_desc_mid",),
                  "k_gather": ("k_gather", "k_rng_ord"),  # (k_rng_ord only when several workgroups share a scan: small batches)

@@ -988,8 +988,10 @@ __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, 
 // workgroups read exactly their own points, already in ring order.
 #define FX_BUCKET_T 512
 #define FX_BUCKET_NW (FX_BUCKET_T / 64)
-extern "C" __global__ __launch_bounds__(FX_BUCKET_T) void k_bucket(FxDevParams P, FxBuffers B, float el0, float inv_step, uint32_t clk_next) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+// MANY: sensors of more than 24 rings (the sort-based ranking below is compiled only into that instance)
+template <bool MANY>
+__device__ __forceinline__ void bucket_body(const FxDevParams &P, const FxBuffers &B, float el0, float inv_step, uint32_t clk_next,
+                                            uint32_t *smem) {
   const uint32_t R = (uint32_t)P.n_rings;
   uint32_t *s_w = smem;            // 48: block helpers, per-wave ring ranges
   uint32_t *cnt = smem + 48;       // [R] total per ring, then running fill
@@ -1062,7 +1064,7 @@ extern "C" __global__ __launch_bounds__(FX_BUCKET_T) void k_bucket(FxDevParams P
     // the lanes sort (ring, lane) keys — a bitonic network over the wavefront, 21 exchanges whatever the number of rings —,
     // a ring's points are then neighbours in lane order, and a point's rank is its distance from the ring's first.
     // (Only for wavefronts without a point on a window boundary — such a point is in two rings; those take the ballots.)
-    const bool by_sort = hi - lo > 24 && !__ballot(mask & (mask - 1u));
+    const bool by_sort = MANY && hi - lo > 24 && !__ballot(mask & (mask - 1u));
     if (by_sort) {
       for (int r = lo + (int)lane; r < hi; r += 64) cw[wave * R + r] = 0u;
       const uint32_t d0 = mask ? (uint32_t)__ffs((int)mask) - 1u : 0u;
@@ -1116,6 +1118,15 @@ extern "C" __global__ __launch_bounds__(FX_BUCKET_T) void k_bucket(FxDevParams P
     }
     __syncthreads();
   }
+}
+
+extern "C" __global__ __launch_bounds__(FX_BUCKET_T) void k_bucket(FxDevParams P, FxBuffers B, float el0, float inv_step, uint32_t clk_next) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  bucket_body<false>(P, B, el0, inv_step, clk_next, smem);
+}
+extern "C" __global__ __launch_bounds__(FX_BUCKET_T) void k_bucket_many(FxDevParams P, FxBuffers B, float el0, float inv_step, uint32_t clk_next) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  bucket_body<true>(P, B, el0, inv_step, clk_next, smem);
 }
 
 // ====================================================================== stage 2b: rings
@@ -1345,10 +1356,10 @@ __device__ __forceinline__ bool ring_body(const FxDevParams &P, const FxBuffers 
 // workgroup each.
 #define FX_RR_QUEUE 96
 #ifndef FX_RR_U
-#define FX_RR_U 8  // LDS / L2 reads in flight in the run tier's pair loops
+#define FX_RR_U 4  // LDS / L2 reads in flight in the run tier's pair loops (8 cost 40 registers more: 3 wavefronts a SIMD instead of 4)
 #endif
 #ifndef FX_RR_CACHE
-#define FX_RR_CACHE 170
+#define FX_RR_CACHE 128
 #endif
 #ifndef FX_RR_S
 #define FX_RR_S 128   // first run tier: segments
@@ -1358,7 +1369,7 @@ __device__ __forceinline__ bool ring_body(const FxDevParams &P, const FxBuffers 
 #endif
 template <uint32_t S, uint32_t RN>
 __host__ __device__ constexpr uint32_t rr_words() {
-  return 152 + 4 * RN + FX_RR_QUEUE + (S + 4) + 4 * S + (RN + 1) + 4 * RN + 4 * RN + 3 * FX_RR_CACHE;
+  return 152 + 4 * RN + (S + 4) + 4 * S + (RN + 1) + 4 * RN + 3 * RN + 3 * FX_RR_CACHE;
 }
 template <uint32_t S, uint32_t RN>
 __device__ __forceinline__ bool ring_runs_body(const FxDevParams &P, const FxBuffers &B, uint32_t scan, uint32_t ring, uint32_t max_pts,
@@ -1370,18 +1381,27 @@ __device__ __forceinline__ bool ring_runs_body(const FxDevParams &P, const FxBuf
   uint32_t *s_w = smem;                    // [152]: block helpers, broadcast slots, sort stack / near-pair list
   uint32_t *rbox = smem + 152;             // [RN][min x, max x, min y, max y] run boxes ...
   float4 *cc = reinterpret_cast<float4 *>(rbox);  // ... and, once the edges are in, [CC] cluster boxes, then centroids (16-byte aligned)
-  uint32_t *wq = rbox + 4 * RN;            // [FX_RR_QUEUE] parked (point, run) items
-  uint32_t *seg_tab = wq + FX_RR_QUEUE;    // [S + 1 (+ 3: alignment)] first point of each segment | its run << 16; seg_tab[n_segs] = n
+  uint32_t *seg_tab = rbox + 4 * RN;       // [S + 1 (+ 3: alignment)] first point of each segment | its run << 16; seg_tab[n_segs] = n
   uint32_t *seg_box = seg_tab + S + 4;     // [S][min x, max x, min y, max y] (ordered uints, then float bits)
   uint32_t *rseg = seg_box + 4 * S;        // [RN + 1] first segment of each run; rseg[n_runs] = n_segs
   uint32_t *rparent = rseg + RN + 1;       // [RN] union-find over runs
   uint32_t *rsize = rparent + RN;          // [RN] points of the component (at its root) | position in PCL's order << 16
   uint32_t *roff = rsize + RN;             // [RN] offset of the run's points inside its cluster
   float *rw = reinterpret_cast<float *>(roff + RN);  // [RN] elevation angle of the run's first point
-  uint32_t *croot = roff + 2 * RN, *crec = croot + CC, *ctmp = crec + CC, *cslot = ctmp + CC;
+  // Per cluster: croot[c] = root run of the cluster cc_order numbered c (low half) | slot of the cluster at position c of
+  // PCL's order (high half: the gate's 0 / 1, then the candidate slot, 0xffff = none), crec, ctmp.  The queue of parked
+  // (point, run) items lives in crec until cc_order writes it.  (Every word saved here is occupancy: the kernel waits on
+  // LDS and L2 round trips, and 10.9 KB instead of 12.3 — with 116 registers instead of 156 — is 15 wavefronts a CU for 12.)
+  uint32_t *croot = roff + 2 * RN, *crec = croot + CC, *ctmp = crec + CC;
+  uint32_t *wq = crec;                     // [FX_RR_QUEUE] parked (point, run) items
+  static_assert(FX_RR_QUEUE <= CC, "the queue borrows crec");
+  auto cl_root = [&](uint32_t c) { return croot[c] & 0xffffu; };
+  auto cl_slot = [&](uint32_t s) { return croot[s] >> 16; };
+  auto cl_set_slot = [&](uint32_t s, uint32_t v) { croot[s] = (croot[s] & 0xffffu) | (v << 16); };
+  constexpr uint32_t kNoSlot = 0xffffu;
   // the ring's first NC points (x, y, z): nine rings in ten fit whole, and every later phase then reads LDS only
   constexpr uint32_t NC = FX_RR_CACHE;
-  float *px = reinterpret_cast<float *>(cslot + CC), *py = px + NC, *pz = py + NC;
+  float *px = reinterpret_cast<float *>(ctmp + CC), *py = px + NC, *pz = py + NC;
   auto sst = [&](uint32_t sg) { return seg_tab[sg] & 0xffffu; };
   auto srun = [&](uint32_t sg) { return seg_tab[sg] >> 16; };
   const size_t ring_slot = (size_t)scan * P.n_rings + ring;
@@ -1645,7 +1665,7 @@ __device__ __forceinline__ bool ring_runs_body(const FxDevParams &P, const FxBuf
 #endif
   uint32_t *bb = reinterpret_cast<uint32_t *>(cc);  // [s][min x, max x, min y, max y] until the centroids go there
   for (uint32_t sI = lane; sI < n_c; sI += 64) {
-    const uint32_t root = croot[crec[sI] & 0xffffu];
+    const uint32_t root = cl_root(crec[sI] & 0xffffu);
     rsize[root] |= (sI + 1u) << 16;  // position in PCL's order, next to the size
     bb[4 * sI + 0] = f2ord(1000.0f);  // ref: node.cpp:289-290
     bb[4 * sI + 1] = f2ord(-1000.0f);
@@ -1670,16 +1690,16 @@ __device__ __forceinline__ bool ring_runs_body(const FxDevParams &P, const FxBuf
     const double minx = ord2f(bb[4 * sI + 0]), maxx = ord2f(bb[4 * sI + 1]);
     const double miny = ord2f(bb[4 * sI + 2]), maxy = ord2f(bb[4 * sI + 3]);
     const double ddx = maxx - minx, ddy = maxy - miny;
-    cslot[sI] = (sqrt(ddx * ddx + ddy * ddy) < P.gate_diameter) ? 1u : 0u;
+    cl_set_slot(sI, (sqrt(ddx * ddx + ddy * ddy) < P.gate_diameter) ? 1u : 0u);
   }
   wave_sync_lds();
   FX_STAMP(8);
   // ---- centroid of the clusters that pass: fp64 sums in ascending member order = the cluster's runs in run order,
   //      each run's points in turn (ref: node.cpp:293-297, 317-320)
   for (uint32_t sI = lane; sI < n_c; sI += 64) {
-    if (cslot[sI] == 0u) continue;
+    if (cl_slot(sI) == 0u) continue;
     const uint32_t rec = crec[sI];
-    const uint32_t sz = rec >> 16, root = croot[rec & 0xffffu];
+    const uint32_t sz = rec >> 16, root = cl_root(rec & 0xffffu);
     double sumx = 0.0, sumy = 0.0, sumz = 0.0;
     uint32_t cnt = 0;
     for (uint32_t r = root; r < n_runs && cnt < sz; ++r) {
@@ -1707,13 +1727,13 @@ __device__ __forceinline__ bool ring_runs_body(const FxDevParams &P, const FxBuf
   uint32_t n_pass = 0, n_mem = 0;
   for (uint32_t b0 = 0; b0 < n_c; b0 += 64) {
     const uint32_t sI = b0 + lane;
-    const bool pass = sI < n_c && cslot[sI] != 0u;
+    const bool pass = sI < n_c && cl_slot(sI) != 0u;
     const uint32_t sz = pass ? (crec[sI] >> 16) : 0u;
     uint32_t tot_p, tot_m;
     const uint32_t slot = block_rank<64>(pass, s_w, tot_p);
     const uint32_t koff = block_excl_scan<64>(sz, s_w, tot_m);
     if (sI < n_c) {
-      cslot[sI] = pass ? (n_pass + slot) : FX_NONE;
+      cl_set_slot(sI, pass ? (n_pass + slot) : kNoSlot);
       ctmp[sI] = n_mem + koff;
     }
     n_pass += tot_p;
@@ -1725,8 +1745,8 @@ __device__ __forceinline__ bool ring_runs_body(const FxDevParams &P, const FxBuf
   float4 *rc = B.ring_cand + ring_slot * P.max_ring_cands;
   uint32_t *rcs = B.ring_cand_size + ring_slot * P.max_ring_cands;
   for (uint32_t sI = lane; sI < n_c; sI += 64) {
-    const uint32_t slot = cslot[sI];
-    if (slot < P.max_ring_cands) {
+    const uint32_t slot = cl_slot(sI);
+    if (slot != kNoSlot && slot < P.max_ring_cands) {
       rc[slot] = cc[sI];
       rcs[slot] = crec[sI] >> 16;
     }
@@ -1744,8 +1764,8 @@ __device__ __forceinline__ bool ring_runs_body(const FxDevParams &P, const FxBuf
       const uint32_t r = srun(sg);
       const uint32_t pos = rsize[rparent[r]] >> 16;
       if (pos == 0) return;
-      const uint32_t slot = cslot[pos - 1u];
-      if (slot == FX_NONE) return;
+      const uint32_t slot = cl_slot(pos - 1u);
+      if (slot == kNoSlot) return;
       const uint32_t dst = ctmp[pos - 1u] + roff[r] + (i - sst(rseg[r]));
       pool[dst] = q;
       pool_c[dst] = slot;
@@ -1772,7 +1792,7 @@ __device__ __forceinline__ bool ring_runs_body(const FxDevParams &P, const FxBuf
   return true;
 }
 #ifndef FX_RUNS_OCC
-#define FX_RUNS_OCC 1
+#define FX_RUNS_OCC 4  // wavefronts a SIMD the register budget is held to (128 registers)
 #endif
 extern "C" __global__ __launch_bounds__(64, FX_RUNS_OCC) void k_rings_runs(FxDevParams P, FxBuffers B, uint32_t max_pts, uint32_t n_items) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -4321,7 +4341,10 @@ void fxk_prep(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t 
 void fxk_bucket(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float el0, float inv_step,
                 uint32_t clk_next) {
   const size_t lds = (48 + (size_t)P.n_rings * (2 + FX_BUCKET_NW) + 1) * 4;
-  hipLaunchKernelGGL(k_bucket, dim3(batch), dim3(FX_BUCKET_T), lds, s, P, B, el0, inv_step, clk_next);
+  if (P.n_rings > 24)
+    hipLaunchKernelGGL(k_bucket_many, dim3(batch), dim3(FX_BUCKET_T), lds, s, P, B, el0, inv_step, clk_next);
+  else
+    hipLaunchKernelGGL(k_bucket, dim3(batch), dim3(FX_BUCKET_T), lds, s, P, B, el0, inv_step, clk_next);
 }
 size_t fxk_ring_runs_lds_bytes(void) { return (size_t)rr_words<FX_RR_S, FX_RR_RN>() * 4; }
 void fxk_rings_runs2(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t max_pts, uint32_t grid) {

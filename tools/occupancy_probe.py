@@ -1,0 +1,13 @@
+import ctypes as C, sys, os
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+from feature_extraction_amd import capi
+lib = capi.load()
+hip = C.CDLL("libamdhip64.so")
+fn = C.cast(getattr(lib, "k_rings_runs"), C.c_void_p)
+n = C.c_int()
+prev = None
+for lds in range(6 * 1024, 16 * 1024 + 1, 128):
+    r = hip.hipOccupancyMaxActiveBlocksPerMultiprocessor(C.byref(n), fn, 64, C.c_size_t(lds))
+    if n.value != prev:
+        print("lds", lds, "-> blocks/CU", n.value, "rc", r)
+        prev = n.value
