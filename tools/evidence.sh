@@ -18,8 +18,8 @@ feature_extraction_amd/bin/fx_multi_cli --batch 1024 --steps 20 --inflight 4 --h
 feature_extraction_amd/bin/fx_batcher_cli --sensors 4 --hz 10 --seconds 3 --out /tmp/batcher_a.bin > "$E/batcher.log" 2>&1
 feature_extraction_amd/bin/fx_batcher_cli --sensors 8 --burst 32 --out /tmp/batcher_b.bin >> "$E/batcher.log" 2>&1
 : > "$E/streaming_latency.jsonl"
-for b in 1 8 16 64; do python3 tools/latency.py $b 200 launch 1 2>/dev/null | tail -1 >> "$E/streaming_latency.jsonl"; done
-python3 tools/latency.py 1 200 launch 0 2>/dev/null | tail -1 >> "$E/streaming_latency.jsonl"
+for b in 1 8 16 64; do python3 tools/latency.py $b 200 launch 1 2>/dev/null | tail -2 >> "$E/streaming_latency.jsonl"; done
+python3 tools/latency.py 1 200 launch 0 2>/dev/null | tail -2 >> "$E/streaming_latency.jsonl"
 bash tools/profile.sh $TAG > "$E/profile.log" 2>&1
 bash tools/profile.sh ${TAG}_c1 --contexts 1 > "$E/profile_c1.log" 2>&1
 FX_PROFILE_PMC=1 bash tools/profile_config.sh $TAG 3 > "$E/profile_cfg3.log" 2>&1
