@@ -410,11 +410,11 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   P.max_ring_points = L.max_ring_points;
   P.list_cap = L.max_neighbors < kListCap ? L.max_neighbors : kListCap;
   P.near_words = fxk_near_words(L.max_points);
-  // dense tier pools (fx_limits.max_dense_points; default: as many entries as the batch has points)
+  // dense tier pools (fx_limits.max_dense_points; default: as many entries as the batch has points, at least 32 scans' worth)
   P.dense_min = kDenseMin;
   P.ovf_cap = L.max_points;
   {
-    const unsigned long long want = L.max_dense_points ? L.max_dense_points : (unsigned long long)L.max_batch * L.max_points;
+    const unsigned long long want = L.max_dense_points ? L.max_dense_points : (unsigned long long)(L.max_batch > 32u ? L.max_batch : 32u) * L.max_points;
     P.dense_cap = (uint32_t)(want > 0xfff00000ull ? 0xfff00000ull : (want < 4096ull ? 4096ull : want));  // (a row takes its support points + 700 entries of it)
     const uint32_t per_row = P.list_cap < P.dense_min ? P.list_cap : P.dense_min;  // a dense row has more support points than this
     const unsigned long long rows = (unsigned long long)P.dense_cap / (per_row ? per_row : 1u) + 1ull;

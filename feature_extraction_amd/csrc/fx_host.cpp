@@ -81,8 +81,10 @@ void fx_limits_default(fx_limits *l, uint32_t max_batch, uint32_t max_points) {
   l->max_neighbors = max_points > 65536u ? 4096u : 1024u;
   l->max_total_keypoints = max_batch * 64u;
   l->max_kpc_points = 4096;
-  // dense tier pools: as many entries as the batch has points (16 + 4 + 8 bytes each)
-  const unsigned long long dp = (unsigned long long)max_batch * max_points;
+  // dense tier pools: as many entries as the batch has points (16 + 4 + 8 bytes each) — a batch averages its scans — but
+  // never fewer than 32 scans' worth: a context for one scan at a time must hold a scan whose keypoints' support sets
+  // overlap many times over (hundreds of keypoints, descriptor radius beyond a metre: the differential fuzz finds them)
+  const unsigned long long dp = (unsigned long long)(max_batch > 32u ? max_batch : 32u) * max_points;
   l->max_dense_points = dp > 0xfff00000ull ? 0xfff00000u : (uint32_t)dp;
 }
 

@@ -91,7 +91,7 @@ typedef struct fx_limits {
   uint32_t max_total_keypoints; /* keypoints per batch (descriptor pool) (def max_batch*64) */
   uint32_t max_kpc_points;      /* keypoint_cloud points per scan        (def 4096) */
   uint32_t max_dense_points;    /* support points per batch the dense descriptor tier sorts (rows of more than 1024
-                                 * support points; def max_batch*max_points; 28 B each).  New in 0.4 */
+                                 * support points; def max(max_batch, 32)*max_points; 28 B each).  New in 0.4 */
 } fx_limits;
 
 /* One scan = what cloudCallback receives after fromPCLPointCloud2

@@ -71,6 +71,7 @@ def test_limits_defaults(fxlib):
             l.max_neighbors, l.max_total_keypoints, l.max_kpc_points, l.max_dense_points) == (
                 1024, 28800, 2048, 256, 2048, 256, 1024, 65536, 4096, 1024 * 28800)
     assert capi.limits(64, 128 * 2048).max_neighbors == 4096  # dense many-ring scans: longer support lists
+    assert capi.limits(1, 28800).max_dense_points == 32 * 28800  # a one-scan context still holds a scan of overlapping support sets
 
 
 def test_shard_plan_is_a_partition():
