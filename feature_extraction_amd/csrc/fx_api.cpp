@@ -412,7 +412,13 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   P.near_words = fxk_near_words(L.max_points);
   // dense tier pools (fx_limits.max_dense_points; default: as many entries as the batch has points, at least 32 scans' worth)
   P.dense_min = kDenseMin;
-  P.ovf_cap = L.max_points;
+  // a scan's overflow region: one entry per point of the scan — in contexts of fewer than 32 scans as many more as keep
+  // the regions at 32 scans' worth together (a single scan whose rows overflow their lists many times over has no batch
+  // to average with: descriptor radii of 2–3 m on the differential fuzz's scenes need up to three entries per point)
+  {
+    const unsigned long long per = (unsigned long long)L.max_points * (L.max_batch >= 32u ? 1u : 32u / (L.max_batch ? L.max_batch : 1u));
+    P.ovf_cap = (uint32_t)(per > 0x7ff00000ull ? 0x7ff00000ull : per);
+  }
   {
     const unsigned long long want = L.max_dense_points ? L.max_dense_points : (unsigned long long)(L.max_batch > 32u ? L.max_batch : 32u) * L.max_points;
     P.dense_cap = (uint32_t)(want > 0xfff00000ull ? 0xfff00000ull : (want < 4096ull ? 4096ull : want));  // (a row takes its support points + 700 entries of it)
@@ -515,8 +521,8 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   FX_A(dev_alloc(c, &b.dense_key, P.dense_cap));
   FX_A(dev_alloc(c, &b.dens_cache, B * L.max_points));
   FX_A(dev_alloc(c, &b.seq, 1));
-  FX_A(dev_alloc(c, &b.ovf_pts, B * P.ovf_cap));
-  FX_A(dev_alloc(c, &b.ovf_kp, B * P.ovf_cap));
+  FX_A(dev_alloc(c, &b.ovf_pts, (size_t)B * P.ovf_cap));
+  FX_A(dev_alloc(c, &b.ovf_kp, (size_t)B * P.ovf_cap));
   FX_A(dev_alloc(c, &b.ovf_cnt, B));
   if (hipMemset(b.dens_cache, 0, B * L.max_points * sizeof(unsigned long long)) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
   if (hipMemset(b.seq, 0, sizeof(unsigned long long)) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
