@@ -1,6 +1,6 @@
 """Diagnostic: differential fuzz on dense many-ring sensors (32 / 64 rings, 512-1024 azimuths): random scenes x random node
 parameters against the oracle.  These scans exercise what the VLP-16 fuzz does not: the second run tier, the workgroup ring
-tier, the large merge tier, the long-list, whole-CU and slab descriptor tiers.
+tier, the large merge tier, the list and dense descriptor tiers.
   python tools/fuzz_dense.py FIRST LAST [N_AZ [RINGS]]      (e.g. 2048 128: BASELINE config 5's shape, seconds per case)"""
 import os
 import sys
@@ -43,6 +43,6 @@ for seed in range(lo, hi):
         bad += 1
         print("MISMATCH", seed, str(e)[:300], dict(R=R, n_az=n_az, over=over))
 print(f"dense seeds {lo}..{hi}: {bad} mismatches, {flagged} flagged, {total_k} keypoints, {time.time() - t0:.0f} s")
-names = ["second run tier", "big merge", "re-gather", "-", "list rows", "workgroup ring tier", "whole-CU rows", "exact-angle rows", "wave rows", "huge merge",
-         "-", "-", "slab rows"]
+names = ["second run tier", "big merge", "-", "-", "list rows", "workgroup ring tier", "dense rows", "-", "wave rows", "huge merge",
+         "-", "-", "dense rows sorted in global memory"]
 print("cases that used: " + ", ".join(f"{n} {int(c)}" for n, c in zip(names, tiers) if n != "-"))
