@@ -933,7 +933,7 @@ fx_status fx_test_elevation_device(int device, const float *xyz, uint32_t n, flo
   FX_HIP(hipSetDevice(device));
   const std::vector<double> at = atan_table();
   char *d = nullptr;
-  const size_t o_tab = (size_t)n * 12, o_fast = o_tab + at.size() * 8, o_exact = o_fast + (size_t)n * 4, o_ok = o_exact + (size_t)n * 4;
+  const size_t o_tab = ((size_t)n * 12 + 7) & ~(size_t)7, o_fast = o_tab + at.size() * 8, o_exact = o_fast + (size_t)n * 4, o_ok = o_exact + (size_t)n * 4;
   FX_HIP(hipMalloc((void **)&d, o_ok + n));
   hipError_t e = hipMemcpy(d, xyz, (size_t)n * 12, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(d + o_tab, at.data(), at.size() * 8, hipMemcpyHostToDevice);
