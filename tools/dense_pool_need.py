@@ -1,6 +1,6 @@
 """Diagnostic: how many dense-tier pool entries the VLP-16 fuzz scenes need (sizing of the default max_dense_points)."""
 import os, sys, ctypes as C
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from feature_extraction_amd import capi
 from tests.test_gpu_fuzz import _case

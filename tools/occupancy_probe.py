@@ -1,5 +1,7 @@
+"""Diagnostic: workgroups of k_rings_runs a CU holds as a function of its dynamic LDS (hipOccupancyMaxActiveBlocksPerMultiprocessor):
+how LDS allocation is granulated on this device.  Run on the GPU box."""
 import ctypes as C, sys, os
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from feature_extraction_amd import capi
 lib = capi.load()
 hip = C.CDLL("libamdhip64.so")
