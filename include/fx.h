@@ -128,7 +128,9 @@ typedef struct fx_batch_view {
   const uint32_t *d_n_keypoints; /* [B] */
   const uint32_t *d_kp_offset;   /* [B+1] exclusive prefix of n_keypoints */
   const float *d_keypoints;      /* [B][max_keypoints][4] */
-  const float *d_descriptors;    /* [max_total_keypoints][1989] */
+  const float *d_descriptors;    /* [max_total_keypoints][1989]; rows [0, total_keypoints) are this batch's.  READ-ONLY: a row
+                                  * keeps its content until a later batch uses it and is then cleared by un-writing what was
+                                  * written to it — writing into this buffer corrupts later batches */
   const uint32_t *d_flags;       /* [B] FX_FLAG_* */
   const uint32_t *d_n_filtered;  /* [B] */
   const float *d_filtered;       /* [B][max_points][4] */
