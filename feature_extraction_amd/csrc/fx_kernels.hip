@@ -2776,7 +2776,6 @@ __device__ __forceinline__ void desc_wave_body(const FxDevParams &P, const FxBuf
     const uint32_t row = B.wave_desc[it];
     const uint2 rm = B.row_map[row];
     const uint32_t scan = rm.x, k = rm.y;
-    const uint32_t ord = k;
     // everything the row needs is fetched in one round trip: the list entries are loaded before the
     // list length is known (slots past the length hold stale data and are ignored)
     const uint32_t nS = B.s_cnt[row];
