@@ -2916,6 +2916,9 @@ extern "C" __global__ __launch_bounds__(FX_WG, FX_GROUP_OCC) void k_desc_group(F
     float4 kp = make_float4(0, 0, 0, 0);
     float2 xa = make_float2(1.f, 0.f);
     float4 lv[FX_GROUP_CAP / FX_GLANES];
+    uint32_t nb_prev = 0;
+    uint2 pb = make_uint2(0u, 0u);
+    static_assert(FX_GROUP_CAP == 4 * FX_GLANES, "a lane fetches four slots of the row's bin list");
     if (live) {
       const uint2 rm = B.row_map[row];
       nS = B.s_cnt[row];
@@ -2925,6 +2928,10 @@ extern "C" __global__ __launch_bounds__(FX_WG, FX_GROUP_OCC) void k_desc_group(F
       for (uint32_t u = 0; u < FX_GROUP_CAP / FX_GLANES; ++u)
         if (gl + u * FX_GLANES < P.list_cap) lv[u] = B.s_pts[(size_t)row * P.list_cap + gl + u * FX_GLANES];
       scan = rm.x, k = rm.y;
+      // (what the row holds from last time, fetched in the same round trip: its bin count and all 64 slots of its bin list —
+      //  four per lane, the unused ones ignored — instead of the count first and then that many bins)
+      nb_prev = B.desc_nbins[row];
+      pb = *reinterpret_cast<const uint2 *>(B.desc_bins + (size_t)row * FX_GROUP_CAP + 4u * gl);
     }
     float *out = B.desc + (size_t)row * FX_DESC_FLOATS;
     // Every descriptor row is cleared here, whichever tier ends up computing it (the keypoint kernels write
@@ -2935,11 +2942,14 @@ extern "C" __global__ __launch_bounds__(FX_WG, FX_GROUP_OCC) void k_desc_group(F
     // kernels — k_prep ran 0.17 ms behind a batch's row clears and 0.13 ms without.)
     uint16_t *my_bins = B.desc_bins + (size_t)row * FX_GROUP_CAP;
     if (live) {
-      const uint32_t nb = B.desc_nbins[row];
-      if (nb > FX_GROUP_CAP) {
+      if (nb_prev > FX_GROUP_CAP) {
         desc_zero_row(out, gl, FX_GLANES);
       } else {
-        for (uint32_t t = gl; t < nb; t += FX_GLANES) out[my_bins[t]] = 0.0f;
+        const uint32_t t0 = 4u * gl;
+        if (t0 + 0u < nb_prev) out[pb.x & 0xffffu] = 0.0f;
+        if (t0 + 1u < nb_prev) out[pb.x >> 16] = 0.0f;
+        if (t0 + 2u < nb_prev) out[pb.y & 0xffffu] = 0.0f;
+        if (t0 + 3u < nb_prev) out[pb.y >> 16] = 0.0f;
       }
     }
     // too long for a group: wavefront rows (<= 256 support points), list rows (<= dense_min), and the dense tier beyond
