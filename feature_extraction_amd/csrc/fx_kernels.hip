@@ -2428,15 +2428,18 @@ __device__ __forceinline__ unsigned long long sc3d_key(uint32_t bin, float d2, u
 #define FX_GATHER_DIRECT 1   // one workgroup per scan: hits go straight to their list slots (positions are LDS counters)
 #endif
 #ifndef FX_GATHER_QUEUE
-#define FX_GATHER_QUEUE 80   // points one wavefront parks before it drains them (drained once more than 16 are waiting)
+#define FX_GATHER_QUEUE 128  // points one wavefront of k_gather parks before it drains them (drained once more than 64 are waiting:
+                             // measured 72 .. 192 — 96 to 160 are level, 1.2 % above 80; k_gather_wide keeps 80: sixteen queues)
 #endif
+#define FX_GATHER_QUEUE_WIDE 80
+__host__ __device__ constexpr uint32_t gather_queue(uint32_t nt) { return nt <= 256u ? (uint32_t)FX_GATHER_QUEUE : (uint32_t)FX_GATHER_QUEUE_WIDE; }
 __host__ __device__ inline uint32_t gather_words(uint32_t mk, uint32_t nt) {
   uint32_t w = 32 + 4 * mk;                                   // scratch, keypoints
   w += FX_GATHER_CELLS + 4;                                   // cell table (the fill cursors borrow the staging area)
   w += ((9 * mk + 1) / 2 + 3) & ~3u;                          // cell lists (uint16)
   w += (5 * mk + 3) & ~3u;                                    // staged hits per keypoint, reserved list positions, list lengths, has-a-neighbour flags, overflow slots
   w += FX_GATHER_STAGE + 4 * FX_GATHER_STAGE;                 // staged hits: meta, points
-  w += (nt / 64) * FX_GATHER_QUEUE * 5;                       // per-wavefront queues: points, cell info
+  w += (nt / 64) * gather_queue(nt) * 5;                      // per-wavefront queues: points, cell info
   return w;
 }
 template <int NT>
@@ -2459,8 +2462,9 @@ __device__ __forceinline__ void gather_body(const FxDevParams &P, const FxBuffer
   float4 *s_spt = reinterpret_cast<float4 *>(s_smeta + FX_GATHER_STAGE);
   uint32_t *s_cur = reinterpret_cast<uint32_t *>(s_spt);        // [CELLS] fill cursors while the lists are built (4 STAGE >= CELLS words)
   const uint32_t scan = blockIdx.y, slice = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float4 *q_pt = s_spt + FX_GATHER_STAGE + wave * FX_GATHER_QUEUE;                                         // this wavefront's queue
-  uint32_t *q_info = reinterpret_cast<uint32_t *>(s_spt + FX_GATHER_STAGE + FX_GATHER_NW * FX_GATHER_QUEUE) + wave * FX_GATHER_QUEUE;
+  constexpr uint32_t kQueue = gather_queue(NT);
+  float4 *q_pt = s_spt + FX_GATHER_STAGE + wave * kQueue;                                                  // this wavefront's queue
+  uint32_t *q_info = reinterpret_cast<uint32_t *>(s_spt + FX_GATHER_STAGE + FX_GATHER_NW * kQueue) + wave * kQueue;
   uint32_t K = B.n_kp[scan];
   if (K == 0) return;
   const uint32_t row0 = B.kp_offset[scan];
@@ -2689,7 +2693,7 @@ __device__ __forceinline__ void gather_body(const FxDevParams &P, const FxBuffer
           q_info[slot] = info;
         }
         qn += (uint32_t)__popcll(m);
-        if (qn > FX_GATHER_QUEUE - 64) drain();
+        if (qn > kQueue - 64) drain();
       }
     }
     nib = nnib;
