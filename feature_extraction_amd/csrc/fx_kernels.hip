@@ -986,7 +986,9 @@ __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, 
 // filtered cloud.  Here one workgroup per scan deals the filtered points to their rings in
 // one stable pass (a point on a window boundary belongs to both rings, A.3), so the ring
 // workgroups read exactly their own points, already in ring order.
+#ifndef FX_BUCKET_T
 #define FX_BUCKET_T 512
+#endif
 #define FX_BUCKET_NW (FX_BUCKET_T / 64)
 // MANY: sensors of more than 24 rings (the sort-based ranking below is compiled only into that instance)
 template <bool MANY>
