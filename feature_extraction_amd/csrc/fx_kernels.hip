@@ -2286,7 +2286,7 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_offsets(FxDevParams P, FxB
 //                   keypoint's support list (a superset of the neighbour query and of every density query);
 //                   (the rows themselves are cleared by k_desc_group, which sees every row once)
 //   k_desc_group    4 keypoints per wavefront: support sets of <= 64 points (the bulk)
-//   k_desc_mid      one launch: one wavefront per keypoint (65..256 support points) and one 256-thread
+//   k_desc_mid      one launch: one wavefront per keypoint (65..192 support points: FX_WAVE_CAP) and one 256-thread
 //                   workgroup per keypoint (lists of up to 1024 entries)
 //                   -- all three: bins + density + weight per neighbour, sort by (bin, d2, index) ==
 //                      PCL's accumulation order, sequential fp32 sum per bin; angles in fp32, exact next to a bin edge --
@@ -2731,7 +2731,9 @@ extern "C" __global__ __launch_bounds__(FX_GATHER_WIDE_T) void k_gather_wide(FxD
 }
 
 // ---------------------------------------------------------------- wavefront tier (runs inside k_desc_mid)
-#define FX_WAVE_CAP 256
+#ifndef FX_WAVE_CAP
+#define FX_WAVE_CAP 192  // support points a wave row holds (multiples of 64; measured 128 / 192 / 256 / 320: k_desc_mid 0.118 / 0.099 / 0.119 / 0.153 ms)
+#endif
 #define FX_WAVE_WORDS (FX_WAVE_CAP * 8)
 // Clears one descriptor row (1989 floats, 4-byte aligned) with `stride` lanes: 16-byte stores over its aligned body.
 __device__ __forceinline__ void desc_zero_row(float *out, uint32_t lane, uint32_t stride) {
@@ -2756,7 +2758,7 @@ __device__ __forceinline__ const FxScTables *tables_to_lds(const FxBuffers &B, u
   return reinterpret_cast<const FxScTables *>(dst);
 }
 
-// One wavefront per keypoint, for the rows in B.wave_desc (support sets of 65..256 points).
+// One wavefront per keypoint, for the rows in B.wave_desc (support sets of 65..FX_WAVE_CAP = 192 points).
 // Angles in fp32; a keypoint with any neighbour whose angle lies within FX_FAST_EPS_DEG of a bin
 // edge is evaluated exactly in place (sc3d_bin), so
 // the result is the exact one either way.
@@ -2958,7 +2960,7 @@ extern "C" __global__ __launch_bounds__(FX_WG, FX_GROUP_OCC) void k_desc_group(F
         if (t0 + 3u < nb_prev) out[pb.y >> 16] = 0.0f;
       }
     }
-    // too long for a group: wavefront rows (<= 256 support points), list rows (<= dense_min), and the dense tier beyond
+    // too long for a group: wavefront rows (<= FX_WAVE_CAP support points), list rows (<= dense_min), and the dense tier beyond
     // that — also every row whose list overflowed its list_cap slots (the rest of it sits in the scan's overflow region)
     const bool too_long = live && (nS > FX_GROUP_CAP || nS > P.list_cap);
     uint32_t dense_fail = 0;
@@ -3386,7 +3388,7 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
   return true;
 }
 
-// List rows (257 .. cap support points): one keypoint per workgroup at a time, from k_gather's list, fp32 angles
+// List rows (FX_WAVE_CAP + 1 .. cap support points): one keypoint per workgroup at a time, from k_gather's list, fp32 angles
 // (exact in place next to a bin edge).
 template <bool FAST, int NT>
 __device__ __forceinline__ void desc_wg_loop(const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap,
@@ -3404,8 +3406,8 @@ __device__ __forceinline__ void desc_wg_loop(const FxDevParams &P, const FxBuffe
 // The fp32 pass runs 256-thread workgroups, four keypoints per CU at a time (most phases of a keypoint are
 // latency chains that leave lanes idle, so concurrency beats width).
 #define FX_DESC_WG_FAST_T 256
-// Both middle tiers in one launch: the first n_wg workgroups take list rows (257..cap support points, one keypoint per
-// workgroup at a time), the others take wave rows (65..256, one keypoint per wavefront).  Neither tier fills the chip
+// Both middle tiers in one launch: the first n_wg workgroups take list rows (193..cap support points, one keypoint per
+// workgroup at a time), the others take wave rows (65..192, one keypoint per wavefront).  Neither tier fills the chip
 // alone (1600 and 900 of the 8192 wave slots on the VLP-16 bench) and neither depends on the other: one after the
 // other they cost 0.135 + 0.075 ms, together about the longer of the two.
 extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_mid(FxDevParams P, FxBuffers B, uint32_t batch, uint32_t cap,
