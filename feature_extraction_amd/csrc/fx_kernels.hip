@@ -1361,7 +1361,7 @@ __device__ __forceinline__ bool ring_body(const FxDevParams &P, const FxBuffers 
 #define FX_RR_U 4  // LDS / L2 reads in flight in the run tier's pair loops (8 cost 40 registers more: 3 wavefronts a SIMD instead of 4)
 #endif
 #ifndef FX_RR_CACHE
-#define FX_RR_CACHE 128
+#define FX_RR_CACHE 64  // the ring's first points kept in LDS (64 / 96 / 128 / 160 measured: 64 makes it 16 wavefronts a CU — 0.123 ms for 0.130)
 #endif
 #ifndef FX_RR_S
 #define FX_RR_S 128   // first run tier: segments
@@ -1393,7 +1393,7 @@ __device__ __forceinline__ bool ring_runs_body(const FxDevParams &P, const FxBuf
   // Per cluster: croot[c] = root run of the cluster cc_order numbered c (low half) | slot of the cluster at position c of
   // PCL's order (high half: the gate's 0 / 1, then the candidate slot, 0xffff = none), crec, ctmp.  The queue of parked
   // (point, run) items lives in crec until cc_order writes it.  (Every word saved here is occupancy: the kernel waits on
-  // LDS and L2 round trips, and 10.9 KB instead of 12.3 — with 116 registers instead of 156 — is 15 wavefronts a CU for 12.)
+  // LDS and L2 round trips, and 10.1 KB instead of 12.3 — with 119 registers instead of 156 — is 16 wavefronts a CU for 12.)
   uint32_t *croot = roff + 2 * RN, *crec = croot + CC, *ctmp = crec + CC;
   uint32_t *wq = crec;                     // [FX_RR_QUEUE] parked (point, run) items
   static_assert(FX_RR_QUEUE <= CC, "the queue borrows crec");
@@ -1401,7 +1401,8 @@ __device__ __forceinline__ bool ring_runs_body(const FxDevParams &P, const FxBuf
   auto cl_slot = [&](uint32_t s) { return croot[s] >> 16; };
   auto cl_set_slot = [&](uint32_t s, uint32_t v) { croot[s] = (croot[s] & 0xffffu) | (v << 16); };
   constexpr uint32_t kNoSlot = 0xffffu;
-  // the ring's first NC points (x, y, z): nine rings in ten fit whole, and every later phase then reads LDS only
+  // the ring's first NC points (x, y, z): later phases read those from LDS, the rest from L2 (more wavefronts a CU are worth
+  // more than a longer cache: FX_RR_CACHE)
   constexpr uint32_t NC = FX_RR_CACHE;
   float *px = reinterpret_cast<float *>(ctmp + CC), *py = px + NC, *pz = py + NC;
   auto sst = [&](uint32_t sg) { return seg_tab[sg] & 0xffffu; };
