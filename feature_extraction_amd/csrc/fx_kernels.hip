@@ -2888,9 +2888,13 @@ __device__ __forceinline__ void desc_wave_body(const FxDevParams &P, const FxBuf
 // Here a wavefront works on FX_GROUPS keypoints at once, FX_GLANES lanes each (fp32 angles, same
 // exactness contract as the wavefront tier).  Rows with more than FX_GROUP_CAP support points go to the
 // wave list, rows with an angle near a bin edge to the exact list.
+#ifndef FX_GLANES
 #define FX_GLANES 16
+#endif
 #define FX_GROUPS (64 / FX_GLANES)
+#ifndef FX_GROUP_CAP
 #define FX_GROUP_CAP 64
+#endif
 #define FX_GROUP_WORDS (FX_GROUP_CAP * 8 + 8)  // per group: support float4, keys, weights, indices + 8 counters
 #ifndef FX_GROUP_UNROLL
 #define FX_GROUP_UNROLL 8
