@@ -6,11 +6,14 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libfx_hip.so")
+# the same sources with -DFX_TEST_HOOKS: the environment hooks tests (and A/B measurements) use to push work through the
+# rarely used tiers and kernels — the product library has none of them compiled in
+LIB_TEST = os.path.join(HERE, "lib", "libfx_hip_test.so")
 SOURCES = ["fx_kernels.hip", "fx_api.cpp", "fx_host.cpp"]
 HEADERS = ["fx_device.h", "fx_sort_replay.h", os.path.join("..", "..", "include", "fx.h")]
 # -ffp-contract=off: the numerics contract forbids FMA contraction (results must follow
 # PCL/FLANN/Eigen operation order); fp32 divide/sqrt stay at hipcc's correctly rounded default.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-Wl,-Bsymbolic"]
 
 
 def hipcc():
@@ -20,12 +23,35 @@ def hipcc():
     raise RuntimeError("hipcc not found (need ROCm; the hot path has no non-HIP build)")
 
 
-def stale():
-    if not os.path.exists(LIB):
+def stale(lib=None):
+    lib = lib or LIB
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _link(lib, extra, verbose):
+    """Compile to a temporary name and rename into place: a process that polls for the library (the other ranks of a
+    multi-GPU bench wait for local rank 0's build) never maps a half-written file."""
+    os.makedirs(os.path.dirname(lib), exist_ok=True)
+    tmp = f"{lib}.{os.getpid()}.tmp"
+    cmd = [hipcc()] + FLAGS + extra + ["-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, lib)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+
+
+def build_test_hooks(force=False, verbose=False):
+    if force or stale(LIB_TEST):
+        _link(LIB_TEST, ["-DFX_TEST_HOOKS"], verbose)
+    return LIB_TEST
 
 
 CLI = os.path.join(HERE, "bin", "fx_cli")
@@ -115,11 +141,8 @@ def build_ros_mock(force=False, verbose=False):
 
 def build(force=False, verbose=False):
     if force or stale():
-        os.makedirs(os.path.dirname(LIB), exist_ok=True)
-        cmd = [hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+        _link(LIB, [], verbose)
+    build_test_hooks(force, verbose)
     build_cli(force, verbose)
     build_batcher(force, verbose)
     try:  # the multi-GPU driver needs RCCL's development files: without them the library and everything else still build

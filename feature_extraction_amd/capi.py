@@ -18,6 +18,7 @@ FX_FEATURE_RECORD_BYTES = 7984
 FX_OK = 0
 FX_ERR_NO_DEVICE = 2
 FX_IN_DEVICE, FX_OUT_HOST, FX_OUT_DEBUG, FX_OUT_CLOUDS = 1, 2, 4, 8
+FX_FLAG_RING_OVERFLOW, FX_FLAG_CAND_OVERFLOW, FX_FLAG_KP_OVERFLOW, FX_FLAG_NBR_OVERFLOW = 0x1, 0x2, 0x4, 0x8
 FX_FLAG_NAMES = {0x1: "RING_OVERFLOW", 0x2: "CAND_OVERFLOW", 0x4: "KP_OVERFLOW", 0x8: "NBR_OVERFLOW",
                  0x10: "TOTAL_KP_OVERFLOW", 0x20: "KPC_OVERFLOW"}
 FX_N_STAGES = 9
@@ -106,12 +107,35 @@ EXPORTS = ("fx_version", "fx_status_str", "fx_last_error", "fx_params_default", 
            "fx_pack_pointxyzi")
 
 _lib = None
+_libs = {}
+# lib/libfx_hip_test.so: the same sources compiled with -DFX_TEST_HOOKS (environment hooks that push work through the rarely
+# used tiers and kernels: FX_FRONT, FX_FRONT_FORCE, FX_MERGE_BIG_CAP, ...).  The product library has none of them.
+TEST_LIB_PATH = os.path.join(_HERE, "lib", "libfx_hip_test.so")
+
+
+class test_hooks:
+    """Context manager: inside it load() (and so Context, params, ...) uses the test build of the library."""
+
+    def __enter__(self):
+        global _lib, LIB_PATH
+        self._saved = (_lib, LIB_PATH)
+        LIB_PATH = TEST_LIB_PATH
+        _lib = _libs.get(LIB_PATH)
+        return load()
+
+    def __exit__(self, *exc):
+        global _lib, LIB_PATH
+        _lib, LIB_PATH = self._saved
+        return False
 
 
 def load():
     """Load libfx_hip.so; raises (never falls back) if it is not built."""
     global _lib
     if _lib is not None:
+        return _lib
+    if LIB_PATH in _libs:
+        _lib = _libs[LIB_PATH]
         return _lib
     try:
         # When torch is going to be used in the same process (tests, bench.py) it must be imported
@@ -172,6 +196,7 @@ def load():
     lib.fx_test_sort_replay_device.argtypes = [C.c_int, _U32P, C.c_uint32, C.c_uint32, _U32P]
     lib.fx_test_elevation_device.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = lib
+    _libs[LIB_PATH] = lib
     return lib
 
 

@@ -6,6 +6,7 @@
 // it also copies the results back and synchronises.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -38,7 +39,16 @@ void fxk_rings_runs(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uin
 void fxk_merge_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap);
 void fxk_merge_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t grid, uint32_t last);
 void fxk_merge_huge(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t ccap, uint32_t grid);
-void fxk_offsets(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
+void fxk_offsets(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t clk_next);
+uint32_t fxk_front_max_rings(void);
+uint32_t fxk_front_merge_cap(void);
+void fxk_front(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float near_margin, float el0, float inv_step,
+               uint32_t clk_slot, uint32_t merge_cap, uint32_t force_redo);
+void fxk_front_redo(hipStream_t s, const FxDevParams &P, const FxBuffers &B, float el0, float inv_step, uint32_t huge_ccap, uint32_t tail_follows,
+                    uint32_t force_tail, uint32_t grid);
+void fxk_tail(hipStream_t s, const FxDevParams &P, const FxBuffers &B, float el0, float inv_step, uint32_t ring_cap, uint32_t merge_cap,
+              uint32_t huge_ccap, uint32_t grid);
+hipError_t fxk_configure_front(const FxDevParams &P, uint32_t ring_cap, uint32_t merge_cap, uint32_t huge_ccap);
 uint32_t fxk_gather_slices(uint32_t batch);
 void fxk_gather(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float box_margin);
 void fxk_desc_group(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid);
@@ -71,6 +81,17 @@ fx_status fail(fx_status s, const std::string &msg) {
   } while (0)
 
 constexpr int kMetaSlots = 8;
+// Test and experiment hooks read the environment only in the TEST build of the library (lib/libfx_hip_test.so, compiled
+// with -DFX_TEST_HOOKS: feature_extraction_amd/build.py); the product library never changes tiers, grids or kernels because
+// of the caller's environment.
+inline const char *test_hook(const char *name) {
+#ifdef FX_TEST_HOOKS
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
 constexpr uint32_t kMergeCapSmall = 512, kListCap = 4096, kDenseMin = 1024;
 }  // namespace
 
@@ -96,7 +117,7 @@ struct fx_ctx {
   uint32_t merge_huge_ccap = 0;  // clusters the large merge tier can order (>= max_keypoints)
   // host-input staging
   float *d_stage = nullptr;
-  std::vector<float> repack;
+  uint32_t stage_stride = 0;  // record stride the staging buffer is sized for
   // pinned host mirrors (lazy)
   uint32_t *h_n_kp = nullptr, *h_kp_offset = nullptr, *h_flags = nullptr, *h_n_filt = nullptr, *h_n_kpc = nullptr,
            *h_n_cand = nullptr, *h_cand_size = nullptr, *h_kpc_cand = nullptr, *h_kp_size = nullptr,
@@ -122,6 +143,14 @@ struct fx_ctx {
   // the previous batch's work for the rarely used tiers (pinned; written by the device: FxBuffers::tier_hint)
   volatile uint32_t *tier_hint = nullptr;
   uint32_t tier_min_grid = 8;  // FX_TIER_MIN_GRID: workgroups those tiers get at least (0: always the full grids)
+  // The fused front kernel (k_front: filter to keypoints in one launch, for scans whose filtered cloud fits LDS) with
+  // k_tail behind it.  A batch that hands more than an eighth of its scans to k_tail sends the next front_retry batches
+  // through the separate kernels (k_prep ... k_merge_*), which are the fast way for large scans.
+  bool front_ok = false;       // sensor within k_front's ring capacity
+  bool front_last = false;     // what the last batch ran
+  uint32_t front_force = 0;    // test hook (FX_FRONT_FORCE)
+  uint32_t front_pause = 0;    // batches left on the separate kernels
+  static constexpr uint32_t front_retry = 64;
 };
 
 namespace {
@@ -175,7 +204,7 @@ std::vector<double> atan_table() {
 
 // Enqueues the stage kernels of one batch on stream s (the whole device-side pipeline between the
 // scan-table upload and the result copies).  Also what a HIP graph of the batch is captured from.
-fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof, bool capture = false) {
+fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof, bool front, bool capture = false) {
   const fx_limits &L = c->lim;
   const FxDevParams &P = c->dp;
   const FxBuffers &B = c->buf;
@@ -214,11 +243,25 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof, bo
   if (batch) {
     const uint32_t merge_small = L.max_candidates < kMergeCapSmall ? L.max_candidates : kMergeCapSmall;
     const uint32_t desc_grid = (uint32_t)c->n_cu * c->desc_wgs_per_cu;  // resident all at once (32 KB LDS each)
-    fxk_prep(s, P, B, batch, c->box_margin, (float)c->params.el0_deg, (float)(1.0 / c->params.el_step_deg),
-             (uint32_t)(c->batch_seq % FX_CLK_SLOTS));
+    const uint32_t clk_slot = (uint32_t)(c->batch_seq % FX_CLK_SLOTS), clk_next = (uint32_t)((c->batch_seq + 1) % FX_CLK_SLOTS);
+    const float el0 = (float)c->params.el0_deg, inv_step = (float)(1.0 / c->params.el_step_deg);
+    if (front) {
+      // stages 0-4 in two launches: k_front, and k_front_redo — workgroups of k_front's shape, a few of them unless the
+      // previous batch had work for it — for the scans that do not fit k_front's tables.  The few of THOSE that need more
+      // LDS than that shape has go on to k_tail (a whole CU per workgroup), launched only when the previous batch handed it
+      // something (or nothing is known yet): an empty launch of it waits for a free CU behind the other batches' k_front.
+      const uint32_t mcap = std::min(fxk_front_merge_cap(), L.max_candidates);
+      const bool tail = hint[7] != 0u || c->front_force >= 2u;
+      fxk_front(s, P, B, batch, c->box_margin, el0, inv_step, clk_slot, mcap, c->front_force >= 1u ? 1u : 0u);
+      for (int i = 1; i <= 4; ++i) FX_HIP(mark(i));
+      fxk_front_redo(s, P, B, el0, inv_step, c->merge_huge_ccap, tail ? 1u : 0u, c->front_force >= 2u ? 1u : 0u, tier_grid(hint[6], 2 * big_grid, batch));
+      if (tail) fxk_tail(s, P, B, el0, inv_step, L.max_ring_points, c->merge_big_cap, c->merge_huge_ccap, tier_grid(hint[7], big_grid, batch));
+      fxk_offsets(s, P, B, batch, clk_next);
+      FX_HIP(mark(5));
+    } else {
+    fxk_prep(s, P, B, batch, c->box_margin, el0, inv_step, clk_slot);
     FX_HIP(mark(1));
-    fxk_bucket(s, P, B, batch, (float)c->params.el0_deg, (float)(1.0 / c->params.el_step_deg),
-               (uint32_t)((c->batch_seq + 1) % FX_CLK_SLOTS));
+    fxk_bucket(s, P, B, batch, el0, inv_step, clk_next);
     FX_HIP(mark(2));
     // one wavefront per (scan, ring): the hardware dispatcher balances the rings, whose costs differ a lot
     // (persistent wavefronts striding over the items: 0.18 ms instead of 0.14)
@@ -236,8 +279,9 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof, bo
     fxk_merge_big(s, P, B, c->merge_big_cap, tier_grid(hint[2], big_grid, batch), c->merge_big_cap >= L.max_candidates);
     if (c->merge_big_cap < L.max_candidates)
       fxk_merge_huge(s, P, B, L.max_candidates, c->merge_huge_ccap, tier_grid(hint[3], big_grid, batch));
-    fxk_offsets(s, P, B, batch);
+    fxk_offsets(s, P, B, batch, clk_next);
     FX_HIP(mark(5));
+    }
     if (P.estimate_descriptors) {
       fxk_gather(s, P, B, batch, c->box_margin);
       if (fxk_gather_slices(batch) > 1) fxk_rng_ord(s, P, B, batch);  // (one workgroup per scan settles the RNG ordinals itself)
@@ -269,14 +313,15 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof, bo
 // Small batches are launch-bound (about 30 launches for a few hundred microseconds of work): replay the
 // sequence as one HIP graph per batch size.  Kernel arguments depend on the batch size only; the scan
 // table lives in the fixed d_meta buffer and is uploaded before the graph runs.
-fx_status launch_graph(fx_ctx *c, hipStream_t s, uint32_t batch) {
+fx_status launch_graph(fx_ctx *c, hipStream_t s, uint32_t batch, bool front) {
   hipGraphExec_t exec = nullptr;
+  const uint32_t key = batch | (front ? 0x80000000u : 0u);
   for (auto &g : c->graphs)
-    if (g.first == batch) exec = g.second;
+    if (g.first == key) exec = g.second;
   if (!exec) {
     hipGraph_t graph = nullptr;
     FX_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    fx_status st = enqueue_stages(c, s, batch, false, true);  // (a graph's grids are fixed: the full ones, bounded by the batch)
+    fx_status st = enqueue_stages(c, s, batch, false, front, true);  // (a graph's grids are fixed: the full ones, bounded by the batch)
     hipError_t e = hipStreamEndCapture(s, &graph);
     if (st != FX_OK) {
       if (graph) (void)hipGraphDestroy(graph);
@@ -290,7 +335,7 @@ fx_status launch_graph(fx_ctx *c, hipStream_t s, uint32_t batch) {
       (void)hipGraphExecDestroy(c->graphs.front().second);
       c->graphs.erase(c->graphs.begin());
     }
-    c->graphs.emplace_back(batch, exec);
+    c->graphs.emplace_back(key, exec);
   }
   FX_HIP(hipGraphLaunch(exec, s));
   return FX_OK;
@@ -336,7 +381,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   // the large tier keeps only parents and a cell sort in LDS
   uint32_t merge_big_cap = L.max_candidates;
   while (fxk_merge_lds_bytes(merge_big_cap, params->n_rings) > kLds) merge_big_cap -= merge_big_cap > 64 ? 64 : 1;
-  if (const char *e = getenv("FX_MERGE_BIG_CAP")) {  // test hook: push scans on to the large merge tier
+  if (const char *e = test_hook("FX_MERGE_BIG_CAP")) {  // test hook: push scans on to the large merge tier
     const uint32_t v = (uint32_t)atoi(e);
     if (v >= 16 && v < merge_big_cap) merge_big_cap = v;
   }
@@ -356,12 +401,12 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   c->device = device_id;
   c->merge_big_cap = merge_big_cap;
   c->merge_huge_ccap = merge_huge_ccap;
-  if (const char *e = getenv("FX_DESC_WGS_PER_CU")) {  // experiment hook: ignored outside 1..32
+  if (const char *e = test_hook("FX_DESC_WGS_PER_CU")) {  // experiment hook: ignored outside 1..32
     const int v = atoi(e);
     if (v >= 1 && v <= 32) c->desc_wgs_per_cu = (uint32_t)v;
   }
-  if (const char *e = getenv("FX_DEBUG_SYNC")) c->debug_sync = atoi(e) != 0;
-  if (const char *e = getenv("FX_GRAPH_MAX_BATCH")) {
+  if (const char *e = test_hook("FX_DEBUG_SYNC")) c->debug_sync = atoi(e) != 0;
+  if (const char *e = test_hook("FX_GRAPH_MAX_BATCH")) {
     const int v = atoi(e);
     if (v >= 0) c->graph_max_batch = (uint32_t)v;
   }
@@ -428,7 +473,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   }
   P.dense_qcap = P.dense_cap > 0x7ff00000u ? 0xfff00000u : 2u * P.dense_cap;  // (cells' queries padded to four: typically 1.2 entries per query)
   P.dense_lds_keys = 14336u;  // FX_DFIN_KL of fx_kernels.hip
-  if (const char *e = getenv("FX_DENSE_LDS_KEYS")) {  // test hook: push rows on to the global-memory key sort (can only lower the cap)
+  if (const char *e = test_hook("FX_DENSE_LDS_KEYS")) {  // test hook: push rows on to the global-memory key sort (can only lower the cap)
     const int v = atoi(e);
     if (v >= 1 && (uint32_t)v < P.dense_lds_keys) P.dense_lds_keys = (uint32_t)v;
   }
@@ -497,6 +542,8 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   FX_A(dev_alloc(c, &b.huge_rings2, (size_t)8 * P.ring_list_cap));
   FX_A(dev_alloc(c, &b.big_merge, B));
   FX_A(dev_alloc(c, &b.huge_merge, B));
+  FX_A(dev_alloc(c, &b.redo, B));
+  FX_A(dev_alloc(c, &b.redo2, B));
   b.merge_sorted = nullptr;
   if (c->merge_big_cap < L.max_candidates) FX_A(dev_alloc(c, &b.merge_sorted, (size_t)B * L.max_candidates));
   FX_A(dev_alloc(c, &b.list_desc, L.max_total_keypoints));
@@ -527,7 +574,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   if (hipMemset(b.dens_cache, 0, B * L.max_points * sizeof(unsigned long long)) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
   if (hipMemset(b.seq, 0, sizeof(unsigned long long)) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
   if (hipMemset(b.ovf_cnt, 0, B * sizeof(uint32_t)) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
-  FX_A(dev_alloc(c, &b.counters, FX_N_COUNTERS));
+  FX_A(dev_alloc(c, &b.counters, FX_N_COUNTER_WORDS));
   {
     uint32_t *h = nullptr;
     FX_A(host_alloc(c, &h, FX_N_HINTS));
@@ -536,7 +583,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
     if (hipHostGetDevicePointer(&dv, h, 0) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipHostGetDevicePointer"));
     b.tier_hint = (uint32_t *)dv;
     c->tier_hint = h;
-    if (const char *e = getenv("FX_TIER_MIN_GRID")) c->tier_min_grid = (uint32_t)std::max(0, atoi(e));
+    if (const char *e = test_hook("FX_TIER_MIN_GRID")) c->tier_min_grid = (uint32_t)std::max(0, atoi(e));
   }
   FX_A(dev_alloc(c, &b.clk, 2 * FX_CLK_SLOTS));
   {
@@ -597,7 +644,15 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
                                   fxk_desc_lds_bytes(P.list_cap < P.dense_min ? P.list_cap : P.dense_min), fxk_gather_lds_bytes(L.max_keypoints));
     if (ce != hipSuccess) return bail(fail(FX_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(ce)));
   }
-  if (hipMemset(b.counters, 0, FX_N_COUNTERS * sizeof(uint32_t)) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
+  if (hipMemset(b.counters, 0, FX_N_COUNTER_WORDS * sizeof(uint32_t)) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
+  c->front_ok = (uint32_t)params->n_rings <= fxk_front_max_rings();
+  if (const char *e = test_hook("FX_FRONT")) c->front_ok = c->front_ok && atoi(e) != 0;  // 0 = the separate kernels (measurements; tests of those kernels)
+  // 1: k_front hands every scan to k_front_redo; 2: and that one every scan to k_tail (tests of those two)
+  if (const char *e = test_hook("FX_FRONT_FORCE")) c->front_force = (uint32_t)std::max(0, atoi(e));
+  if (c->front_ok) {
+    hipError_t ce = fxk_configure_front(P, L.max_ring_points, c->merge_big_cap, c->merge_huge_ccap);
+    if (ce != hipSuccess) return bail(fail(FX_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(ce)));
+  }
   if (hipMemset(b.kp_offset, 0, (B + 1) * sizeof(uint32_t)) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
   if (hipMemset(b.n_kp, 0, B * sizeof(uint32_t)) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
 #undef FX_A
@@ -738,6 +793,10 @@ fx_status fx_get_stage_bytes(fx_ctx *c, fx_stage_bytes *out) {
   rd[2] = 16.0 * n_ring, wr[2] = 20.0 * n_rc + 20.0 * n_mem;                   // ring tiers: ring points; candidates + sizes, members + their candidate
   rd[3] = 0, wr[3] = 0;                                                         // (the larger ring tiers' share is counted with the first)
   rd[4] = 20.0 * n_rc + 20.0 * n_mem, wr[4] = 24.0 * nc + 20.0 * nk + 20.0 * nkpc;  // merge: candidates, members; keypoints_full + maps, keypoints, keypoint_cloud
+  if (c->front_last) {  // k_front: the scan in; ~cloud, near bits, ring counts, keypoints_full + maps, keypoints, keypoint_cloud out — no intermediates
+    wr[0] += wr[4];
+    for (int i = 1; i <= 4; ++i) rd[i] = wr[i] = 0;
+  }
   if (desc) {
     rd[5] = 16.0 * near_pts + 16.0 * nk, wr[5] = 16.0 * (s_small + s_mid + s_dense) + 40.0 * nk;  // k_gather: near sectors; support lists + row tables
     rd[6] = 16.0 * s_small + 44.0 * total_kp, wr[6] = 7956.0 * total_kp;       // k_desc_group: short lists; every row (cleared here)
@@ -780,42 +839,43 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
     }
   }
   if (!in_dev && batch) {
-    if (!c->d_stage) {
+    // Host scans go over as they are, whatever their record stride (16: packed x y z i; 32: pcl::PointXYZI in memory, what
+    // the reference-side binding has — ref: node.cpp:81): the kernels stride over the records (FxScanMeta::stride_f), so
+    // nothing is repacked on the host and nothing is waited for.  The staging buffer holds max_batch scans of the widest
+    // stride seen so far.
+    uint32_t stride = 16;
+    for (uint32_t i = 0; i < batch; ++i) stride = std::max(stride, scans[i].stride_bytes);
+    if (!c->d_stage || stride > c->stage_stride) {
+      if (c->d_stage) {  // (an earlier batch issued without FX_OUT_HOST may still be reading it)
+        FX_HIP(hipStreamSynchronize(s));
+        FX_HIP(hipFree(c->d_stage));
+        c->d_stage = nullptr;
+      }
       void *q = nullptr;
-      hipError_t e = hipMalloc(&q, (size_t)L.max_batch * L.max_points * 16);
+      hipError_t e = hipMalloc(&q, (size_t)L.max_batch * L.max_points * stride);
       if (e != hipSuccess) return fail(FX_ERR_OOM, std::string("staging hipMalloc: ") + hipGetErrorString(e));
       c->d_stage = (float *)q;
+      c->stage_stride = stride;
     }
+    const size_t slot_bytes = (size_t)L.max_points * c->stage_stride;
     for (uint32_t i = 0; i < batch; ++i) {
       const fx_scan_desc &d = scans[i];
-      float *dst = c->d_stage + (size_t)i * L.max_points * 4;
-      hm[i].pts = dst;
-      hm[i].stride_f = 4;
+      uint8_t *dst = (uint8_t *)c->d_stage + (size_t)i * slot_bytes;
+      hm[i].pts = (const float *)dst;
+      hm[i].stride_f = d.stride_bytes / 4;
       if (!d.n_points) continue;
-      if (d.stride_bytes == 16) {
-        // full-size scans that follow one another in host memory (a stacked batch) go over in one copy
-        uint32_t j = i;
-        size_t bytes = (size_t)d.n_points * 16;
-        while (d.n_points == L.max_points && j + 1 < batch && scans[j + 1].stride_bytes == 16 &&
-               scans[j + 1].n_points == L.max_points &&
-               (const uint8_t *)scans[j + 1].points == (const uint8_t *)scans[j].points + (size_t)L.max_points * 16) {
-          ++j;
-          bytes += (size_t)L.max_points * 16;
-          hm[j].pts = c->d_stage + (size_t)j * L.max_points * 4;
-          hm[j].stride_f = 4;
-        }
-        FX_HIP(hipMemcpyAsync(dst, d.points, bytes, hipMemcpyHostToDevice, s));
-        i = j;
-      } else {
-        // wider records (pcl::PointXYZI in memory: 32 bytes) are repacked on the host.  The copy is ordered on the
-        // context's stream — an earlier batch issued without FX_OUT_HOST may still be reading d_stage — and
-        // waited for, because the repack buffer is reused by the next scan.
-        c->repack.resize((size_t)d.n_points * 4);
-        const uint8_t *src = (const uint8_t *)d.points;
-        for (uint32_t p = 0; p < d.n_points; ++p) std::memcpy(&c->repack[(size_t)p * 4], src + (size_t)p * d.stride_bytes, 16);
-        FX_HIP(hipMemcpyAsync(dst, c->repack.data(), (size_t)d.n_points * 16, hipMemcpyHostToDevice, s));
-        FX_HIP(hipStreamSynchronize(s));
+      // full-size scans that follow one another in host memory (a stacked batch) go over in one copy
+      uint32_t j = i;
+      size_t bytes = (size_t)d.n_points * d.stride_bytes;
+      while (d.n_points == L.max_points && d.stride_bytes == c->stage_stride && j + 1 < batch && scans[j + 1].stride_bytes == d.stride_bytes &&
+             scans[j + 1].n_points == L.max_points && (const uint8_t *)scans[j + 1].points == (const uint8_t *)scans[j].points + slot_bytes) {
+        ++j;
+        bytes += slot_bytes;
+        hm[j].pts = (const float *)((uint8_t *)c->d_stage + (size_t)j * slot_bytes);
+        hm[j].stride_f = d.stride_bytes / 4;
       }
+      FX_HIP(hipMemcpyAsync(dst, d.points, bytes, hipMemcpyHostToDevice, s));
+      i = j;
     }
   }
   if (batch) FX_HIP(hipMemcpyAsync(c->d_meta, hm, (size_t)batch * sizeof(FxScanMeta), hipMemcpyHostToDevice, s));
@@ -826,10 +886,20 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
   const FxDevParams &P = c->dp;
   const FxBuffers &B = c->buf;
   const bool prof = c->profiling;
+  // front kernel or separate kernels (see fx_ctx::front_pause): tier_hint[6] is what the last COMPLETED batch handed to k_tail
+  bool front = c->front_ok;
+  if (front && c->front_pause) {
+    --c->front_pause;
+    front = false;
+  } else if (front && !c->front_force && c->front_last && c->tier_hint[6] != 0xffffffffu && c->tier_hint[6] > (c->last_batch + 7u) / 8u) {
+    c->front_pause = fx_ctx::front_retry;
+    front = false;
+  }
   if (!prof && !c->debug_sync && batch && batch <= c->graph_max_batch && s != nullptr)
-    FX_TRY(launch_graph(c, s, batch));
+    FX_TRY(launch_graph(c, s, batch, front));
   else
-    FX_TRY(enqueue_stages(c, s, batch, prof));
+    FX_TRY(enqueue_stages(c, s, batch, prof, front));
+  c->front_last = front;
   if (prof) ++c->ev_count;
   ++c->batch_seq;
   c->last_batch = batch;

@@ -50,6 +50,9 @@ class StreamBatcher {
       : cb_(std::move(cb)), max_batch_(max_batch), max_points_(max_points) {
     fx_limits lim;
     fx_limits_default(&lim, max_batch, max_points);
+    // the descriptor pool holds every scan's keypoint capacity (the default, 64 a scan, is an average for large batches:
+    // a batch of one or two scans with more keypoints than that would flag FX_FLAG_TOTAL_KP_OVERFLOW)
+    lim.max_total_keypoints = max_batch * lim.max_keypoints;
     if (fx_create(&params, &lim, device, &ctx_) != FX_OK) throw std::runtime_error(std::string("fx_create: ") + fx_last_error());
     fx_set_graph_batch(ctx_, max_batch < 16u ? max_batch : 16u);  // the launch-bound sizes: one graph per batch size
     estimate_descriptors_ = params.estimate_descriptors != 0;
@@ -149,8 +152,12 @@ class StreamBatcher {
         r.keypoints.resize(K);
         if (K) std::memcpy(r.keypoints.data(), v.h_keypoints + (size_t)i * v.max_keypoints * 4, (size_t)K * sizeof(Point));
         if (estimate_descriptors_ && K) {
-          r.descriptors.resize(K);
-          std::memcpy(r.descriptors.data(), v.h_descriptors + (size_t)v.h_kp_offset[i] * FX_DESC_FLOATS, (size_t)K * sizeof(Descriptor));
+          // rows of this scan the pool holds (all of them unless FX_FLAG_TOTAL_KP_OVERFLOW is set, which r.flags reports:
+          // kp_offset and n_keypoints are not clamped to the pool, the copied rows are)
+          const uint32_t off = v.h_kp_offset[i] < v.total_keypoints ? v.h_kp_offset[i] : v.total_keypoints;
+          const uint32_t rows = K < v.total_keypoints - off ? K : v.total_keypoints - off;
+          r.descriptors.resize(rows);
+          if (rows) std::memcpy(r.descriptors.data(), v.h_descriptors + (size_t)off * FX_DESC_FLOATS, (size_t)rows * sizeof(Descriptor));
         }
         r.latency_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - batch[i].t0).count();
         cb_(std::move(r));

@@ -1,7 +1,7 @@
 // fx_batcher_cli — S simulated sensors (one producer thread each) push synthetic VLP-16 scans at HZ for SECONDS
 // through fx::StreamBatcher (fx_batcher.hpp); every scan's keypoints and descriptors are written to OUT for the test
 // to compare with the oracle, and the latency distribution / batch sizes are printed.
-//   fx_batcher_cli [--sensors S] [--hz HZ] [--seconds T] [--burst N] [--out FILE] [--default]
+//   fx_batcher_cli [--sensors S] [--hz HZ] [--seconds T] [--burst N] [--out FILE] [--default] [--poles P] [--max-batch B]
 // Scan q of sensor s is fx_synth_scan(seed 1000 + 1000 s + q), roll 0.02, pitch -0.015.
 // OUT: per scan {u32 sensor, u32 seq, u32 flags, u32 K, K x float4 keypoints, K x 1989 float descriptors}.
 #include <algorithm>
@@ -13,7 +13,7 @@
 
 int main(int argc, char **argv) {
   try {
-    uint32_t sensors = 4, burst = 0;
+    uint32_t sensors = 4, burst = 0, poles = 0, max_batch = 64;
     double hz = 10.0, seconds = 2.0;
     bool launch = true;
     const char *out_path = nullptr;
@@ -24,6 +24,8 @@ int main(int argc, char **argv) {
       else if (!std::strcmp(argv[i], "--burst") && i + 1 < argc) burst = (uint32_t)std::atoi(argv[++i]);
       else if (!std::strcmp(argv[i], "--out") && i + 1 < argc) out_path = argv[++i];
       else if (!std::strcmp(argv[i], "--default")) launch = false;
+      else if (!std::strcmp(argv[i], "--poles") && i + 1 < argc) poles = (uint32_t)std::atoi(argv[++i]);
+      else if (!std::strcmp(argv[i], "--max-batch") && i + 1 < argc) max_batch = (uint32_t)std::atoi(argv[++i]);
     }
     fx_params p;
     if (launch) fx_params_launch(&p); else fx_params_default(&p);
@@ -36,12 +38,13 @@ int main(int argc, char **argv) {
     for (uint32_t s = 0; s < sensors; ++s)
       for (uint32_t q = 0; q < per_sensor; ++q) {
         fx_synth_cfg_vlp16(&cfg, 1000 + 1000ull * s + q);
+        if (poles) cfg.n_poles = poles;
         fx_synth_scan(&cfg, scans[(size_t)s * per_sensor + q].data(), N);
       }
     std::mutex rm;
     std::vector<fx::StreamBatcher::Result> results;
     std::vector<uint32_t> seq_of;  // id -> sequence number within its sensor
-    fx::StreamBatcher batcher(p, 64, N, 0, [&](fx::StreamBatcher::Result &&r) {
+    fx::StreamBatcher batcher(p, max_batch, N, 0, [&](fx::StreamBatcher::Result &&r) {
       std::lock_guard<std::mutex> lk(rm);
       results.push_back(std::move(r));
     });

@@ -52,11 +52,13 @@ struct FxScTables {
 
 // Every device buffer of a context.
 #define FX_CLK_SLOTS 64
-#define FX_N_COUNTERS 40
+#define FX_N_COUNTERS 40  // counters k_prep / k_front clear for the batch
+#define FX_CNT_REDO 40    // counters[40]: scans k_front hands to k_front_redo, [41]: scans that hands to k_tail (cleared by k_offsets, after their readers)
+#define FX_N_COUNTER_WORDS 48
 #define FX_ATAN_N 64      // table step of k_prep's arctangent: 1 / 64 over [0, 1]
 #define FX_ATAN_DEG 6     // degree of the expansion about a table point (|offset| <= 1 / 128: truncation below 2^-51)
 #define FX_ROW_DIRTY 0xffffffffu
-#define FX_N_HINTS 8      // tier_hint[]: 0 / 1 rings handed to the second run tier / the workgroup tier (largest XCD class), 2 big merges, 3 huge merges, 4 dense rows, 5 dense support points
+#define FX_N_HINTS 8      // tier_hint[]: 0 / 1 rings handed to the second run tier / the workgroup tier (largest XCD class), 2 big merges, 3 huge merges, 4 dense rows, 5 dense support points, 6 scans k_front handed to k_front_redo, 7 scans that handed to k_tail
 #define FX_CNT_QPOOL 32   // counters[32]: entries of the dense tier's query pool in use
 #define FX_CNT_LARGE2 16  // counters[16 + c]: rings of XCD class c the second run tier hands to the workgroup tier
 #define FX_CNT_LARGE 24  // counters[24 + c]: ... to the large tier
@@ -107,6 +109,8 @@ struct FxBuffers {
   uint32_t *huge_rings2;  // [B*n_rings]  rings the second run tier hands to the workgroup tier, by XCD class
   uint32_t *big_merge;    // [B]
   uint32_t *huge_merge;   // [B]  scans with more candidates than the LDS merge tiers hold
+  uint32_t *redo;         // [B]  scans that do not fit k_front's LDS tables: k_front_redo runs the general kernels' bodies on them
+  uint32_t *redo2;        // [B]  ... and those that need more LDS than k_front_redo has: k_tail (a whole CU per workgroup)
   float4 *merge_sorted;   // [B][max_candidates] (x, y, pseudo z, id) in bin order: k_merge_huge's pair tests (allocated only when that tier exists)
   uint32_t *list_desc;    // [max_total_kp]  rows whose list is too long for one wavefront (257 .. dense_min support points)
   uint32_t *wave_desc;    // [max_total_kp]  rows with 65..256 support points (one wavefront each)
@@ -137,7 +141,7 @@ struct FxBuffers {
   unsigned long long *clk;     // [FX_CLK_SLOTS][2] k_prep's first start / last end on the device's constant-rate clock, by batch
   unsigned long long *stamps;  // [32] diagnostic build only (-DFX_STAMPS)
   uint32_t *tier_hint;    // [FX_N_HINTS], pinned HOST memory: the batch's counts of work for the rarely used tiers, which the host sizes the next batch's launches of those tiers by (k_offsets, k_desc_mid write them; grid sizes only — never what is computed)
-  uint32_t *counters;     // [FX_N_COUNTERS]: 16.. / 24.. rings handed on per XCD class; 1 big_merge, 4 list_desc, 6 dense rows (2 / 3 / 7 / 10: by size class), 8 wave_desc, 9 huge_merge, 12 key pool used, 13 sorted pool used, 14 density items, 15 / 11 / 5 / 0 tickets of k_dense_density / sort / finish_s / finish_l
+  uint32_t *counters;     // [FX_N_COUNTER_WORDS]: 16.. / 24.. rings handed on per XCD class; 1 big_merge, 4 list_desc, 6 dense rows (2 / 3 / 7 / 10: by size class), 8 wave_desc, 9 huge_merge, 12 key pool used, 13 sorted pool used, 14 density items, 15 / 11 / 5 / 0 tickets of k_dense_density / sort / finish_s / finish_l
 };
 
 #endif

@@ -19,6 +19,7 @@
 #include <float.h>
 #include <math.h>
 #include <type_traits>
+#include <algorithm>
 
 #include "fx_device.h"
 #include "fx_sort_replay.h"
@@ -30,6 +31,9 @@
 #define FX_NWAVE (FX_WG / 64)
 
 namespace {
+
+// two floats an instruction (v_pk_mul_f32 / v_pk_add_f32: IEEE per component, the same bits as the scalar forms)
+typedef float fx_f2 __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------ wave / block helpers
 __device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
@@ -731,6 +735,7 @@ __device__ __forceinline__ uint32_t cc_order(uint32_t n, const uint32_t *parent,
 #ifndef FX_PREP_U
 #define FX_PREP_U 4
 #endif
+static_assert(FX_PREP_U % 2 == 0, "the tile's points are rotated in pairs");
 #define FX_PREP_TILE (FX_PREP_T * FX_PREP_U)  // 2048 points = 32 groups of 64 = one word of near bits
 typedef float __attribute__((address_space(1))) gfloat;
 
@@ -814,22 +819,31 @@ __device__ __forceinline__ uint32_t ring_membership(float el, const float2 *win,
 #ifndef FX_PREP_OCC
 #define FX_PREP_OCC 4  // waves per SIMD the register budget is held to: 4 = two workgroups per CU (129 registers would mean one)
 #endif
-__global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, FxBuffers B, float near_margin, float el0, float inv_step, uint32_t clk_slot) {
-  constexpr int NW = FX_PREP_T / 64;
-  constexpr uint32_t kTile = FX_PREP_TILE;           // points per tile; wave w owns [256 w, 256 w + 256) of it
 #ifndef FX_PREP_KEEP
-#define FX_PREP_KEEP (FX_PREP_TILE + FX_PREP_TILE / 2)
+#define FX_PREP_KEEP (FX_PREP_TILE + FX_PREP_TILE / 2)  // survivors buffered between sweeps
 #endif
-  constexpr uint32_t kKeep = FX_PREP_KEEP;           // survivors buffered between sweeps
-  const uint32_t scan = blockIdx.x;
-  const FxScanMeta M = B.meta[scan];
-  __shared__ uint32_t s_cnt[2][NW];                  // per wave: survivors of the tile; by tile parity
-  __shared__ float s_keep[3 * kKeep];                // un-rotated survivors (x, y, z) waiting for the elevation sweep
-  __shared__ uint32_t s_ring[FX_MAX_RINGS];          // survivors per ring (a window-boundary point counts in both rings)
-  __shared__ double s_atan[(FX_ATAN_N + 1) * (FX_ATAN_DEG + 1)];  // elevation_fast's table
+// LDS of the streaming pass (static arrays in k_prep, carved from the dynamic image in k_front)
+struct PrepLds {
+  uint32_t *cnt;       // [2][FX_PREP_T / 64] per wave: survivors of the tile; by tile parity
+  float *keep;         // [3 * FX_PREP_KEEP] un-rotated survivors (x, y, z) waiting for the elevation sweep
+  uint32_t *ring;      // [n_rings] survivors per ring (a window-boundary point counts in both rings)
+  double *atan;        // [(FX_ATAN_N + 1) * (FX_ATAN_DEG + 1)] elevation_fast's table
   // the ring windows (a sweep then loads nothing from global memory: the wait for such a load would also be one for the
   // acknowledgement of the sweep's earlier stores — vmcnt counts loads and stores in issue order)
-  __shared__ float2 s_win[FX_MAX_RINGS];
+  float2 *win;         // [n_rings]
+};
+// The streaming pass over one scan (n > 0) by one FX_PREP_T-thread workgroup: writes the filtered cloud and the near bits,
+// leaves the ring counts in L.ring; returns the number of survivors.  Ends with a barrier.
+__device__ __forceinline__ uint32_t prep_stream(const FxDevParams &P, const FxBuffers &B, const FxScanMeta &M, uint32_t scan,
+                                                float near_margin, float el0, float inv_step, const PrepLds &L) {
+  constexpr int NW = FX_PREP_T / 64;
+  constexpr uint32_t kTile = FX_PREP_TILE;           // points per tile; wave w owns [256 w, 256 w + 256) of it
+  constexpr uint32_t kKeep = FX_PREP_KEEP;
+  uint32_t *const s_cnt = L.cnt;
+  float *const s_keep = L.keep;
+  uint32_t *const s_ring = L.ring;
+  double *const s_atan = L.atan;
+  float2 *const s_win = L.win;
   float4 *out = B.filt + (size_t)scan * P.max_points;
   uint32_t *near_bits = B.near_bits + (size_t)scan * P.near_words;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -838,19 +852,8 @@ __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, 
   // (global address space stated: a generic-pointer load would be a flat load, which also counts as an
   //  LDS access and gets waited for at the next LDS instruction)
   const gfloat *gpts = (const gfloat *)M.pts;
-  // execution span of this launch on the device's constant-rate clock (first workgroup's start, last workgroup's end):
-  // what rocprofv3 reports as the kernel's duration; HIP events around the launch also count its wait for free CUs
-  if (tid == 0) atomicMin(&B.clk[2 * clk_slot], (unsigned long long)wall_clock64());
   const uint32_t R = (uint32_t)P.n_rings;
-  if (n == 0) {  // empty scan (ref: node.cpp:209-210, 263-264): its pointer may be null — nothing is loaded
-    if (tid == 0) {
-      B.n_filt[scan] = 0u;
-      B.flags[scan] = 0u;
-    }
-    for (uint32_t r = tid; r < R; r += FX_PREP_T) B.ring_cnt[(size_t)scan * R + r] = 0u;
-    if (scan == 0 && tid < FX_N_COUNTERS) B.counters[tid] = 0u;
-    return;
-  }
+  FX_STAMP_INIT(B.stamps);
   for (uint32_t r = tid; r < R; r += FX_PREP_T) s_ring[r] = 0u;  // (ordered before the first sweep by the tile barriers)
   for (uint32_t r = tid; r < (FX_ATAN_N + 1) * (FX_ATAN_DEG + 1); r += FX_PREP_T) s_atan[r] = B.atan_tab[r];
   for (uint32_t r = tid; r < R; r += FX_PREP_T) s_win[r] = B.ring_win[r];
@@ -862,7 +865,7 @@ __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, 
       const uint32_t i = t0 + wave * (64 * FX_PREP_U) + u * 64 + lane;
       const gfloat *q = gpts + (size_t)min(i, n - 1u) * M.stride_f;  // clamped: no branch around the load
       // (the record's fourth word is never used and the compiler narrows the load to 12 bytes a lane — measured faster
-      //  than the full 16-byte load: 0.17 against 0.20 ms)
+      //  than the full 16-byte load in round 1, 0.17 against 0.20 ms; level in round 4, 0.128 against 0.133)
       // past the end: a NaN x makes all three rotated coordinates NaN, which fail every range test below
       v[u] = make_float4(i < n ? q[0] : NAN, q[1], q[2], 0.f);
     }
@@ -879,7 +882,7 @@ __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, 
       float el;
       if (!elevation_fast(x, y, z, s_atan, el)) el = elevation_deg(x, y, z);
       out[base + j] = make_float4(rx, ry, rz, el);
-      // ring counts for k_bucket's split (it then reads the filtered cloud once, not twice)
+      // ring counts for the ring split (it then reads the filtered cloud once, not twice)
       int r_first;
       const uint32_t mask = isfinite(el) ? ring_membership(el, s_win, P.n_rings, el0, inv_step, r_first) : 0u;
 #pragma unroll
@@ -888,6 +891,7 @@ __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, 
     }
     base += buffered;
     buffered = 0;
+    FX_STAMP(28);
   };
   // Range tests with both ends clamped to the finite floats: a NaN or an infinite coordinate fails them (PassThrough drops
   // non-finite points first, ref: SURVEY.md A.2), a finite one compares as in PCL's !(v < min || v > max); an infinite or
@@ -898,54 +902,71 @@ __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, 
               ny1 = hi_lim(P.y_max + near_margin), nz0 = lo_lim(P.z_min - near_margin), nz1 = hi_lim(P.z_max + near_margin);
   const float fx0 = lo_lim(P.x_min), fx1 = hi_lim(P.x_max), fy0 = lo_lim(P.y_min), fy1 = hi_lim(P.y_max), fz0 = lo_lim(P.z_min),
               fz1 = hi_lim(P.z_max);
+  // (Measured in round 4, profiles/r04_front_experiments.md: what a tile costs is ISSUING its loads — 4000 of a tile's 9000
+  //  cycles pass between the first and the last of a wavefront's eight load instructions, the memory pipeline being full —,
+  //  not waiting for them: a second tile of loads in flight, tile buffers that take turns without the register copies below
+  //  (a copy waits for the copied register's load) and 16-byte loads all left the kernel's time where it was.)
   float4 v[FX_PREP_U], nv[FX_PREP_U];
   load_tile(0, v);
+  FX_STAMP(24);
   for (uint32_t t0 = 0; t0 < n; t0 += kTile) {
     load_tile(t0 + kTile, nv);
+    FX_STAMP(30);
     bool keep[FX_PREP_U];
     unsigned long long mask[FX_PREP_U];
     uint32_t wave_cnt = 0;
-    unsigned long long sect[(FX_PREP_U + 3) / 4] = {};  // one bit per four consecutive points (one 64-byte sector) of this wave's 64 U
+    uint32_t nq[FX_PREP_U];  // 1: some point of this lane's group of four (one 64-byte sector) is near the box
+    // pcl::transformPointCloud, dense branch: ((m0 x + m1 y) + m2 z) + t, t = 0 — two points an instruction (packed fp32: the
+    // kernel is bound by instruction issue; the + 0 of the translation only turns -0 into +0, which no range test sees: the
+    // sweep, whose values are stored, keeps it)
+    float rxs[FX_PREP_U], rys[FX_PREP_U], rzs[FX_PREP_U];
+#pragma unroll
+    for (int u = 0; u < FX_PREP_U; u += 2) {
+      const fx_f2 X = {v[u].x, v[u + 1].x}, Y = {v[u].y, v[u + 1].y}, Z = {v[u].z, v[u + 1].z};
+      const fx_f2 a = (M.R[0] * X + M.R[1] * Y) + M.R[2] * Z;
+      const fx_f2 b = (M.R[3] * X + M.R[4] * Y) + M.R[5] * Z;
+      const fx_f2 c = (M.R[6] * X + M.R[7] * Y) + M.R[8] * Z;
+      rxs[u] = a.x, rxs[u + 1] = a.y, rys[u] = b.x, rys[u + 1] = b.y, rzs[u] = c.x, rzs[u + 1] = c.y;
+    }
 #pragma unroll
     for (int u = 0; u < FX_PREP_U; ++u) {
-      const float x = v[u].x, y = v[u].y, z = v[u].z;
-      // pcl::transformPointCloud, dense branch: ((m0 x + m1 y) + m2 z) + t, t = 0
-      const float rx = ((M.R[0] * x + M.R[1] * y) + M.R[2] * z) + 0.0f;
-      const float ry = ((M.R[3] * x + M.R[4] * y) + M.R[5] * z) + 0.0f;
-      const float rz = ((M.R[6] * x + M.R[7] * y) + M.R[8] * z) + 0.0f;
+      const float rx = rxs[u], ry = rys[u], rz = rzs[u];
       const bool near = rx >= nx0 && rx <= nx1 && ry >= ny0 && ry <= ny1 && rz >= nz0 && rz <= nz1;
       const bool k = rx >= fx0 && rx <= fx1 && ry >= fy0 && ry <= fy1 && rz >= fz0 && rz <= fz1;
       keep[u] = k;
       mask[u] = __ballot(k);
       wave_cnt += (uint32_t)__popcll(mask[u]);
-      {
-        // sector s of this load holds lanes 4 s .. 4 s + 3: bits 0, 4, 8, ... of the OR, squeezed to 16 adjacent bits
-        unsigned long long x = __ballot(near);
-        x = (x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x1111111111111111ull;
-        x = (x | (x >> 3)) & 0x0303030303030303ull;
-        x = (x | (x >> 6)) & 0x000f000f000f000full;
-        x = (x | (x >> 12)) & 0x000000ff000000ffull;
-        x = (x | (x >> 24)) & 0xffffull;
-        sect[u / 4] |= x << (16 * (u % 4));
-      }
+      // sector s of this load holds lanes 4 s .. 4 s + 3: the OR over the four, in all of them (two quad swizzles)
+      uint32_t q = near ? 1u : 0u;
+      q |= (uint32_t)__builtin_amdgcn_mov_dpp((int)q, 0xB1, 0xf, 0xf, true);  // quad_perm [1, 0, 3, 2]
+      q |= (uint32_t)__builtin_amdgcn_mov_dpp((int)q, 0x4E, 0xf, 0xf, true);  // quad_perm [2, 3, 0, 1]
+      nq[u] = q;
     }
+    // The wavefront's 64 sector bits (load u's sixteen at 16 u ..: pure sector order) in one ballot: lane 4 k + g of sector k
+    // offers load g's flag, lane 16 g + k fetches it.  (Squeezing every fourth bit out of four ballots cost a hundred scalar
+    // instructions a tile — a quarter of the loop, which is bound by instruction issue.)
+    static_assert(FX_PREP_U == 4, "one ballot holds the sector bits of four loads");
+    const uint32_t offer = (lane & 2u) ? ((lane & 1u) ? nq[3] : nq[2]) : ((lane & 1u) ? nq[1] : nq[0]);
+    const unsigned long long sect =
+        __ballot(__builtin_amdgcn_ds_bpermute((int)((((lane & 15u) << 2) | (lane >> 4)) << 2), (int)offer) != 0);
     if (lane == 0) {
-      s_cnt[parity][wave] = wave_cnt;
-      // (pure sector order: bit s of the scan is bit s % 32 of word s / 32)
-#pragma unroll
-      for (int h = 0; h < FX_PREP_U / 2; ++h)
-        near_bits[(t0 / kTile) * (kTile / 128) + wave * (FX_PREP_U / 2) + h] = (uint32_t)(sect[h / 2] >> (32 * (h % 2)));
+      s_cnt[parity * NW + wave] = wave_cnt;
+      // (bit s of the scan is bit s % 32 of word s / 32)
+      near_bits[(t0 / kTile) * (kTile / 128) + wave * 2] = (uint32_t)sect;
+      near_bits[(t0 / kTile) * (kTile / 128) + wave * 2 + 1] = (uint32_t)(sect >> 32);
     }
     // One barrier per tile: it orders this tile's counts before their readers, the previous sweep's
     // reads of s_keep before this tile's writes, and (a wave cannot be two tiles ahead of another) the
     // readers of the other parity's counts before they are overwritten next tile.
+    FX_STAMP(25);
     __syncthreads();
+    FX_STAMP(26);
     // buffer slot = survivors already buffered + those of earlier waves + of earlier slices of my wave
     //               + of earlier lanes of my slice: input order is kept
     uint32_t before = 0, tile_total = 0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
-      const uint32_t c = s_cnt[parity][w];
+      const uint32_t c = s_cnt[parity * NW + w];
       before += (w < (int)wave) ? c : 0u;
       tile_total += c;
     }
@@ -962,16 +983,46 @@ __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, 
     }
     buffered += tile_total;
     parity ^= 1u;
+    FX_STAMP(27);
     if (buffered > kKeep - kTile) {  // the next tile might not fit (workgroup-uniform)
       __syncthreads();
       sweep();
     }
 #pragma unroll
     for (int u = 0; u < FX_PREP_U; ++u) v[u] = nv[u];
+    FX_STAMP(29);
   }
   __syncthreads();
   sweep();
   __syncthreads();
+  return base;
+}
+
+__global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, FxBuffers B, float near_margin, float el0, float inv_step, uint32_t clk_slot) {
+  constexpr int NW = FX_PREP_T / 64;
+  const uint32_t scan = blockIdx.x;
+  const FxScanMeta M = B.meta[scan];
+  __shared__ uint32_t s_cnt[2 * NW];
+  __shared__ float s_keep[3 * FX_PREP_KEEP];
+  __shared__ uint32_t s_ring[FX_MAX_RINGS];
+  __shared__ double s_atan[(FX_ATAN_N + 1) * (FX_ATAN_DEG + 1)];
+  __shared__ float2 s_win[FX_MAX_RINGS];
+  const uint32_t tid = threadIdx.x;
+  // execution span of this launch on the device's constant-rate clock (first workgroup's start, last workgroup's end):
+  // what rocprofv3 reports as the kernel's duration; HIP events around the launch also count its wait for free CUs
+  if (tid == 0) atomicMin(&B.clk[2 * clk_slot], (unsigned long long)wall_clock64());
+  const uint32_t R = (uint32_t)P.n_rings;
+  if (M.n == 0) {  // empty scan (ref: node.cpp:209-210, 263-264): its pointer may be null — nothing is loaded
+    if (tid == 0) {
+      B.n_filt[scan] = 0u;
+      B.flags[scan] = 0u;
+    }
+    for (uint32_t r = tid; r < R; r += FX_PREP_T) B.ring_cnt[(size_t)scan * R + r] = 0u;
+    if (scan == 0 && tid < FX_N_COUNTERS) B.counters[tid] = 0u;
+    return;
+  }
+  const PrepLds L{s_cnt, s_keep, s_ring, s_atan, s_win};
+  const uint32_t base = prep_stream(P, B, M, scan, near_margin, el0, inv_step, L);
   for (uint32_t r = tid; r < R; r += FX_PREP_T) B.ring_cnt[(size_t)scan * R + r] = s_ring[r];
   if (tid == 0) {
     B.n_filt[scan] = base;
@@ -991,36 +1042,32 @@ __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, 
 #endif
 #define FX_BUCKET_NW (FX_BUCKET_T / 64)
 // MANY: sensors of more than 24 rings (the sort-based ranking below is compiled only into that instance)
-template <bool MANY>
-__device__ __forceinline__ void bucket_body(const FxDevParams &P, const FxBuffers &B, float el0, float inv_step, uint32_t clk_next,
-                                            uint32_t *smem) {
+template <bool MANY, int NT>
+__device__ __forceinline__ void bucket_body(const FxDevParams &P, const FxBuffers &B, uint32_t scan, float el0, float inv_step, uint32_t *smem) {
+  constexpr int NWV = NT / 64;
   const uint32_t R = (uint32_t)P.n_rings;
   uint32_t *s_w = smem;            // 48: block helpers, per-wave ring ranges
   uint32_t *cnt = smem + 48;       // [R] total per ring, then running fill
   uint32_t *off = cnt + R;         // [R + 1]
-  uint32_t *cw = off + R + 1;      // [FX_BUCKET_NW][R] per-wave counts of the current chunk
-  const uint32_t scan = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (scan == 0 && tid == 0) {  // the clock slot the next batch's k_prep stamps
-    B.clk[2 * clk_next] = ~0ull;
-    B.clk[2 * clk_next + 1] = 0ull;
-  }
+  uint32_t *cw = off + R + 1;      // [NT / 64][R] per-wave counts of the current chunk
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t nf = B.n_filt[scan];
   const float4 *f = B.filt + (size_t)scan * P.max_points;
-  for (uint32_t r = tid; r < R; r += FX_BUCKET_T) cnt[r] = B.ring_cnt[(size_t)scan * R + r];  // counted by k_prep's sweep
+  for (uint32_t r = tid; r < R; r += NT) cnt[r] = B.ring_cnt[(size_t)scan * R + r];  // counted by k_prep's sweep
   __syncthreads();
   uint32_t total = 0;
-  for (uint32_t b0 = 0; b0 < R; b0 += FX_BUCKET_T) {
+  for (uint32_t b0 = 0; b0 < R; b0 += NT) {
     const uint32_t r = b0 + tid;
     const uint32_t c = r < R ? cnt[r] : 0u;
     uint32_t tot;
-    const uint32_t ex = block_excl_scan<FX_BUCKET_T>(c, s_w, tot);
+    const uint32_t ex = block_excl_scan<NT>(c, s_w, tot);
     if (r < R) off[r] = total + ex;
     total += tot;
   }
   __syncthreads();
   const bool overflow = total > P.ring_slot_cap;
   uint32_t *g_off = B.ring_off + (size_t)scan * R, *g_cnt = B.ring_cnt + (size_t)scan * R;
-  for (uint32_t r = tid; r < R; r += FX_BUCKET_T) {
+  for (uint32_t r = tid; r < R; r += NT) {
     g_off[r] = overflow ? 0u : off[r];
     g_cnt[r] = overflow ? 0u : cnt[r];
     cnt[r] = 0;  // becomes the running fill
@@ -1031,7 +1078,7 @@ __device__ __forceinline__ void bucket_body(const FxDevParams &P, const FxBuffer
   }
   __syncthreads();
   float4 *dst = B.ring_pts + (size_t)scan * P.ring_slot_cap;
-  for (uint32_t b0 = 0; b0 < nf; b0 += FX_BUCKET_T) {
+  for (uint32_t b0 = 0; b0 < nf; b0 += NT) {
     const uint32_t i = b0 + tid;
     float4 v = make_float4(0, 0, 0, 0);
     int r_first = 0;
@@ -1049,14 +1096,14 @@ __device__ __forceinline__ void bucket_body(const FxDevParams &P, const FxBuffer
     }
     if (lane == 0) {
       s_w[wave] = (uint32_t)lo;
-      s_w[FX_BUCKET_NW + wave] = (uint32_t)hi;
+      s_w[NWV + wave] = (uint32_t)hi;
     }
     __syncthreads();
     lo = 0x7fffffff, hi = -1;
 #pragma unroll
-    for (int w = 0; w < FX_BUCKET_NW; ++w) {
+    for (int w = 0; w < NWV; ++w) {
       lo = min(lo, (int)s_w[w]);
-      hi = max(hi, (int)s_w[FX_BUCKET_NW + w]);
+      hi = max(hi, (int)s_w[NWV + w]);
     }
     lo = max(lo, 0);
     hi = min(hi, (int)R);
@@ -1107,28 +1154,36 @@ __device__ __forceinline__ void bucket_body(const FxDevParams &P, const FxBuffer
         const uint32_t r = (uint32_t)(r_first + d);
         uint32_t before = 0;
 #pragma unroll
-        for (int w = 0; w < FX_BUCKET_NW; ++w) before += (w < (int)wave) ? cw[w * R + r] : 0u;
+        for (int w = 0; w < NWV; ++w) before += (w < (int)wave) ? cw[w * R + r] : 0u;
         dst[off[r] + cnt[r] + before + my_rank[d]] = v;
       }
     }
     __syncthreads();
-    for (int r = lo + (int)tid; r < hi; r += FX_BUCKET_T) {
+    for (int r = lo + (int)tid; r < hi; r += NT) {
       uint32_t c = 0;
 #pragma unroll
-      for (int w = 0; w < FX_BUCKET_NW; ++w) c += cw[w * R + r];
+      for (int w = 0; w < NWV; ++w) c += cw[w * R + r];
       cnt[r] += c;
     }
     __syncthreads();
   }
 }
 
+__device__ __forceinline__ void clk_reset(const FxBuffers &B, uint32_t clk_next) {  // the clock slot the next batch's k_prep stamps
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    B.clk[2 * clk_next] = ~0ull;
+    B.clk[2 * clk_next + 1] = 0ull;
+  }
+}
 extern "C" __global__ __launch_bounds__(FX_BUCKET_T) void k_bucket(FxDevParams P, FxBuffers B, float el0, float inv_step, uint32_t clk_next) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  bucket_body<false>(P, B, el0, inv_step, clk_next, smem);
+  clk_reset(B, clk_next);
+  bucket_body<false, FX_BUCKET_T>(P, B, blockIdx.x, el0, inv_step, smem);
 }
 extern "C" __global__ __launch_bounds__(FX_BUCKET_T) void k_bucket_many(FxDevParams P, FxBuffers B, float el0, float inv_step, uint32_t clk_next) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  bucket_body<true>(P, B, el0, inv_step, clk_next, smem);
+  clk_reset(B, clk_next);
+  bucket_body<true, FX_BUCKET_T>(P, B, blockIdx.x, el0, inv_step, smem);
 }
 
 // ====================================================================== stage 2b: rings
@@ -1884,19 +1939,16 @@ extern "C" __global__ __launch_bounds__(FX_RING_LARGE_T) void k_rings_large(FxDe
 // k_merge_big: what fits 160 KB), or — scans with more candidates than LDS holds as points (a 128-ring scan under the
 // launch preset has ~5000) — coordinates left in HBM (k_merge_huge: the scan's `cand` rows, L2 resident).
 #define FX_MERGE_HEAD 160  // scratch words in front: block helpers [0..15], broadcast [16..31], sort stack [32..151]
-__host__ __device__ inline uint32_t merge_bins(uint32_t cap) { return cap <= 1024u ? 1024u : 4096u; }
-__host__ __device__ inline uint32_t merge_aux_words(uint32_t cap) {
-  const uint32_t a = merge_bins(cap) + 4 + (cap + 1) / 2;  // bin table + candidate ids (uint16); later the sizes
-  return a > cap ? a : cap;
+__host__ __device__ constexpr uint32_t merge_bins(uint32_t cap) { return cap <= 1024u ? 1024u : 4096u; }
+__host__ __device__ constexpr uint32_t merge_aux_words(uint32_t cap) {
+  // bin table + candidate ids (uint16); later the sizes
+  return merge_bins(cap) + 4 + (cap + 1) / 2 > cap ? merge_bins(cap) + 4 + (cap + 1) / 2 : cap;
 }
 // LDS words: lds_pts tiers hold (x, y, pseudo z, elevation), true z and the member lists on chip
-__host__ __device__ inline size_t merge_words(uint32_t cap, uint32_t ccap, uint32_t n_rings, bool lds_pts) {
-  size_t w = FX_MERGE_HEAD + ((2 * (n_rings + 1) + 3) & ~3u);
-  if (lds_pts) w += 5 * (size_t)cap + cap;  // pt, cz, member lists (2 x uint16 per candidate)
-  w += cap;                                 // parent
-  w += merge_aux_words(cap);
-  w += 3 * (size_t)ccap;                    // croot, crec, tmp / member-list bases
-  return w;
+__host__ __device__ constexpr size_t merge_words(uint32_t cap, uint32_t ccap, uint32_t n_rings, bool lds_pts) {
+  return FX_MERGE_HEAD + ((2 * (n_rings + 1) + 3) & ~3u) + (lds_pts ? 5 * (size_t)cap + cap : 0)  // pt, cz, member lists (2 x uint16 per candidate)
+         + cap                                                                                       // parent
+         + merge_aux_words(cap) + 3 * (size_t)ccap;                                                  // croot, crec, tmp / member-list bases
 }
 
 // largest r with base[r] <= idx, base = exclusive prefix with base[R] = total > idx
@@ -1912,10 +1964,20 @@ __device__ __forceinline__ uint32_t prefix_owner(const uint32_t *base, uint32_t 
   return lo;
 }
 
+// The candidates of a scan as the fused front kernel (k_front) leaves them in LDS: per ring-cluster position g in PCL's
+// order, rec[g] = size << 16 | root run, slot[g] = bit 31: the cluster passed the diameter gate | its ordinal in
+// keypoints_full; centroid[root run] = (x, y, z, elevation).
+struct FrontCands {
+  const uint32_t *rec, *slot;
+  const float4 *centroid;
+  uint32_t n_c, C;
+};
 // Returns false when the scan has more candidates than this tier holds (the caller defers it to the next one).
-template <int NT, bool LDS_PTS>
+// FRONT: the candidates come from k_front's LDS tables (FC) instead of the ring kernels' rows in HBM, and keypoint_cloud
+// has been written by the caller.
+template <int NT, bool LDS_PTS, bool FRONT = false>
 __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers &B, uint32_t scan, uint32_t cap, uint32_t ccap,
-                                           uint32_t *smem, bool last_tier) {
+                                           uint32_t *smem, bool last_tier, const FrontCands *FC = nullptr) {
   unsigned long long *const stamp_base = B.stamps ? B.stamps + 32 : nullptr;
   FX_STAMP_INIT(stamp_base);
   const uint32_t tid = threadIdx.x;
@@ -1945,15 +2007,19 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
 
   // ---- ring bases
   uint32_t C = 0;
-  for (uint32_t b0 = 0; b0 < R; b0 += NT) {
-    const uint32_t r = b0 + tid;
-    const uint32_t c = r < R ? rcnt[r] : 0u;
-    uint32_t tot;
-    const uint32_t ex = block_excl_scan<NT>(c, s_w, tot);
-    if (r < R) rbase[r] = C + ex;
-    C += tot;
+  if (FRONT) {
+    C = FC->C;
+  } else {
+    for (uint32_t b0 = 0; b0 < R; b0 += NT) {
+      const uint32_t r = b0 + tid;
+      const uint32_t c = r < R ? rcnt[r] : 0u;
+      uint32_t tot;
+      const uint32_t ex = block_excl_scan<NT>(c, s_w, tot);
+      if (r < R) rbase[r] = C + ex;
+      C += tot;
+    }
+    if (tid == 0) rbase[R] = C;
   }
-  if (tid == 0) rbase[R] = C;
   if (C > P.max_candidates) {
     if (tid == 0) {
       atomicOr(&B.flags[scan], FX_FLAG_CAND_OVERFLOW);
@@ -1990,15 +2056,27 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
     return cand[i];
   };
   // all candidates in parallel (each finds its ring in the prefix table)
-  for (uint32_t idx = tid; idx < C; idx += NT) {
-    const uint32_t r = prefix_owner(rbase, R, idx), j = idx - rbase[r];
-    const float4 v = B.ring_cand[((size_t)scan * R + r) * P.max_ring_cands + j];
+  for (uint32_t t = tid; t < (FRONT ? FC->n_c : C); t += NT) {
+    uint32_t idx = t, size;
+    float4 v;
+    if (FRONT) {
+      const uint32_t w = FC->slot[t];
+      if (!(w >> 31)) continue;  // the cluster did not pass the gate
+      idx = w & 0x7fffffffu;
+      const uint32_t rec = FC->rec[t];
+      v = FC->centroid[rec & 0xffffu];
+      size = rec >> 16;
+    } else {
+      const uint32_t r = prefix_owner(rbase, R, idx), j = idx - rbase[r];
+      v = B.ring_cand[((size_t)scan * R + r) * P.max_ring_cands + j];
+      size = B.ring_cand_size[((size_t)scan * R + r) * P.max_ring_cands + j];
+    }
     if (LDS_PTS) {
       pt[idx] = make_float4(v.x, v.y, pseudo_z(v.w), v.w);
       cz[idx] = v.z;
     }
     cand[idx] = v;
-    cand_size[idx] = B.ring_cand_size[((size_t)scan * R + r) * P.max_ring_cands + j];
+    cand_size[idx] = size;
     parent[idx] = idx;
     atomicAdd(&bin[bin_of(cell_x(v.x), cell_y(v.y))], 1u);
   }
@@ -2065,12 +2143,17 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
       const float4 v = merge_pt(i);
       const uint32_t b = bin_of(cell_x(v.x) + (int)(d % 3u) - 1, cell_y(v.y) + (int)(d / 3u) - 1);
       const uint32_t q0 = b ? bin[b - 1] : 0u, q1 = bin[b];
-      for (uint32_t q = q0; q < q1; q += 2) {
-        const uint32_t j0 = sorted[q], j1 = sorted[min(q + 1u, q1 - 1u)];
-        const float4 u0 = merge_pt(j0), u1 = merge_pt(j1);
+      for (uint32_t q = q0; q < q1; q += 4) {  // (four entries per trip, ids and points loaded before any is used: a pole's bin holds a candidate per ring)
+        uint32_t j[4];
+        float4 u[4];
+#pragma unroll
+        for (uint32_t e = 0; e < 4; ++e) j[e] = sorted[min(q + e, q1 - 1u)];
+#pragma unroll
+        for (uint32_t e = 0; e < 4; ++e) u[e] = merge_pt(j[e]);
         // every pair once (j > i)
-        if (j0 > i && dist2(v.x, v.y, v.z, u0.x, u0.y, u0.z) < P.r2_merge) uf_union(parent, j0, i);
-        if (q + 1u < q1 && j1 > i && dist2(v.x, v.y, v.z, u1.x, u1.y, u1.z) < P.r2_merge) uf_union(parent, j1, i);
+#pragma unroll
+        for (uint32_t e = 0; e < 4; ++e)
+          if (q + e < q1 && j[e] > i && dist2(v.x, v.y, v.z, u[e].x, u[e].y, u[e].z) < P.r2_merge) uf_union(parent, j[e], i);
       }
     }
     __syncthreads();
@@ -2163,6 +2246,14 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
     FX_STAMP(9);
   }
 
+  if (FRONT) {  // (keypoint_cloud and its count are the caller's)
+    if (tid == 0) {
+      B.n_cand[scan] = C;
+      B.n_kp[scan] = K;
+    }
+    __syncthreads();
+    return true;
+  }
   // ---- keypoint_cloud: chunks into ring order, candidate slot -> ordinal in keypoints_full
   const uint32_t *koff = B.ring_off + (size_t)scan * R;
   const uint32_t *kcnt = B.kpc_ring_cnt + (size_t)scan * R;
@@ -2249,8 +2340,761 @@ extern "C" __global__ __launch_bounds__(FX_MBIG_T) void k_merge_huge(FxDevParams
   }
 }
 
+// ====================================================================== stages 1-3 in one launch: k_front
+// Scans whose filtered cloud fits LDS (every VLP-16-class scan: ~2600 survivors of 28 800 points) go from the input to
+// keypoints in ONE launch — filter, ring split, per-ring clustering, secondary merge — without their intermediates ever
+// leaving the chip (ref: node.cpp:147-259 is one call chain).  The separate kernels wrote the filtered cloud, read it
+// back to write the ring-major copy, read that to write candidates and member pools, and read those to merge:
+// 0.26 GB of a 1024-scan batch's 1.12 GB, and four of its fifteen dependent launches.
+//   A  the streaming pass of k_prep (prep_stream): ~cloud and near bits to HBM, ring counts in LDS;
+//   B  the ring split of k_bucket with an LDS destination: ring-major x / y / z (+ the survivor's index: elevation and
+//      the member copies come from ~cloud, which the workgroup has just written — L2 hits);
+//   C  getCylinderSegments for ALL rings of the scan at once by the whole workgroup (a scan's rings are unequal — two
+//      ground rings of ~500 points, most of ~70 — so a ring per wavefront would leave the workgroup waiting for its two
+//      slowest wavefronts): the run tier's scheme (ring_runs_body) on one table of runs / 16-point segments over the
+//      concatenated rings — runs never cross a ring start, near run pairs are looked for inside a ring only —; PCL's
+//      cluster order per ring (the replay's partition phase: a ring per wavefront; its ranking: a cluster per thread);
+//   D  the secondary merge (merge_body) on the candidates in LDS; keypoint_cloud written straight in its final order.
+// Anything that does not fit the tables below hands the scan to k_tail, which runs the general kernels' bodies on it
+// from ~cloud: more ring entries than FX_FRONT_CAP, more runs than FX_FRONT_RUNS, more near run pairs than
+// FX_FRONT_PAIRS, more candidates than the small merge tier holds, or any of the limits the general kernels flag.
+#define FX_FRONT_T FX_PREP_T
+#define FX_FRONT_NW (FX_FRONT_T / 64)
+#ifndef FX_FRONT_CAP
+#define FX_FRONT_CAP (FX_PREP_KEEP + 256)  // ring-major entries (and survivors): the staging buffer of the streaming pass becomes the points (the bench scenes have 2580 on average, 3219 at most)
+#endif
+#ifndef FX_FRONT_RUNS
+#define FX_FRONT_RUNS 512          // runs (and clusters) of all rings together (the bench scenes have 370 on average, 450 at most)
+#endif
+#define FX_FRONT_SEGS (FX_FRONT_CAP / 16 + FX_FRONT_RUNS)  // a segment starts at every run start and at every multiple of 16
+#define FX_FRONT_RMAX 32           // rings
+#define FX_FRONT_PAIRS 512         // near run pairs
+#define FX_FRONT_QUEUE 96          // parked (point, run) items per wavefront
+#define FX_FRONT_BLOCKS (FX_FRONT_CAP / 64)
+#define FX_FRONT_MERGE 512         // candidates (k_merge_small's capacity)
+#define FX_FRONT_SORTW (FX_SORT_STACK_WORDS + 192)  // per wavefront: the replay's stack and position tables (192 clusters a ring; beyond: one lane)
+__host__ __device__ constexpr uint32_t a4(uint32_t v) { return (v + 3u) & ~3u; }
+struct FrontOff {  // word offsets into the LDS image
+  static constexpr uint32_t px = 0, py = FX_FRONT_CAP, pz = 2 * FX_FRONT_CAP, sidx = 3 * FX_FRONT_CAP;  // sidx: uint16
+  static constexpr uint32_t s_w = sidx + FX_FRONT_CAP / 2;                // [64] block helpers 0..15, broadcast slots 16..
+  static constexpr uint32_t r_off = s_w + 64;                             // [RMAX + 1] first ring-major entry of each ring
+  static constexpr uint32_t r_cnt = r_off + FX_FRONT_RMAX + 4;            // [RMAX] entries per ring
+  static constexpr uint32_t r_run0 = r_cnt + FX_FRONT_RMAX;               // [RMAX + 1] first run of each ring
+  static constexpr uint32_t r_cb = r_run0 + FX_FRONT_RMAX + 4;            // [RMAX + 1] first cluster of each ring
+  static constexpr uint32_t smask = r_cb + FX_FRONT_RMAX + 4;             // [BLOCKS] uint64: run starts
+  static constexpr uint32_t gmask = smask + 2 * FX_FRONT_BLOCKS;          // [BLOCKS] uint64: segment starts
+  static constexpr uint32_t run_base = gmask + 2 * FX_FRONT_BLOCKS;       // [BLOCKS] runs before the block
+  static constexpr uint32_t seg_base = run_base + FX_FRONT_BLOCKS;        // [BLOCKS] segments before the block
+  static constexpr uint32_t seg_start = seg_base + FX_FRONT_BLOCKS;       // uint16 [SEGS + 1]
+  static constexpr uint32_t seg_box = a4(seg_start + (FX_FRONT_SEGS + 2) / 2);  // [SEGS][min x, max x, min y, max y]
+  static constexpr uint32_t rbox = seg_box + 4 * FX_FRONT_SEGS;           // [RUNS][4] run boxes, then cluster boxes, then centroids
+  static constexpr uint32_t rseg = rbox + 4 * FX_FRONT_RUNS;              // uint16 [RUNS + 1] first segment of each run
+  static constexpr uint32_t rparent = a4(rseg + (FX_FRONT_RUNS + 2) / 2); // [RUNS] union-find over runs
+  static constexpr uint32_t rsize = rparent + FX_FRONT_RUNS;              // [RUNS] points of the component | (position in PCL's order + 1) << 16
+  static constexpr uint32_t roff = rsize + FX_FRONT_RUNS;                 // uint16 [RUNS] clusters before the run, then the run's offset inside its cluster
+  static constexpr uint32_t croot = a4(roff + FX_FRONT_RUNS / 2);         // uint16 [RUNS + 8] root run by discovery ordinal, then member offsets
+  static constexpr uint32_t crec = croot + FX_FRONT_RUNS / 2 + 4;         // [RUNS + 4]
+  static constexpr uint32_t ctmp = crec + FX_FRONT_RUNS + 4;              // [RUNS + 4]
+  static constexpr uint32_t end = ctmp + FX_FRONT_RUNS + 4;
+  // overlays: the streaming pass's tables and the split's counters live in the (not yet used) segment boxes, the ring-start
+  // bits, the near pairs and the wavefronts' queues in the (not yet used) cluster tables, the replay's scratch in the
+  // (no longer used) segment boxes
+  static constexpr uint32_t atan = seg_box, win = atan + a4(2 * (FX_ATAN_N + 1) * (FX_ATAN_DEG + 1)), cnt = win + 2 * FX_FRONT_RMAX,
+                            cw = cnt + 2 * FX_FRONT_NW, a_end = cw + 2 * FX_FRONT_NW * FX_FRONT_RMAX;
+  static constexpr uint32_t rsm = croot, pairs = croot, queues = pairs + FX_FRONT_PAIRS, q_end = queues + FX_FRONT_NW * FX_FRONT_QUEUE;
+};
+static_assert(FrontOff::end * 4 <= 80 * 1024, "two workgroups of k_front a CU");
+static_assert(FrontOff::a_end <= FrontOff::rbox && FrontOff::q_end <= FrontOff::end, "k_front overlays");
+static_assert(FX_FRONT_NW * FX_FRONT_SORTW <= 4 * FX_FRONT_SEGS, "k_front: the replay's scratch borrows the segment boxes");
+static_assert(FX_FRONT_RUNS <= 1024 && FX_FRONT_CAP <= 4096 && FX_FRONT_BLOCKS <= 64 && FX_FRONT_RMAX <= 64 && FX_FRONT_CAP % 64 == 0 &&
+                  FX_FRONT_CAP >= FX_PREP_KEEP, "k_front packings");
+static_assert((FrontOff::smask % 2) == 0 && (FrontOff::rsm % 2) == 0 && (FrontOff::seg_box % 4) == 0 && (FrontOff::rbox % 4) == 0, "k_front alignment");
+__host__ __device__ inline size_t front_lds_bytes() { return (size_t)FrontOff::end * 4; }
+
+__device__ __forceinline__ unsigned long long le_mask64(uint32_t lane) { return lane == 63u ? ~0ull : ((2ull << lane) - 1ull); }
+
+extern "C" __global__ __launch_bounds__(FX_FRONT_T, FX_PREP_OCC) void k_front(FxDevParams P, FxBuffers B, float near_margin, float el0, float inv_step,
+                                                                           uint32_t clk_slot, uint32_t merge_cap, uint32_t force_redo) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  using O = FrontOff;
+  constexpr uint32_t NT = FX_FRONT_T, NW = FX_FRONT_NW, CAP = FX_FRONT_CAP, RUNS = FX_FRONT_RUNS, SEGS = FX_FRONT_SEGS;
+  static_assert(merge_words(FX_FRONT_MERGE, FX_FRONT_MERGE, FX_FRONT_RMAX, true) <= 3 * FX_FRONT_CAP, "the merge's image borrows the points");
+  const uint32_t scan = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t R = (uint32_t)P.n_rings;
+  float *px = reinterpret_cast<float *>(smem + O::px), *py = reinterpret_cast<float *>(smem + O::py), *pz = reinterpret_cast<float *>(smem + O::pz);
+  uint16_t *sidx = reinterpret_cast<uint16_t *>(smem + O::sidx);
+  uint32_t *s_w = smem + O::s_w, *r_off = smem + O::r_off, *r_cnt = smem + O::r_cnt, *r_run0 = smem + O::r_run0, *r_cb = smem + O::r_cb;
+  unsigned long long *smask = reinterpret_cast<unsigned long long *>(smem + O::smask), *gmask = reinterpret_cast<unsigned long long *>(smem + O::gmask);
+  uint32_t *run_base = smem + O::run_base, *seg_base = smem + O::seg_base;
+  uint16_t *seg_start = reinterpret_cast<uint16_t *>(smem + O::seg_start), *rseg = reinterpret_cast<uint16_t *>(smem + O::rseg),
+           *roff = reinterpret_cast<uint16_t *>(smem + O::roff);
+  uint32_t *seg_box = smem + O::seg_box, *rbox = smem + O::rbox, *rparent = smem + O::rparent, *rsize = smem + O::rsize;
+  uint16_t *croot = reinterpret_cast<uint16_t *>(smem + O::croot);
+  uint32_t *crec = smem + O::crec, *ctmp = smem + O::ctmp;
+  {  // the support-list counters of the batch are cleared here, a slice per scan (k_gather fills them)
+    const uint32_t per = (P.max_total_kp + gridDim.x - 1) / gridDim.x;
+    const uint32_t z0 = scan * per, z1 = min(z0 + per, P.max_total_kp);
+    for (uint32_t t = z0 + tid; t < z1; t += NT) B.s_cnt[t] = 0u;
+    if (tid == 0) B.ovf_cnt[scan] = 0u;  // entries in the scan's overflow region (k_gather)
+  }
+  const FxScanMeta M = B.meta[scan];
+  FX_STAMP_INIT(B.stamps);
+  if (tid == 0) atomicMin(&B.clk[2 * clk_slot], (unsigned long long)wall_clock64());
+  auto stamp_end = [&]() {
+    if (tid == 0) atomicMax(&B.clk[2 * clk_slot + 1], (unsigned long long)wall_clock64());
+  };
+  auto no_keypoints = [&]() {  // ref: node.cpp:209-210, 263-264
+    if (tid == 0) {
+      B.n_cand[scan] = 0u;
+      B.n_kp[scan] = 0u;
+      B.n_kpc[scan] = 0u;
+    }
+  };
+  if (M.n == 0) {  // empty scan: its pointer may be null — nothing is loaded
+    if (tid == 0) {
+      B.n_filt[scan] = 0u;
+      B.flags[scan] = 0u;
+    }
+    no_keypoints();
+    for (uint32_t r = tid; r < R; r += NT) B.ring_cnt[(size_t)scan * R + r] = 0u;
+    if (scan == 0 && tid < FX_N_COUNTERS) B.counters[tid] = 0u;
+    return;
+  }
+  // ---------------------------------------------------------------- A: the streaming pass
+  const PrepLds PL{smem + O::cnt, px, r_cnt, reinterpret_cast<double *>(smem + O::atan), reinterpret_cast<float2 *>(smem + O::win)};
+  const uint32_t nf = prep_stream(P, B, M, scan, near_margin, el0, inv_step, PL);
+  FX_STAMP(1);
+  for (uint32_t r = tid; r < R; r += NT) B.ring_cnt[(size_t)scan * R + r] = r_cnt[r];  // (k_tail's ring split starts from these)
+  if (tid == 0) {
+    B.n_filt[scan] = nf;
+    B.flags[scan] = 0u;
+  }
+  if (scan == 0 && tid < FX_N_COUNTERS) B.counters[tid] = 0u;  // work-list counters of the batch (not the one k_front itself adds to)
+  uint32_t n = 0, ring_max = 0;
+  for (uint32_t r = 0; r < R; ++r) {
+    const uint32_t c = r_cnt[r];
+    n += c;
+    ring_max = max(ring_max, c);
+  }
+  auto redo = [&]() {  // (workgroup-uniform) the general kernels' bodies take the scan from ~cloud: k_front_redo
+    if (tid == 0) B.redo[atomicAdd(&B.counters[FX_CNT_REDO], 1u)] = scan;
+    stamp_end();
+  };
+  if (n > CAP || nf > CAP || ring_max > P.max_ring_points || force_redo) {  // (force_redo: the test build's hook)
+    redo();
+    return;
+  }
+  if (n == 0) {
+    no_keypoints();
+    stamp_end();
+    return;
+  }
+  // ---------------------------------------------------------------- B: ring split into LDS (ref: node.cpp:195-202)
+  // A stable counting sort by ring with two barriers: every wavefront owns a contiguous slice of ~cloud, ranks its own
+  // points ring by ring (a ballot per ring present in 64 points, a running count per (wavefront, ring) in LDS), the counts
+  // of the wavefronts before it make the slice's base in every ring, and the points go to their places.
+  const float4 *f = B.filt + (size_t)scan * P.max_points;
+  {
+    const float2 *s_win = PL.win;
+    uint32_t *cw = smem + O::cw, *cbase = cw + NW * FX_FRONT_RMAX;  // [NW][R] points of the wavefront's slice per ring; its first place per ring
+    if (tid < 64) {
+      const uint32_t c = tid < R ? r_cnt[tid] : 0u;
+      uint32_t inc = c;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(inc, d, 64);
+        if ((int)lane >= d) inc += t;
+      }
+      if (tid <= R) r_off[tid] = inc - c;  // (r_off[R] = n)
+    }
+    FX_STAMP(16);
+    wg_global_sync();  // (~cloud was written by the other wavefronts' sweeps)
+    FX_STAMP(17);
+    constexpr uint32_t kSub = (CAP + 64 * NW - 1) / (64 * NW);   // 64-point pieces of a wavefront's slice at most
+    const uint32_t S = ((nf + 64u * NW - 1u) / (64u * NW)) * 64u;  // slice length
+    float4 pre[kSub];  // the whole cloud's loads are in flight at once
+#pragma unroll
+    for (uint32_t u = 0; u < kSub; ++u) pre[u] = f[min(wave * S + u * 64u + lane, nf - 1u)];
+    uint32_t mask[kSub], place[kSub][3];
+    int r_first[kSub];
+    uint32_t run_cnt = 0;  // lane r: points of ring r in this wavefront's slice so far (no LDS round trip per ring in the loop below)
+#pragma unroll
+    for (uint32_t u = 0; u < kSub; ++u) {
+      mask[u] = 0, r_first[u] = 0;
+      place[u][0] = place[u][1] = place[u][2] = 0;
+      if (u * 64u >= S) continue;  // (workgroup-uniform)
+      const uint32_t i = wave * S + u * 64u + lane;
+      if (i < nf && isfinite(pre[u].w)) mask[u] = ring_membership(pre[u].w, s_win, P.n_rings, el0, inv_step, r_first[u]);
+      int lo = mask[u] ? r_first[u] : 0x7fffffff, hi = mask[u] ? r_first[u] + 3 : -1;  // rings present in these 64 points: [lo, hi)
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) {
+        lo = min(lo, __shfl_xor(lo, d, 64));
+        hi = max(hi, __shfl_xor(hi, d, 64));
+      }
+      lo = __builtin_amdgcn_readfirstlane(max(lo, 0));
+      hi = __builtin_amdgcn_readfirstlane(min(hi, (int)R));
+      for (int r = lo; r < hi; ++r) {
+        const int d = r - r_first[u];
+        const bool in = mask[u] && d >= 0 && d < 3 && (mask[u] & (1u << d));
+        const unsigned long long m = __ballot(in);
+        if (!m) continue;
+        const uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)run_cnt, r) + lanes_below(m);
+        if (in) {
+          if (d == 0)
+            place[u][0] = at;
+          else if (d == 1)
+            place[u][1] = at;
+          else
+            place[u][2] = at;
+        }
+        if ((int)lane == r) run_cnt += (uint32_t)__popcll(m);
+      }
+    }
+    if (lane < R) cw[wave * R + lane] = run_cnt;
+    FX_STAMP(18);
+    __syncthreads();
+    for (uint32_t t = tid; t < NW * R; t += NT) {
+      const uint32_t w = t / R, r = t - w * R;
+      uint32_t before = r_off[r];
+      for (uint32_t x = 0; x < w; ++x) before += cw[x * R + r];
+      cbase[t] = before;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < kSub; ++u) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        if (mask[u] & (1u << d)) {
+          const uint32_t pos = cbase[wave * R + (uint32_t)(r_first[u] + d)] + place[u][d];
+          px[pos] = pre[u].x, py[pos] = pre[u].y, pz[pos] = pre[u].z;
+          sidx[pos] = (uint16_t)(wave * S + u * 64u + lane);
+        }
+      }
+    }
+    __syncthreads();
+    FX_STAMP(19);
+  }
+  // ---------------------------------------------------------------- C: getCylinderSegments, all rings (ref: node.cpp:261-327)
+  FX_STAMP(2);
+  const float r2 = P.r2_cluster;
+  const uint32_t nblk = (n + 63u) >> 6;
+  auto run_at = [&](uint32_t i) { return run_base[i >> 6] + (uint32_t)__popcll(smask[i >> 6] & le_mask64(i & 63u)) - 1u; };
+  auto run_first = [&](uint32_t r) { return (uint32_t)seg_start[rseg[r]]; };
+  {
+    unsigned long long *rsm = reinterpret_cast<unsigned long long *>(smem + O::rsm);  // bit i: entry i is the first of its ring
+    for (uint32_t t = tid; t < 4 * SEGS; t += NT) seg_box[t] = (t & 1u) ? f2ord(-INFINITY) : f2ord(INFINITY);
+    for (uint32_t t = tid; t < 4 * RUNS; t += NT) rbox[t] = (t & 1u) ? f2ord(-INFINITY) : f2ord(INFINITY);
+    if (tid < FX_FRONT_BLOCKS) rsm[tid] = 0ull;
+    __syncthreads();
+    if (tid < R && r_cnt[tid]) atomicOr(&rsm[r_off[tid] >> 6], 1ull << (r_off[tid] & 63u));
+    __syncthreads();
+    // ---- run labelling: an entry starts a run when it starts its ring or is not closer than the tolerance to its predecessor
+    for (uint32_t b0 = 0; b0 < n; b0 += NT) {
+      const uint32_t i = b0 + tid, k = i >> 6;
+      const bool in = i < n;
+      bool start = false;
+      if (in) {
+        start = (rsm[k] >> lane) & 1ull;
+        if (!start) start = !(dist2(px[i], py[i], pz[i], px[i - 1], py[i - 1], pz[i - 1]) < r2);  // (entry 0 starts a ring)
+      }
+      const unsigned long long m = __ballot(start), g = __ballot(in && (start || (i & 15u) == 0u));
+      if (lane == 0 && b0 + wave * 64u < n) smask[k] = m, gmask[k] = g;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const uint32_t rc = tid < nblk ? (uint32_t)__popcll(smask[tid]) : 0u, sc = tid < nblk ? (uint32_t)__popcll(gmask[tid]) : 0u;
+      uint32_t ir = rc, is = sc;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t tr = __shfl_up(ir, d, 64), ts = __shfl_up(is, d, 64);
+        if ((int)lane >= d) ir += tr, is += ts;
+      }
+      if (tid < FX_FRONT_BLOCKS) run_base[tid] = ir - rc, seg_base[tid] = is - sc;
+      if (tid == 63) s_w[20] = ir, s_w[21] = is;
+    }
+    __syncthreads();
+  }
+  const uint32_t n_runs = s_w[20], n_segs = s_w[21];
+  FX_STAMP(3);
+  if (n_runs > RUNS) {  // (then the segments fit too: at most one per run and one per 16 entries)
+    redo();
+    return;
+  }
+  for (uint32_t b0 = 0; b0 < n; b0 += NT) {
+    const uint32_t i = b0 + tid;
+    if (i < n) {
+      const unsigned long long sm = smask[i >> 6], gm = gmask[i >> 6], le = le_mask64(lane);
+      const uint32_t r = run_base[i >> 6] + (uint32_t)__popcll(sm & le) - 1u, sg = seg_base[i >> 6] + (uint32_t)__popcll(gm & le) - 1u;
+      if ((gm >> lane) & 1ull) seg_start[sg] = (uint16_t)i;
+      if ((sm >> lane) & 1ull) rseg[r] = (uint16_t)sg;
+      const uint32_t ox = f2ord(px[i]), oy = f2ord(py[i]);
+      atomicMin(&seg_box[4 * sg + 0], ox);
+      atomicMax(&seg_box[4 * sg + 1], ox);
+      atomicMin(&seg_box[4 * sg + 2], oy);
+      atomicMax(&seg_box[4 * sg + 3], oy);
+    }
+  }
+  if (tid == 0) {
+    seg_start[n_segs] = (uint16_t)n;
+    rseg[n_runs] = (uint16_t)n_segs;
+    s_w[16] = 0u;  // near run pairs
+    s_w[17] = 0u;  // a ring with more candidates than max_ring_candidates
+  }
+  if (tid <= R) r_run0[tid] = (tid < R && r_off[tid] < n) ? run_at(r_off[tid]) : n_runs;  // (an empty ring: the next ring's first run)
+  __syncthreads();
+  // ---- segment boxes -> floats, folded into the run boxes; union-find over runs
+  for (uint32_t sg = tid; sg < n_segs; sg += NT) {
+    const uint32_t r = run_at(seg_start[sg]);
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+      const uint32_t o = seg_box[4 * sg + k];
+      seg_box[4 * sg + k] = __float_as_uint(ord2f(o));
+      if (k & 1)
+        atomicMax(&rbox[4 * r + k], o);
+      else
+        atomicMin(&rbox[4 * r + k], o);
+    }
+  }
+  __syncthreads();
+  for (uint32_t r = tid; r < n_runs; r += NT) {
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) rbox[4 * r + k] = __float_as_uint(ord2f(rbox[4 * r + k]));
+    rparent[r] = r;
+    rsize[r] = 0u;
+  }
+  __syncthreads();
+  const float4 *sbox4 = reinterpret_cast<const float4 *>(seg_box);
+  FX_STAMP(4);
+  float4 *rbox4 = reinterpret_cast<float4 *>(rbox);
+  const float r2_pad = r2 * 1.001f;  // box distances are lower bounds; pad them against fp32 rounding
+  {
+    // ---- near run pairs of the same ring.  A run's work is the later runs of its ring — two ground rings of ~90 runs hold
+    //      most of a scan's (a, b) tests —, so the tests are laid end to end (prefix of the runs' work in rsize, idle until
+    //      the sizes are summed) and dealt to the lanes in equal contiguous shares.
+    uint32_t *pairs = smem + O::pairs;
+    uint32_t W = 0;
+    for (uint32_t b0 = 0; b0 < n_runs; b0 += NT) {
+      const uint32_t a = b0 + tid;
+      uint32_t w_a = 0;
+      if (a < n_runs) {
+        const uint32_t end_a = r_run0[prefix_owner(r_run0, R, a) + 1u];  // first run of the next ring
+        roff[a] = (uint16_t)end_a;
+        w_a = end_a - a - 1u;
+      }
+      uint32_t tot;
+      const uint32_t ex = block_excl_scan<NT>(w_a, s_w, tot);
+      if (a < n_runs) rsize[a] = W + ex;
+      W += tot;
+    }
+    __syncthreads();
+    {
+      const uint32_t q = (W + NT - 1u) / NT;
+      uint32_t flat = tid * q;
+      const uint32_t flat_end = min(flat + q, W);
+      if (flat < flat_end) {
+        uint32_t lo = 0, hi = n_runs;  // the run of test `flat`: the last one whose tests start at or before it (it has tests: see the prefix)
+        while (hi - lo > 1) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (rsize[mid] <= flat)
+            lo = mid;
+          else
+            hi = mid;
+        }
+        uint32_t a = lo, end_a = roff[a], b = a + 1u + (flat - rsize[a]);
+        float4 ba = rbox4[a];
+        for (; flat < flat_end; ++flat) {
+          const float4 bx = rbox4[b];
+          const float dx = fmaxf(fmaxf(bx.x - ba.y, ba.x - bx.y), 0.0f);
+          const float dy = fmaxf(fmaxf(bx.z - ba.w, ba.z - bx.w), 0.0f);
+          if (!(dx * dx + dy * dy > r2_pad)) {  // (rare)
+            const uint32_t slot = atomicAdd(&s_w[16], 1u);
+            if (slot < FX_FRONT_PAIRS) pairs[slot] = (a << 16) | b;
+          }
+          if (++b == end_a && flat + 1u < flat_end) {  // the next run that has later runs in its ring
+            do {
+              ++a;
+              end_a = roff[a];
+            } while (end_a == a + 1u);
+            ba = rbox4[a];
+            b = a + 1u;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const uint32_t n_rp = s_w[16];
+    FX_STAMP(5);
+    if (tid == 0) {
+      FX_COUNT(20, n_rp);
+      FX_COUNT(21, n_runs);
+      FX_COUNT(22, n);
+      FX_COUNT(23, 1);
+    }
+    if (n_rp > FX_FRONT_PAIRS) {  // runs all over each other (unordered input)
+      redo();
+      return;
+    }
+    // ---- cross-run edges: the points of the earlier run of every near pair against the later run's box; near
+    //      (point, run) items are parked and drained with all lanes busy: the run's segments' boxes, then their points.
+    //      Every pair that could be an edge is examined: exact for any input order.
+    uint32_t *wq = smem + O::queues + wave * FX_FRONT_QUEUE;
+    uint32_t wq_n = 0;
+    auto drain = [&]() {
+      wave_sync_lds();
+      for (uint32_t t = lane; t < wq_n; t += 64) {
+        const uint32_t item = wq[t];
+        const uint32_t i = item & 0xfffu, b = (item >> 12) & 0x3ffu, a = item >> 22;
+        if (uf_find(rparent, a) == uf_find(rparent, b)) continue;  // already one component
+        const float qx = px[i], qy = py[i], qz = pz[i];
+        bool linked = false;
+        for (uint32_t sg = rseg[b]; sg < rseg[b + 1] && !linked; ++sg) {
+          const float4 sb = sbox4[sg];
+          const float dx = fmaxf(fmaxf(sb.x - qx, qx - sb.y), 0.0f);
+          const float dy = fmaxf(fmaxf(sb.z - qy, qy - sb.w), 0.0f);
+          if (dx * dx + dy * dy > r2_pad) continue;
+          const uint32_t j1 = seg_start[sg + 1];
+          for (uint32_t j = seg_start[sg]; j < j1 && !linked; j += 4) {
+            float jx[4], jy[4], jz[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+              const uint32_t ju = min(j + u, j1 - 1u);
+              jx[u] = px[ju], jy[u] = py[ju], jz[u] = pz[ju];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) linked |= dist2(qx, qy, qz, jx[u], jy[u], jz[u]) < r2;
+          }
+          if (linked) uf_union(rparent, b, a);  // the two runs are one component now; more edges add nothing
+        }
+      }
+      wave_sync_lds();
+      wq_n = 0;
+    };
+    for (uint32_t t = wave; t < n_rp; t += NW) {
+      const uint32_t pr = pairs[t], a = pr >> 16, b = pr & 0xffffu;
+      const uint32_t i_end = run_first(a + 1u);
+      {
+        // In an azimuth-ordered ring the edge between two near runs, when there is one, is mostly between the end of the
+        // earlier and the start of the later (an arc behind a pole's shadow): found at once, the pair needs nothing else.
+        const uint32_t ia = i_end - 1u, ib = run_first(b);
+        if (dist2(px[ib], py[ib], pz[ib], px[ia], py[ia], pz[ia]) < r2) {
+          if (lane == 0) uf_union(rparent, b, a);
+          continue;
+        }
+      }
+      const float4 bb = rbox4[b];
+      for (uint32_t i0 = run_first(a); i0 < i_end; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        bool ok = false;
+        if (i < i_end) {
+          const float qx = px[i], qy = py[i];
+          const float dx = fmaxf(fmaxf(bb.x - qx, qx - bb.y), 0.0f);
+          const float dy = fmaxf(fmaxf(bb.z - qy, qy - bb.w), 0.0f);
+          ok = !(dx * dx + dy * dy > r2_pad);
+        }
+        const unsigned long long mk = __ballot(ok);
+        if (mk) {
+          if (ok) wq[wq_n + lanes_below(mk)] = i | (b << 12) | (a << 22);
+          wq_n += (uint32_t)__popcll(mk);
+          if (wq_n > FX_FRONT_QUEUE - 64) drain();
+        }
+      }
+    }
+    if (wq_n) drain();
+    __syncthreads();
+  }
+  // ---- roots (read-only finds, then the owners overwrite), sizes = sums of run lengths
+  FX_STAMP(6);
+  for (uint32_t r = tid; r < n_runs; r += NT) {
+    ctmp[r] = uf_find_ro(rparent, r);
+    rsize[r] = 0u;  // (held the near-pair work prefix)
+  }
+  __syncthreads();
+  for (uint32_t r = tid; r < n_runs; r += NT) {
+    const uint32_t root = ctmp[r];
+    rparent[r] = root;
+    atomicAdd(&rsize[root], run_first(r + 1u) - run_first(r));
+  }
+  __syncthreads();
+  // ---- size-admissible clusters in discovery order (ascending root run: ring by ring, and inside a ring by smallest
+  FX_STAMP(7);
+  //      point index: SURVEY.md A.5); crec = size << 16 | discovery ordinal (only the size is ever compared)
+  uint32_t n_c = 0;
+  for (uint32_t b0 = 0; b0 < n_runs; b0 += NT) {
+    const uint32_t r = b0 + tid;
+    bool acc = false;
+    uint32_t sz = 0;
+    if (r < n_runs && rparent[r] == r) {
+      sz = rsize[r];
+      acc = sz >= P.min_count && sz <= P.max_count;
+    }
+    uint32_t tot;
+    const uint32_t rank = block_rank<NT>(acc, s_w, tot);
+    if (r < n_runs) roff[r] = (uint16_t)(n_c + rank);  // clusters before run r
+    if (acc) {
+      croot[n_c + rank] = (uint16_t)r;
+      crec[n_c + rank] = (sz << 16) | (n_c + rank);
+    }
+    n_c += tot;
+  }
+  __syncthreads();
+  if (tid <= R) r_cb[tid] = (tid < R && r_run0[tid] < n_runs) ? (uint32_t)roff[r_run0[tid]] : n_c;
+  __syncthreads();
+  FX_STAMP(8);
+  // ---- PCL's cluster order, ring by ring: std::sort(rbegin, rend, bySize) replayed (csrc/fx_sort_replay.h) — its
+  //      partition phase (only above 16 clusters) a ring per wavefront, its insertion phase — a stable sort — as a ranking
+  {
+    int *stk = reinterpret_cast<int *>(seg_box + wave * FX_FRONT_SORTW);
+    uint16_t *pos = reinterpret_cast<uint16_t *>(stk + FX_SORT_STACK_WORDS);
+    for (uint32_t ring = wave; ring < R; ring += NW) {
+      const uint32_t lo = r_cb[ring], nc = r_cb[ring + 1] - lo;
+      if (nc <= FX_SORT_THRESHOLD) continue;
+      if (nc <= 64) {
+        sort_partition_wave<1>(crec + lo, (int)nc, stk, pos, pos + nc);
+      } else if (nc <= 128) {
+        sort_partition_wave<2>(crec + lo, (int)nc, stk, pos, pos + nc);
+      } else if (nc <= 192) {
+        sort_partition_wave<3>(crec + lo, (int)nc, stk, pos, pos + nc);
+      } else if (lane == 0) {
+        fx_sort_detail::RevView v{crec + lo, (int)nc};
+        fx_sort_partition_phase(v, (int)nc, stk);
+      }
+    }
+  }
+  __syncthreads();
+  FX_STAMP(9);
+  for (uint32_t g = tid; g < n_c; g += NT) {
+    const uint32_t ring = prefix_owner(r_cb, R, g), lo = r_cb[ring], hi = r_cb[ring + 1];
+    const uint32_t rec = crec[g], sz = rec >> 16;
+    uint32_t p = lo;
+    for (uint32_t d = lo; d < hi; ++d) {
+      const uint32_t sd = crec[d] >> 16;
+      p += (sd > sz || (sd == sz && d < g)) ? 1u : 0u;
+    }
+    ctmp[p] = rec;
+  }
+  __syncthreads();
+  FX_STAMP(10);
+  // ---- cluster boxes = folds of run boxes (min / max are exact whatever the order): roots to ordered uints, the others in
+  for (uint32_t r = tid; r < n_runs; r += NT) {
+    if (rparent[r] != r) continue;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) rbox[4 * r + k] = f2ord(__uint_as_float(rbox[4 * r + k]));
+  }
+  for (uint32_t g = tid; g < n_c; g += NT) crec[g] = ctmp[g];
+  __syncthreads();
+  for (uint32_t r = tid; r < n_runs; r += NT) {
+    const uint32_t root = rparent[r];
+    if (root == r) continue;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+      const uint32_t o = f2ord(__uint_as_float(rbox[4 * r + k]));
+      if (k & 1)
+        atomicMax(&rbox[4 * root + k], o);
+      else
+        atomicMin(&rbox[4 * root + k], o);
+    }
+  }
+  __syncthreads();
+  // ---- diameter gate per cluster, in PCL's cluster order (ref: node.cpp:289-290, 314-316); crec becomes size << 16 | root run
+  for (uint32_t g = tid; g < n_c; g += NT) {
+    const uint32_t rec = crec[g], root = croot[rec & 0xffffu];
+    const double minx = fminf(1000.0f, ord2f(rbox[4 * root + 0])), maxx = fmaxf(-1000.0f, ord2f(rbox[4 * root + 1]));
+    const double miny = fminf(1000.0f, ord2f(rbox[4 * root + 2])), maxy = fmaxf(-1000.0f, ord2f(rbox[4 * root + 3]));
+    const double ddx = maxx - minx, ddy = maxy - miny;
+    ctmp[g] = (sqrt(ddx * ddx + ddy * ddy) < P.gate_diameter) ? 1u : 0u;
+    rsize[root] |= (g + 1u) << 16;  // position in PCL's order (all rings), next to the size
+  }
+  __syncthreads();  // (every reader of croot's ordinals is done: crec may take the roots)
+  for (uint32_t g = tid; g < n_c; g += NT) {
+    const uint32_t rec = crec[g];
+    crec[g] = (rec & 0xffff0000u) | croot[rec & 0xffffu];
+  }
+  __syncthreads();
+  FX_STAMP(11);
+  // ---- centroid of the clusters that pass: fp64 sums in ascending member order = the cluster's runs in run order,
+  //      each run's points in turn (ref: node.cpp:293-297, 317-320); the intensity is the lowest-index member's elevation
+  for (uint32_t g = tid; g < n_c; g += NT) {
+    if (ctmp[g] == 0u) continue;
+    const uint32_t rec = crec[g], sz = rec >> 16, root = rec & 0xffffu;
+    const float el = f[sidx[run_first(root)]].w;
+    const uint32_t r_end = r_run0[prefix_owner(r_cb, R, g) + 1u];
+    double sumx = 0.0, sumy = 0.0, sumz = 0.0;
+    uint32_t cnt = 0;
+    for (uint32_t r = root; r < r_end && cnt < sz; ++r) {
+      if (rparent[r] != root) continue;
+      roff[r] = (uint16_t)cnt;
+      const uint32_t i0 = run_first(r), i1 = run_first(r + 1u);
+      for (uint32_t i = i0; i < i1; i += 4) {
+        float x[4], y[4], z[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+          const uint32_t iu = min(i + u, i1 - 1u);
+          x[u] = px[iu], y[u] = py[iu], z[u] = pz[iu];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+          if (i + u >= i1) continue;
+          sumx += (double)x[u];
+          sumy += (double)y[u];
+          sumz += (double)z[u];
+        }
+      }
+      cnt += i1 - i0;
+    }
+    rbox4[root] = make_float4((float)(sumx / (double)sz), (float)(sumy / (double)sz), (float)(sumz / (double)sz), el);
+  }
+  __syncthreads();
+  FX_STAMP(12);
+  // ---- ordinals in keypoints_full (ring order, then PCL's order: ref node.cpp:205) and offsets of the members in
+  //      keypoint_cloud (:206, 323) of the clusters that pass
+  uint32_t C = 0, n_mem = 0;
+  uint16_t *ckoff = croot;
+  for (uint32_t b0 = 0; b0 < n_c; b0 += NT) {
+    const uint32_t g = b0 + tid;
+    const bool pass = g < n_c && ctmp[g] != 0u;
+    const uint32_t sz = pass ? (crec[g] >> 16) : 0u;
+    uint32_t tot_p, tot_m;
+    const uint32_t rank = block_rank<NT>(pass, s_w, tot_p);
+    const uint32_t koff = block_excl_scan<NT>(sz, s_w, tot_m);
+    if (g < n_c) {
+      ctmp[g] = (C + rank) | (pass ? 0x80000000u : 0u);
+      ckoff[g] = (uint16_t)(n_mem + koff);  // (at most FX_FRONT_CAP members)
+    }
+    C += tot_p;
+    n_mem += tot_m;
+  }
+  if (tid == 0) ctmp[n_c] = C;
+  __syncthreads();
+  if (tid < R && (ctmp[r_cb[tid + 1]] & 0x7fffffffu) - (ctmp[r_cb[tid]] & 0x7fffffffu) > P.max_ring_cands) s_w[17] = 1u;
+  __syncthreads();
+  if (s_w[17] || C > merge_cap || n_mem > P.max_kpc) {  // (the general kernels flag what they have to)
+    redo();
+    return;
+  }
+  FX_STAMP(13);
+  // ---- keypoint_cloud in its final order (every entry: its run, its cluster, its place)
+  {
+    float4 *kpc = B.kpc + (size_t)scan * P.max_kpc;
+    uint32_t *kpc_c = B.kpc_cand + (size_t)scan * P.max_kpc;
+    for (uint32_t i = tid; i < n; i += NT) {
+      const uint32_t r = run_at(i), g1 = rsize[rparent[r]] >> 16;
+      if (g1 == 0u) continue;  // not a size-admissible cluster
+      const uint32_t w = ctmp[g1 - 1u];
+      if (!(w >> 31)) continue;
+      const uint32_t dst = ckoff[g1 - 1u] + roff[r] + (i - run_first(r));
+      kpc[dst] = f[sidx[i]];
+      kpc_c[dst] = w & 0x7fffffffu;
+    }
+    if (tid == 0) B.n_kpc[scan] = n_mem;
+  }
+  FX_STAMP(14);
+  // ---------------------------------------------------------------- D: secondary merge (ref: node.cpp:209-257)
+  const FrontCands FC{crec, ctmp, rbox4, n_c, C};
+  merge_body<NT, true, true>(P, B, scan, merge_cap, merge_cap, smem, true, &FC);
+  FX_STAMP(15);
+  stamp_end();
+}
+
+// The scans k_front could not take (k_front_redo, a workgroup of k_front's shape each — 512 threads, the same LDS image — so
+// that a launch that finds nothing to do slips in beside the other batches' k_front workgroups instead of waiting for a whole
+// free CU): the general kernels' bodies as far as that image holds them (the ring split to HBM, every ring through the
+// workgroup tier, the merge tiers), starting from ~cloud and the ring counts.  front_general returns false when something
+// does not fit (a ring of more than FX_FRONT_G_CAP1 points with more than FX_FRONT_G_CCAP2 size-admissible clusters, more
+// candidates than either merge tier holds here): such a scan needs k_tail's whole-CU workgroup, which the host launches
+// when the previous batch needed it (tail_follows); a scan that needs it when it was not launched is flagged (never
+// silent), and the next batch gets it.
+#define FX_FRONT_G_WORDS (FrontOff::end - SegCfg<FX_FRONT_T>::kWords)
+#define FX_FRONT_G_CAP1 ((FX_FRONT_G_WORDS / (FX_RING_WORDS_PER_POINT + FX_RING_WORDS_PER_CLUSTER)) & ~3u)  // points = clusters
+#define FX_FRONT_G_CCAP2 224u                                                                          // clusters of a larger ring
+#define FX_FRONT_G_CAP2 (((FX_FRONT_G_WORDS - FX_RING_WORDS_PER_CLUSTER * FX_FRONT_G_CCAP2) / FX_RING_WORDS_PER_POINT) & ~3u)
+__host__ __device__ constexpr uint32_t front_merge_cap_lds() {  // candidates the LDS merge tier holds in k_front's image
+  uint32_t c = 512;
+  while (merge_words(c + 64, c + 64, FX_FRONT_RMAX, true) <= FrontOff::end) c += 64;
+  return c;
+}
+__device__ __forceinline__ bool front_general(const FxDevParams &P, const FxBuffers &B, uint32_t scan, float el0, float inv_step, uint32_t huge_ccap,
+                                           uint32_t *smem) {
+  constexpr int NT = FX_FRONT_T;
+  const uint32_t R = (uint32_t)P.n_rings;
+  if (R > 24)
+    bucket_body<true, NT>(P, B, scan, el0, inv_step, smem);
+  else
+    bucket_body<false, NT>(P, B, scan, el0, inv_step, smem);
+  wg_global_sync();
+  bool ok = true;
+  for (uint32_t ring = 0; ring < R && ok; ++ring) {
+    const uint32_t n = B.ring_cnt[(size_t)scan * R + ring];
+    if (n > P.max_ring_points)
+      ring_body<NT>(P, B, scan, ring, P.max_ring_points, P.max_ring_points, smem, true);  // (flags the scan, touches no LDS)
+    else if (n <= FX_FRONT_G_CAP1)
+      ok = ring_body<NT>(P, B, scan, ring, FX_FRONT_G_CAP1, FX_FRONT_G_CAP1, smem, false);
+    else if (n <= FX_FRONT_G_CAP2)
+      ok = ring_body<NT>(P, B, scan, ring, FX_FRONT_G_CAP2, FX_FRONT_G_CCAP2, smem, false);
+    else
+      ok = false;
+    __syncthreads();
+  }
+  if (!ok) return false;
+  wg_global_sync();
+  constexpr uint32_t kCapLds = front_merge_cap_lds();
+  const uint32_t cap1 = min(kCapLds, P.max_candidates);
+  if (merge_body<NT, true>(P, B, scan, cap1, cap1, smem, cap1 >= P.max_candidates)) return true;
+  __syncthreads();
+  if (merge_words(P.max_candidates, huge_ccap, R, false) > FrontOff::end) return false;
+  merge_body<NT, false>(P, B, scan, P.max_candidates, huge_ccap, smem, true);
+  return true;
+}
+
+extern "C" __global__ __launch_bounds__(FX_FRONT_T) void k_front_redo(FxDevParams P, FxBuffers B, float el0, float inv_step, uint32_t huge_ccap,
+                                                                    uint32_t tail_follows, uint32_t force_tail) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const uint32_t n_redo = B.counters[FX_CNT_REDO];
+  for (uint32_t w = blockIdx.x; w < n_redo; w += gridDim.x) {
+    const uint32_t scan = B.redo[w];
+    const bool done = !force_tail && front_general(P, B, scan, el0, inv_step, huge_ccap, smem);  // (force_tail: the test build's hook)
+    __syncthreads();
+    if (!done && threadIdx.x == 0) {
+      B.redo2[atomicAdd(&B.counters[FX_CNT_REDO + 1], 1u)] = scan;
+      if (!tail_follows) {
+        atomicOr(&B.flags[scan], FX_FLAG_RING_OVERFLOW | FX_FLAG_CAND_OVERFLOW);
+        B.n_cand[scan] = 0u;
+        B.n_kp[scan] = 0u;
+        B.n_kpc[scan] = 0u;
+      }
+    }
+  }
+}
+
+// The scans k_front could not take, one 1024-thread workgroup each: the general kernels' bodies one after the other — ring
+// split to HBM, every ring through the workgroup tier, the merge tiers.  Slow per scan and rare by construction (the host
+// goes back to the separate kernels when a batch hands over more than an eighth of its scans).
+#define FX_TAIL_T 1024
+extern "C" __global__ __launch_bounds__(FX_TAIL_T) void k_tail(FxDevParams P, FxBuffers B, float el0, float inv_step, uint32_t ring_cap, uint32_t merge_cap,
+                                                             uint32_t merge_last, uint32_t huge_ccap) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const uint32_t n_redo = B.counters[FX_CNT_REDO + 1];
+  for (uint32_t w = blockIdx.x; w < n_redo; w += gridDim.x) {
+    const uint32_t scan = B.redo2[w];
+    if (P.n_rings > 24)
+      bucket_body<true, FX_TAIL_T>(P, B, scan, el0, inv_step, smem);
+    else
+      bucket_body<false, FX_TAIL_T>(P, B, scan, el0, inv_step, smem);
+    wg_global_sync();
+    for (uint32_t ring = 0; ring < (uint32_t)P.n_rings; ++ring) {
+      ring_body<FX_TAIL_T>(P, B, scan, ring, ring_cap, ring_cap, smem, true);
+      __syncthreads();
+    }
+    wg_global_sync();
+    if (!merge_body<FX_TAIL_T, true>(P, B, scan, merge_cap, merge_cap, smem, merge_last != 0)) {
+      __syncthreads();
+      merge_body<FX_TAIL_T, false>(P, B, scan, P.max_candidates, huge_ccap, smem, true);
+    }
+    __syncthreads();
+  }
+}
+
 // ====================================================================== stage 4: offsets
-extern "C" __global__ __launch_bounds__(FX_WG) void k_offsets(FxDevParams P, FxBuffers B, uint32_t batch) {
+extern "C" __global__ __launch_bounds__(FX_WG) void k_offsets(FxDevParams P, FxBuffers B, uint32_t batch, uint32_t clk_next) {
   __shared__ uint32_t s_w[FX_NWAVE];
   uint32_t run = 0;
   for (uint32_t b0 = 0; b0 < batch; b0 += FX_WG) {
@@ -2275,6 +3119,12 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_offsets(FxDevParams P, FxB
     B.tier_hint[1] = l2;
     B.tier_hint[2] = B.counters[1];
     B.tier_hint[3] = B.counters[9];
+    B.tier_hint[6] = B.counters[FX_CNT_REDO];  // scans k_front handed to k_tail (which has read the count by now)
+    B.tier_hint[7] = B.counters[FX_CNT_REDO + 1];  // scans k_front_redo handed to k_tail
+    B.counters[FX_CNT_REDO] = 0u;
+    B.counters[FX_CNT_REDO + 1] = 0u;
+    B.clk[2 * clk_next] = ~0ull;  // the clock slot the next batch's first kernel stamps
+    B.clk[2 * clk_next + 1] = 0ull;
     B.kp_offset[batch] = run;
     B.seq[0] += 1ull;  // batch tag of the dense tier's density cache (device side: a replayed HIP graph advances it too)
   }
@@ -3785,7 +4635,6 @@ extern "C" __global__ __launch_bounds__(FX_DSORT_T) void k_dense_sort(FxDevParam
 // (Per-lane walks straight from global memory were measured: 64 scattered 16-byte loads per instruction keep the
 //  texture unit busier than the 24 arithmetic instructions they feed — 3.8 ms against 2.1 ms for a wave-uniform
 //  stream of the whole box, which tests 2-3 times as many targets as a lane needs.)
-typedef float fx_f2 __attribute__((ext_vector_type(2)));
 #define FX_DDENS_T 256
 #define FX_DDENS_Q (4 * FX_DDENS_T)  // queries per work item
 #define FX_DDENS_C 2048              // targets per window
@@ -4387,8 +5236,38 @@ void fxk_merge_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint
 void fxk_merge_huge(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t ccap, uint32_t grid) {
   hipLaunchKernelGGL(k_merge_huge, dim3(grid), dim3(FX_MBIG_T), fxk_merge_huge_lds_bytes(cap, ccap, P.n_rings), s, P, B, cap, ccap);
 }
-void fxk_offsets(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch) {
-  hipLaunchKernelGGL(k_offsets, dim3(1), dim3(FX_WG), 0, s, P, B, batch);
+void fxk_offsets(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t clk_next) {
+  hipLaunchKernelGGL(k_offsets, dim3(1), dim3(FX_WG), 0, s, P, B, batch, clk_next);
+}
+// the fused front kernel takes sensors of up to FX_FRONT_RMAX rings (scans that do not fit its tables go on to k_tail)
+uint32_t fxk_front_max_rings(void) { return FX_FRONT_RMAX; }
+uint32_t fxk_front_merge_cap(void) { return FX_FRONT_MERGE; }
+void fxk_front(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float near_margin, float el0, float inv_step,
+               uint32_t clk_slot, uint32_t merge_cap, uint32_t force_redo) {
+  hipLaunchKernelGGL(k_front, dim3(batch), dim3(FX_FRONT_T), front_lds_bytes(), s, P, B, near_margin, el0, inv_step, clk_slot, merge_cap, force_redo);
+}
+void fxk_front_redo(hipStream_t s, const FxDevParams &P, const FxBuffers &B, float el0, float inv_step, uint32_t huge_ccap, uint32_t tail_follows,
+                    uint32_t force_tail, uint32_t grid) {
+  hipLaunchKernelGGL(k_front_redo, dim3(grid), dim3(FX_FRONT_T), front_lds_bytes(), s, P, B, el0, inv_step, huge_ccap, tail_follows, force_tail);
+}
+size_t fxk_tail_lds_bytes(const FxDevParams &P, uint32_t ring_cap, uint32_t merge_cap, uint32_t huge_ccap) {
+  size_t b = (48 + (size_t)P.n_rings * (2 + FX_TAIL_T / 64) + 1) * 4;
+  b = std::max(b, (size_t)(SegCfg<FX_TAIL_T>::kWords + FX_RING_WORDS_PER_POINT * ring_cap + FX_RING_WORDS_PER_CLUSTER * ring_cap) * 4);
+  b = std::max(b, merge_words(merge_cap, merge_cap, P.n_rings, true) * 4);
+  if (merge_cap < P.max_candidates) b = std::max(b, merge_words(P.max_candidates, huge_ccap, P.n_rings, false) * 4);
+  return b;
+}
+void fxk_tail(hipStream_t s, const FxDevParams &P, const FxBuffers &B, float el0, float inv_step, uint32_t ring_cap, uint32_t merge_cap,
+              uint32_t huge_ccap, uint32_t grid) {
+  hipLaunchKernelGGL(k_tail, dim3(grid), dim3(FX_TAIL_T), fxk_tail_lds_bytes(P, ring_cap, merge_cap, huge_ccap), s, P, B, el0, inv_step, ring_cap,
+                     merge_cap, merge_cap >= P.max_candidates ? 1u : 0u, huge_ccap);
+}
+hipError_t fxk_configure_front(const FxDevParams &P, uint32_t ring_cap, uint32_t merge_cap, uint32_t huge_ccap) {
+  hipError_t e = hipFuncSetAttribute((const void *)k_front, hipFuncAttributeMaxDynamicSharedMemorySize, (int)front_lds_bytes());
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void *)k_front_redo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)front_lds_bytes());
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute((const void *)k_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fxk_tail_lds_bytes(P, ring_cap, merge_cap, huge_ccap));
 }
 // one workgroup per scan when the batch fills the GPU anyway (it is then the only writer of the scan's lists: no
 // global atomics, and it settles the RNG ordinals itself), several when it does not (streaming)

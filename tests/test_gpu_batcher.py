@@ -29,12 +29,14 @@ def _read(path):
     return out
 
 
-def _check(got, oracle, sensors, per_sensor):
+def _check(got, oracle, sensors, per_sensor, poles=None, min_k=0):
     p = capi.params("launch")
     assert len(got) == sensors * per_sensor
     total_k = 0
     for (s, q), (flags, kp, desc) in sorted(got.items()):
-        ora = oracle.run(p, util.vlp16_scan(1000 + 1000 * s + q), roll=0.02, pitch=-0.015)
+        scan = util.vlp16_scan(1000 + 1000 * s + q) if poles is None else capi.synth_scan(capi.synth_cfg(1000 + 1000 * s + q, n_poles=poles))
+        ora = oracle.run(p, scan, roll=0.02, pitch=-0.015)
+        assert len(ora["keypoints"]) >= min_k
         assert flags == 0
         util.assert_bit_equal(kp, ora["keypoints"], f"sensor {s} scan {q} keypoints")
         o = ora["descriptors"]
@@ -64,3 +66,14 @@ def test_burst_grows_the_batches(fxlib, oracle, tmp_path):
     m = re.search(r"(\d+) scans in (\d+) batches \(largest (\d+)\)", r.stdout)
     assert m and int(m.group(1)) == 48 and int(m.group(2)) < 48 and int(m.group(3)) > 1, r.stdout
     _check(_read(out), oracle, 4, 12)
+
+
+def test_scans_with_more_keypoints_than_the_pool_average(fxlib, oracle, tmp_path):
+    """a one- or two-scan batch with more than 64 keypoints a scan (the default pool's average) must not read past
+    the pool: the batcher sizes the pool for max_batch * max_keypoints rows and clamps what it copies."""
+    exe = build.build_batcher()
+    out = tmp_path / "poles.bin"
+    r = subprocess.run([exe, "--sensors", "1", "--burst", "3", "--poles", "256", "--max-batch", "2", "--out", str(out)], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    _check(_read(out), oracle, 1, 3, poles=256, min_k=65)

@@ -70,10 +70,11 @@ def test_128_rings_by_4096_azimuths(fxlib, oracle):
     ctx.close()
 
 
-def test_large_merge_tier_on_vlp16_scans(fxlib, oracle, monkeypatch):
+def test_large_merge_tier_on_vlp16_scans(fx_hooks, oracle):
     """The large merge tier (cell-sorted ids + union-find in LDS, coordinates in HBM) on ordinary scans: the test
-    hook lowers the LDS tier's capacity so that every scan with more than 16 candidates takes it."""
-    monkeypatch.setenv("FX_MERGE_BIG_CAP", "16")
+    hooks take the separate kernels (k_front has its own merge) and lower the LDS tier's capacity so that every scan with
+    more than 16 candidates takes it."""
+    fx_hooks(FX_FRONT=0, FX_MERGE_BIG_CAP=16)
     scans = [util.vlp16_scan(1000 + b) for b in range(6)] + [np.zeros((0, 4), np.float32)]
     for preset in ("launch", "default"):
         p = capi.params(preset)
@@ -183,8 +184,12 @@ def test_stage_timings_are_reported(fxlib):
     ctx.close()
 
 
-def test_stage_bytes_follow_the_batch_counts(fxlib, oracle):
-    """fx_get_stage_bytes: every stage's own algorithmic bytes (the per-kernel roofline's numerator) from the batch's counts."""
+@pytest.mark.parametrize("front", [1, 0])
+def test_stage_bytes_follow_the_batch_counts(fx_hooks, oracle, front):
+    """fx_get_stage_bytes: every stage's own algorithmic bytes (the per-kernel roofline's numerator) from the batch's counts —
+    with the fused front kernel (stage 0 = the scan in, every detector output out, no intermediates) and with the separate
+    kernels."""
+    fx_hooks(FX_FRONT=front)
     B = 3
     scans = [util.vlp16_scan(1000 + b) for b in range(B)]
     p = capi.params("launch")
@@ -194,8 +199,14 @@ def test_stage_bytes_follow_the_batch_counts(fxlib, oracle):
     n_f = sum(len(g["filtered"]) for g in got)
     K = sum(g["n_keypoints"] for g in got)
     assert sb["k_prep"][0] == 16.0 * 28800 * B
-    assert abs(sb["k_prep"][1] - (16.0 * n_f + 28800 * B / 32.0 + 4.0 * 16 * B)) < 1e-6
-    assert sb["k_bucket"][0] == 16.0 * n_f and sb["k_bucket"][1] >= 16.0 * n_f  # (a window-boundary point is in two rings)
+    prep_out = 16.0 * n_f + 28800 * B / 32.0 + 4.0 * 16 * B
+    if front:
+        det_out = sum(24.0 * len(g["candidates"]) + 20.0 * g["n_keypoints"] + 20.0 * len(g["kpc"]) for g in got)
+        assert abs(sb["k_prep"][1] - (prep_out + det_out)) < 1e-6
+        assert all(sb[k] == (0.0, 0.0) for k in ("k_bucket", "k_rings_runs", "k_rings_large", "k_merge"))
+    else:
+        assert abs(sb["k_prep"][1] - prep_out) < 1e-6
+        assert sb["k_bucket"][0] == 16.0 * n_f and sb["k_bucket"][1] >= 16.0 * n_f  # (a window-boundary point is in two rings)
     assert sb["k_desc_group"][1] == 7956.0 * K
     support = sum(int(x) for g in got for x in g["kp_neighbors"])  # neighbours <= support points
     assert sb["k_gather"][1] >= 16.0 * support and sb["k_gather"][0] > 0

@@ -120,6 +120,34 @@ def test_pcl_stride32_and_device_input(fxlib, oracle):
     ctx.close()
 
 
+def test_host_batches_of_mixed_record_strides(fxlib, oracle):
+    """Host scans go to the device as they are: ragged batches that mix 16-byte and 32-byte (pcl::PointXYZI) records, a
+    context that first sees 16-byte records and then wider ones (the staging buffer grows), an empty scan in between."""
+    p = capi.params("launch")
+    base = [util.vlp16_scan(1000 + b) for b in range(5)]
+    base[1] = base[1][:17000]
+    base[3] = base[3][:9001]
+    oras = [oracle.run(p, s, roll=0.02, pitch=-0.015) for s in base]
+    def wide(s):
+        w = np.full((len(s), 8), 7.0, np.float32)
+        w[:, :3] = s[:, :3]
+        return w
+    ctx = capi.Context(p, capi.limits(6, 28800))
+    flags = capi.FX_OUT_HOST | capi.FX_OUT_CLOUDS | capi.FX_OUT_DEBUG
+    for strides in ([16] * 5, [32, 16, 32, 32, 16], [32] * 5, [16, 32, 16, 16, 32]):
+        arrs = [wide(s) if st == 32 else s for s, st in zip(base, strides)]
+        arrs.insert(2, np.zeros((0, 4), np.float32))
+        st_all = strides[:2] + [16] + strides[2:]
+        descs = ctx.make_descs([a.ctypes.data if len(a) else 0 for a in arrs], [len(a) for a in arrs], 16, 0.02, -0.015)
+        for d, st in zip(descs, st_all):
+            d.stride_bytes = st
+        got = ctx.unpack(ctx.process_raw(descs, len(arrs), flags))
+        assert got[2]["n_keypoints"] == 0 and len(got[2]["filtered"]) == 0
+        for b, (g, o) in enumerate(zip(got[:2] + got[3:], oras)):
+            util.compare_scan(g, o, tag=f"strides {strides} scan {b}")
+    ctx.close()
+
+
 def test_argument_errors(fxlib):
     ctx = capi.Context(capi.params("default"), capi.limits(2, 1000))
     s = util.vlp16_scan(1)[:500]
@@ -195,11 +223,11 @@ def test_overflowed_lists_take_the_dense_tier(fxlib, oracle):
     _cmp(oracle, p, capi.limits(3, 28800, max_neighbors=32), scans, 0.02, -0.015, "dense tier, batch of 3")
 
 
-def test_dense_tier_key_sort_in_global_memory(fxlib, oracle, monkeypatch):
+def test_dense_tier_key_sort_in_global_memory(fx_hooks, oracle):
     """k_dense_finish_l sorts up to 16384 keys in LDS; rows beyond that sort in their region of the key pool. Reached
     here by lowering the LDS capacity (FX_DENSE_LDS_KEYS is read at fx_create; it can only lower it)."""
     s = util.vlp16_scan(1000)
-    monkeypatch.setenv("FX_DENSE_LDS_KEYS", "20")
+    fx_hooks(FX_DENSE_LDS_KEYS=20)
     _cmp(oracle, capi.params("launch"), capi.limits(1, 28800, max_neighbors=64), [s], 0.02, -0.015, "dense tier, global key sort")
 
 

@@ -13,6 +13,13 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def separate_kernels(fx_hooks):
+    """These cases are about k_rings_runs / k_rings_runs2 / k_rings_large: the test build's hook takes the separate
+    kernels instead of the fused front kernel (tests/test_gpu_front.py runs the same shapes through that one)."""
+    fx_hooks(FX_FRONT=0)
+
+
 def ring_points(ring, az_deg, rng_m):
     """Returns of VLP-16 ring `ring` (elevation -15 + 2 ring degrees) at the given azimuths / ranges, in that order."""
     el = np.radians(-15.0 + 2.0 * ring)

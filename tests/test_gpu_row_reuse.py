@@ -70,7 +70,7 @@ def test_row_history_with_a_changing_batch_size_matches_a_fresh_context(fxlib):
     ctx.close()
 
 
-def test_tier_grids_follow_the_previous_batch_without_changing_results(fxlib, oracle, monkeypatch):
+def test_tier_grids_follow_the_previous_batch_without_changing_results(fx_hooks, oracle):
     """The grids of the rarely used tiers follow the context's previous batch (FxBuffers::tier_hint): a dense batch right
     after sparse ones runs its dense tier on the smallest grids, a sparse one after it on wide ones — same results either
     way, and with FX_TIER_MIN_GRID=0 (always the full grids)."""
@@ -83,7 +83,7 @@ def test_tier_grids_follow_the_previous_batch_without_changing_results(fxlib, or
     lib = capi.load()
     lib.fx_debug_tier_hints.argtypes = [C.c_void_p, C.c_void_p]
     for min_grid in ("8", "1", "0"):
-        monkeypatch.setenv("FX_TIER_MIN_GRID", min_grid)
+        fx_hooks(FX_TIER_MIN_GRID=min_grid)
         ctx = capi.Context(p, capi.limits(2, 28800))
         seen = []
         for scans, oras, tag in (([sparse], [ora_s], "sparse"), ([sparse, sparse], [ora_s, ora_s], "sparse x2"),
