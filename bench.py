@@ -404,6 +404,16 @@ def main():
     dom_ms = mean_timings(per_ctx_steps)[dom]
     dom_exec_ms = exec_span.get(dom)  # (k_prep only: first workgroup's start to last workgroup's end, device clock)
     profile_all(0)
+    # ---- the same kernel with ONE batch on the chip (outside the timed region): what a kernel trace of `--contexts 1` shows
+    #      (profiles/*_c1_kernel_stats.csv) — with batches in flight a launch's span stretches with whatever shares the chip
+    n_alone = 20
+    ctxs[0].set_profiling(n_alone, stages=[dom])
+    with torch.cuda.stream(streams[0]):
+        for i in range(n_alone):
+            ctxs[0].process_raw(descs_b if i % 2 else descs, B, capi.FX_IN_DEVICE)
+    torch.cuda.synchronize(dev)
+    dom_alone_ms = float(np.mean([ctxs[0].timings(back)[0][dom] for back in range(n_alone)]))
+    ctxs[0].set_profiling(0)
 
     # ---- what the batch produced (for the algorithmic byte count) + a parity spot check
     v = ctx.process_raw(descs_b, B, capi.FX_IN_DEVICE | capi.FX_OUT_HOST)
@@ -413,6 +423,7 @@ def main():
     k_total = (int(v.total_keypoints) + k_total_b) / 2.0  # keypoints per step: the two alternating batches' mean
     flags_or |= int(np.bitwise_or.reduce(np.ctypeslib.as_array(v.h_flags, shape=(B,)))) if B else 0
     stage_bytes = ctx.stage_bytes()  # algorithmic bytes (read, written) of every stage of that batch, from its own counts
+    front = ctx.front_active()
     # non-zero descriptor values of that batch (a row of 1980 bins holds a dozen): what the descriptor stage physically has to
     # store — it writes those and un-writes the row's previous ones — where B_alg counts the whole 7956-byte row
     total_rows = int(v.total_keypoints)
@@ -459,6 +470,8 @@ def main():
         # The named kernel's OWN algorithmic bytes per launch (fx_get_stage_bytes: what it must read of its inputs and write
         # of its outputs, once each, from the batch's counts): the bandwidth statement about that kernel.
         phys_bytes = (stage_bytes["k_prep"][0] + stage_bytes["k_prep"][1] + stage_bytes["k_merge"][1] + 8.0 * desc_nnz)
+        # (stage 0 is ONE kernel either way: k_front — filter to keypoints — for scans that fit its LDS tables, else k_prep)
+        dom_kernel = "k_front" if (dom == "k_prep" and front) else dom
         own_r, own_w = stage_bytes[dom]
         own_bytes = own_r + own_w
         achieved = own_bytes / (dom_ms * 1e-3) / 1e9
@@ -469,7 +482,7 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 # stage -> kernels launched inside it (PMC rows are per kernel)
-                traffic = sum(tj.get(k, 0.0) for k in capi.STAGE_KERNELS.get(dom, (dom,))) or None
+                traffic = tj.get(dom_kernel) or sum(tj.get(k, 0.0) for k in capi.STAGE_KERNELS.get(dom, (dom,))) or None
                 traffic_total = sum(x for k, x in tj.items() if k.startswith("k_"))
             except Exception:
                 traffic = traffic_total = None
@@ -492,13 +505,17 @@ def main():
                        "parallelism": f"frame-sharded x{world}" + (", all-gather of keypoint records (RCCL)" if world > 1 else ""),
                        "keypoints_per_scan": k_all / (world * B), "flags_or": flags_or, "batches_in_flight": K,
                        "gathered_record_flags_or": flag_msg},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": dom_kernel, "stage": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "definition": "achieved = this kernel's own algorithmic bytes per launch (alg_bytes_read + alg_bytes_written, "
                                        "fx_get_stage_bytes) / kernel_ms; path_frac = the whole path's algorithmic bytes per step "
                                        "(SURVEY.md 8d) / ms_per_step / peak: the figure to hold against north_star's 0.40",
                          "alg_bytes_per_launch": own_bytes, "alg_bytes_read": own_r, "alg_bytes_written": own_w,
                          "kernel_ms": dom_ms,
+                         # one batch on the chip at a time (20 steps after the timed region): the figure a kernel trace of
+                         # `bench.py --contexts 1` reproduces (profiles/*_c1_kernel_stats.csv)
+                         "kernel_ms_one_at_a_time": dom_alone_ms,
+                         "frac_one_at_a_time": own_bytes / (dom_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "kernel_ms_source": f"HIP events around this kernel on the launch stream, inside the timed region, {K} batches in flight "
                                              "(also counts the launch's wait for free CUs behind the other batches)",
                          "selected_by": dom_rule,

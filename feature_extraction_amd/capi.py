@@ -27,9 +27,10 @@ STAGE_NAMES = ("k_prep", "k_bucket", "k_rings_runs", "k_rings_large", "k_merge",
 # stages that are one kernel launch (eligible as the roofline line's dominant kernel: their HIP-event span is that kernel)
 SINGLE_LAUNCH_STAGES = ("k_prep", "k_bucket", "k_rings_runs", "k_gather", "k_desc_group", "k_desc_mid")
 # kernels launched inside each timed stage (rocprofv3 / PMC rows are per kernel name)
-STAGE_KERNELS = {"k_bucket": ("k_bucket", "k_bucket_many"),  # (k_bucket_many: sensors of more than 24 rings)
+STAGE_KERNELS = {"k_prep": ("k_prep", "k_front"),  # (k_front: stages 0-4 of scans that fit its LDS tables, in one launch)
+                 "k_bucket": ("k_bucket", "k_bucket_many"),  # (k_bucket_many: sensors of more than 24 rings)
                  "k_rings_large": ("k_rings_runs2", "k_rings_large"),  # (k_rings_runs2: sensors of more than 16 rings)
-                 "k_merge": ("k_merge_small", "k_merge_big", "k_merge_huge", "k_offsets"),
+                 "k_merge": ("k_merge_small", "k_merge_big", "k_merge_huge", "k_front_redo", "k_tail", "k_offsets"),
                  "k_desc_mid": ("k_desc_mid",),
                  "k_gather": ("k_gather", "k_rng_ord"),  # (k_rng_ord only when several workgroups share a scan: small batches)
                  "k_desc_rare": ("k_dense_sort", "k_dense_density", "k_dense_finish_s", "k_dense_finish_l")}
@@ -99,7 +100,8 @@ class FxSynthCfg(C.Structure):
 
 
 # every symbol include/fx.h declares (tests/test_capi_symbols.py checks the list against the header)
-EXPORTS = ("fx_version", "fx_status_str", "fx_last_error", "fx_params_default", "fx_params_launch",
+FX_HEADER_VERSION = (0 << 16) | 5  # the include/fx.h these ctypes structures mirror
+EXPORTS = ("fx_version", "fx_check_abi", "fx_status_str", "fx_last_error", "fx_params_default", "fx_params_launch",
            "fx_limits_default", "fx_create", "fx_destroy", "fx_set_stream", "fx_get_stream", "fx_set_graph_batch", "fx_set_profiling", "fx_set_profiling_stages", "fx_get_timings",
            "fx_get_stage_bytes", "fx_get_limits", "fx_process_batch", "fx_synchronize", "fx_pack_features", "fx_pack_keypoint_records",
            "fx_rotation_from_roll_pitch", "fx_sc3d_tables", "fx_sc3d_xaxis", "fx_synth_cfg_vlp16",
@@ -150,6 +152,11 @@ def load():
             "(hipcc --offload-arch=gfx950). The hot path has no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
     lib.fx_version.restype = C.c_uint32
+    # the ABI guard before anything else: these structures must be the library's (include/fx.h fx_check_abi)
+    lib.fx_last_error.restype = C.c_char_p
+    lib.fx_check_abi.argtypes = [C.c_uint32, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]
+    if lib.fx_check_abi(FX_HEADER_VERSION, C.sizeof(FxParams), C.sizeof(FxLimits), C.sizeof(FxScanDesc), C.sizeof(FxBatchView)) != FX_OK:
+        raise RuntimeError(f"{LIB_PATH}: {lib.fx_last_error().decode()}")
     lib.fx_status_str.restype = C.c_char_p
     lib.fx_status_str.argtypes = [C.c_int]
     lib.fx_last_error.restype = C.c_char_p
@@ -309,6 +316,12 @@ class Context:
         check(self.lib.fx_get_timings(self.handle, back, C.byref(t)))
         self.last_k_prep_exec_ms = t.k_prep_exec_ms
         return {STAGE_NAMES[i]: t.ms[i] for i in range(FX_N_STAGES)}, t.total_ms
+
+    def front_active(self):
+        """True when the last batch went through the fused front kernel (k_front: stages 0-4 in one launch)."""
+        self.lib.fx_debug_front.argtypes = [C.c_void_p]
+        self.lib.fx_debug_front.restype = C.c_int
+        return bool(self.lib.fx_debug_front(self.handle))
 
     def stage_bytes(self):
         """Algorithmic bytes (read, written) per stage of the last batch: {stage: (read, written)}."""

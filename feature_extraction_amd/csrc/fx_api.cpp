@@ -27,6 +27,8 @@ size_t fxk_merge_lds_bytes(uint32_t cap, uint32_t n_rings);
 size_t fxk_desc_lds_bytes(uint32_t cap);
 size_t fxk_gather_lds_bytes(uint32_t max_keypoints);
 uint32_t fxk_dense_cells(void);
+uint32_t fxk_group_cap(void);
+uint32_t fxk_dfin_kl(void);
 void fxk_dense(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t n_cu, uint32_t rows, uint32_t items);
 size_t fxk_merge_huge_lds_bytes(uint32_t cap, uint32_t ccap, uint32_t n_rings);
 hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t merge_huge, size_t desc_big, size_t gather);
@@ -149,6 +151,12 @@ struct fx_ctx {
   bool front_ok = false;       // sensor within k_front's ring capacity
   bool front_last = false;     // what the last batch ran
   uint32_t front_force = 0;    // test hook (FX_FRONT_FORCE)
+  // A batch that failed after its kernels were enqueued leaves state the next batch would build on: descriptor rows are
+  // cleared by un-writing what the last batch recorded for them (desc_nbins / desc_bins), the work-list counters are
+  // cleared by the batch's first kernel, the tier hints size the next grids.  The next batch then starts from scratch:
+  // every row is cleared whole, counters and hints are reset (fx_process_batch).
+  bool state_suspect = false;
+  uint32_t fail_after = 0;     // test hook (FX_FAIL_AFTER_ENQUEUE = n: the n-th batch returns an error after its kernels were enqueued)
   uint32_t front_pause = 0;    // batches left on the separate kernels
   static constexpr uint32_t front_retry = 64;
 };
@@ -346,6 +354,19 @@ extern "C" {
 
 const char *fx_last_error(void) { return g_last_error.c_str(); }
 
+fx_status fx_check_abi(uint32_t header_version, size_t sizeof_params, size_t sizeof_limits, size_t sizeof_scan_desc, size_t sizeof_batch_view) {
+  const uint32_t lib_version = ((uint32_t)FX_VERSION_MAJOR << 16) | FX_VERSION_MINOR;
+  if (header_version == lib_version && sizeof_params == sizeof(fx_params) && sizeof_limits == sizeof(fx_limits) &&
+      sizeof_scan_desc == sizeof(fx_scan_desc) && sizeof_batch_view == sizeof(fx_batch_view))
+    return FX_OK;
+  char msg[256];
+  snprintf(msg, sizeof msg, "caller compiled against fx.h %u.%u (fx_params %zu, fx_limits %zu, fx_scan_desc %zu, fx_batch_view %zu bytes); "
+           "this library is %u.%u (%zu, %zu, %zu, %zu)", header_version >> 16, header_version & 0xffffu, sizeof_params, sizeof_limits,
+           sizeof_scan_desc, sizeof_batch_view, lib_version >> 16, lib_version & 0xffffu, sizeof(fx_params), sizeof(fx_limits),
+           sizeof(fx_scan_desc), sizeof(fx_batch_view));
+  return fail(FX_ERR_INVALID_ARG, msg);
+}
+
 fx_status fx_create(const fx_params *params, const fx_limits *limits, int device_id, fx_ctx **out) {
   if (!params || !limits || !out) return fail(FX_ERR_INVALID_ARG, "null argument");
   *out = nullptr;
@@ -472,7 +493,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
     P.max_dense_rows = (uint32_t)(rows < L.max_total_keypoints ? rows : L.max_total_keypoints);
   }
   P.dense_qcap = P.dense_cap > 0x7ff00000u ? 0xfff00000u : 2u * P.dense_cap;  // (cells' queries padded to four: typically 1.2 entries per query)
-  P.dense_lds_keys = 14336u;  // FX_DFIN_KL of fx_kernels.hip
+  P.dense_lds_keys = fxk_dfin_kl();
   if (const char *e = test_hook("FX_DENSE_LDS_KEYS")) {  // test hook: push rows on to the global-memory key sort (can only lower the cap)
     const int v = atoi(e);
     if (v >= 1 && (uint32_t)v < P.dense_lds_keys) P.dense_lds_keys = (uint32_t)v;
@@ -532,7 +553,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   FX_A(dev_alloc(c, &b.n_kpc, B));
   FX_A(dev_alloc(c, &b.desc, (size_t)L.max_total_keypoints * FX_DESC_FLOATS + 4));
   FX_A(dev_alloc(c, &b.desc_nbins, (size_t)L.max_total_keypoints));
-  FX_A(dev_alloc(c, &b.desc_bins, (size_t)L.max_total_keypoints * 64));  // (FX_GROUP_CAP of fx_kernels.hip)
+  FX_A(dev_alloc(c, &b.desc_bins, (size_t)L.max_total_keypoints * fxk_group_cap()));
   // rows start out zero with nothing recorded in them: k_desc_group then clears a row by un-writing what it wrote last time
   if (hipMemset(b.desc, 0, ((size_t)L.max_total_keypoints * FX_DESC_FLOATS + 4) * sizeof(float)) != hipSuccess ||
       hipMemset(b.desc_nbins, 0, (size_t)L.max_total_keypoints * sizeof(uint32_t)) != hipSuccess)
@@ -649,6 +670,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   if (const char *e = test_hook("FX_FRONT")) c->front_ok = c->front_ok && atoi(e) != 0;  // 0 = the separate kernels (measurements; tests of those kernels)
   // 1: k_front hands every scan to k_front_redo; 2: and that one every scan to k_tail (tests of those two)
   if (const char *e = test_hook("FX_FRONT_FORCE")) c->front_force = (uint32_t)std::max(0, atoi(e));
+  if (const char *e = test_hook("FX_FAIL_AFTER_ENQUEUE")) c->fail_after = (uint32_t)std::max(0, atoi(e));
   if (c->front_ok) {
     hipError_t ce = fxk_configure_front(P, L.max_ring_points, c->merge_big_cap, c->merge_huge_ccap);
     if (ce != hipSuccess) return bail(fail(FX_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(ce)));
@@ -882,6 +904,23 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
   FX_HIP(hipEventRecord(c->meta_ev[slot], s));
   c->meta_used[slot] = true;
 
+  // ---- state a failed batch may have left behind (see fx_ctx::state_suspect)
+  if (c->state_suspect) {
+    FX_HIP(hipMemsetAsync(c->buf.desc_nbins, 0xff, (size_t)L.max_total_keypoints * sizeof(uint32_t), s));  // FX_ROW_DIRTY: clear whole
+    FX_HIP(hipMemsetAsync(c->buf.counters, 0, FX_N_COUNTER_WORDS * sizeof(uint32_t), s));
+    FX_HIP(hipStreamSynchronize(s));  // (the hints are host memory the device writes: nothing of the failed batch may land after the reset)
+    for (int i = 0; i < FX_N_HINTS; ++i) c->tier_hint[i] = 0xffffffffu;
+    c->front_pause = 0;
+    c->state_suspect = false;
+  }
+  struct Suspect {  // armed from the first launch to the successful return
+    fx_ctx *c;
+    bool armed = false;
+    ~Suspect() {
+      if (armed) c->state_suspect = true;
+    }
+  } suspect{c};
+  suspect.armed = true;
   // ---- kernels
   const FxDevParams &P = c->dp;
   const FxBuffers &B = c->buf;
@@ -900,6 +939,12 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
   else
     FX_TRY(enqueue_stages(c, s, batch, prof, front));
   c->front_last = front;
+#ifdef FX_TEST_HOOKS
+  if (c->fail_after && c->batch_seq + 1 == c->fail_after) {  // a failure after the kernels went out
+    ++c->batch_seq;
+    return fail(FX_ERR_HIP, "FX_FAIL_AFTER_ENQUEUE (test hook)");
+  }
+#endif
   if (prof) ++c->ev_count;
   ++c->batch_seq;
   c->last_batch = batch;
@@ -921,7 +966,10 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
   out->d_n_kpc = B.n_kpc;
   out->d_kpc = (const float *)B.kpc;
 
-  if (!(flags & FX_OUT_HOST)) return FX_OK;
+  if (!(flags & FX_OUT_HOST)) {
+    suspect.armed = false;
+    return FX_OK;
+  }
   const size_t Bm = L.max_batch;
   FX_TRY(host_alloc(c, &c->h_n_kp, Bm));
   FX_TRY(host_alloc(c, &c->h_kp_offset, Bm + 1));
@@ -993,6 +1041,7 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
   out->h_flags = c->h_flags;
   out->h_n_filtered = c->h_n_filt;
   out->h_n_kpc = c->h_n_kpc;
+  suspect.armed = false;
   return FX_OK;
 }
 
@@ -1049,6 +1098,8 @@ fx_status fx_debug_tier_hints(fx_ctx *c, uint32_t *out /* FX_N_HINTS = 8 words *
   for (int i = 0; i < FX_N_HINTS; ++i) out[i] = c->tier_hint[i];
   return FX_OK;
 }
+// Diagnostic: 1 when the last batch went through the fused front kernel (k_front), 0 when through the separate kernels.
+int fx_debug_front(fx_ctx *c) { return c && c->front_last ? 1 : 0; }
 // Diagnostic: the work-list counters of the last batch (rings / scans / keypoint rows deferred to larger tiers).
 fx_status fx_debug_counters(fx_ctx *c, uint32_t *out8 /* 16 words */) {
   if (!c || !out8) return fail(FX_ERR_INVALID_ARG, "null argument");

@@ -5184,6 +5184,9 @@ size_t fxk_dense_finish_lds_bytes(int large) {
   return (2 * k + k / 2 + 1984 + FX_TABLE_WORDS + 16) * 4;
 }
 uint32_t fxk_dense_cells(void) { return FX_DCELLS; }
+// build parameters of this translation unit the host sizes buffers by (a build with other values must not outrun them)
+uint32_t fxk_group_cap(void) { return FX_GROUP_CAP; }  // bins k_desc_group records per row (FxBuffers::desc_bins)
+uint32_t fxk_dfin_kl(void) { return FX_DFIN_KL; }      // binned neighbours k_dense_finish_l sorts in LDS
 size_t fxk_desc_lds_bytes(uint32_t cap) { return (size_t)(16 + FX_DESC_WORDS_PER_POINT * cap + FX_DESC_BINS) * 4; }
 
 hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t merge_huge, size_t desc_big, size_t gather) {

@@ -140,6 +140,7 @@ class FeatureExtractionNode {
     fx_limits_default(&l, 1, max_points_);
     l.max_total_keypoints = l.max_keypoints;
     l.max_kpc_points = max_points_;
+    check(FX_CHECK_ABI());  // (this translation unit's fx.h against the library's)
     check(fx_create(&p, &l, device_, &ctx_));
   }
   static void check(fx_status s) {

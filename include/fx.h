@@ -22,7 +22,7 @@ extern "C" {
 #endif
 
 #define FX_VERSION_MAJOR 0
-#define FX_VERSION_MINOR 4
+#define FX_VERSION_MINOR 5
 
 /* pcl::ShapeContext1980: 12 azimuth x 11 elevation x 15 radius bins + rf[9]
  * (ref: include/feature_extraction/feature_extraction_node.h:35-53,75). */
@@ -173,6 +173,15 @@ typedef struct fx_timings {
 typedef struct fx_ctx fx_ctx;
 
 uint32_t fx_version(void);
+/* ABI guard.  The structs of this header may grow at their END between minor versions (fx_limits did in 0.4) and the
+ * library reads every member: a caller compiled against another header must not get as far as fx_create.  Pass the version and
+ * the sizes the caller was compiled with (FX_CHECK_ABI() does); FX_ERR_INVALID_ARG, with the mismatch in fx_last_error(),
+ * when they are not the library's.  Always initialise fx_params / fx_limits with fx_params_default / fx_params_launch /
+ * fx_limits_default of the same library before overriding members. */
+fx_status fx_check_abi(uint32_t header_version, size_t sizeof_params, size_t sizeof_limits, size_t sizeof_scan_desc,
+                       size_t sizeof_batch_view);
+#define FX_CHECK_ABI() \
+  fx_check_abi(((uint32_t)FX_VERSION_MAJOR << 16) | FX_VERSION_MINOR, sizeof(fx_params), sizeof(fx_limits), sizeof(fx_scan_desc), sizeof(fx_batch_view))
 const char *fx_status_str(fx_status s);
 /* message of the last failing call on this thread (HIP error string etc.) */
 const char *fx_last_error(void);

@@ -35,10 +35,34 @@ def test_struct_sizes_match_header(fxlib):
 
 
 def test_version_and_status_strings(fxlib):
-    assert fxlib.fx_version() == (0 << 16) | 4  # FX_VERSION_MAJOR << 16 | FX_VERSION_MINOR (include/fx.h)
+    assert fxlib.fx_version() == (0 << 16) | 5 == capi.FX_HEADER_VERSION  # FX_VERSION_MAJOR << 16 | FX_VERSION_MINOR (include/fx.h)
     for code in range(6):
         assert fxlib.fx_status_str(code)
     assert b"no CPU fallback" in fxlib.fx_status_str(capi.FX_ERR_NO_DEVICE)
+
+
+def test_abi_guard_refuses_other_headers(fxlib):
+    """fx_limits grew in 0.4 and the library reads every member — a caller compiled against another header (another
+    version, or a struct of another size) is refused by fx_check_abi before it gets to fx_create."""
+    sizes = [C.sizeof(capi.FxParams), C.sizeof(capi.FxLimits), C.sizeof(capi.FxScanDesc), C.sizeof(capi.FxBatchView)]
+    assert fxlib.fx_check_abi(capi.FX_HEADER_VERSION, *sizes) == capi.FX_OK
+    assert fxlib.fx_check_abi((0 << 16) | 3, *sizes) == 1  # FX_ERR_INVALID_ARG
+    assert b"0.3" in fxlib.fx_last_error()
+    assert fxlib.fx_check_abi(capi.FX_HEADER_VERSION, sizes[0], sizes[1] - 4, sizes[2], sizes[3]) == 1  # 0.3's nine-word fx_limits
+    assert b"fx_limits 36" in fxlib.fx_last_error()
+
+
+def test_product_library_has_no_environment_hooks(fxlib):
+    """the shipped library must not change tiers, grids or kernels because of the caller's environment — the hooks
+    tests use are compiled only into lib/libfx_hip_test.so (-DFX_TEST_HOOKS)."""
+    from feature_extraction_amd import build
+    product = open(build.LIB, "rb").read()
+    test = open(build.build_test_hooks(), "rb").read()
+    for name in (b"FX_MERGE_BIG_CAP", b"FX_FRONT_FORCE", b"FX_TIER_MIN_GRID", b"FX_DENSE_LDS_KEYS", b"FX_GRAPH_MAX_BATCH", b"FX_DEBUG_SYNC",
+                 b"FX_FAIL_AFTER_ENQUEUE"):
+        assert name not in product, name
+        assert name in test, name
+    assert b"getenv" not in product or b"FX_" not in product[product.find(b"getenv") - 64:product.find(b"getenv") + 64]
 
 
 def test_no_device_means_error_not_fallback(fxlib):

@@ -97,3 +97,39 @@ def test_tier_grids_follow_the_previous_batch_without_changing_results(fx_hooks,
             seen.append(int(hints[4]))
         ctx.close()
         assert seen[0] == 0 and seen[2] > 0 and seen[3] > seen[2] and seen[4] == 0, seen  # dense rows of each batch
+
+
+def test_a_failed_batch_leaves_nothing_for_the_next_one_to_build_on(fx_hooks, oracle):
+    """a batch that fails after its kernels were enqueued (the test build's hook returns FX_ERR_HIP from the third
+    fx_process_batch at that point) — and whatever scribbled into the descriptor rows meanwhile — must not show in the next batch:
+    every row is then cleared whole, counters and tier hints start over.  Compared with the oracle and with a fresh context."""
+    import torch
+    fx_hooks(FX_FAIL_AFTER_ENQUEUE=3)
+    p = capi.params("launch")
+    lim = capi.limits(4, 28800, max_total_keypoints=4 * 256)
+    ctx = capi.Context(p, lim)
+    a = [util.vlp16_scan(3400 + b, n_poles=128) for b in range(4)]
+    b = [util.vlp16_scan(3500 + b) for b in range(3)]
+    _check(ctx, oracle, p, a, "before the failure, a")
+    _check(ctx, oracle, p, b, "before the failure, b")
+    with pytest.raises(capi.FxError, match="FX_FAIL_AFTER_ENQUEUE"):
+        ctx.process_host(a)
+    ctx.synchronize()
+    # what a half-finished pipeline (or a caller that ignored the READ-ONLY rule of d_descriptors) might leave in the rows
+    descs = ctx.make_descs([0], [0])
+    v = ctx.process_raw(descs, 0, 0)  # (an empty batch: the view's device pointers)
+    import ctypes as C
+    n_f4 = 4 * 256 * capi.FX_DESC_FLOATS // 4  # the whole pool, as 16-byte records: written through the library's own unpack kernel
+    junk = torch.full((n_f4, 4), 7.0, dtype=torch.float32, device="cuda")
+    lay = capi.FxPc2Layout(16, 0, 4, 8, 12, 0)
+    capi.check(ctx.lib.fx_unpack_pointcloud2(ctx.handle, C.c_void_p(junk.data_ptr()), n_f4, C.byref(lay), C.c_void_p(v.d_descriptors)))
+    ctx.synchronize()
+    fx_hooks(FX_FAIL_AFTER_ENQUEUE=0)
+    got = _check(ctx, oracle, p, b[::-1], "after the failure")
+    fresh = capi.Context(p, lim)
+    want = fresh.process_host(b[::-1], roll=0.02, pitch=-0.015)
+    for g, w in zip(got, want):
+        assert np.array_equal(g["descriptors"].view(np.uint32), w["descriptors"].view(np.uint32))
+    _check(ctx, oracle, p, a, "and the batch after that")
+    fresh.close()
+    ctx.close()

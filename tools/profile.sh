@@ -9,7 +9,11 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 10 --warmup 2 --no-cpu-baseline --no-extras --check 0 $*"
+# the hardware queues bench.py asks for (its os.environ.setdefault comes too late under the profiler, whose preloaded library
+# has started the runtime by then): without them the four contexts' streams share queues and the trace shows another overlap
+export GPU_MAX_HW_QUEUES=8
+# 100 timed steps, one region (bench.py would repeat it for a second: counters are per launch, one region is enough)
+ARGS="--steps 100 --repeats 1 --warmup 2 --no-cpu-baseline --no-extras --check 0 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$R/bench.py" $ARGS > "$OUT/bench_trace.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python3 "$R/bench.py" $ARGS > "$OUT/bench_fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python3 "$R/bench.py" $ARGS > "$OUT/bench_write.log" 2>&1

@@ -61,4 +61,7 @@ if glob.glob(os.path.join(src, "fetch/**/*_counter_collection.csv"), recursive=T
         w.writerows(rows)
     for r in rows[:12]:
         print(r)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import sq_summary  # noqa: E402
+sq_summary.write_table(src, os.path.join(dst, f"{tag}_cfg{cfg}_sq_counters.csv"), counter, "k_prep")
 print(open(os.path.join(dst, f"{tag}_cfg{cfg}_run.txt")).read())

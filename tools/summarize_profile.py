@@ -62,9 +62,45 @@ def counter(pattern, cname):
 
 
 fetch, dur_f, calls = counter("fetch/**/*_counter_collection.csv", "FETCH_SIZE")
+FIRST = "k_front" if calls.get("k_front") else "k_prep"  # the kernel launched once per batch
 if not n_batches:
-    n_batches = calls["k_prep"]
+    n_batches = calls[FIRST]
 print(f"{n_batches} batches in the counter passes")
+# ---- does the trace show the run it claims to?
+#  (1) the named kernel's average duration in the trace against the SAME run's own measurements of it (bench.py's line in
+#      bench_trace.log: kernel_exec_ms = device-clock span of the launch, kernel_ms = HIP events around it): more than 15 %
+#      apart means the trace is not of that run, and profiles/traffic.json is NOT written;
+#  (2) for information: the sum of all kernels' durations per batch / batches in flight against the run's ms_per_step (they
+#      meet only when the chip is never idle: under the profiler every launch costs more and the batches overlap less), and
+#      the profiled run's throughput (compare with the unprofiled default run, profiles/TAG_bench_default_run.json).
+consistent = True
+check_lines = []
+try:
+    bench_line = [l for l in open(one("bench_trace.log")) if l.startswith('{"metric')][-1]
+    bj = json.loads(bench_line)
+    stats = list(csv.DictReader(open(os.path.join(dst, f"{tag}_kernel_stats.csv"))))
+    first_calls = max(int(r["Calls"]) for r in stats if short(r["Name"]) == FIRST)
+    per_batch_ms = sum(float(r["TotalDurationNs"]) for r in stats if short(r["Name"]).startswith("k_")) / first_calls * 1e-6
+    k_ctx = bj["config"]["batches_in_flight"]
+    rf = bj["roofline"]
+    named = rf["kernel"]
+    avg_ms = [float(r["AverageNs"]) for r in stats if short(r["Name"]) == named][0] * 1e-6
+    own = rf.get("kernel_exec_ms") or rf["kernel_ms"]
+    ratio = avg_ms / own
+    check_lines.append(f"{named}: rocprofv3 average {avg_ms:.4f} ms; the same run's own clock {rf.get('kernel_exec_ms')} ms (device span), "
+                       f"{rf['kernel_ms']:.4f} ms (HIP events): ratio to the run's own {ratio:.2f}")
+    check_lines.append(f"own algorithmic bytes {rf['alg_bytes_per_launch']:.0f} / rocprofv3 average = {rf['alg_bytes_per_launch'] / (avg_ms * 1e-3) / 1e9:.0f} GB/s "
+                       f"= {rf['alg_bytes_per_launch'] / (avg_ms * 1e-3) / 1e9 / 8000:.3f} of the HBM peak (the line of that run says {rf['frac']:.3f} by HIP events, "
+                       f"{rf.get('frac_exec')} by the device span)")
+    check_lines.append(f"sum of kernel durations per batch {per_batch_ms:.3f} ms / {k_ctx} in flight = {per_batch_ms / k_ctx:.3f} ms; the run's ms_per_step "
+                       f"{bj['ms_per_step']:.3f}; the profiled run made {bj['value']:.0f} scans/s")
+    consistent = 0.85 <= ratio <= 1.15
+    if not consistent:
+        check_lines.append("!! the trace's average and the run's own clock are more than 15 % apart: profiles/traffic.json is NOT updated from this run")
+    open(os.path.join(dst, f"{tag}_trace_check.txt"), "w").write("\n".join(check_lines) + "\n")
+    print("\n".join(check_lines))
+except Exception as e:  # (a run without a bench line)
+    print("consistency check skipped:", e)
 write, _, _ = counter("write/**/*_counter_collection.csv", "WRITE_SIZE")
 rows, traffic = [], {}
 for k in sorted(fetch, key=lambda k: -dur_f[k]):
@@ -82,45 +118,12 @@ with open(os.path.join(dst, f"{tag}_hbm_traffic.csv"), "w", newline="") as f:
                 "hbm_MB_per_batch=(2*FETCH+WRITE)", "hbm_GB_per_s"])
     w.writerows(rows)
 traffic["_source"] = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), run {tag}; bytes per batch of the bench workload"
-json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+if consistent:
+    json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 # ---- SQ counters (two passes of eight): where the wave cycles of every kernel go
-sq_names = ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
-            "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VMEM",
-            "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAVES", "SQ_ACTIVE_INST_VMEM"]
-if glob.glob(os.path.join(src, "sq1/**/*_counter_collection.csv"), recursive=True):
-    sq, sq_dur = {}, {}
-    for i, cname in enumerate(sq_names):
-        tot, d, cl = counter(("sq1" if i < 8 else "sq2") + "/**/*_counter_collection.csv", cname)
-        sq[cname] = tot
-        if cname == "SQ_WAVE_CYCLES":
-            sq_dur, nb_sq = d, cl["k_prep"]
-    with open(os.path.join(dst, f"{tag}_sq_counters.csv"), "w", newline="") as f:
-        w = csv.writer(f)
-        w.writerow(["kernel", "ms_per_batch(pmc run)", "waves_per_batch", "wave_Mcycles_per_batch(quad-cycles x4)",
-                    "frac_wait_any(s_waitcnt/barrier)", "frac_wait_inst_any(issue stall)", "frac_active_inst_any",
-                    "frac_active_valu", "frac_active_lds", "frac_wait_inst_lds", "frac_active_vmem",
-                    "mean_waves_in_flight(of 8192 slots)", "valu_insts_per_wave", "lds_insts_per_wave", "salu_insts_per_wave",
-                    "vmem_insts_per_wave", "lds_bank_conflict_frac_of_lds_active"])
-        for k in sorted(sq_dur, key=lambda k: -sq_dur[k]):
-            if not k.startswith("k_"):
-                continue
-            wc = sq["SQ_WAVE_CYCLES"][k]
-            if wc <= 0:
-                continue
-            waves = max(sq["SQ_WAVES"].get(k, 0.0), 1.0)
-            ms = sq_dur[k] / nb_sq
-            # SQ_WAVE_CYCLES and the WAIT / ACTIVE counters are in quad-cycles (MI355X_MICROARCH.md, cycle constants);
-            # mean waves in flight = wave cycles / kernel cycles, with the kernel's cycles from its duration at 2.4 GHz
-            in_flight = (wc * 4.0 / nb_sq) / (ms * 1e-3 * 2.4e9) if ms > 0 else 0.0
-            fr = lambda n: f"{sq[n].get(k, 0.0) / wc:.3f}"  # noqa: E731
-            lds_act = sq["SQ_LDS_IDX_ACTIVE"].get(k, 0.0)
-            w.writerow([k, f"{ms:.4f}", f"{waves / nb_sq:.0f}", f"{wc * 4.0 / nb_sq / 1e6:.2f}", fr("SQ_WAIT_ANY"), fr("SQ_WAIT_INST_ANY"),
-                        fr("SQ_ACTIVE_INST_ANY"), fr("SQ_ACTIVE_INST_VALU"), fr("SQ_ACTIVE_INST_LDS"), fr("SQ_WAIT_INST_LDS"),
-                        fr("SQ_ACTIVE_INST_VMEM"), f"{in_flight:.0f}",
-                        f"{sq['SQ_INSTS_VALU'].get(k, 0.0) / waves:.0f}", f"{sq['SQ_INSTS_LDS'].get(k, 0.0) / waves:.0f}",
-                        f"{sq['SQ_INSTS_SALU'].get(k, 0.0) / waves:.0f}", f"{sq['SQ_INSTS_VMEM'].get(k, 0.0) / waves:.0f}",
-                        f"{sq['SQ_LDS_BANK_CONFLICT'].get(k, 0.0) / lds_act:.3f}" if lds_act > 0 else ""])
-    print(open(os.path.join(dst, f"{tag}_sq_counters.csv")).read())
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import sq_summary  # noqa: E402
+sq_summary.write_table(src, os.path.join(dst, f"{tag}_sq_counters.csv"), counter, FIRST)
 log = one("bench_trace.log")
 line = [l for l in open(log) if l.startswith('{"metric')]
 if line:
