@@ -54,6 +54,17 @@ def build_test_hooks(force=False, verbose=False):
     return LIB_TEST
 
 
+LIB_TRIG = os.path.join(HERE, "lib", "libfx_hip_trigf32.so")
+
+
+def build_trig_literal(force=False, verbose=False):
+    """Measurement build (-DFX_TRIG_LITERAL_F32): phi / theta as PCL writes them — the device's atan2f / acosf, no exact
+    re-evaluation next to a bin edge.  tools/trig_policy.py and tests/test_gpu_trig_policy.py compare it with the product."""
+    if force or stale(LIB_TRIG):
+        _link(LIB_TRIG, ["-DFX_TRIG_LITERAL_F32"], verbose)
+    return LIB_TRIG
+
+
 CLI = os.path.join(HERE, "bin", "fx_cli")
 CLI_SOURCES = ["fx_cli.cpp", "fx_node.hpp", "fx_pcd.hpp"]
 

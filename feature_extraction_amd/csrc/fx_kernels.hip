@@ -4637,7 +4637,9 @@ extern "C" __global__ __launch_bounds__(FX_DSORT_T) void k_dense_sort(FxDevParam
 //  stream of the whole box, which tests 2-3 times as many targets as a lane needs.)
 #define FX_DDENS_T 256
 #define FX_DDENS_Q (4 * FX_DDENS_T)  // queries per work item
+#ifndef FX_DDENS_C
 #define FX_DDENS_C 2048              // targets per window
+#endif
 extern "C" __global__ __launch_bounds__(FX_DDENS_T) void k_dense_density(FxDevParams P, FxBuffers B) {
   __shared__ uint32_t s_tab[FX_DCELLS + 1];     // s_tab[c] = start of cell c, s_tab[c + 1] = its end
   __shared__ float4 s_t[FX_DDENS_C];

@@ -28,6 +28,22 @@ inline uint32_t owner_of(uint64_t scan, uint64_t total, uint32_t world) {
   return r;
 }
 
+// Records every rank contributes to the all-gather of a stream of `total` scans: the plan's largest block (a collective
+// takes equal contributions; a rank whose block is a scan shorter pads it with an empty record), and the row of stream
+// position `scan` in the gathered table (rank blocks of block_size records one after the other).
+inline uint64_t block_size(uint64_t total, uint32_t world) {
+  uint64_t b = 0;
+  for (uint32_t r = 0; r < world; ++r) {
+    const auto s = shard_range(total, world, r);
+    b = s.second - s.first > b ? s.second - s.first : b;
+  }
+  return b;
+}
+inline uint64_t table_row(uint64_t scan, uint64_t total, uint32_t world) {
+  const uint32_t o = owner_of(scan, total, world);
+  return (uint64_t)o * block_size(total, world) + (scan - shard_range(total, world, o).first);
+}
+
 // One scan's record: (1 + rec_kp) float4 = header {n_kp, flags, 0, 0} as uint32, then rec_kp (x, y, z, elevation)
 // entries, zero padded.
 struct KeypointRecordView {

@@ -18,6 +18,9 @@ int main(int argc, char **argv) {
     const uint32_t o = fx::owner_of(s, total, world);
     const auto os = fx::shard_range(total, world, o);
     if (s < os.first || s >= os.second) return 3;
+    // its row in the padded gathered table lies in its owner's block, behind the rows of the block's earlier scans
+    const uint64_t row = fx::table_row(s, total, world), bs = fx::block_size(total, world);
+    if (row / bs != o || row % bs != s - os.first || os.second - os.first > bs || bs > os.second - os.first + 1) return 7;
   }
   FILE *in = std::fopen(argv[4], "rb"), *out = std::fopen(argv[5], "wb");
   if (!in || !out) return 4;
@@ -31,6 +34,11 @@ int main(int argc, char **argv) {
     fx::pack_record(rec.data(), kp.data(), n, 0u, rec_kp);
     const fx::KeypointRecordView v = fx::record_of(rec.data(), 0, rec_kp);
     if (v.n_keypoints() != (n < rec_kp ? n : rec_kp)) return 6;
+    std::fwrite(rec.data(), sizeof(float), rec.size(), out);
+  }
+  // the padding of a short block: empty records up to the plan's block size (what the rank hands the collective)
+  for (uint64_t s = span.second - span.first; s < fx::block_size(total, world); ++s) {
+    fx::pack_record(rec.data(), nullptr, 0u, 0u, rec_kp);
     std::fwrite(rec.data(), sizeof(float), rec.size(), out);
   }
   std::fclose(in);

@@ -27,6 +27,30 @@ def owner_of(scan, total, world):
     return r
 
 
+def block_size(total, world):
+    """Records every rank contributes to the all-gather of a stream of `total` scans: the largest block of the plan (a
+    collective takes equal contributions; the ranks whose block is one scan shorter pad theirs with an empty record)."""
+    return max(shard_range(total, world, r)[1] - shard_range(total, world, r)[0] for r in range(world)) if world else 0
+
+
+def pad_block(rec, total, world):
+    """A rank's [b, 1 + rec_kp, 4] records padded with empty records (n_kp = 0) to block_size(total, world)."""
+    bs = block_size(total, world)
+    if rec.shape[0] == bs:
+        return rec
+    out = np.zeros((bs,) + rec.shape[1:], rec.dtype)
+    out[:rec.shape[0]] = rec
+    return out
+
+
+def stream_order(table, total, world):
+    """The gathered table ([world * block_size, 1 + rec_kp, 4], rank blocks one after the other, padded) -> the `total`
+    records of the stream in stream order (the padding dropped)."""
+    bs = block_size(total, world)
+    rows = [r * bs + i for r in range(world) for i in range(shard_range(total, world, r)[1] - shard_range(total, world, r)[0])]
+    return table[rows]
+
+
 def pack_records(keypoints_per_scan, flags_per_scan, rec_kp=REC_KP):
     """Host-side statement of fx_pack_keypoint_records (used by the CPU tests)."""
     B = len(keypoints_per_scan)

@@ -11,7 +11,7 @@ import pytest
 from feature_extraction_amd import build, sharding
 
 
-@pytest.mark.parametrize("total,world,rec_kp", [(6, 2, 127), (7, 2, 256), (5, 3, 256), (3, 4, 64)])
+@pytest.mark.parametrize("total,world,rec_kp", [(6, 2, 127), (7, 2, 256), (5, 3, 256), (3, 4, 64), (21, 8, 512), (8, 8, 512), (5, 8, 256)])
 def test_ranks_tile_the_stream_and_records_match(tmp_path, total, world, rec_kp):
     build.build_multi()
     exe = build.SELFTEST
@@ -33,9 +33,12 @@ def test_ranks_tile_the_stream_and_records_match(tmp_path, total, world, rec_kp)
         spans.append(tuple(int(x) for x in out.split()))
     assert spans == [sharding.shard_range(total, world, r) for r in range(world)]
     assert spans[0][0] == 0 and spans[-1][1] == total and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
-    got = np.concatenate([np.fromfile(tmp_path / f"out{r}.bin", np.float32) for r in range(world)])
+    # every rank hands the collective block_size records (short blocks padded with empty ones): the gathered table
+    bs = sharding.block_size(total, world)
+    table = np.concatenate([np.fromfile(tmp_path / f"out{r}.bin", np.float32) for r in range(world)]).reshape(world * bs, 1 + rec_kp, 4)
     want = sharding.pack_records(kps, [0] * total, rec_kp=rec_kp)  # (a stride below a scan's count truncates and flags it)
-    assert np.array_equal(got.view(np.uint32), want.reshape(-1).view(np.uint32))
+    got = sharding.stream_order(table, total, world)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     for s in range(total):
         o = sharding.owner_of(s, total, world)
         assert spans[o][0] <= s < spans[o][1]

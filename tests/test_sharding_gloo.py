@@ -15,6 +15,7 @@ from tests import util
 
 TOTAL = 6
 REC_KP = 256  # bench.py's record stride: the contexts' keypoint capacity (limits.max_keypoints), never truncating
+_CACHE = {}
 
 
 def _free_port():
@@ -25,14 +26,15 @@ def _free_port():
     return port
 
 
-def _records_for(span):
+def _records_for(span, rec_kp=REC_KP):
     p = capi.params("launch")
     kps, flags = [], []
     for b in range(*span):
-        r = oracle_py.run(p, util.vlp16_scan(1000 + b, n_az=450), roll=0.02, pitch=-0.015)
-        kps.append(r["keypoints"])
+        if b not in _CACHE:
+            _CACHE[b] = oracle_py.run(p, util.vlp16_scan(1000 + b, n_az=450), roll=0.02, pitch=-0.015)["keypoints"]
+        kps.append(_CACHE[b])
         flags.append(0)
-    return sharding.pack_records(kps, flags, rec_kp=REC_KP)
+    return sharding.pack_records(kps, flags, rec_kp=rec_kp) if kps else np.zeros((0, 1 + rec_kp, 4), np.float32)
 
 
 def _worker(rank, world, port, out_path):
@@ -66,3 +68,31 @@ def test_two_rank_gather_equals_unsharded(tmp_path):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     per_scan = sharding.unpack_records(got)
     assert sum(k for k, _, _ in per_scan) > 0 and all(f == 0 for _, f, _ in per_scan)
+
+
+def _worker_uneven(rank, world, port, total, rec_kp, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    span = sharding.shard_range(total, world, rank)
+    rec = torch.from_numpy(sharding.pad_block(_records_for(span, rec_kp), total, world))  # short blocks padded with empty records
+    assert rec.shape[0] == sharding.block_size(total, world)
+    table = sharding.all_gather_records(rec, world)
+    if rank == 0:
+        np.save(out_path, table.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_a_stream_that_does_not_divide_and_a_record_stride_of_512(tmp_path):
+    """the node's shape — eight ranks —, a stream of 21 scans (blocks of two and three: every rank hands the
+    collective three records, the short blocks padded) and records of 512 keypoints."""
+    total, world, rec_kp = 21, 8, 512
+    out = str(tmp_path / "gathered8.npy")
+    mp.spawn(_worker_uneven, args=(world, _free_port(), total, rec_kp, out), nprocs=world, join=True)
+    table = np.load(out)
+    assert table.shape == (world * sharding.block_size(total, world), 1 + rec_kp, 4)
+    got = sharding.stream_order(table, total, world)
+    want = _records_for((0, total), rec_kp)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert sum(k for k, _, _ in sharding.unpack_records(got)) > 0
