@@ -410,8 +410,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   if (merge_big_cap < L.max_candidates &&
       (L.max_candidates > 65535 || fxk_merge_huge_lds_bytes(L.max_candidates, merge_huge_ccap, params->n_rings) > kLds))
     return fail(FX_ERR_INVALID_ARG, "max_candidates (with max_keypoints) exceeds the LDS budget of the large merge tier (<= ~16000)");
-  if (fxk_gather_lds_bytes(L.max_keypoints) > kLds)
-    return fail(FX_ERR_INVALID_ARG, "max_keypoints exceeds the LDS budget of the support gather (<= ~2300)");
+  if (fxk_gather_lds_bytes(L.max_keypoints) > kLds) return fail(FX_ERR_INVALID_ARG, "support gather: LDS tables beyond the budget (build parameter FX_GATHER_KCAP)");
   if (L.max_keypoints > 65535 || L.max_candidates > 32768 || L.max_ring_points > 32768)
     return fail(FX_ERR_INVALID_ARG, "limit exceeds the 16-bit packing of the order replay");
 

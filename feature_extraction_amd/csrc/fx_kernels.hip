@@ -3285,6 +3285,7 @@ __device__ __forceinline__ unsigned long long sc3d_key(uint32_t bin, float d2, u
                              // measured 72 .. 192 — 96 to 160 are level, 1.2 % above 80; k_gather_wide keeps 80: sixteen queues)
 #endif
 #define FX_GATHER_QUEUE_WIDE 80
+#define FX_GATHER_KCAP 2048  // keypoints the LDS tables hold (148 KB with the wide workgroup's queues); scans with more are gathered in passes
 __host__ __device__ constexpr uint32_t gather_queue(uint32_t nt) { return nt <= 256u ? (uint32_t)FX_GATHER_QUEUE : (uint32_t)FX_GATHER_QUEUE_WIDE; }
 __host__ __device__ inline uint32_t gather_words(uint32_t mk, uint32_t nt) {
   uint32_t w = 32 + 4 * mk;                                   // scratch, keypoints
@@ -3295,10 +3296,13 @@ __host__ __device__ inline uint32_t gather_words(uint32_t mk, uint32_t nt) {
   w += (nt / 64) * gather_queue(nt) * 5;                      // per-wavefront queues: points, cell info
   return w;
 }
-template <int NT>
+// PASSES: contexts whose max_keypoints exceeds FX_GATHER_KCAP (the instance without the pass loop keeps its registers)
+template <int NT, bool PASSES>
 __device__ __forceinline__ void gather_body(const FxDevParams &P, const FxBuffers &B, float box_margin, uint32_t *smem) {
   constexpr uint32_t FX_GATHER_NW = NT / 64;
-  const uint32_t MK = P.max_keypoints;
+  // keypoints the LDS tables hold at a time: a scan with more (a forest under the launch preset) is gathered in passes —
+  // the scan's near sectors are streamed once per FX_GATHER_KCAP keypoints
+  const uint32_t MK = PASSES ? (uint32_t)FX_GATHER_KCAP : P.max_keypoints;  // (the host launches the PASSES instance beyond FX_GATHER_KCAP)
   uint32_t *s_w = smem;                                          // 0..5 keypoint box, 8 staged hits
   float4 *s_kp = reinterpret_cast<float4 *>(smem + 32);          // 16-byte aligned
   uint32_t *s_cell = smem + 32 + 4 * MK;                         // [CELLS + 4] list start | entries << 20
@@ -3318,23 +3322,28 @@ __device__ __forceinline__ void gather_body(const FxDevParams &P, const FxBuffer
   constexpr uint32_t kQueue = gather_queue(NT);
   float4 *q_pt = s_spt + FX_GATHER_STAGE + wave * kQueue;                                                  // this wavefront's queue
   uint32_t *q_info = reinterpret_cast<uint32_t *>(s_spt + FX_GATHER_STAGE + FX_GATHER_NW * kQueue) + wave * kQueue;
-  uint32_t K = B.n_kp[scan];
-  if (K == 0) return;
-  const uint32_t row0 = B.kp_offset[scan];
-  if (row0 >= P.max_total_kp) return;
-  if (row0 + K > P.max_total_kp) K = P.max_total_kp - row0;
+  uint32_t K_all = B.n_kp[scan];
+  if (K_all == 0) return;
+  const uint32_t row_first = B.kp_offset[scan];
+  if (row_first >= P.max_total_kp) return;
+  if (row_first + K_all > P.max_total_kp) K_all = P.max_total_kp - row_first;
   const FxScanMeta M = B.meta[scan];
+  const bool passes = PASSES && K_all > MK;  // (then the has-a-neighbour flags of all keypoints meet in HBM, as with several workgroups a scan)
+  if (tid == 0) s_w[9] = 0;  // entries in the scan's overflow region (one workgroup per scan)
+  uint32_t kb = 0;
+  do {
+  const uint32_t K = PASSES ? min(MK, K_all - kb) : K_all, row0 = row_first + kb;
+  __syncthreads();  // (the previous pass is done with the tables)
   // row -> (scan, keypoint) map for the per-keypoint kernels (one load instead of a binary search)
   if (slice == 0)
-    for (uint32_t k = tid; k < K; k += NT) B.row_map[row0 + k] = make_uint2(scan, k);
+    for (uint32_t k = tid; k < K; k += NT) B.row_map[row0 + k] = make_uint2(scan, kb + k);
   // keypoints of the scan -> LDS; their bounding box (ordered-uint atomics) for a cheap reject
   if (tid < 6) s_w[tid] = (tid & 1) ? f2ord(-INFINITY) : f2ord(INFINITY);
   if (tid == 0) s_w[8] = 0;  // staged hits
-  if (tid == 0) s_w[9] = 0;  // entries in the scan's overflow region (one workgroup per scan)
   for (uint32_t c = tid; c < FX_GATHER_CELLS; c += NT) s_cell[c] = 0;
   __syncthreads();
   for (uint32_t k = tid; k < K; k += NT) {
-    const float4 kp = B.keypoints[(size_t)scan * P.max_keypoints + k];
+    const float4 kp = B.keypoints[(size_t)scan * P.max_keypoints + kb + k];
     s_kp[k] = kp;
     s_kcnt[k] = 0;
     s_kpos[k] = 0;
@@ -3465,10 +3474,10 @@ __device__ __forceinline__ void gather_body(const FxDevParams &P, const FxBuffer
         if (d2 < P.r2_support) {
           // 3DSC draws its x-axis only for keypoints that have a neighbour (d2 < R^2: the descriptor kernels' count)
           if (d2 < P.r2_search) {
-            if (solo)
+            if (solo && !passes)
               s_knbr[k] = 1u;
             else
-              B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = 1u;  // (cleared by the merge stage; k_rng_ord reads it)
+              B.kp_nbrs[(size_t)scan * P.max_keypoints + kb + k] = 1u;  // (cleared by the merge stage; k_rng_ord reads it)
           }
           // One workgroup per scan: the list position is the workgroup's own LDS counter, so the hit goes straight to
           // its slot (no staging, no flush, no workgroup barrier in the tile loop).  Several workgroups per scan
@@ -3557,11 +3566,10 @@ __device__ __forceinline__ void gather_body(const FxDevParams &P, const FxBuffer
   __syncthreads();
   flush(s_w[8]);
   if (solo) {
-    if (tid == 0) B.ovf_cnt[scan] = s_w[9];
     for (uint32_t k = tid; k < K; k += NT) B.s_cnt[row0 + k] = s_kpos[k];
     // RNG ordinals: keypoint k takes the x-axis number (keypoints before it that have a neighbour)
     __syncthreads();
-    if (wave == 0) {
+    if (wave == 0 && !passes) {
       uint32_t base = 0;
       for (uint32_t k0 = 0; k0 < K; k0 += 64) {
         const uint32_t k = k0 + lane;
@@ -3571,14 +3579,35 @@ __device__ __forceinline__ void gather_body(const FxDevParams &P, const FxBuffer
       }
     }
   }
+  } while (PASSES && (kb += MK) < K_all);
+  if (solo) {
+    if (tid == 0) B.ovf_cnt[scan] = s_w[9];
+    if (passes) {  // the ordinals over all passes' flags
+      wg_global_sync();
+      if (wave == 0) {
+        uint32_t base = 0;
+        for (uint32_t k0 = 0; k0 < K_all; k0 += 64) {
+          const uint32_t k = k0 + lane;
+          const unsigned long long m = __ballot(k < K_all && B.kp_nbrs[(size_t)scan * P.max_keypoints + k] != 0u);
+          if (k < K_all) B.row_xa[row_first + k] = B.xaxis[base + lanes_below(m)];
+          base += (uint32_t)__popcll(m);
+        }
+      }
+    }
+  }
 }
 extern "C" __global__ __launch_bounds__(FX_GATHER_T) void k_gather(FxDevParams P, FxBuffers B, float box_margin) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  gather_body<FX_GATHER_T>(P, B, box_margin, smem);
+  gather_body<FX_GATHER_T, false>(P, B, box_margin, smem);
 }
 extern "C" __global__ __launch_bounds__(FX_GATHER_WIDE_T) void k_gather_wide(FxDevParams P, FxBuffers B, float box_margin) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  gather_body<FX_GATHER_WIDE_T>(P, B, box_margin, smem);
+  gather_body<FX_GATHER_WIDE_T, false>(P, B, box_margin, smem);
+}
+// contexts of more than FX_GATHER_KCAP keypoints a scan: the wide workgroup, whatever the batch (its tables take most of a CU's LDS)
+extern "C" __global__ __launch_bounds__(FX_GATHER_WIDE_T) void k_gather_passes(FxDevParams P, FxBuffers B, float box_margin) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  gather_body<FX_GATHER_WIDE_T, true>(P, B, box_margin, smem);
 }
 
 // ---------------------------------------------------------------- wavefront tier (runs inside k_desc_mid)
@@ -5180,7 +5209,7 @@ void fxk_rings_large(hipStream_t s, const FxDevParams &P, const FxBuffers &B, ui
 }
 size_t fxk_merge_lds_bytes(uint32_t cap, uint32_t n_rings) { return merge_words(cap, cap, n_rings, true) * 4; }
 size_t fxk_merge_huge_lds_bytes(uint32_t cap, uint32_t ccap, uint32_t n_rings) { return merge_words(cap, ccap, n_rings, false) * 4; }
-size_t fxk_gather_lds_bytes(uint32_t max_keypoints) { return (size_t)gather_words(max_keypoints, FX_GATHER_WIDE_T) * 4; }
+size_t fxk_gather_lds_bytes(uint32_t max_keypoints) { return (size_t)gather_words(std::min(max_keypoints, (uint32_t)FX_GATHER_KCAP), FX_GATHER_WIDE_T) * 4; }
 size_t fxk_dense_finish_lds_bytes(int large) {
   const size_t k = large ? FX_DFIN_KL : FX_DFIN_KS;
   return (2 * k + k / 2 + 1984 + FX_TABLE_WORDS + 16) * 4;
@@ -5198,6 +5227,8 @@ hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t merge_huge, s
   e = hipFuncSetAttribute((const void *)k_gather, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gather);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void *)k_gather_wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gather);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void *)k_gather_passes, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gather);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void *)k_rings_large, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_big);
   if (e != hipSuccess) return e;
@@ -5285,10 +5316,12 @@ hipError_t fxk_configure_front(const FxDevParams &P, uint32_t ring_cap, uint32_t
 uint32_t fxk_gather_slices(uint32_t batch) { return batch >= 64u ? FX_GATHER_SLICES : (batch >= 16u ? 4u : 16u); }
 void fxk_gather(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float box_margin) {
   const uint32_t slices = fxk_gather_slices(batch);
-  if (slices == 1 && batch < 1024u)
-    hipLaunchKernelGGL(k_gather_wide, dim3(1, batch), dim3(FX_GATHER_WIDE_T), (size_t)gather_words(P.max_keypoints, FX_GATHER_WIDE_T) * 4, s, P, B, box_margin);
+  if (P.max_keypoints > FX_GATHER_KCAP)
+    hipLaunchKernelGGL(k_gather_passes, dim3(slices, batch), dim3(FX_GATHER_WIDE_T), (size_t)gather_words(FX_GATHER_KCAP, FX_GATHER_WIDE_T) * 4, s, P, B, box_margin);
+  else if (slices == 1 && batch < 1024u)
+    hipLaunchKernelGGL(k_gather_wide, dim3(1, batch), dim3(FX_GATHER_WIDE_T), (size_t)gather_words(std::min(P.max_keypoints, (uint32_t)FX_GATHER_KCAP), FX_GATHER_WIDE_T) * 4, s, P, B, box_margin);
   else
-    hipLaunchKernelGGL(k_gather, dim3(slices, batch), dim3(FX_GATHER_T), (size_t)gather_words(P.max_keypoints, FX_GATHER_T) * 4, s, P, B, box_margin);
+    hipLaunchKernelGGL(k_gather, dim3(slices, batch), dim3(FX_GATHER_T), (size_t)gather_words(std::min(P.max_keypoints, (uint32_t)FX_GATHER_KCAP), FX_GATHER_T) * 4, s, P, B, box_margin);
 }
 void fxk_desc_group(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid) {
   hipLaunchKernelGGL(k_desc_group, dim3(grid), dim3(FX_WG), (size_t)(FX_NWAVE * FX_GROUPS * FX_GROUP_WORDS + FX_TABLE_WORDS) * 4, s, P, B, batch);

@@ -1,7 +1,8 @@
 """Streaming latency: one fx_process_batch call per scan (or per small batch),
 host buffer in -> keypoints + descriptors back in pinned host memory, as the ROS shell would call it.
 
-  python tools/latency.py [batch=1] [calls=300] [preset=launch] [graph=0|1]
+  python tools/latency.py [batch=1] [calls=300] [preset=launch] [graph=0|1] [stride_bytes=16|32]
+(stride 32: pcl::PointXYZI records in host memory, what the reference-side binding has — ref: node.cpp:81)
 """
 import json, os, sys, time
 import numpy as np
@@ -12,14 +13,22 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 calls = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 preset = sys.argv[3] if len(sys.argv) > 3 else "launch"
 graph = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+stride = int(sys.argv[5]) if len(sys.argv) > 5 else 16
 capi.load()
 scans = [capi.synth_scan(capi.synth_cfg(1000 + b)) for b in range(max(B, 16))]
+if stride == 32:
+    wide = []
+    for s in scans:
+        w = np.zeros((len(s), 8), np.float32)
+        w[:, :3] = s[:, :3]
+        wide.append(w)
+    scans = wide
 ctx = capi.Context(capi.params(preset), capi.limits(B, 28800))
 ctx.set_graph_batch(B if graph else 0)
 sets = []
 for j in range(len(scans) // B):
     part = scans[j * B:(j + 1) * B]
-    sets.append(ctx.make_descs([s.ctypes.data for s in part], [len(s) for s in part], 16, 0.02, -0.015))
+    sets.append(ctx.make_descs([s.ctypes.data for s in part], [len(s) for s in part], stride, 0.02, -0.015))
 for mode, flags in (("host->host (keypoints + descriptors)", capi.FX_OUT_HOST),):
     for w in range(20):
         ctx.process_raw(sets[w % len(sets)], B, flags)
@@ -29,7 +38,7 @@ for mode, flags in (("host->host (keypoints + descriptors)", capi.FX_OUT_HOST),)
         v = ctx.process_raw(sets[i % len(sets)], B, flags)
         t[i] = time.perf_counter() - t0
     t *= 1e3
-    print(json.dumps({"mode": mode, "batch": B, "calls": calls, "preset": preset, "graph": graph, "ms_median": float(np.median(t)),
+    print(json.dumps({"mode": mode, "batch": B, "calls": calls, "preset": preset, "graph": graph, "stride_bytes": stride, "ms_median": float(np.median(t)),
                       "ms_p99": float(np.percentile(t, 99)), "ms_min": float(t.min()),
                       "keypoints_last": int(v.total_keypoints)}))
 # where the time goes: device spans of the stages (HIP events) for the same call pattern
