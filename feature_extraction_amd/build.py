@@ -154,6 +154,7 @@ def build(force=False, verbose=False):
     if force or stale():
         _link(LIB, [], verbose)
     build_test_hooks(force, verbose)
+    build_trig_literal(force, verbose)
     build_cli(force, verbose)
     build_batcher(force, verbose)
     try:  # the multi-GPU driver needs RCCL's development files: without them the library and everything else still build
