@@ -13,7 +13,10 @@ SOURCES = ["fx_kernels.hip", "fx_api.cpp", "fx_host.cpp"]
 HEADERS = ["fx_device.h", "fx_sort_replay.h", os.path.join("..", "..", "include", "fx.h")]
 # -ffp-contract=off: the numerics contract forbids FMA contraction (results must follow
 # PCL/FLANN/Eigen operation order); fp32 divide/sqrt stay at hipcc's correctly rounded default.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-Wl,-Bsymbolic"]
+# -O2, not -O3: the kernels are big (k_front 60 KB, k_rings_runs 42 KB of code against a 64 KB instruction cache that two CUs
+# share) and -O3's extra unrolling and inlining costs more in instruction fetches than it saves: measured in one gpurun call,
+# alternating, the headline 2.22e6 scans/s against 2.19e6 (profiles/r04_front_experiments.md).
+FLAGS = ["--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-Wl,-Bsymbolic"]
 
 
 def hipcc():

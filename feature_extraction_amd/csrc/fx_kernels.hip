@@ -831,14 +831,23 @@ struct PrepLds {
   // the ring windows (a sweep then loads nothing from global memory: the wait for such a load would also be one for the
   // acknowledgement of the sweep's earlier stores — vmcnt counts loads and stores in issue order)
   float2 *win;         // [n_rings]
+  float *el;           // KEEP only: [keep_cap] the survivors' elevation angles
+  uint32_t keep_cap;   // KEEP only: survivors `keep` holds
 };
 // The streaming pass over one scan (n > 0) by one FX_PREP_T-thread workgroup: writes the filtered cloud and the near bits,
 // leaves the ring counts in L.ring; returns the number of survivors.  Ends with a barrier.
+// KEEP (k_front): the survivors STAY in the buffer — un-rotated x y z in L.keep, elevations in L.el, in input order —: the
+// ring split then needs nothing from HBM (reading ~cloud back cost a wait for the sweeps' stores, an L2 round trip and
+// 50 MB of HBM traffic a batch).  A scan with more survivors than L.keep_cap makes the pass return FX_NONE at the tile that
+// no longer fits (the caller runs the recycling instance over the whole scan again: rare, and such a scan is
+// k_front_redo's anyway).
+template <bool KEEP = false>
 __device__ __forceinline__ uint32_t prep_stream(const FxDevParams &P, const FxBuffers &B, const FxScanMeta &M, uint32_t scan,
                                                 float near_margin, float el0, float inv_step, const PrepLds &L) {
   constexpr int NW = FX_PREP_T / 64;
   constexpr uint32_t kTile = FX_PREP_TILE;           // points per tile; wave w owns [256 w, 256 w + 256) of it
   constexpr uint32_t kKeep = FX_PREP_KEEP;
+  uint32_t swept = 0;            // KEEP: survivors of the buffer the sweep has done
   uint32_t *const s_cnt = L.cnt;
   float *const s_keep = L.keep;
   uint32_t *const s_ring = L.ring;
@@ -874,7 +883,7 @@ __device__ __forceinline__ uint32_t prep_stream(const FxDevParams &P, const FxBu
   // overflow on the next tile, with every lane busy, instead of after each tile with a few.
   // Called by the whole workgroup after a barrier.
   auto sweep = [&]() {
-    for (uint32_t j = tid; j < buffered; j += FX_PREP_T) {
+    for (uint32_t j = (KEEP ? swept : 0u) + tid; j < buffered; j += FX_PREP_T) {
       const float x = s_keep[3 * j], y = s_keep[3 * j + 1], z = s_keep[3 * j + 2];
       const float rx = ((M.R[0] * x + M.R[1] * y) + M.R[2] * z) + 0.0f;
       const float ry = ((M.R[3] * x + M.R[4] * y) + M.R[5] * z) + 0.0f;
@@ -882,6 +891,7 @@ __device__ __forceinline__ uint32_t prep_stream(const FxDevParams &P, const FxBu
       float el;
       if (!elevation_fast(x, y, z, s_atan, el)) el = elevation_deg(x, y, z);
       out[base + j] = make_float4(rx, ry, rz, el);
+      if (KEEP) L.el[j] = el;
       // ring counts for the ring split (it then reads the filtered cloud once, not twice)
       int r_first;
       const uint32_t mask = isfinite(el) ? ring_membership(el, s_win, P.n_rings, el0, inv_step, r_first) : 0u;
@@ -889,8 +899,11 @@ __device__ __forceinline__ uint32_t prep_stream(const FxDevParams &P, const FxBu
       for (int d = 0; d < 3; ++d)
         if (mask & (1u << d)) atomicAdd(&s_ring[r_first + d], 1u);
     }
-    base += buffered;
-    buffered = 0;
+    if (!KEEP) {  // the buffer is emptied by every sweep
+      base += buffered;
+      buffered = 0;
+    }
+    swept = buffered;
     FX_STAMP(28);
   };
   // Range tests with both ends clamped to the finite floats: a NaN or an infinite coordinate fails them (PassThrough drops
@@ -970,6 +983,10 @@ __device__ __forceinline__ uint32_t prep_stream(const FxDevParams &P, const FxBu
       before += (w < (int)wave) ? c : 0u;
       tile_total += c;
     }
+    if (KEEP && buffered + tile_total > L.keep_cap) {  // (workgroup-uniform) the survivors no longer fit
+      __syncthreads();
+      return FX_NONE;
+    }
     uint32_t pos = buffered + before;
 #pragma unroll
     for (int u = 0; u < FX_PREP_U; ++u) {
@@ -984,7 +1001,8 @@ __device__ __forceinline__ uint32_t prep_stream(const FxDevParams &P, const FxBu
     buffered += tile_total;
     parity ^= 1u;
     FX_STAMP(27);
-    if (buffered > kKeep - kTile) {  // the next tile might not fit (workgroup-uniform)
+    // recycling: the next tile might not fit; KEEP: enough survivors wait for the sweep to keep every lane busy (workgroup-uniform)
+    if (KEEP ? buffered - swept >= 2u * FX_PREP_T : buffered > kKeep - kTile) {
       __syncthreads();
       sweep();
     }
@@ -995,7 +1013,7 @@ __device__ __forceinline__ uint32_t prep_stream(const FxDevParams &P, const FxBu
   __syncthreads();
   sweep();
   __syncthreads();
-  return base;
+  return base + buffered;
 }
 
 __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, FxBuffers B, float near_margin, float el0, float inv_step, uint32_t clk_slot) {
@@ -1021,8 +1039,8 @@ __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, 
     if (scan == 0 && tid < FX_N_COUNTERS) B.counters[tid] = 0u;
     return;
   }
-  const PrepLds L{s_cnt, s_keep, s_ring, s_atan, s_win};
-  const uint32_t base = prep_stream(P, B, M, scan, near_margin, el0, inv_step, L);
+  const PrepLds L{s_cnt, s_keep, s_ring, s_atan, s_win, nullptr, 0u};
+  const uint32_t base = prep_stream<false>(P, B, M, scan, near_margin, el0, inv_step, L);
   for (uint32_t r = tid; r < R; r += FX_PREP_T) B.ring_cnt[(size_t)scan * R + r] = s_ring[r];
   if (tid == 0) {
     B.n_filt[scan] = base;
@@ -2396,15 +2414,16 @@ struct FrontOff {  // word offsets into the LDS image
   static constexpr uint32_t crec = croot + FX_FRONT_RUNS / 2 + 4;         // [RUNS + 4]
   static constexpr uint32_t ctmp = crec + FX_FRONT_RUNS + 4;              // [RUNS + 4]
   static constexpr uint32_t end = ctmp + FX_FRONT_RUNS + 4;
-  // overlays: the streaming pass's tables and the split's counters live in the (not yet used) segment boxes, the ring-start
+  // overlays: the streaming pass's tables, the survivors' elevations and the split's counters live in the (not yet used)
+  // segment / run tables, the ring-start
   // bits, the near pairs and the wavefronts' queues in the (not yet used) cluster tables, the replay's scratch in the
   // (no longer used) segment boxes
   static constexpr uint32_t atan = seg_box, win = atan + a4(2 * (FX_ATAN_N + 1) * (FX_ATAN_DEG + 1)), cnt = win + 2 * FX_FRONT_RMAX,
-                            cw = cnt + 2 * FX_FRONT_NW, a_end = cw + 2 * FX_FRONT_NW * FX_FRONT_RMAX;
+                            cw = cnt + 2 * FX_FRONT_NW, el = cw + 2 * FX_FRONT_NW * FX_FRONT_RMAX, a_end = el + FX_FRONT_CAP;
   static constexpr uint32_t rsm = croot, pairs = croot, queues = pairs + FX_FRONT_PAIRS, q_end = queues + FX_FRONT_NW * FX_FRONT_QUEUE;
 };
 static_assert(FrontOff::end * 4 <= 80 * 1024, "two workgroups of k_front a CU");
-static_assert(FrontOff::a_end <= FrontOff::rbox && FrontOff::q_end <= FrontOff::end, "k_front overlays");
+static_assert(FrontOff::a_end <= FrontOff::croot && FrontOff::q_end <= FrontOff::end, "k_front overlays");
 static_assert(FX_FRONT_NW * FX_FRONT_SORTW <= 4 * FX_FRONT_SEGS, "k_front: the replay's scratch borrows the segment boxes");
 static_assert(FX_FRONT_RUNS <= 1024 && FX_FRONT_CAP <= 4096 && FX_FRONT_BLOCKS <= 64 && FX_FRONT_RMAX <= 64 && FX_FRONT_CAP % 64 == 0 &&
                   FX_FRONT_CAP >= FX_PREP_KEEP, "k_front packings");
@@ -2461,8 +2480,10 @@ extern "C" __global__ __launch_bounds__(FX_FRONT_T, FX_PREP_OCC) void k_front(Fx
     return;
   }
   // ---------------------------------------------------------------- A: the streaming pass
-  const PrepLds PL{smem + O::cnt, px, r_cnt, reinterpret_cast<double *>(smem + O::atan), reinterpret_cast<float2 *>(smem + O::win)};
-  const uint32_t nf = prep_stream(P, B, M, scan, near_margin, el0, inv_step, PL);
+  float *s_el = reinterpret_cast<float *>(smem + O::el);
+  const PrepLds PL{smem + O::cnt, px, r_cnt, reinterpret_cast<double *>(smem + O::atan), reinterpret_cast<float2 *>(smem + O::win), s_el, CAP};
+  uint32_t nf = prep_stream<true>(P, B, M, scan, near_margin, el0, inv_step, PL);
+  if (nf == FX_NONE) nf = prep_stream<false>(P, B, M, scan, near_margin, el0, inv_step, PL);  // (more survivors than the buffer keeps: once more, recycling it)
   FX_STAMP(1);
   for (uint32_t r = tid; r < R; r += NT) B.ring_cnt[(size_t)scan * R + r] = r_cnt[r];  // (k_tail's ring split starts from these)
   if (tid == 0) {
@@ -2490,9 +2511,11 @@ extern "C" __global__ __launch_bounds__(FX_FRONT_T, FX_PREP_OCC) void k_front(Fx
     return;
   }
   // ---------------------------------------------------------------- B: ring split into LDS (ref: node.cpp:195-202)
-  // A stable counting sort by ring with two barriers: every wavefront owns a contiguous slice of ~cloud, ranks its own
-  // points ring by ring (a ballot per ring present in 64 points, a running count per (wavefront, ring) in LDS), the counts
-  // of the wavefronts before it make the slice's base in every ring, and the points go to their places.
+  // A stable counting sort by ring with three barriers and nothing from HBM: the survivors are still in LDS (un-rotated, in
+  // input order: the streaming pass's buffer) with their elevations.  Every wavefront owns a contiguous slice, ranks its
+  // points ring by ring (a ballot per ring present in 64 points, running counts in registers), the counts of the wavefronts
+  // before it make the slice's base in every ring; every lane then rotates its points (registers), and — once every lane has
+  // read its points: the ring-major arrays take the buffer's place — the points go to their places.
   const float4 *f = B.filt + (size_t)scan * P.max_points;
   {
     const float2 *s_win = PL.win;
@@ -2508,24 +2531,26 @@ extern "C" __global__ __launch_bounds__(FX_FRONT_T, FX_PREP_OCC) void k_front(Fx
       if (tid <= R) r_off[tid] = inc - c;  // (r_off[R] = n)
     }
     FX_STAMP(16);
-    wg_global_sync();  // (~cloud was written by the other wavefronts' sweeps)
-    FX_STAMP(17);
     constexpr uint32_t kSub = (CAP + 64 * NW - 1) / (64 * NW);   // 64-point pieces of a wavefront's slice at most
     const uint32_t S = ((nf + 64u * NW - 1u) / (64u * NW)) * 64u;  // slice length
-    float4 pre[kSub];  // the whole cloud's loads are in flight at once
-#pragma unroll
-    for (uint32_t u = 0; u < kSub; ++u) pre[u] = f[min(wave * S + u * 64u + lane, nf - 1u)];
-    uint32_t mask[kSub], place[kSub][3];
-    int r_first[kSub];
+    // per point: its first ring (a point is in one ring, or — exactly on a window's edge — in that one and the next) and its
+    // place among the wavefront's points of that ring; the second ring's place in a register of its own
+    uint32_t ring_a[kSub], place_b[kSub];  // ring_a: ring | 0x100: also in ring + 1 | place in the ring << 16; FX_NONE: in no ring
     uint32_t run_cnt = 0;  // lane r: points of ring r in this wavefront's slice so far (no LDS round trip per ring in the loop below)
 #pragma unroll
     for (uint32_t u = 0; u < kSub; ++u) {
-      mask[u] = 0, r_first[u] = 0;
-      place[u][0] = place[u][1] = place[u][2] = 0;
+      ring_a[u] = FX_NONE, place_b[u] = 0;
       if (u * 64u >= S) continue;  // (workgroup-uniform)
       const uint32_t i = wave * S + u * 64u + lane;
-      if (i < nf && isfinite(pre[u].w)) mask[u] = ring_membership(pre[u].w, s_win, P.n_rings, el0, inv_step, r_first[u]);
-      int lo = mask[u] ? r_first[u] : 0x7fffffff, hi = mask[u] ? r_first[u] + 3 : -1;  // rings present in these 64 points: [lo, hi)
+      const float el = i < nf ? s_el[i] : NAN;
+      uint32_t mask = 0;
+      int r_first = 0;
+      if (isfinite(el)) mask = ring_membership(el, s_win, P.n_rings, el0, inv_step, r_first);
+      // (windows of neighbouring rings share their edge only: at most two memberships, in consecutive rings)
+      const int ra = mask ? r_first + (__ffs((int)mask) - 1) : -1;
+      const bool two = (mask & (mask - 1u)) != 0u;
+      if (mask) ring_a[u] = (uint32_t)ra | (two ? 0x100u : 0u);
+      int lo = mask ? ra : 0x7fffffff, hi = mask ? ra + (two ? 2 : 1) : -1;  // rings present in these 64 points: [lo, hi)
 #pragma unroll
       for (int d = 32; d > 0; d >>= 1) {
         lo = min(lo, __shfl_xor(lo, d, 64));
@@ -2534,25 +2559,29 @@ extern "C" __global__ __launch_bounds__(FX_FRONT_T, FX_PREP_OCC) void k_front(Fx
       lo = __builtin_amdgcn_readfirstlane(max(lo, 0));
       hi = __builtin_amdgcn_readfirstlane(min(hi, (int)R));
       for (int r = lo; r < hi; ++r) {
-        const int d = r - r_first[u];
-        const bool in = mask[u] && d >= 0 && d < 3 && (mask[u] & (1u << d));
-        const unsigned long long m = __ballot(in);
+        const bool in_a = r == ra, in_b = two && r == ra + 1;
+        const unsigned long long m = __ballot(in_a || in_b);
         if (!m) continue;
         const uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)run_cnt, r) + lanes_below(m);
-        if (in) {
-          if (d == 0)
-            place[u][0] = at;
-          else if (d == 1)
-            place[u][1] = at;
-          else
-            place[u][2] = at;
-        }
+        if (in_a) ring_a[u] |= at << 16;
+        if (in_b) place_b[u] = at;
         if ((int)lane == r) run_cnt += (uint32_t)__popcll(m);
       }
     }
     if (lane < R) cw[wave * R + lane] = run_cnt;
+    FX_STAMP(17);
+    // this lane's points, rotated as the sweep rotated them for ~cloud (pcl::transformPointCloud's order, ref: node.cpp:161-166)
+    float rx[kSub], ry[kSub], rz[kSub];
+#pragma unroll
+    for (uint32_t u = 0; u < kSub; ++u) {
+      const uint32_t i = min(wave * S + u * 64u + lane, nf - 1u);
+      const float x = px[3 * i], y = px[3 * i + 1], z = px[3 * i + 2];  // (the buffer: x y z per survivor, where px / py / pz will be)
+      rx[u] = ((M.R[0] * x + M.R[1] * y) + M.R[2] * z) + 0.0f;
+      ry[u] = ((M.R[3] * x + M.R[4] * y) + M.R[5] * z) + 0.0f;
+      rz[u] = ((M.R[6] * x + M.R[7] * y) + M.R[8] * z) + 0.0f;
+    }
     FX_STAMP(18);
-    __syncthreads();
+    __syncthreads();  // (every count is in; every lane has read its points)
     for (uint32_t t = tid; t < NW * R; t += NT) {
       const uint32_t w = t / R, r = t - w * R;
       uint32_t before = r_off[r];
@@ -2562,16 +2591,18 @@ extern "C" __global__ __launch_bounds__(FX_FRONT_T, FX_PREP_OCC) void k_front(Fx
     __syncthreads();
 #pragma unroll
     for (uint32_t u = 0; u < kSub; ++u) {
-#pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        if (mask[u] & (1u << d)) {
-          const uint32_t pos = cbase[wave * R + (uint32_t)(r_first[u] + d)] + place[u][d];
-          px[pos] = pre[u].x, py[pos] = pre[u].y, pz[pos] = pre[u].z;
-          sidx[pos] = (uint16_t)(wave * S + u * 64u + lane);
-        }
+      if (ring_a[u] == FX_NONE) continue;
+      const uint32_t ra = ring_a[u] & 0xffu;
+      uint32_t pos = cbase[wave * R + ra] + (ring_a[u] >> 16);
+      px[pos] = rx[u], py[pos] = ry[u], pz[pos] = rz[u];
+      sidx[pos] = (uint16_t)(wave * S + u * 64u + lane);
+      if (ring_a[u] & 0x100u) {
+        pos = cbase[wave * R + ra + 1u] + place_b[u];
+        px[pos] = rx[u], py[pos] = ry[u], pz[pos] = rz[u];
+        sidx[pos] = (uint16_t)(wave * S + u * 64u + lane);
       }
     }
-    __syncthreads();
+    wg_global_sync();  // (the ring-major points are in; ~cloud, written by the sweeps, is read below: cluster intensities, member copies)
     FX_STAMP(19);
   }
   // ---------------------------------------------------------------- C: getCylinderSegments, all rings (ref: node.cpp:261-327)

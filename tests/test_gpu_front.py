@@ -151,3 +151,17 @@ def test_window_boundary_points_and_duplicates(fxlib, oracle):
     s = np.concatenate(pts + [util.vlp16_scan(5)[:6000, :4].astype(np.float64)]).astype(np.float32)
     got, hints = _run(oracle, [s, s[::-1].copy()], "window edges", max_keypoints=512, max_total_keypoints=1024)
     assert hints == (0, 0)
+
+
+def test_many_clusters_in_one_ring_and_a_32_ring_sensor(fxlib, oracle):
+    """More than 192 clusters in one ring (the order replay's partition phase by one lane), and k_front's ring capacity: 32."""
+    lim = dict(max_ring_candidates=512, max_keypoints=512, max_total_keypoints=4096)
+    tight = capi.params("launch", cluster_tolerance=0.5)  # (returns of one range shell 0.7 - 0.9 m apart stay clusters of their own)
+    got, hints = _run(oracle, [isolated_points(9, 200), isolated_points(9, 256), np.concatenate([isolated_points(8, 190), isolated_points(9, 193)])],
+                      "many clusters a ring", p=tight, **lim)
+    assert hints == (0, 0) and [len(g["candidates"]) for g in got] == [200, 256, 383]
+    p = capi.params("launch", n_rings=32, el0_deg=-15.0, el_step_deg=1.0, secondary_max=32, cluster_tolerance=0.5)
+    scans = [isolated_points(9, 200), interleaved_arc(6, 60, step_m=0.15),
+             np.concatenate([isolated_points(7, 100), long_ring_with_late_poles(), two_arcs_in_blocks(9)]), util.vlp16_scan(1000)]
+    got, hints = _run(oracle, scans, "32 rings", p=p, roll=0.01, pitch=-0.01, **lim)
+    assert hints == (0, 0) and [g["flags"] for g in got] == [0] * len(scans)

@@ -1,4 +1,7 @@
-"""Diagnostic: the differential fuzz of tests/test_gpu_fuzz.py over an arbitrary seed range, both merge tiers.\n  python tools/fuzz_more.py FIRST LAST"""
+"""Diagnostic: the differential fuzz of tests/test_gpu_fuzz.py over an arbitrary seed range, through every front path: the
+fused front kernel (product library), and — test build — the separate kernels, those with the large merge tier, every scan
+through k_front_redo, every scan through k_tail.
+  python tools/fuzz_more.py FIRST LAST [paths=front,separate,separate-large-merge,front-redo,front-tail]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -6,24 +9,32 @@ from feature_extraction_amd import capi
 from oracle import oracle_py as O
 from tests import util
 from tests.test_gpu_fuzz import _case
+PATHS = {"front": None, "separate": dict(FX_FRONT="0"), "separate-large-merge": dict(FX_FRONT="0", FX_MERGE_BIG_CAP="16"),
+         "front-redo": dict(FX_FRONT_FORCE="1"), "front-tail": dict(FX_FRONT_FORCE="2")}
+HOOKS = ("FX_FRONT", "FX_MERGE_BIG_CAP", "FX_FRONT_FORCE")
 t0 = time.time(); bad = 0; total_k = 0
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
+paths = sys.argv[3].split(",") if len(sys.argv) > 3 else list(PATHS)
+lim = dict(max_candidates=3500, max_kpc_points=57600, max_keypoints=1024, max_total_keypoints=1024, max_ring_candidates=512)
 for seed in range(lo, hi):
     s, p, roll, pitch, what = _case(seed)
-    for tier in ("lds", "large"):
-        if tier == "large":
-            os.environ["FX_MERGE_BIG_CAP"] = "16"
+    ora = O.run(p, s, roll=roll, pitch=pitch)
+    for path in paths:
+        for h in HOOKS:
+            os.environ.pop(h, None)
+        env = PATHS[path]
+        if env is None:
+            ctx = capi.Context(p, capi.limits(1, 28800, **lim))
         else:
-            os.environ.pop("FX_MERGE_BIG_CAP", None)
-        ctx = capi.Context(p, capi.limits(1, 28800, max_candidates=3500, max_kpc_points=57600, max_keypoints=1024, max_total_keypoints=1024, max_ring_candidates=512))
+            os.environ.update(env)
+            with capi.test_hooks():
+                ctx = capi.Context(p, capi.limits(1, 28800, **lim))
         got = ctx.process_host([s], roll=roll, pitch=pitch)[0]
         ctx.close()
-        if tier == "lds":
-            ora = O.run(p, s, roll=roll, pitch=pitch)
         try:
-            st = util.compare_scan(got, ora, tag=f"seed {seed} {tier}")
+            st = util.compare_scan(got, ora, tag=f"seed {seed} {path}")
             total_k += st["K"]
         except AssertionError as e:
             bad += 1
-            print("MISMATCH", seed, tier, str(e)[:300], what)
-print(f"seeds {lo}..{hi}: {bad} mismatches, {total_k} keypoints, {time.time() - t0:.0f} s")
+            print("MISMATCH", seed, path, str(e)[:300], what)
+print(f"seeds {lo}..{hi} x {paths}: {bad} mismatches, {total_k} keypoints, {time.time() - t0:.0f} s")
