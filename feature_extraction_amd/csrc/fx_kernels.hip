@@ -4801,7 +4801,14 @@ extern "C" __global__ __launch_bounds__(FX_DDENS_T) void k_dense_density(FxDevPa
     const uint32_t t_tot = s_cat[unr];
     const fx_f2 ax = {q[0].x, q[1].x}, ay = {q[0].y, q[1].y}, az = {q[0].z, q[1].z};
     const fx_f2 bx = {q[2].x, q[3].x}, by = {q[2].y, q[3].y}, bz = {q[2].z, q[3].z};
-    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    // Counting d2 < r2 without a compare and an add-with-carry per test: with S a power of two, fma(d2, -S, r2 S) is the
+    // exactly scaled difference rounded once — positive, zero or negative as r2 - d2 is (-inf when d2 S overflows) — at
+    // least 2^76 in magnitude unless zero, so the instruction's clamp to [0, 1] turns it into 1.0f or 0.0f; the counts add
+    // up exactly in fp32 (below 2^21).  Two tests per packed instruction, two instructions instead of four.
+    const float kS = __uint_as_float(min(354u - ((__float_as_uint(r2d) >> 23) & 0xffu), 254u) << 23);  // r2 S in [2^100, 2^101)
+                                                                                          // (fx_create: r2 >= 1e-30, so ulp(r2) S >= 1)
+    const fx_f2 nS2 = {-kS, -kS}, rS2 = {r2d * kS, r2d * kS};
+    fx_f2 ca = {0.0f, 0.0f}, cb = {0.0f, 0.0f};
 #ifdef FX_STAMPS
     unsigned long long n_tests = 0, n_wave = 0;
 #endif
@@ -4846,27 +4853,32 @@ extern "C" __global__ __launch_bounds__(FX_DDENS_T) void k_dense_density(FxDevPa
           n_wave += mx;
         }
 #endif
-#pragma unroll 2
-        for (uint32_t i = i0; i < i1; ++i) {
-          const float4 t = s_t[i];
+        auto test = [&](const float4 t) {
           // FLANN L2_Simple, query - point, ((dx dx) + dy dy) + dz dz: two queries per packed instruction
           const fx_f2 dxa = ax - t.x, dya = ay - t.y, dza = az - t.z;
           const fx_f2 dxb = bx - t.x, dyb = by - t.y, dzb = bz - t.z;
           fx_f2 ra = dxa * dxa, rb2 = dxb * dxb;
           ra = ra + dya * dya, rb2 = rb2 + dyb * dyb;
           ra = ra + dza * dza, rb2 = rb2 + dzb * dzb;
-          c0 += ra.x < r2d ? 1u : 0u;
-          c1 += ra.y < r2d ? 1u : 0u;
-          c2 += rb2.x < r2d ? 1u : 0u;
-          c3 += rb2.y < r2d ? 1u : 0u;
+          fx_f2 ia, ib;
+          asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(ia) : "v"(ra), "s"(nS2), "v"(rS2));
+          asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(ib) : "v"(rb2), "s"(nS2), "v"(rS2));
+          ca = ca + ia, cb = cb + ib;
+        };
+        uint32_t i = i0;
+        for (; i + 1u < i1; i += 2u) {  // (unrolled by hand: the pragma gives up on a loop with inline assembly)
+          const float4 t0 = s_t[i], t1 = s_t[i + 1u];
+          test(t0);
+          test(t1);
         }
+        if (i < i1) test(s_t[i]);
       }
       __syncthreads();
     }
 #ifdef FX_STAMPS
     if (B.stamps) {  // diagnostic: targets walked per lane, per wavefront (row by row: the longest lane), true densities, queries
       unsigned long long nq = 0, dsum = 0;
-      const uint32_t cc[4] = {c0, c1, c2, c3};
+      const uint32_t cc[4] = {(uint32_t)ca.x, (uint32_t)ca.y, (uint32_t)cb.x, (uint32_t)cb.y};
       for (int u = 0; u < 4; ++u)
         if (q[u].x < 1.0e38f) nq += 1, dsum += cc[u];
       const bool wide = any_q && G.cx(bx1) - G.cx(bx0) > 1u;
@@ -4880,7 +4892,7 @@ extern "C" __global__ __launch_bounds__(FX_DDENS_T) void k_dense_density(FxDevPa
 #endif
     // ---- counts -> the scan's density cache (k_dense_finish of every row that has the point as a neighbour reads them)
     unsigned long long *cache = B.dens_cache + (size_t)scan * P.max_points;
-    const uint32_t cnt[4] = {c0, c1, c2, c3};
+    const uint32_t cnt[4] = {(uint32_t)ca.x, (uint32_t)ca.y, (uint32_t)cb.x, (uint32_t)cb.y};
 #pragma unroll
     for (int u = 0; u < 4; ++u)
       if (q[u].x < 1.0e38f) cache[__float_as_uint(q[u].w)] = tag | (unsigned long long)cnt[u];
@@ -5363,12 +5375,18 @@ void fxk_desc_mid(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint3
   hipLaunchKernelGGL(k_desc_mid, dim3(n_wg + n_wave), dim3(FX_WG), lds_wave > lds_wg ? lds_wave : lds_wg, s, P, B, batch, cap, n_wg);
 }
 // (rows and items are taken by ticket: any grid is correct; the full ones are what is resident at once)
-void fxk_dense(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t n_cu, uint32_t rows, uint32_t items) {
+// part 0: k_dense_sort and k_dense_density; 1: k_dense_finish_s; 2: k_dense_finish_l (the two finishing kernels take different
+// rows and both need every density of part 0: the host may run them side by side)
+void fxk_dense(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t n_cu, uint32_t rows, uint32_t items, int part) {
   auto grid = [](uint32_t want, uint32_t full) { return want < full ? (want ? want : 1u) : full; };
-  hipLaunchKernelGGL(k_dense_sort, dim3(grid(rows, n_cu * (1024 / FX_DSORT_T))), dim3(FX_DSORT_T), 0, s, P, B);
-  hipLaunchKernelGGL(k_dense_density, dim3(grid(items, n_cu * 3)), dim3(FX_DDENS_T), 0, s, P, B);
-  hipLaunchKernelGGL(k_dense_finish_s, dim3(grid(rows, n_cu * 3)), dim3(FX_DFIN_TS), fxk_dense_finish_lds_bytes(0), s, P, B);
-  hipLaunchKernelGGL(k_dense_finish_l, dim3(grid(rows, n_cu)), dim3(FX_DFIN_TL), fxk_dense_finish_lds_bytes(1), s, P, B);
+  if (part == 0) {
+    hipLaunchKernelGGL(k_dense_sort, dim3(grid(rows, n_cu * (1024 / FX_DSORT_T))), dim3(FX_DSORT_T), 0, s, P, B);
+    hipLaunchKernelGGL(k_dense_density, dim3(grid(items, n_cu * 3)), dim3(FX_DDENS_T), 0, s, P, B);
+  } else if (part == 1) {
+    hipLaunchKernelGGL(k_dense_finish_s, dim3(grid(rows, n_cu * 3)), dim3(FX_DFIN_TS), fxk_dense_finish_lds_bytes(0), s, P, B);
+  } else {
+    hipLaunchKernelGGL(k_dense_finish_l, dim3(grid(rows, n_cu)), dim3(FX_DFIN_TL), fxk_dense_finish_lds_bytes(1), s, P, B);
+  }
 }
 extern "C" __global__ __launch_bounds__(FX_WG) void k_test_elevation(const float *xyz, uint32_t n, const double *tab, float *fast, uint8_t *ok,
                                                                      float *exact) {
