@@ -29,7 +29,7 @@ size_t fxk_gather_lds_bytes(uint32_t max_keypoints);
 uint32_t fxk_dense_cells(void);
 uint32_t fxk_group_cap(void);
 uint32_t fxk_dfin_kl(void);
-void fxk_dense(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t n_cu, uint32_t rows, uint32_t items, int part);
+void fxk_dense(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t n_cu, uint32_t rows, uint32_t items);
 size_t fxk_merge_huge_lds_bytes(uint32_t cap, uint32_t ccap, uint32_t n_rings);
 hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t merge_huge, size_t desc_big, size_t gather);
 uint32_t fxk_near_words(uint32_t max_points);
@@ -107,11 +107,6 @@ struct fx_ctx {
   std::vector<void *> dev_allocs;
   std::vector<void *> host_allocs;
   hipStream_t own_stream = nullptr, stream = nullptr;
-  // The dense descriptor tier runs beside k_desc_mid on a stream of its own when the previous batch had rows for it (two
-  // launches that each leave most of the chip idle; contexts in flight fill that too, a single context cannot)
-  hipStream_t side_stream = nullptr;
-  hipEvent_t side_ev[3] = {};  // fork (k_desc_group done), densities done, join
-  int dense_fork = -1;         // test hook (FX_DENSE_FORK): 0 never, 1 always, -1 by the previous batch's dense rows
   // per-batch scan table: ring of pinned slots so back-to-back batches never overwrite one in flight
   FxScanMeta *h_meta[kMetaSlots] = {};
   hipEvent_t meta_ev[kMetaSlots] = {};
@@ -301,32 +296,17 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof, bo
       FX_HIP(mark(6));
       fxk_desc_group(s, P, B, batch, desc_grid);
       FX_HIP(mark(7));
-      // the dense tier: larger support sets and overflowed lists (empty launches on sparse scans).  Everything it needs is
-      // there once k_desc_group has run (row classes, lists); k_desc_mid takes other rows.
-      const uint32_t max_rows = batch * L.max_keypoints < L.max_total_keypoints ? batch * L.max_keypoints : L.max_total_keypoints;
-      const uint32_t rows = tier_grid(hint[4], 3 * big_grid, max_rows);
-      // density items: 1024 queries each, at most one a row more than the support points fill
-      const uint32_t items = hint[5] == 0xffffffffu ? 3 * big_grid : tier_grid(hint[4] + hint[5] / 1024u, 3 * big_grid, 0xffffffffu);
-      const bool fork = c->side_stream && !c->debug_sync &&
-                        (c->dense_fork >= 0 ? c->dense_fork != 0 : (!capture && hint[4] != 0xffffffffu && hint[4] >= 32u));  // (a few rows: not worth two events)
-      if (fork) {  // side: sort, densities, k_dense_finish_l;  here: k_desc_mid, then k_dense_finish_s
-        hipStream_t side = c->side_stream;
-        FX_HIP(hipEventRecord(c->side_ev[0], s));
-        FX_HIP(hipStreamWaitEvent(side, c->side_ev[0], 0));
-        fxk_dense(side, P, B, big_grid, rows, items, 0);
-        FX_HIP(hipEventRecord(c->side_ev[1], side));
-        fxk_dense(side, P, B, big_grid, rows, items, 2);
-        FX_HIP(hipEventRecord(c->side_ev[2], side));
-      }
       // wave rows and list rows (lists of up to dense_min entries, four keypoints per CU in flight) share a launch
       fxk_desc_mid(s, P, B, batch, P.list_cap < P.dense_min ? P.list_cap : P.dense_min, big_grid * 4, big_grid * 4);
       FX_HIP(mark(8));
-      if (fork) {
-        FX_HIP(hipStreamWaitEvent(s, c->side_ev[1], 0));
-        fxk_dense(s, P, B, big_grid, rows, items, 1);
-        FX_HIP(hipStreamWaitEvent(s, c->side_ev[2], 0));
-      } else {
-        for (int part = 0; part < 3; ++part) fxk_dense(s, P, B, big_grid, rows, items, part);
+      // the dense tier: larger support sets and overflowed lists (empty launches on sparse scans)
+      // (beside k_desc_mid on a second stream of the context: measured and dropped, profiles/r04_front_experiments.md)
+      {
+        const uint32_t max_rows = batch * L.max_keypoints < L.max_total_keypoints ? batch * L.max_keypoints : L.max_total_keypoints;
+        const uint32_t rows = tier_grid(hint[4], 3 * big_grid, max_rows);
+        // density items: 1024 queries each, at most one a row more than the support points fill
+        const uint32_t items = hint[5] == 0xffffffffu ? 3 * big_grid : tier_grid(hint[4] + hint[5] / 1024u, 3 * big_grid, 0xffffffffu);
+        fxk_dense(s, P, B, big_grid, rows, items);
       }
     } else {
       for (int i = 6; i <= 8; ++i) FX_HIP(mark(i));
@@ -681,10 +661,6 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess)
     return bail(fail(FX_ERR_HIP, "hipStreamCreate"));
   c->stream = c->own_stream;
-  if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipStreamCreate"));
-  for (hipEvent_t &e : c->side_ev)
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipEventCreate"));
-  if (const char *e = test_hook("FX_DENSE_FORK")) c->dense_fork = atoi(e) != 0 ? 1 : 0;
   {
     hipError_t ce = fxk_configure(fxk_ring_large_lds_bytes(L.max_ring_points, L.max_ring_points), fxk_merge_lds_bytes(c->merge_big_cap, params->n_rings),
                                   c->merge_big_cap < L.max_candidates ? fxk_merge_huge_lds_bytes(L.max_candidates, c->merge_huge_ccap, params->n_rings) : 0,
@@ -720,9 +696,6 @@ void fx_destroy(fx_ctx *c) {
     if (c->meta_ev[i]) (void)hipEventDestroy(c->meta_ev[i]);
   for (hipEvent_t e : c->ev_ring) (void)hipEventDestroy(e);
   for (auto &g : c->graphs) (void)hipGraphExecDestroy(g.second);
-  for (hipEvent_t e : c->side_ev)
-    if (e) (void)hipEventDestroy(e);
-  if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -937,7 +910,6 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
   if (c->state_suspect) {
     FX_HIP(hipMemsetAsync(c->buf.desc_nbins, 0xff, (size_t)L.max_total_keypoints * sizeof(uint32_t), s));  // FX_ROW_DIRTY: clear whole
     FX_HIP(hipMemsetAsync(c->buf.counters, 0, FX_N_COUNTER_WORDS * sizeof(uint32_t), s));
-    if (c->side_stream) FX_HIP(hipStreamSynchronize(c->side_stream));  // (work of the failed batch that was never joined)
     FX_HIP(hipStreamSynchronize(s));  // (the hints are host memory the device writes: nothing of the failed batch may land after the reset)
     for (int i = 0; i < FX_N_HINTS; ++i) c->tier_hint[i] = 0xffffffffu;
     c->front_pause = 0;

@@ -5375,18 +5375,12 @@ void fxk_desc_mid(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint3
   hipLaunchKernelGGL(k_desc_mid, dim3(n_wg + n_wave), dim3(FX_WG), lds_wave > lds_wg ? lds_wave : lds_wg, s, P, B, batch, cap, n_wg);
 }
 // (rows and items are taken by ticket: any grid is correct; the full ones are what is resident at once)
-// part 0: k_dense_sort and k_dense_density; 1: k_dense_finish_s; 2: k_dense_finish_l (the two finishing kernels take different
-// rows and both need every density of part 0: the host may run them side by side)
-void fxk_dense(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t n_cu, uint32_t rows, uint32_t items, int part) {
+void fxk_dense(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t n_cu, uint32_t rows, uint32_t items) {
   auto grid = [](uint32_t want, uint32_t full) { return want < full ? (want ? want : 1u) : full; };
-  if (part == 0) {
-    hipLaunchKernelGGL(k_dense_sort, dim3(grid(rows, n_cu * (1024 / FX_DSORT_T))), dim3(FX_DSORT_T), 0, s, P, B);
-    hipLaunchKernelGGL(k_dense_density, dim3(grid(items, n_cu * 3)), dim3(FX_DDENS_T), 0, s, P, B);
-  } else if (part == 1) {
-    hipLaunchKernelGGL(k_dense_finish_s, dim3(grid(rows, n_cu * 3)), dim3(FX_DFIN_TS), fxk_dense_finish_lds_bytes(0), s, P, B);
-  } else {
-    hipLaunchKernelGGL(k_dense_finish_l, dim3(grid(rows, n_cu)), dim3(FX_DFIN_TL), fxk_dense_finish_lds_bytes(1), s, P, B);
-  }
+  hipLaunchKernelGGL(k_dense_sort, dim3(grid(rows, n_cu * (1024 / FX_DSORT_T))), dim3(FX_DSORT_T), 0, s, P, B);
+  hipLaunchKernelGGL(k_dense_density, dim3(grid(items, n_cu * 3)), dim3(FX_DDENS_T), 0, s, P, B);
+  hipLaunchKernelGGL(k_dense_finish_s, dim3(grid(rows, n_cu * 3)), dim3(FX_DFIN_TS), fxk_dense_finish_lds_bytes(0), s, P, B);
+  hipLaunchKernelGGL(k_dense_finish_l, dim3(grid(rows, n_cu)), dim3(FX_DFIN_TL), fxk_dense_finish_lds_bytes(1), s, P, B);
 }
 extern "C" __global__ __launch_bounds__(FX_WG) void k_test_elevation(const float *xyz, uint32_t n, const double *tab, float *fast, uint8_t *ok,
                                                                      float *exact) {

@@ -1,8 +1,10 @@
-"""Diagnostic: bench.py's other_configs entries alone (configs 3 and 5 with batches in flight).  python tools/other_configs.py [in_flight]"""
+"""Diagnostic: bench.py's other_configs entries alone (configs 3 and 5 with batches in flight).  python tools/other_configs.py [in_flight [library file]]"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from feature_extraction_amd import capi
+if len(sys.argv) > 2:
+    capi.LIB_PATH = os.path.join(os.path.dirname(capi.LIB_PATH), sys.argv[2])
 capi.load()
 import bench
 dev = torch.device("cuda", 0)
