@@ -565,6 +565,7 @@ def main():
                                         "(fx_process_batch with FX_OUT_HOST), 3 contexts on 3 host threads / streams")
             for c in h2h:
                 c.close()
+            del hs, h2h  # (streams that stay alive keep hardware queues: the contexts below would share what is left)
             del d_in
             torch.cuda.empty_cache()
             out["other_configs"] = {name: run_other_config(name, cfg, capi, torch, dev, threads, roll, pitch)

@@ -4687,11 +4687,17 @@ extern "C" __global__ __launch_bounds__(FX_DSORT_T) void k_dense_sort(FxDevParam
   }
 }
 
-// Density of up to 1024 consecutive queries of a row by one workgroup, four per lane (consecutive in cell order, so
-// almost always in one cell).  The cell rows within reach of any of the workgroup's queries — per row one contiguous
-// run of the sorted region — pass through LDS in windows of FX_DDENS_C targets; every lane walks, per row, the part
-// of the window that the density spheres of ITS queries can reach (the row narrowed to the sphere's chord) and tests
-// each target against its four queries with packed fp32 arithmetic in FLANN's operation order.
+// Density of up to 1024 consecutive queries of a row by one workgroup.  The queries are taken in QUADS (four consecutive
+// in cell order, so almost always in one cell): a quad shares one walk over the targets, four tests per target with packed
+// fp32 arithmetic in FLANN's operation order.  The cell rows within reach of any of the workgroup's queries — per row
+// one contiguous run of the sorted region — pass through LDS in windows of FX_DDENS_C targets; per window, every lane lists
+// for ITS quad the part of each row that the quad's density spheres can reach (the row narrowed to the sphere's chord):
+// (quad, first, length) UNITS.  The units of a wavefront's 64 quads are then counting-sorted by length and dealt to its
+// lanes 64 at a time, longest first — a wavefront's trip costs its longest lane, and the quads of a wavefront differ a lot:
+// with every lane walking its own quad's rows in step a wavefront made 853 trips a quad where the mean lane needed 474
+// (config 3; 1159 / 632 on config 5: profiles/r04_front_experiments.md), because ring arcs cross the cell rows at different
+// places for lanes a few cells apart and queries — the points no earlier row has claimed — lie in neighbourhoods of
+// different density.  Counts go to LDS accumulators per query.
 // (Per-lane walks straight from global memory were measured: 64 scattered 16-byte loads per instruction keep the
 //  texture unit busier than the 24 arithmetic instructions they feed — 3.8 ms against 2.1 ms for a wave-uniform
 //  stream of the whole box, which tests 2-3 times as many targets as a lane needs.)
@@ -4700,17 +4706,40 @@ extern "C" __global__ __launch_bounds__(FX_DSORT_T) void k_dense_sort(FxDevParam
 #ifndef FX_DDENS_C
 #define FX_DDENS_C 2048              // targets per window
 #endif
+#ifndef FX_DDENS_RUNS
+#define FX_DDENS_RUNS 8              // units a lane lists per pass
+#endif
+#define FX_DDENS_BINS 48             // length classes of the units (exponent, two mantissa bits)
+static_assert(FX_DDENS_C <= 2048, "k_dense_density packs a unit as quad (6 bits) | first (11) | length - 1 (11)");
+// length class, longest first: bin 0 holds the longest units
+__device__ __forceinline__ uint32_t ddens_bin(uint32_t len) {  // len in [1, 2048]
+  const uint32_t e = 31u - (uint32_t)__clz((int)len);           // 0 .. 11
+  const uint32_t m = e >= 2u ? (len >> (e - 2u)) & 3u : (len << (2u - e)) & 3u;
+  return (FX_DDENS_BINS - 1u) - (e * 4u + m);
+}
 extern "C" __global__ __launch_bounds__(FX_DDENS_T) void k_dense_density(FxDevParams P, FxBuffers B) {
-  __shared__ uint32_t s_tab[FX_DCELLS + 1];     // s_tab[c] = start of cell c, s_tab[c + 1] = its end
-  __shared__ float4 s_t[FX_DDENS_C];
-  __shared__ uint32_t s_cat[FX_DDENS_T];  // start of every row of the box (<= 176) in the concatenation of the rows' runs; before that: the quads' weights
+  __shared__ float s_t[3 * FX_DDENS_C];                    // the window: x | y | z
+  __shared__ float4 s_q[4 * FX_DDENS_T];                   // per quad: x of its four queries, y, z, their counts (as uint32)
+  __shared__ uint32_t s_unit[FX_DDENS_RUNS * FX_DDENS_T];  // per wavefront: its lanes' units, then the same sorted by length
+  __shared__ uint32_t s_hist[(FX_DDENS_T / 64) * FX_DDENS_BINS];
+  __shared__ uint32_t s_cat[FX_DDENS_T];    // start of every row of the box (<= 176) in the concatenation of the rows' runs
+  __shared__ uint32_t s_row0[FX_DDENS_T];   // sorted-region position of the first target of every row of the box
   __shared__ uint32_t s_w[16];
-  const uint32_t tid = threadIdx.x;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t n_items = B.counters[14];
   if (n_items == 0u) return;
   const unsigned long long tag = B.seq[0] << FX_DENS_BITS;
   const float r2d = P.r2_density;
   const float r_d = sqrtf(r2d);
+  // Counting d2 < r2 without a compare and an add-with-carry per test: with S a power of two, fma(d2, -S, r2 S) is the
+  // exactly scaled difference rounded once — positive, zero or negative as r2 - d2 is (-inf when d2 S overflows) — at
+  // least 2^76 in magnitude unless zero, so the instruction's clamp to [0, 1] turns it into 1.0f or 0.0f; the counts add
+  // up exactly in fp32 (below 2^21).  Two tests per packed instruction, two instructions instead of four.
+  const float kS = __uint_as_float(min(354u - ((__float_as_uint(r2d) >> 23) & 0xffu), 254u) << 23);  // r2 S in [2^100, 2^101)
+                                                                                        // (fx_create: r2 >= 1e-30, so ulp(r2) S >= 1)
+  const fx_f2 nS2 = {-kS, -kS}, rS2 = {r2d * kS, r2d * kS};
+  uint32_t *const w_unit = s_unit + wave * (FX_DDENS_RUNS * 64u);
+  uint32_t *const w_hist = s_hist + wave * FX_DDENS_BINS;
   while (true) {
     __syncthreads();
     if (tid == 0) s_w[0] = atomicAdd(&B.counters[15], 1u);
@@ -4726,32 +4755,35 @@ extern "C" __global__ __launch_bounds__(FX_DDENS_T) void k_dense_density(FxDevPa
     const float cw = 1.0f / G.inv_cw, ch = 1.0f / G.inv_ch;
     const float4 *pts = B.dense_pts + off;
     const uint32_t *qlist = B.dense_q + B.dense_qoff[slot];
-    const uint32_t *table = B.dense_cells + (size_t)slot * FX_DCELLS;
-    for (uint32_t t = tid; t < FX_DCELLS; t += FX_DDENS_T) s_tab[t + 1] = table[t];
-    if (tid == 0) s_tab[0] = 0u;
-    const uint32_t my_quad = tid;  // (dealing the quads to the lanes by the number of targets around them was measured: 951 trips a
-                                   //  wavefront against 856 — lanes that are not neighbours in space walk different rows at the same time)
-    // ---- this lane's four queries and their box (coordinates)
+    const uint32_t *table = B.dense_cells + (size_t)slot * FX_DCELLS;  // table[c] = end of cell c in the sorted region
+    auto cell_start = [&](uint32_t c) -> uint32_t { return c ? table[c - 1u] : 0u; };
+    // ---- this lane's quad: its four queries and their box
     float4 q[4];
+    uint32_t qid[4];
     float bx0 = INFINITY, bx1 = -INFINITY, by0 = INFINITY, by1 = -INFINITY, bz0 = INFINITY, bz1 = -INFINITY;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const uint32_t qi = qb + 4u * my_quad + (uint32_t)u;
+      const uint32_t qi = qb + 4u * tid + (uint32_t)u;
       q[u] = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.0f);  // (no query: its differences overflow to infinity, never below the radius)
+      qid[u] = FX_NONE;
       const uint32_t qp = qi < n_q ? qlist[qi] : FX_NONE;  // (FX_NONE: padding at the end of a cell row)
       if (qp != FX_NONE) {
         q[u] = pts[qp];
-        q[u].w = __uint_as_float(__float_as_uint(q[u].w) & ~FX_DQ_WON);
+        qid[u] = __float_as_uint(q[u].w) & ~FX_DQ_WON;
         bx0 = fminf(bx0, q[u].x), bx1 = fmaxf(bx1, q[u].x);
         by0 = fminf(by0, q[u].y), by1 = fmaxf(by1, q[u].y);
         bz0 = fminf(bz0, q[u].z), bz1 = fmaxf(bz1, q[u].z);
       }
     }
+    s_q[4u * tid] = make_float4(q[0].x, q[1].x, q[2].x, q[3].x);
+    s_q[4u * tid + 1u] = make_float4(q[0].y, q[1].y, q[2].y, q[3].y);
+    s_q[4u * tid + 2u] = make_float4(q[0].z, q[1].z, q[2].z, q[3].z);
+    s_q[4u * tid + 3u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // (four uint32 zeros)
     const bool any_q = bx0 <= bx1;
     // Margins: a point's cell comes from a rounded product, so cell borders are taken a thousandth of a cell wide.
     const float eps_w = 1e-3f * cw, eps_h = 1e-3f * ch;
     const float rr = r_d * 1.0001f;
-    // rows (cy, cz) the lane walks: two cells either side in y, one layer either side in z (dense_grid)
+    // rows (cy, cz) the quad reaches: two cells either side in y, one layer either side in z (dense_grid)
     uint32_t ylo = 0, ny = 0, zlo = 0, n_rows = 0;
     if (any_q) {
       const uint32_t cy0 = G.cy(by0), cy1 = G.cy(by1), cz0 = G.cz(bz0), cz1 = G.cz(bz1);
@@ -4769,46 +4801,31 @@ extern "C" __global__ __launch_bounds__(FX_DDENS_T) void k_dense_density(FxDevPa
     const uint32_t UY0 = s_w[4], UY1 = s_w[5], UZ0 = s_w[6], UZ1 = s_w[7], UX0 = s_w[8], UX1 = s_w[9];
     if (UY0 > UY1) continue;  // (an item without queries: never emitted)
     const uint32_t uny = UY1 - UY0 + 1u, unr = uny * (UZ1 - UZ0 + 1u);
-    // ---- the rows of the box laid end to end: s_cat[r] = start of row r in that concatenation
-    if (tid < 64) {
-      const uint32_t per = (unr + 63u) / 64u;
-      uint32_t sum = 0;
-      for (uint32_t u = 0; u < per; ++u) {
-        const uint32_t r = tid * per + u;
-        if (r < unr) {
-          const uint32_t base = ((UZ0 + r / uny) * FX_DG + UY0 + r % uny) * FX_DG;
-          sum += s_tab[base + UX1 + 1u] - s_tab[base + UX0];
-        }
+    // ---- the rows of the box laid end to end: s_cat[r] = start of row r in that concatenation, s_row0[r] in the sorted region
+    {
+      uint32_t len = 0;
+      if (tid < unr) {
+        const uint32_t base = ((UZ0 + tid / uny) * FX_DG + UY0 + tid % uny) * FX_DG;
+        const uint32_t r0 = cell_start(base + UX0);
+        s_row0[tid] = r0;
+        len = table[base + UX1] - r0;
       }
-      uint32_t incl = sum;
+      // (unr <= 175 < 256: one value a thread, an inclusive scan over the workgroup through s_cat)
+      uint32_t incl = len;
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) {
         const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
-        if ((int)tid >= d) incl += o;
+        if ((int)lane >= d) incl += o;
       }
-      uint32_t run = incl - sum;
-      for (uint32_t u = 0; u < per; ++u) {
-        const uint32_t r = tid * per + u;
-        if (r < unr) {
-          const uint32_t base = ((UZ0 + r / uny) * FX_DG + UY0 + r % uny) * FX_DG;
-          s_cat[r] = run;
-          run += s_tab[base + UX1 + 1u] - s_tab[base + UX0];
-        }
-      }
-      if (tid == 63) s_cat[unr] = incl;
+      if (lane == 63u) s_w[10 + wave] = incl;
+      __syncthreads();
+      uint32_t before = 0;
+      for (uint32_t v = 0; v < wave; ++v) before += s_w[10 + v];
+      if (tid < unr) s_cat[tid] = before + incl - len;
+      if (tid == unr) s_cat[unr] = before + incl - len;  // (len = 0 there: the total)
     }
     __syncthreads();
     const uint32_t t_tot = s_cat[unr];
-    const fx_f2 ax = {q[0].x, q[1].x}, ay = {q[0].y, q[1].y}, az = {q[0].z, q[1].z};
-    const fx_f2 bx = {q[2].x, q[3].x}, by = {q[2].y, q[3].y}, bz = {q[2].z, q[3].z};
-    // Counting d2 < r2 without a compare and an add-with-carry per test: with S a power of two, fma(d2, -S, r2 S) is the
-    // exactly scaled difference rounded once — positive, zero or negative as r2 - d2 is (-inf when d2 S overflows) — at
-    // least 2^76 in magnitude unless zero, so the instruction's clamp to [0, 1] turns it into 1.0f or 0.0f; the counts add
-    // up exactly in fp32 (below 2^21).  Two tests per packed instruction, two instructions instead of four.
-    const float kS = __uint_as_float(min(354u - ((__float_as_uint(r2d) >> 23) & 0xffu), 254u) << 23);  // r2 S in [2^100, 2^101)
-                                                                                          // (fx_create: r2 >= 1e-30, so ulp(r2) S >= 1)
-    const fx_f2 nS2 = {-kS, -kS}, rS2 = {r2d * kS, r2d * kS};
-    fx_f2 ca = {0.0f, 0.0f}, cb = {0.0f, 0.0f};
 #ifdef FX_STAMPS
     unsigned long long n_tests = 0, n_wave = 0;
 #endif
@@ -4825,77 +4842,123 @@ extern "C" __global__ __launch_bounds__(FX_DDENS_T) void k_dense_density(FxDevPa
           else
             hi = mid;
         }
-        const uint32_t base = ((UZ0 + lo / uny) * FX_DG + UY0 + lo % uny) * FX_DG;
-        s_t[f] = pts[s_tab[base + UX0] + (g - s_cat[lo])];
+        const float4 t = pts[s_row0[lo] + (g - s_cat[lo])];
+        s_t[f] = t.x, s_t[FX_DDENS_C + f] = t.y, s_t[2 * FX_DDENS_C + f] = t.z;
       }
       __syncthreads();
-      // ---- every lane: its rows, each narrowed to the chord of the density sphere, as far as they lie in the window
-      for (uint32_t r = 0, cy = ylo, cz = zlo; r < n_rows; ++r, cz += (cy + 1u == ylo + ny) ? 1u : 0u, cy = (cy + 1u == ylo + ny) ? ylo : cy + 1u) {
-        const float y0 = G.gy0 + (float)cy * cw - eps_w, y1 = G.gy0 + (float)(cy + 1u) * cw + eps_w;
-        const float z0 = G.gz0 + (float)cz * ch - eps_h, z1 = G.gz0 + (float)(cz + 1u) * ch + eps_h;
-        // (edge cells also hold what the clamp put there: they extend outwards without limit)
-        const float dy = fmaxf(fmaxf(cy == 0u ? 0.0f : y0 - by1, cy == FX_DG - 1u ? 0.0f : by0 - y1), 0.0f);
-        const float dz = fmaxf(fmaxf(cz == 0u ? 0.0f : z0 - bz1, cz == FX_DGZ - 1u ? 0.0f : bz0 - z1), 0.0f);
-        const float h2 = rr * rr - (dy * dy + dz * dz);
-        if (!(h2 > 0.0f)) continue;  // the row is out of reach
-        const float h = sqrtf(h2) * 1.0001f + eps_w;
-        const uint32_t base = (cz * FX_DG + cy) * FX_DG;
-        const uint32_t ur = (cz - UZ0) * uny + (cy - UY0);
-        // window-relative positions of the run [start(cxl), end(cxh)) of this row
-        const uint32_t shift = s_cat[ur] - s_tab[base + UX0];  // sorted-region position -> concatenation position (mod 2^32)
-        const uint32_t g0 = s_tab[base + G.cx(bx0 - h)] + shift, g1 = s_tab[base + G.cx(bx1 + h) + 1u] + shift;
-        const uint32_t i0 = g0 > w ? g0 - w : 0u, i1 = g1 > w ? min(g1 - w, wn) : 0u;
+      // ---- passes: every lane lists up to FX_DDENS_RUNS units of its quad, the wavefront sorts and walks them
+      uint32_t r = 0, cy = ylo, cz = zlo;
+      while (__any(r < n_rows)) {
+        uint32_t run[FX_DDENS_RUNS];
+        uint32_t n_run = 0;
+        if (lane < FX_DDENS_BINS) w_hist[lane] = 0u;
+        for (; r < n_rows && n_run < FX_DDENS_RUNS; ++r, cz += (cy + 1u == ylo + ny) ? 1u : 0u, cy = (cy + 1u == ylo + ny) ? ylo : cy + 1u) {
+          const float y0 = G.gy0 + (float)cy * cw - eps_w, y1 = G.gy0 + (float)(cy + 1u) * cw + eps_w;
+          const float z0 = G.gz0 + (float)cz * ch - eps_h, z1 = G.gz0 + (float)(cz + 1u) * ch + eps_h;
+          // (edge cells also hold what the clamp put there: they extend outwards without limit)
+          const float dy = fmaxf(fmaxf(cy == 0u ? 0.0f : y0 - by1, cy == FX_DG - 1u ? 0.0f : by0 - y1), 0.0f);
+          const float dz = fmaxf(fmaxf(cz == 0u ? 0.0f : z0 - bz1, cz == FX_DGZ - 1u ? 0.0f : bz0 - z1), 0.0f);
+          const float h2 = rr * rr - (dy * dy + dz * dz);
+          if (!(h2 > 0.0f)) continue;  // the row is out of reach
+          const float h = sqrtf(h2) * 1.0001f + eps_w;
+          const uint32_t base = (cz * FX_DG + cy) * FX_DG;
+          const uint32_t ur = (cz - UZ0) * uny + (cy - UY0);
+          // window-relative positions of the run [start(cxl), end(cxh)) of this row
+          const uint32_t shift = s_cat[ur] - s_row0[ur];  // sorted-region position -> concatenation position (mod 2^32)
+          const uint32_t g0 = cell_start(base + G.cx(bx0 - h)) + shift, g1 = table[base + G.cx(bx1 + h)] + shift;
+          const uint32_t i0 = g0 > w ? g0 - w : 0u, i1 = g1 > w ? min(g1 - w, wn) : 0u;
+          if (i1 > i0) {
+            const uint32_t u = lane | i0 << 6 | (i1 - i0 - 1u) << 17;
+#pragma unroll
+            for (int k = 0; k < FX_DDENS_RUNS; ++k)
+              if ((uint32_t)k == n_run) run[k] = u;
+            ++n_run;
+          }
+        }
+        wave_sync_lds();  // (the histogram is clear)
+#pragma unroll
+        for (int k = 0; k < FX_DDENS_RUNS; ++k)
+          if ((uint32_t)k < n_run) atomicAdd(&w_hist[ddens_bin((run[k] >> 17) + 1u)], 1u);
+        wave_sync_lds();
+        uint32_t n_units;
+        {  // exclusive prefix over the bins (longest first)
+          const uint32_t h = lane < FX_DDENS_BINS ? w_hist[lane] : 0u;
+          uint32_t incl = h;
+#pragma unroll
+          for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+            if ((int)lane >= d) incl += o;
+          }
+          n_units = (uint32_t)__shfl((int)incl, 63, 64);
+          wave_sync_lds();
+          if (lane < FX_DDENS_BINS) w_hist[lane] = incl - h;
+        }
+        wave_sync_lds();
+#pragma unroll
+        for (int k = 0; k < FX_DDENS_RUNS; ++k)
+          if ((uint32_t)k < n_run) w_unit[atomicAdd(&w_hist[ddens_bin((run[k] >> 17) + 1u)], 1u)] = run[k];
+        wave_sync_lds();
+        for (uint32_t j = 0; j < n_units; j += 64u) {
+          if (j + lane < n_units) {
+            const uint32_t u = w_unit[j + lane];
+            const uint32_t quad = wave * 64u + (u & 63u), i0 = (u >> 6) & 2047u, i1 = i0 + (u >> 17) + 1u;
+            const float4 qx = s_q[4u * quad], qy = s_q[4u * quad + 1u], qz = s_q[4u * quad + 2u];
+            const fx_f2 ax = {qx.x, qx.y}, ay = {qy.x, qy.y}, az = {qz.x, qz.y};
+            const fx_f2 bx = {qx.z, qx.w}, by = {qy.z, qy.w}, bz = {qz.z, qz.w};
+            fx_f2 ca = {0.0f, 0.0f}, cb = {0.0f, 0.0f};
+            auto test = [&](const float tx, const float ty, const float tz) {
+              // FLANN L2_Simple, query - point, ((dx dx) + dy dy) + dz dz: two queries per packed instruction
+              const fx_f2 dxa = ax - tx, dya = ay - ty, dza = az - tz;
+              const fx_f2 dxb = bx - tx, dyb = by - ty, dzb = bz - tz;
+              fx_f2 ra = dxa * dxa, rb2 = dxb * dxb;
+              ra = ra + dya * dya, rb2 = rb2 + dyb * dyb;
+              ra = ra + dza * dza, rb2 = rb2 + dzb * dzb;
+              fx_f2 ia, ib;
+              asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(ia) : "v"(ra), "s"(nS2), "v"(rS2));
+              asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(ib) : "v"(rb2), "s"(nS2), "v"(rS2));
+              ca = ca + ia, cb = cb + ib;
+            };
+            uint32_t i = i0;
+            for (; i + 1u < i1; i += 2u) {  // (unrolled by hand: the pragma gives up on a loop with inline assembly)
+              const float tx0 = s_t[i], ty0 = s_t[FX_DDENS_C + i], tz0 = s_t[2 * FX_DDENS_C + i];
+              const float tx1 = s_t[i + 1u], ty1 = s_t[FX_DDENS_C + i + 1u], tz1 = s_t[2 * FX_DDENS_C + i + 1u];
+              test(tx0, ty0, tz0);
+              test(tx1, ty1, tz1);
+            }
+            if (i < i1) test(s_t[i], s_t[FX_DDENS_C + i], s_t[2 * FX_DDENS_C + i]);
+            uint32_t *cnt = reinterpret_cast<uint32_t *>(&s_q[4u * quad + 3u]);
+            atomicAdd(&cnt[0], (uint32_t)ca.x), atomicAdd(&cnt[1], (uint32_t)ca.y);
+            atomicAdd(&cnt[2], (uint32_t)cb.x), atomicAdd(&cnt[3], (uint32_t)cb.y);
 #ifdef FX_STAMPS
-        if (i1 > i0) n_tests += i1 - i0;
-        {
-          uint32_t mx = i1 > i0 ? i1 - i0 : 0u;
-          for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
-          n_wave += mx;
-        }
+            n_tests += i1 - i0;
 #endif
-        auto test = [&](const float4 t) {
-          // FLANN L2_Simple, query - point, ((dx dx) + dy dy) + dz dz: two queries per packed instruction
-          const fx_f2 dxa = ax - t.x, dya = ay - t.y, dza = az - t.z;
-          const fx_f2 dxb = bx - t.x, dyb = by - t.y, dzb = bz - t.z;
-          fx_f2 ra = dxa * dxa, rb2 = dxb * dxb;
-          ra = ra + dya * dya, rb2 = rb2 + dyb * dyb;
-          ra = ra + dza * dza, rb2 = rb2 + dzb * dzb;
-          fx_f2 ia, ib;
-          asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(ia) : "v"(ra), "s"(nS2), "v"(rS2));
-          asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(ib) : "v"(rb2), "s"(nS2), "v"(rS2));
-          ca = ca + ia, cb = cb + ib;
-        };
-        uint32_t i = i0;
-        for (; i + 1u < i1; i += 2u) {  // (unrolled by hand: the pragma gives up on a loop with inline assembly)
-          const float4 t0 = s_t[i], t1 = s_t[i + 1u];
-          test(t0);
-          test(t1);
+          }
+#ifdef FX_STAMPS
+          n_wave += (w_unit[j] >> 17) + 1u;  // (sorted: the slot's first unit is its longest)
+#endif
         }
-        if (i < i1) test(s_t[i]);
+        wave_sync_lds();  // (the units are read: the next pass may overwrite them)
       }
       __syncthreads();
     }
+    // ---- counts -> the scan's density cache (k_dense_finish of every row that has the point as a neighbour reads them)
+    const uint32_t *cnt = reinterpret_cast<const uint32_t *>(&s_q[4u * tid + 3u]);
 #ifdef FX_STAMPS
-    if (B.stamps) {  // diagnostic: targets walked per lane, per wavefront (row by row: the longest lane), true densities, queries
+    if (B.stamps) {  // diagnostic: targets walked per quad, per wavefront (slot by slot: the longest unit), true densities, queries
       unsigned long long nq = 0, dsum = 0;
-      const uint32_t cc[4] = {(uint32_t)ca.x, (uint32_t)ca.y, (uint32_t)cb.x, (uint32_t)cb.y};
       for (int u = 0; u < 4; ++u)
-        if (q[u].x < 1.0e38f) nq += 1, dsum += cc[u];
-      const bool wide = any_q && G.cx(bx1) - G.cx(bx0) > 1u;
+        if (qid[u] != FX_NONE) nq += 1, dsum += cnt[u];
       atomicAdd(&B.stamps[44 + 0], n_tests);
       atomicAdd(&B.stamps[44 + 1], dsum);
       atomicAdd(&B.stamps[44 + 2], nq);
-      if ((tid & 63u) == 0) atomicAdd(&B.stamps[44 + 3], n_wave);
+      if (lane == 0) atomicAdd(&B.stamps[44 + 3], n_wave);
       if (any_q) atomicAdd(&B.stamps[44 + 4], 1ull);
-      if (wide) atomicAdd(&B.stamps[63], 1ull);
     }
 #endif
-    // ---- counts -> the scan's density cache (k_dense_finish of every row that has the point as a neighbour reads them)
     unsigned long long *cache = B.dens_cache + (size_t)scan * P.max_points;
-    const uint32_t cnt[4] = {(uint32_t)ca.x, (uint32_t)ca.y, (uint32_t)cb.x, (uint32_t)cb.y};
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      if (q[u].x < 1.0e38f) cache[__float_as_uint(q[u].w)] = tag | (unsigned long long)cnt[u];
+      if (qid[u] != FX_NONE) cache[qid[u]] = tag | (unsigned long long)cnt[u];
   }
 }
 

@@ -36,8 +36,8 @@ rows = max(v[base + 6], 1)
 print(f"{name}: k_dense_sort rows {rows:.0f} (stamped workgroups only), support {v[base + 7] / rows:.0f}, overflow region {v[base + 8] / rows:.0f}")
 for k, nm in {1: "clear + pass 1 (histogram)", 2: "prefix", 3: "pass 2 (scatter)", 4: "pass 3 (claims, query list)", 5: "items"}.items():
     print(f"   {nm:32s} {v[base + k] / rows:10.0f} cycles per row (100 MHz clock x ?)")
-# k_dense_density's diagnostic counters (columns 44..48, 63: free of the ring / merge / descriptor kernels' stamps)
-t, d, q, wv, lanes, wide = v[44], v[45], v[46], v[47], v[48], v[63]
+# k_dense_density's diagnostic counters (columns 44..48: free of the ring / merge / descriptor kernels' stamps)
+t, d, q, wv, lanes = v[44], v[45], v[46], v[47], v[48]
 if q:
-    print(f"k_dense_density: {q:.0f} queries on {lanes:.0f} lanes ({q / lanes:.2f} per lane; {wide / lanes * 100:.1f} % of the lanes span more than two cells); "
-          f"targets walked per lane {t / lanes:.0f}, per wavefront (sum over rows of the longest lane) {wv / (lanes / 64):.0f} per 64 lanes; true density per query {d / q:.0f}")
+    print(f"k_dense_density: {q:.0f} queries in {lanes:.0f} quads ({q / lanes:.2f} per quad); targets walked per quad {t / lanes:.0f}, "
+          f"trips per wavefront and 64 quads (unit slots: the longest unit of each) {wv / (lanes / 64):.0f}; true density per query {d / q:.0f}")
