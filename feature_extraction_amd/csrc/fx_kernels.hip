@@ -4692,12 +4692,12 @@ extern "C" __global__ __launch_bounds__(FX_DSORT_T) void k_dense_sort(FxDevParam
 // fp32 arithmetic in FLANN's operation order.  The cell rows within reach of any of the workgroup's queries — per row
 // one contiguous run of the sorted region — pass through LDS in windows of FX_DDENS_C targets; per window, every lane lists
 // for ITS quad the part of each row that the quad's density spheres can reach (the row narrowed to the sphere's chord):
-// (quad, first, length) UNITS.  The units of a wavefront's 64 quads are then counting-sorted by length and dealt to its
-// lanes 64 at a time, longest first — a wavefront's trip costs its longest lane, and the quads of a wavefront differ a lot:
-// with every lane walking its own quad's rows in step a wavefront made 853 trips a quad where the mean lane needed 474
-// (config 3; 1159 / 632 on config 5: profiles/r04_front_experiments.md), because ring arcs cross the cell rows at different
-// places for lanes a few cells apart and queries — the points no earlier row has claimed — lie in neighbourhoods of
-// different density.  Counts go to LDS accumulators per query.
+// (quad, first, length) UNITS.  The units of the workgroup's 256 quads are then counting-sorted by length and its wavefronts
+// take them 64 at a time, longest first, from a shared counter — a wavefront's trip costs its longest lane, and the quads
+// differ a lot: with every lane walking its own quad's rows in step a wavefront made 853 trips a quad where the mean lane
+// needed 474 (config 3; 1159 / 632 on config 5: profiles/r04_front_experiments.md), because ring arcs cross the cell rows at
+// different places for lanes a few cells apart and queries — the points no earlier row has claimed — lie in neighbourhoods
+// of different density.  Counts go to LDS accumulators per query.
 // (Per-lane walks straight from global memory were measured: 64 scattered 16-byte loads per instruction keep the
 //  texture unit busier than the 24 arithmetic instructions they feed — 3.8 ms against 2.1 ms for a wave-uniform
 //  stream of the whole box, which tests 2-3 times as many targets as a lane needs.)
@@ -4709,19 +4709,41 @@ extern "C" __global__ __launch_bounds__(FX_DSORT_T) void k_dense_sort(FxDevParam
 #ifndef FX_DDENS_RUNS
 #define FX_DDENS_RUNS 8              // units a lane lists per pass
 #endif
-#define FX_DDENS_BINS 48             // length classes of the units (exponent, two mantissa bits)
-static_assert(FX_DDENS_C <= 2048, "k_dense_density packs a unit as quad (6 bits) | first (11) | length - 1 (11)");
+#define FX_DDENS_BINS 96             // length classes of the units (exponent, three mantissa bits)
+static_assert(FX_DDENS_C <= 2048 && FX_DDENS_T == 256, "k_dense_density packs a unit as quad (8 bits) | first (11) | length - 1 (11)");
+static_assert(FX_DDENS_BINS <= FX_DDENS_T, "one bin a thread in the prefix");
 // length class, longest first: bin 0 holds the longest units
 __device__ __forceinline__ uint32_t ddens_bin(uint32_t len) {  // len in [1, 2048]
   const uint32_t e = 31u - (uint32_t)__clz((int)len);           // 0 .. 11
-  const uint32_t m = e >= 2u ? (len >> (e - 2u)) & 3u : (len << (2u - e)) & 3u;
-  return (FX_DDENS_BINS - 1u) - (e * 4u + m);
+  const uint32_t m = e >= 3u ? (len >> (e - 3u)) & 7u : (len << (3u - e)) & 7u;
+  return (FX_DDENS_BINS - 1u) - (e * 8u + m);
+}
+// exclusive prefix of one value a thread over a 256-thread workgroup (tmp: four words; contains one barrier; total: the sum)
+__device__ __forceinline__ uint32_t wg256_prefix(uint32_t v, uint32_t *tmp, uint32_t &total) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+    if ((int)lane >= d) incl += o;
+  }
+  if (lane == 63u) tmp[wave] = incl;
+  __syncthreads();
+  uint32_t before = 0;
+  total = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < 4u; ++w) {
+    const uint32_t t = tmp[w];
+    before += w < wave ? t : 0u;
+    total += t;
+  }
+  return before + incl - v;
 }
 extern "C" __global__ __launch_bounds__(FX_DDENS_T) void k_dense_density(FxDevParams P, FxBuffers B) {
   __shared__ float s_t[3 * FX_DDENS_C];                    // the window: x | y | z
   __shared__ float4 s_q[4 * FX_DDENS_T];                   // per quad: x of its four queries, y, z, their counts (as uint32)
-  __shared__ uint32_t s_unit[FX_DDENS_RUNS * FX_DDENS_T];  // per wavefront: its lanes' units, then the same sorted by length
-  __shared__ uint32_t s_hist[(FX_DDENS_T / 64) * FX_DDENS_BINS];
+  __shared__ uint32_t s_unit[FX_DDENS_RUNS * FX_DDENS_T];  // the units of a pass, sorted by length
+  __shared__ uint32_t s_hist[FX_DDENS_BINS];
   __shared__ uint32_t s_cat[FX_DDENS_T];    // start of every row of the box (<= 176) in the concatenation of the rows' runs
   __shared__ uint32_t s_row0[FX_DDENS_T];   // sorted-region position of the first target of every row of the box
   __shared__ uint32_t s_w[16];
@@ -4738,8 +4760,6 @@ extern "C" __global__ __launch_bounds__(FX_DDENS_T) void k_dense_density(FxDevPa
   const float kS = __uint_as_float(min(354u - ((__float_as_uint(r2d) >> 23) & 0xffu), 254u) << 23);  // r2 S in [2^100, 2^101)
                                                                                         // (fx_create: r2 >= 1e-30, so ulp(r2) S >= 1)
   const fx_f2 nS2 = {-kS, -kS}, rS2 = {r2d * kS, r2d * kS};
-  uint32_t *const w_unit = s_unit + wave * (FX_DDENS_RUNS * 64u);
-  uint32_t *const w_hist = s_hist + wave * FX_DDENS_BINS;
   while (true) {
     __syncthreads();
     if (tid == 0) s_w[0] = atomicAdd(&B.counters[15], 1u);
@@ -4803,26 +4823,15 @@ extern "C" __global__ __launch_bounds__(FX_DDENS_T) void k_dense_density(FxDevPa
     const uint32_t uny = UY1 - UY0 + 1u, unr = uny * (UZ1 - UZ0 + 1u);
     // ---- the rows of the box laid end to end: s_cat[r] = start of row r in that concatenation, s_row0[r] in the sorted region
     {
-      uint32_t len = 0;
+      uint32_t len = 0, total;
       if (tid < unr) {
         const uint32_t base = ((UZ0 + tid / uny) * FX_DG + UY0 + tid % uny) * FX_DG;
         const uint32_t r0 = cell_start(base + UX0);
         s_row0[tid] = r0;
         len = table[base + UX1] - r0;
       }
-      // (unr <= 175 < 256: one value a thread, an inclusive scan over the workgroup through s_cat)
-      uint32_t incl = len;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
-        if ((int)lane >= d) incl += o;
-      }
-      if (lane == 63u) s_w[10 + wave] = incl;
-      __syncthreads();
-      uint32_t before = 0;
-      for (uint32_t v = 0; v < wave; ++v) before += s_w[10 + v];
-      if (tid < unr) s_cat[tid] = before + incl - len;
-      if (tid == unr) s_cat[unr] = before + incl - len;  // (len = 0 there: the total)
+      const uint32_t excl = wg256_prefix(len, &s_w[10], total);  // (unr <= 175 < 256: one row a thread)
+      if (tid <= unr) s_cat[tid] = excl;                          // (s_cat[unr] = the total)
     }
     __syncthreads();
     const uint32_t t_tot = s_cat[unr];
@@ -4846,12 +4855,13 @@ extern "C" __global__ __launch_bounds__(FX_DDENS_T) void k_dense_density(FxDevPa
         s_t[f] = t.x, s_t[FX_DDENS_C + f] = t.y, s_t[2 * FX_DDENS_C + f] = t.z;
       }
       __syncthreads();
-      // ---- passes: every lane lists up to FX_DDENS_RUNS units of its quad, the wavefront sorts and walks them
+      // ---- passes: every lane lists up to FX_DDENS_RUNS units of its quad, the workgroup sorts them, its wavefronts walk them
       uint32_t r = 0, cy = ylo, cz = zlo;
-      while (__any(r < n_rows)) {
+      while (true) {
         uint32_t run[FX_DDENS_RUNS];
         uint32_t n_run = 0;
-        if (lane < FX_DDENS_BINS) w_hist[lane] = 0u;
+        if (tid < FX_DDENS_BINS) s_hist[tid] = 0u;
+        if (tid == 0) s_w[1] = 0u;  // the slot counter
         for (; r < n_rows && n_run < FX_DDENS_RUNS; ++r, cz += (cy + 1u == ylo + ny) ? 1u : 0u, cy = (cy + 1u == ylo + ny) ? ylo : cy + 1u) {
           const float y0 = G.gy0 + (float)cy * cw - eps_w, y1 = G.gy0 + (float)(cy + 1u) * cw + eps_w;
           const float z0 = G.gz0 + (float)cz * ch - eps_h, z1 = G.gz0 + (float)(cz + 1u) * ch + eps_h;
@@ -4868,40 +4878,37 @@ extern "C" __global__ __launch_bounds__(FX_DDENS_T) void k_dense_density(FxDevPa
           const uint32_t g0 = cell_start(base + G.cx(bx0 - h)) + shift, g1 = table[base + G.cx(bx1 + h)] + shift;
           const uint32_t i0 = g0 > w ? g0 - w : 0u, i1 = g1 > w ? min(g1 - w, wn) : 0u;
           if (i1 > i0) {
-            const uint32_t u = lane | i0 << 6 | (i1 - i0 - 1u) << 17;
+            const uint32_t u = tid | i0 << 8 | (i1 - i0 - 1u) << 19;
 #pragma unroll
             for (int k = 0; k < FX_DDENS_RUNS; ++k)
               if ((uint32_t)k == n_run) run[k] = u;
             ++n_run;
           }
         }
-        wave_sync_lds();  // (the histogram is clear)
+        if (!__syncthreads_or((int)n_run)) break;  // (no lane listed anything: every lane is through its rows; the histogram is clear)
 #pragma unroll
         for (int k = 0; k < FX_DDENS_RUNS; ++k)
-          if ((uint32_t)k < n_run) atomicAdd(&w_hist[ddens_bin((run[k] >> 17) + 1u)], 1u);
-        wave_sync_lds();
+          if ((uint32_t)k < n_run) atomicAdd(&s_hist[ddens_bin((run[k] >> 19) + 1u)], 1u);
+        __syncthreads();
         uint32_t n_units;
         {  // exclusive prefix over the bins (longest first)
-          const uint32_t h = lane < FX_DDENS_BINS ? w_hist[lane] : 0u;
-          uint32_t incl = h;
-#pragma unroll
-          for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
-            if ((int)lane >= d) incl += o;
-          }
-          n_units = (uint32_t)__shfl((int)incl, 63, 64);
-          wave_sync_lds();
-          if (lane < FX_DDENS_BINS) w_hist[lane] = incl - h;
+          const uint32_t h = tid < FX_DDENS_BINS ? s_hist[tid] : 0u;
+          const uint32_t excl = wg256_prefix(h, &s_w[10], n_units);
+          if (tid < FX_DDENS_BINS) s_hist[tid] = excl;
         }
-        wave_sync_lds();
+        __syncthreads();
 #pragma unroll
         for (int k = 0; k < FX_DDENS_RUNS; ++k)
-          if ((uint32_t)k < n_run) w_unit[atomicAdd(&w_hist[ddens_bin((run[k] >> 17) + 1u)], 1u)] = run[k];
-        wave_sync_lds();
-        for (uint32_t j = 0; j < n_units; j += 64u) {
+          if ((uint32_t)k < n_run) s_unit[atomicAdd(&s_hist[ddens_bin((run[k] >> 19) + 1u)], 1u)] = run[k];
+        __syncthreads();
+        while (true) {  // slots of 64 units, longest first, to whichever wavefront is free
+          uint32_t j = 0;
+          if (lane == 0) j = atomicAdd(&s_w[1], 64u);
+          j = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);
+          if (j >= n_units) break;
           if (j + lane < n_units) {
-            const uint32_t u = w_unit[j + lane];
-            const uint32_t quad = wave * 64u + (u & 63u), i0 = (u >> 6) & 2047u, i1 = i0 + (u >> 17) + 1u;
+            const uint32_t u = s_unit[j + lane];
+            const uint32_t quad = u & 255u, i0 = (u >> 8) & 2047u, i1 = i0 + (u >> 19) + 1u;
             const float4 qx = s_q[4u * quad], qy = s_q[4u * quad + 1u], qz = s_q[4u * quad + 2u];
             const fx_f2 ax = {qx.x, qx.y}, ay = {qy.x, qy.y}, az = {qz.x, qz.y};
             const fx_f2 bx = {qx.z, qx.w}, by = {qy.z, qy.w}, bz = {qz.z, qz.w};
@@ -4934,13 +4941,14 @@ extern "C" __global__ __launch_bounds__(FX_DDENS_T) void k_dense_density(FxDevPa
 #endif
           }
 #ifdef FX_STAMPS
-          n_wave += (w_unit[j] >> 17) + 1u;  // (sorted: the slot's first unit is its longest)
+          n_wave += (s_unit[j] >> 19) + 1u;  // (sorted: the slot's first unit is its longest)
 #endif
         }
-        wave_sync_lds();  // (the units are read: the next pass may overwrite them)
+        __syncthreads();  // (the units are read: the next pass may overwrite them)
       }
-      __syncthreads();
+      // (the pass loop leaves through a barrier: the window may be overwritten)
     }
+    __syncthreads();  // (every wavefront's counts are in)
     // ---- counts -> the scan's density cache (k_dense_finish of every row that has the point as a neighbour reads them)
     const uint32_t *cnt = reinterpret_cast<const uint32_t *>(&s_q[4u * tid + 3u]);
 #ifdef FX_STAMPS
