@@ -4838,58 +4838,71 @@ extern "C" __global__ __launch_bounds__(FX_DDENS_T) void k_dense_density(FxDevPa
 #ifdef FX_STAMPS
     unsigned long long n_tests = 0, n_wave = 0;
 #endif
+    uint32_t r0 = 0, cy0 = ylo, cz0 = zlo;  // the lane's first row with targets the windows so far have not covered
     for (uint32_t w = 0; w < t_tot; w += FX_DDENS_C) {
       const uint32_t wn = min((uint32_t)FX_DDENS_C, t_tot - w);
       // ---- the window: concatenation position -> row (binary search) -> sorted-region position
-      for (uint32_t f = tid; f < wn; f += FX_DDENS_T) {
-        const uint32_t g = w + f;
-        uint32_t lo = 0, hi = unr;  // invariant: s_cat[lo] <= g < s_cat[hi]
+      if (tid < wn) {
+        uint32_t lo = 0, hi = unr;  // invariant: s_cat[lo] <= g < s_cat[hi]; a binary search for the thread's first target ...
         while (hi - lo > 1u) {
           const uint32_t mid = (lo + hi) >> 1;
-          if (s_cat[mid] <= g)
+          if (s_cat[mid] <= w + tid)
             lo = mid;
           else
             hi = mid;
         }
-        const float4 t = pts[s_row0[lo] + (g - s_cat[lo])];
-        s_t[f] = t.x, s_t[FX_DDENS_C + f] = t.y, s_t[2 * FX_DDENS_C + f] = t.z;
+        for (uint32_t f = tid; f < wn; f += FX_DDENS_T) {
+          const uint32_t g = w + f;
+          while (s_cat[lo + 1u] <= g) ++lo;  // ... a step or two for the next ones (s_cat[unr] = t_tot > g)
+          const float4 t = pts[s_row0[lo] + (g - s_cat[lo])];
+          s_t[f] = t.x, s_t[FX_DDENS_C + f] = t.y, s_t[2 * FX_DDENS_C + f] = t.z;
+        }
       }
       __syncthreads();
       // ---- passes: every lane lists up to FX_DDENS_RUNS units of its quad, the workgroup sorts them, its wavefronts walk them
-      uint32_t r = 0, cy = ylo, cz = zlo;
+      // (the rows come in the order of the concatenation, so a lane's cursor r0 only moves forward: rows that end before the
+      //  window are behind it, the row loop stops at the first row that starts after the window)
+      uint32_t r = r0, cy = cy0, cz = cz0, lim = n_rows;
       while (true) {
-        uint32_t run[FX_DDENS_RUNS];
         uint32_t n_run = 0;
         if (tid < FX_DDENS_BINS) s_hist[tid] = 0u;
         if (tid == 0) s_w[1] = 0u;  // the slot counter
-        for (; r < n_rows && n_run < FX_DDENS_RUNS; ++r, cz += (cy + 1u == ylo + ny) ? 1u : 0u, cy = (cy + 1u == ylo + ny) ? ylo : cy + 1u) {
-          const float y0 = G.gy0 + (float)cy * cw - eps_w, y1 = G.gy0 + (float)(cy + 1u) * cw + eps_w;
-          const float z0 = G.gz0 + (float)cz * ch - eps_h, z1 = G.gz0 + (float)(cz + 1u) * ch + eps_h;
+        while (r < lim && n_run < FX_DDENS_RUNS) {
+          const uint32_t rcy = cy, rcz = cz;
+          ++r, cz += (cy + 1u == ylo + ny) ? 1u : 0u, cy = (cy + 1u == ylo + ny) ? ylo : cy + 1u;  // (the next row)
+          const uint32_t ur = (rcz - UZ0) * uny + (rcy - UY0);
+          const uint32_t rb = s_cat[ur], re = s_cat[ur + 1u];
+          if (rb >= w + wn) {  // this row and the ones after it: later windows
+            --r, cy = rcy, cz = rcz;
+            lim = r;
+            break;
+          }
+          if (re <= w + wn) r0 = r, cy0 = cy, cz0 = cz;  // nothing of this row beyond the window (nor of the rows before it)
+          if (re <= w) continue;
+          const float y0 = G.gy0 + (float)rcy * cw - eps_w, y1 = G.gy0 + (float)(rcy + 1u) * cw + eps_w;
+          const float z0 = G.gz0 + (float)rcz * ch - eps_h, z1 = G.gz0 + (float)(rcz + 1u) * ch + eps_h;
           // (edge cells also hold what the clamp put there: they extend outwards without limit)
-          const float dy = fmaxf(fmaxf(cy == 0u ? 0.0f : y0 - by1, cy == FX_DG - 1u ? 0.0f : by0 - y1), 0.0f);
-          const float dz = fmaxf(fmaxf(cz == 0u ? 0.0f : z0 - bz1, cz == FX_DGZ - 1u ? 0.0f : bz0 - z1), 0.0f);
+          const float dy = fmaxf(fmaxf(rcy == 0u ? 0.0f : y0 - by1, rcy == FX_DG - 1u ? 0.0f : by0 - y1), 0.0f);
+          const float dz = fmaxf(fmaxf(rcz == 0u ? 0.0f : z0 - bz1, rcz == FX_DGZ - 1u ? 0.0f : bz0 - z1), 0.0f);
           const float h2 = rr * rr - (dy * dy + dz * dz);
           if (!(h2 > 0.0f)) continue;  // the row is out of reach
           const float h = sqrtf(h2) * 1.0001f + eps_w;
-          const uint32_t base = (cz * FX_DG + cy) * FX_DG;
-          const uint32_t ur = (cz - UZ0) * uny + (cy - UY0);
+          const uint32_t base = (rcz * FX_DG + rcy) * FX_DG;
           // window-relative positions of the run [start(cxl), end(cxh)) of this row
-          const uint32_t shift = s_cat[ur] - s_row0[ur];  // sorted-region position -> concatenation position (mod 2^32)
+          const uint32_t shift = rb - s_row0[ur];  // sorted-region position -> concatenation position (mod 2^32)
           const uint32_t g0 = cell_start(base + G.cx(bx0 - h)) + shift, g1 = table[base + G.cx(bx1 + h)] + shift;
           const uint32_t i0 = g0 > w ? g0 - w : 0u, i1 = g1 > w ? min(g1 - w, wn) : 0u;
-          if (i1 > i0) {
-            const uint32_t u = tid | i0 << 8 | (i1 - i0 - 1u) << 19;
-#pragma unroll
-            for (int k = 0; k < FX_DDENS_RUNS; ++k)
-              if ((uint32_t)k == n_run) run[k] = u;
-            ++n_run;
-          }
+          if (i1 > i0) s_unit[n_run++ * FX_DDENS_T + tid] = tid | i0 << 8 | (i1 - i0 - 1u) << 19;  // (the lane's own column for now)
         }
         if (!__syncthreads_or((int)n_run)) break;  // (no lane listed anything: every lane is through its rows; the histogram is clear)
+        uint32_t run[FX_DDENS_RUNS];
 #pragma unroll
         for (int k = 0; k < FX_DDENS_RUNS; ++k)
-          if ((uint32_t)k < n_run) atomicAdd(&s_hist[ddens_bin((run[k] >> 19) + 1u)], 1u);
-        __syncthreads();
+          if ((uint32_t)k < n_run) {
+            run[k] = s_unit[k * FX_DDENS_T + tid];
+            atomicAdd(&s_hist[ddens_bin((run[k] >> 19) + 1u)], 1u);
+          }
+        __syncthreads();  // (every lane has its column in registers: the sorted list may overwrite it)
         uint32_t n_units;
         {  // exclusive prefix over the bins (longest first)
           const uint32_t h = tid < FX_DDENS_BINS ? s_hist[tid] : 0u;
