@@ -500,6 +500,11 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
     const int v = atoi(e);
     if (v >= 1 && (uint32_t)v < P.dense_lds_keys) P.dense_lds_keys = (uint32_t)v;
   }
+  P.dense_won_points = 0xffffffffu;  // (the kernel's own bit map bounds it)
+  if (const char *e = test_hook("FX_DENSE_WON_POINTS")) {  // test hook: rows of more points mark their queries in the sorted region itself
+    const int v = atoi(e);
+    if (v >= 0) P.dense_won_points = (uint32_t)v;
+  }
   P.ring_slot_cap = 2 * L.max_points;  // worst case: every point on a window boundary, i.e. in two rings
   P.ring_list_cap = ((L.max_batch + 7) / 8) * (uint32_t)params->n_rings;  // rings of the scans of one XCD class
 

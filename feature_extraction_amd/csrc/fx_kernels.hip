@@ -4420,7 +4420,47 @@ __device__ __forceinline__ void dense_row_failed(const FxDevParams &P, const FxB
   desc_fill_nan(B.desc + (size_t)row * FX_DESC_FLOATS, threadIdx.x, nt);
 }
 
+// In-place exclusive prefix over the FX_DCELLS entries of an LDS table by all NT threads of the workgroup (PAD: every entry
+// rounded up to a multiple of four first); returns the total.  tmp: NT / 64 words.  Contains barriers; the caller adds one
+// before the table is read.
+template <int NT, bool PAD>
+__device__ __forceinline__ uint32_t dense_cells_prefix(uint32_t *cells, uint32_t *tmp) {
+  constexpr uint32_t per = (FX_DCELLS + NT - 1) / NT;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  uint32_t sum = 0;
+  for (uint32_t u = 0; u < per; ++u) {
+    const uint32_t ci = tid * per + u;
+    const uint32_t c = ci < FX_DCELLS ? cells[ci] : 0u;
+    sum += PAD ? (c + 3u) & ~3u : c;
+  }
+  uint32_t incl = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+    if ((int)lane >= d) incl += o;
+  }
+  if (lane == 63u) tmp[wave] = incl;
+  __syncthreads();
+  uint32_t run = incl - sum, total = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < NT / 64; ++w) {
+    const uint32_t t = tmp[w];
+    run += w < wave ? t : 0u;
+    total += t;
+  }
+  for (uint32_t u = 0; u < per; ++u) {
+    const uint32_t ci = tid * per + u;
+    if (ci < FX_DCELLS) {
+      const uint32_t c = PAD ? (cells[ci] + 3u) & ~3u : cells[ci];
+      cells[ci] = run;
+      run += c;
+    }
+  }
+  return total;
+}
+
 extern "C" __global__ __launch_bounds__(FX_DSORT_T) void k_dense_sort(FxDevParams P, FxBuffers B) {
+  __shared__ uint32_t s_scan[FX_DSORT_T / 64];
   __shared__ uint32_t cell_end[FX_DCELLS + 1];
   __shared__ uint32_t s_w[16];
   const uint32_t tid = threadIdx.x;
@@ -4454,13 +4494,17 @@ extern "C" __global__ __launch_bounds__(FX_DSORT_T) void k_dense_sort(FxDevParam
 #ifdef FX_STAMPS
     stamp_prev_ = __builtin_amdgcn_s_memtime();
 #endif
-    for (uint32_t t = tid; t < FX_DCELLS + 1; t += FX_DSORT_T) cell_end[t] = 0;
+    const bool in_lds = nS <= min(32u * FX_DSORT_WONW, P.dense_won_points);
+    for (uint32_t t = tid; t < FX_DCELLS + 1; t += FX_DSORT_T) cell_end[t] = 0u, cell_q[t] = 0u;
+    if (in_lds)
+      for (uint32_t t = tid; t < (nS + 31u) / 32u; t += FX_DSORT_T) won_bits[t] = 0u;
     if (tid < 16) s_w[tid] = 0;
     __syncthreads();
     // every support point of the row: its list, then its entries of the scan's overflow region; four loads in flight
-    // per lane (a pass is a chain of L2 round trips otherwise)
+    // per lane (a pass is a chain of L2 round trips otherwise).  fn(v, u) sees the four points of a lane one after the
+    // other, then done() once: what it starts for a point (an atomic whose result it needs) it finishes there.
     uint32_t mine = 0;
-    auto each_point = [&](auto &&fn) {
+    auto each_point = [&](auto &&fn, auto &&done) {
       for (uint32_t e0 = 0; e0 < n_list; e0 += 4u * FX_DSORT_T) {
         float4 v[4];
 #pragma unroll
@@ -4469,8 +4513,8 @@ extern "C" __global__ __launch_bounds__(FX_DSORT_T) void k_dense_sort(FxDevParam
           if (e < n_list) v[u] = lst[e];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (e0 + (uint32_t)u * FX_DSORT_T + tid < n_list) fn(v[u]);
+        for (int u = 0; u < 4; ++u) fn(v[u], u, e0 + (uint32_t)u * FX_DSORT_T + tid < n_list);
+        done();
       }
       for (uint32_t e0 = 0; e0 < n_ovf; e0 += 4u * FX_DSORT_T) {
         uint32_t kk[4];
@@ -4484,15 +4528,15 @@ extern "C" __global__ __launch_bounds__(FX_DSORT_T) void k_dense_sort(FxDevParam
         for (int u = 0; u < 4; ++u)
           if (kk[u] == k) v[u] = ovf[e0 + (uint32_t)u * FX_DSORT_T + tid];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (kk[u] == k) {
-            fn(v[u]);
-            ++mine;
-          }
+        for (int u = 0; u < 4; ++u) {
+          fn(v[u], u, kk[u] == k);
+          mine += kk[u] == k ? 1u : 0u;
+        }
+        done();
       }
     };
     // ---- pass 1: support points per cell
-    each_point([&](const float4 &v) { atomicAdd(&cell_end[G.cell(v.x, v.y, v.z)], 1u); });
+    each_point([&](const float4 &v, int, bool valid) { if (valid) atomicAdd(&cell_end[G.cell(v.x, v.y, v.z)], 1u); }, [] {});
     if (mine) atomicAdd(&s_w[8], mine);
     __syncthreads();
     FX_STAMP(1);
@@ -4500,126 +4544,76 @@ extern "C" __global__ __launch_bounds__(FX_DSORT_T) void k_dense_sort(FxDevParam
       dense_row_failed(P, B, slot, row, scan, k, FX_DSORT_T);
       continue;
     }
-    if (tid < 64) {  // counts -> exclusive starts, in place, by one wavefront
-      constexpr uint32_t per = (FX_DCELLS + 63) / 64;
-      uint32_t sum = 0;
-      for (uint32_t u = 0; u < per; ++u) {
-        const uint32_t ci = tid * per + u;
-        sum += ci < FX_DCELLS ? cell_end[ci] : 0u;
-      }
-      uint32_t incl = sum;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
-        if ((int)tid >= d) incl += o;
-      }
-      uint32_t run = incl - sum;
-      for (uint32_t u = 0; u < per; ++u) {
-        const uint32_t ci = tid * per + u;
-        if (ci < FX_DCELLS) {
-          const uint32_t c = cell_end[ci];
-          cell_end[ci] = run;
-          run += c;
-        }
-      }
-    }
+    dense_cells_prefix<FX_DSORT_T, false>(cell_end, s_scan);  // counts -> exclusive starts, in place
     __syncthreads();
     FX_STAMP(2);
-    // ---- pass 2: every point to its cell (the fill turns a cell's start into its end = the next cell's start)
-    each_point([&](const float4 &v) { dst[atomicAdd(&cell_end[G.cell(v.x, v.y, v.z)], 1u)] = v; });
+    // ---- pass 2: every point to its cell (the fill turns a cell's start into its end = the next cell's start), and on
+    //      the way: neighbours (d2 < R^2; the count 3DSC reports), binned neighbours (not the keypoint's own point), and the
+    //      queries: binned neighbours whose density this row is the first to claim — claimed here, counted per cell and
+    //      remembered (a bit map in LDS over the sorted positions; the top bit of the point's index word in the sorted region
+    //      for rows beyond 65536 support points).  Batch tags only grow and a claim is the largest word of its batch: one
+    //      atomic max both tests and claims; a lane's four are in flight together.
+    unsigned long long *cache = B.dens_cache + (size_t)scan * P.max_points;
+    const unsigned long long claim = (seq << FX_DENS_BITS) | FX_DENS_MASK;
+    uint32_t n_nb = 0, n_use = 0;
+    {
+      float4 pv[4];
+      uint32_t pp[4];
+      unsigned long long old[4];
+      bool use[4], val[4];
+      each_point(
+          [&](const float4 &v, int u, bool valid) {
+            val[u] = valid, use[u] = false, pv[u] = v;
+            if (!valid) return;
+            pp[u] = atomicAdd(&cell_end[G.cell(v.x, v.y, v.z)], 1u);
+            const float d2 = dist2(kp.x, kp.y, kp.z, v.x, v.y, v.z);
+            const bool nb = d2 < P.r2_search;
+            use[u] = nb && !sc3d_is_origin(d2);
+            n_nb += nb ? 1u : 0u;
+            n_use += use[u] ? 1u : 0u;
+#ifdef FX_NO_DEDUPE  // (diagnostic: every row computes all its neighbours' densities itself)
+            old[u] = 0ull;
+            if (use[u]) atomicMax(cache + __float_as_uint(v.w), claim);
+#else
+            old[u] = use[u] ? atomicMax(cache + __float_as_uint(v.w), claim) : claim;
+#endif
+          },
+          [&] {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              if (!val[u]) continue;
+              const bool won = use[u] && (old[u] >> FX_DENS_BITS) != seq;  // this row computes the point's density
+              float4 v = pv[u];
+              if (won) {
+                atomicAdd(&cell_q[G.cell(v.x, v.y, v.z)], 1u);
+                if (in_lds)
+                  atomicOr(&won_bits[pp[u] >> 5], 1u << (pp[u] & 31u));
+                else
+                  v.w = __uint_as_float(__float_as_uint(v.w) | FX_DQ_WON);
+              }
+              dst[pp[u]] = v;
+            }
+          });
+    }
+    if (n_nb) atomicAdd(&s_w[9], n_nb);
+    if (n_use) atomicAdd(&s_w[10], n_use);
     // (the sorted region is re-read below by other waves of this workgroup: they share the CU's L1, and the barrier's
     //  workgroup-scope fences order the stores — an agent-scope __threadfence() would write the L2 back each time)
     wg_global_sync();
     FX_STAMP(3);
     for (uint32_t t = tid; t < FX_DCELLS; t += FX_DSORT_T) table[t] = cell_end[t];  // cell c = [c ? end[c - 1] : 0, end[c])
-    // ---- pass 3, over the sorted region: neighbours (d2 < R^2; the count 3DSC reports), binned neighbours (not the
-    //      keypoint's own point), and the queries: binned neighbours whose density this row is the first to claim
-    unsigned long long *cache = B.dens_cache + (size_t)scan * P.max_points;
-    const unsigned long long claim = (seq << FX_DENS_BITS) | FX_DENS_MASK;
-    // The list is built cell by cell, every cell's part padded to a multiple of four entries: k_dense_density gives a lane
-    // four consecutive queries, and four queries of ONE cell have a box no larger than the cell.  (Unpadded, 4 % of the
-    // lanes held queries of three or more cells — the sparse stretches of a row, the edges of what other rows had
-    // claimed — walked twice as far as the others, and nearly every wavefront had one: 974 trips a wavefront against
-    // 509 a lane.)  Pass a: claim, count per cell, remember the winners (a bit map in LDS; the top bit of the point's
-    // index word in the sorted region for rows beyond 65536 support points).  Then a padded prefix over the cells and
-    // the row's share of the query pool.  Pass b: every winner to its cell's part of the list.
-    const bool in_lds = nS <= 32u * FX_DSORT_WONW;
-    for (uint32_t t = tid; t < FX_DCELLS + 1; t += FX_DSORT_T) cell_q[t] = 0u;
-    if (in_lds)
-      for (uint32_t t = tid; t < (nS + 31u) / 32u; t += FX_DSORT_T) won_bits[t] = 0u;
-    __syncthreads();
-    const uint32_t lane = tid & 63u;
-    uint32_t n_nb = 0, n_use = 0;
-    // (four points per lane at a time: their loads, then their claims, are in flight together — the pass is a chain of L2
-    //  round trips otherwise)
-    for (uint32_t p0 = 0; p0 < nS; p0 += 4u * FX_DSORT_T) {
-      float4 v[4];
-      bool use[4];
-#pragma unroll
-      for (uint32_t u = 0; u < 4; ++u) {
-        const uint32_t p = p0 + u * FX_DSORT_T + tid;
-        v[u] = p < nS ? dst[p] : make_float4(INFINITY, INFINITY, INFINITY, 0.0f);
-      }
-      unsigned long long old[4];
-#pragma unroll
-      for (uint32_t u = 0; u < 4; ++u) {
-        const float d2 = dist2(kp.x, kp.y, kp.z, v[u].x, v[u].y, v[u].z);  // (no point: infinite)
-        const bool nb = d2 < P.r2_search;
-        use[u] = nb && !sc3d_is_origin(d2);
-        n_nb += (uint32_t)__popcll(__ballot(nb));
-        n_use += (uint32_t)__popcll(__ballot(use[u]));
-        // batch tags only grow and a claim is the largest word of its batch: one atomic max both tests and claims
-#ifdef FX_NO_DEDUPE  // (diagnostic: every row computes all its neighbours' densities itself)
-        old[u] = 0ull;
-        if (use[u]) atomicMax(cache + __float_as_uint(v[u].w), claim);
-#else
-        old[u] = use[u] ? atomicMax(cache + __float_as_uint(v[u].w), claim) : claim;
-#endif
-      }
-#pragma unroll
-      for (uint32_t u = 0; u < 4; ++u) {
-        if (use[u] && (old[u] >> FX_DENS_BITS) != seq) {  // won: this row computes the point's density
-          const uint32_t p = p0 + u * FX_DSORT_T + tid;
-          atomicAdd(&cell_q[G.cell(v[u].x, v[u].y, v[u].z)], 1u);
-          if (in_lds)
-            atomicOr(&won_bits[p >> 5], 1u << (p & 31u));
-          else
-            reinterpret_cast<uint32_t *>(dst + p)[3] = __float_as_uint(v[u].w) | FX_DQ_WON;
-        }
-      }
-    }
-    if (lane == 0) {  // (the ballots above are wave-wide: one lane reports them)
-      if (n_nb) atomicAdd(&s_w[9], n_nb);
-      if (n_use) atomicAdd(&s_w[10], n_use);
-    }
-    wg_global_sync();  // (the marks in the sorted region are re-read below when the bit map is too small)
-    if (tid < 64) {  // padded counts -> cell starts, in place, by one wavefront
-      constexpr uint32_t per = (FX_DCELLS + 63) / 64;
-      uint32_t sum = 0;
-      for (uint32_t u = 0; u < per; ++u) {
-        const uint32_t ci = tid * per + u;
-        sum += ci < FX_DCELLS ? (cell_q[ci] + 3u) & ~3u : 0u;
-      }
-      uint32_t incl = sum;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
-        if ((int)tid >= d) incl += o;
-      }
-      uint32_t run = incl - sum;
-      for (uint32_t u = 0; u < per; ++u) {
-        const uint32_t ci = tid * per + u;
-        if (ci < FX_DCELLS) {
-          const uint32_t c = (cell_q[ci] + 3u) & ~3u;
-          cell_q[ci] = run;
-          run += c;
-        }
-      }
-      if (tid == 63) {  // the row's share of the query pool
-        s_w[12] = incl;
-        const uint32_t qo = atomicAdd(&B.counters[FX_CNT_QPOOL], incl);
+    // ---- the query list, cell by cell, every cell's part padded to a multiple of four entries: k_dense_density takes the
+    // queries in quads, and four queries of ONE cell have a box no larger than the cell.  (Unpadded, 4 % of the quads held
+    // queries of three or more cells — the sparse stretches of a row, the edges of what other rows had claimed — and
+    // walked twice as far as the others.)  A padded prefix over the cells and the row's share of the query pool; then
+    // every winner to its cell's part of the list.
+    {
+      const uint32_t total = dense_cells_prefix<FX_DSORT_T, true>(cell_q, s_scan);
+      if (tid == 0) {  // the row's share of the query pool
+        s_w[12] = total;
+        const uint32_t qo = atomicAdd(&B.counters[FX_CNT_QPOOL], total);
         s_w[13] = qo;
-        s_w[14] = (qo <= P.dense_qcap && incl <= P.dense_qcap - qo) ? 1u : 0u;
+        s_w[14] = (qo <= P.dense_qcap && total <= P.dense_qcap - qo) ? 1u : 0u;
       }
     }
     __syncthreads();
@@ -4630,6 +4624,8 @@ extern "C" __global__ __launch_bounds__(FX_DSORT_T) void k_dense_sort(FxDevParam
       continue;
     }
     uint32_t *qlist = B.dense_q + qoff;
+    // (one lane per cell walking the cell's stretch of the bit map instead — no loads of the sorted region — was measured:
+    //  46 000 cycles a row against 30 000, a dense cell is one lane's serial loop)
     for (uint32_t p0 = 0; p0 < nS; p0 += 4u * FX_DSORT_T) {
       float4 v[4];
       bool won[4];

@@ -231,6 +231,17 @@ def test_dense_tier_key_sort_in_global_memory(fx_hooks, oracle):
     _cmp(oracle, capi.params("launch"), capi.limits(1, 28800, max_neighbors=64), [s], 0.02, -0.015, "dense tier, global key sort")
 
 
+def test_dense_tier_query_marks_in_the_sorted_region(fx_hooks, oracle):
+    """k_dense_sort remembers which support points a row won (whose density it computes) in an LDS bit map of 65536 sorted
+    positions; rows with more support points mark them in the sorted region itself. Reached here by lowering that capacity
+    (FX_DENSE_WON_POINTS, read at fx_create)."""
+    fx_hooks(FX_DENSE_WON_POINTS=16)
+    s = util.vlp16_scan(1000)
+    _cmp(oracle, capi.params("launch"), capi.limits(1, 28800, max_neighbors=64), [s], 0.02, -0.015, "dense tier, marks in the sorted region")
+    s = util.vlp16_scan(1000, n_poles=8, x_lo=3.0, x_hi=8.0, y_lo=-4.0, y_hi=4.0)
+    _cmp(oracle, capi.params("default", descriptor_radius=4.0), capi.limits(1, 28800), [s], tag="dense neighbourhoods, marks in the sorted region")
+
+
 def test_dense_tier_pool_exhaustion_is_flagged(fxlib, oracle):
     """A sorted pool too small for the batch's dense rows: FX_FLAG_NBR_OVERFLOW on the scan, NaN descriptors for the rows
     that did not fit, every other row still exact."""
