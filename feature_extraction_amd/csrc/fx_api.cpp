@@ -279,7 +279,7 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof, bo
     const bool runs2 = c->params.n_rings > 16;
     // (these two take the list of XCD class blockIdx % 8: grids are multiples of 8, the hints the longest class list)
     const uint32_t n_items = batch * (uint32_t)c->params.n_rings;
-    if (runs2) fxk_rings_runs2(s, P, B, L.max_ring_points, 8 * tier_grid(hint[0], (big_grid * 6 + 7) / 8, (n_items + 7) / 8, 8));
+    if (runs2) fxk_rings_runs2(s, P, B, L.max_ring_points, 8 * tier_grid(hint[0], (big_grid * 7 + 7) / 8, (n_items + 7) / 8, 8));  // (seven a CU: 21 KB of LDS each)
     fxk_rings_large(s, P, B, L.max_ring_points, L.max_ring_points, 8 * tier_grid(hint[runs2 ? 1 : 0], (big_grid + 7) / 8, (n_items + 7) / 8, 8),
                     runs2 ? 1u : 0u);
     FX_HIP(mark(4));

@@ -53,9 +53,10 @@ struct FxScTables {
 
 // Every device buffer of a context.
 #define FX_CLK_SLOTS 64
-#define FX_N_COUNTERS 40  // counters k_prep / k_front clear for the batch
-#define FX_CNT_REDO 40    // counters[40]: scans k_front hands to k_front_redo, [41]: scans that hands to k_tail (cleared by k_offsets, after their readers)
-#define FX_N_COUNTER_WORDS 48
+#define FX_N_COUNTERS 48  // counters k_prep / k_front clear for the batch
+#define FX_CNT_REDO 48    // counters[48]: scans k_front hands to k_front_redo, [49]: scans that hands to k_tail (cleared by k_offsets, after their readers)
+#define FX_N_COUNTER_WORDS 56
+#define FX_CNT_RUNS2_TICKET 40  // counters[40 + c]: next ring of XCD class c's list for k_rings_runs2
 #define FX_ATAN_N 64      // table step of k_prep's arctangent: 1 / 64 over [0, 1]
 #define FX_ATAN_DEG 6     // degree of the expansion about a table point (|offset| <= 1 / 128: truncation below 2^-51)
 #define FX_ROW_DIRTY 0xffffffffu

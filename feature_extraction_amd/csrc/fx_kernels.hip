@@ -1907,7 +1907,13 @@ extern "C" __global__ __launch_bounds__(64) void k_rings_runs2(FxDevParams P, Fx
   const uint32_t cls = blockIdx.x & 7u;  // block b takes the list of XCD class b mod 8 (the grid is a multiple of 8)
   const uint32_t n_big = B.counters[FX_CNT_LARGE + cls];
   const uint32_t *items = B.huge_rings + (size_t)cls * P.ring_list_cap;
-  for (uint32_t w = blockIdx.x >> 3; w < n_big; w += gridDim.x >> 3) {
+  // (rings by ticket: these cost 0.1 - 0.2 ms each and differ; dealt by stride, a batch of config 3 — 434 rings a class on
+  //  192 wavefronts — took as long as the wavefront with three of them)
+  while (true) {
+    uint32_t w = 0;
+    if (threadIdx.x == 0) w = atomicAdd(&B.counters[FX_CNT_RUNS2_TICKET + cls], 1u);
+    w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
+    if (w >= n_big) break;
     const uint32_t item = items[w];
     if (!ring_runs_body<384, 256>(P, B, item / P.n_rings, item % P.n_rings, max_pts, smem)) {
       if (threadIdx.x == 0) {
