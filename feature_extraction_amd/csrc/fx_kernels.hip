@@ -1962,6 +1962,9 @@ extern "C" __global__ __launch_bounds__(FX_RING_LARGE_T) void k_rings_large(FxDe
 // Three tiers share this code: coordinates in LDS (k_merge_small: <= 512 candidates, one workgroup per scan;
 // k_merge_big: what fits 160 KB), or — scans with more candidates than LDS holds as points (a 128-ring scan under the
 // launch preset has ~5000) — coordinates left in HBM (k_merge_huge: the scan's `cand` rows, L2 resident).
+#ifndef FX_MERGE_HUGE_U
+#define FX_MERGE_HUGE_U 8  // entries of a bin k_merge_huge's pair loop loads per trip
+#endif
 #define FX_MERGE_HEAD 160  // scratch words in front: block helpers [0..15], broadcast [16..31], sort stack [32..151]
 __host__ __device__ constexpr uint32_t merge_bins(uint32_t cap) { return cap <= 1024u ? 1024u : 4096u; }
 __host__ __device__ constexpr uint32_t merge_aux_words(uint32_t cap) {
@@ -2144,20 +2147,55 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
     //  lanes, not the sum over nine bins of the longest; two entries per trip, loaded before either is used; the
     //  distance test comes before any union-find lookup — one LDS round trip against several dependent ones)
     if (!LDS_PTS) {
-      for (uint32_t t = tid; t < 9u * C; t += NT) {
-        const uint32_t p = t / 9u, d = t - 9u * p;
-        const float4 v = msort[p];
-        const uint32_t i = __float_as_uint(v.w);
-        const uint32_t b = bin_of(cell_x(v.x) + (int)(d % 3u) - 1, cell_y(v.y) + (int)(d / 3u) - 1);
-        const uint32_t q0 = b ? bin[b - 1] : 0u, q1 = bin[b];
-        for (uint32_t q = q0; q < q1; q += 4) {
-          float4 u[4];
+      // Coordinates in HBM (k_merge_huge): bin by bin.  A wavefront takes a bin T, its entries 64 at a time one per lane
+      // (the TARGETS: one coalesced load), and walks the entries of the nine bins around it (the SOURCES: up to 64 of
+      // their concatenation per coalesced load, handed round by readlane).  Every lane then tests its target against the
+      // same source — all lanes busy in a pole's bin (a candidate per ring: 100 x 100 pairs), eight cache lines per load
+      // where one work item per (candidate, bin) with its own stride through the bin cost a cache line per entry and lane:
+      // 550 000 scattered 16-byte loads a scan of config 5, the L1's whole time.  Pairs that are already in one set
+      // (after the first few unions of a pole: nearly all) are recognised by their parents before any union is tried.
+      const uint32_t lane = tid & 63u, wave = tid >> 6;
+      const int nbm = (int)nb_mask;
+      for (uint32_t T = wave; T < NB; T += NT / 64) {
+        const uint32_t t0 = T ? bin[T - 1u] : 0u, t1 = bin[T];
+        if (t1 == t0) continue;
+        const int cxT = (int)(T & nb_mask), cyT = (int)(T >> nb_shift);
+        uint32_t st[9], cum[10];  // the nine source bins: first entry, entries before it in their concatenation
+        cum[0] = 0u;
 #pragma unroll
-          for (uint32_t e = 0; e < 4; ++e) u[e] = msort[min(q + e, q1 - 1u)];
+        for (int d = 0; d < 9; ++d) {
+          const uint32_t S = (uint32_t)(((cxT + d % 3 - 1) & nbm) | (((cyT + d / 3 - 1) & nbm) << nb_shift));
+          const uint32_t s0 = S ? bin[S - 1u] : 0u;
+          st[d] = s0;
+          cum[d + 1] = cum[d] + (bin[S] - s0);
+        }
+        const uint32_t total = cum[9];
+        for (uint32_t tc = t0; tc < t1; tc += 64u) {
+          const bool has = tc + lane < t1;
+          const float4 vj = msort[min(tc + lane, t1 - 1u)];
+          const uint32_t j = has ? __float_as_uint(vj.w) : 0u;  // (0: never larger than a source's id)
+          uint32_t rj = has ? uf_find(parent, j) : 0u;
+          for (uint32_t base = 0; base < total; base += 64u) {
+            const uint32_t g = min(base + lane, total - 1u);
+            uint32_t s_at = st[0] + g;
 #pragma unroll
-          for (uint32_t e = 0; e < 4; ++e) {
-            const uint32_t j = __float_as_uint(u[e].w);
-            if (q + e < q1 && j > i && dist2(v.x, v.y, v.z, u[e].x, u[e].y, u[e].z) < P.r2_merge) uf_union(parent, j, i);
+            for (int d = 1; d < 9; ++d)
+              if (g >= cum[d]) s_at = st[d] + (g - cum[d]);
+            const float4 vs = msort[s_at];
+            const uint32_t n = min(64u, total - base);
+            for (uint32_t e = 0; e < n; ++e) {
+              const float sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vs.x), (int)e));
+              const float sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vs.y), (int)e));
+              const float sz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vs.z), (int)e));
+              const uint32_t i = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(vs.w), (int)e);
+              // every pair once (j > i)
+              if (j > i && dist2(sx, sy, sz, vj.x, vj.y, vj.z) < P.r2_merge) {
+                if (((volatile lds_u32 *)parent)[i] != rj) {
+                  uf_union(parent, j, i);
+                  rj = uf_find(parent, j);
+                }
+              }
+            }
           }
         }
       }
