@@ -51,7 +51,8 @@ OTHER_CONFIGS = {
     "config5_dense_128x2048_R2m_batch64": dict(
         batch=64, n_uniq=8, synth=dict(n_rings=128, n_az=2048, el0_deg=-25.0, el_step_deg=40.0 / 127, n_poles=256),
         preset="launch", params=dict(n_rings=128, el0_deg=-25.0, el_step_deg=40.0 / 127, secondary_max=128, descriptor_radius=2.0),
-        limits=dict(max_candidates=8192, max_kpc_points=65536, max_keypoints=512, max_total_keypoints=64 * 256)),
+        limits=dict(max_candidates=8192, max_kpc_points=65536, max_keypoints=512, max_total_keypoints=64 * 256),
+        in_flight=6),  # (64-scan batches: several kernels are one workgroup a scan; measured 2 / 4 / 6 / 8 in flight: 4.4 / 7.5 / 8.1 / 6.1e4)
 }
 
 
@@ -568,7 +569,7 @@ def main():
             del hs, h2h  # (streams that stay alive keep hardware queues: the contexts below would share what is left)
             del d_in
             torch.cuda.empty_cache()
-            out["other_configs"] = {name: run_other_config(name, cfg, capi, torch, dev, threads, roll, pitch)
+            out["other_configs"] = {name: run_other_config(name, cfg, capi, torch, dev, threads, roll, pitch, in_flight=cfg.get("in_flight", 4))
                                     for name, cfg in OTHER_CONFIGS.items()}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(params, host, roll, pitch, threads)
