@@ -3923,27 +3923,61 @@ extern "C" __global__ __launch_bounds__(FX_WG, FX_GROUP_OCC) void k_desc_group(F
     // that — also every row whose list overflowed its list_cap slots (the rest of it sits in the scan's overflow region)
     const bool too_long = live && (nS > FX_GROUP_CAP || nS > P.list_cap);
     uint32_t dense_fail = 0;
-    if (too_long && gl == 0) {
-      if (nS > P.dense_min || nS > P.list_cap) {
+    {
+      // The rows a wavefront hands on draw their list positions together: one atomic per list and wavefront instead of one
+      // (dense rows: three) per row — on config 3 half of the 40 000 rows of a batch are handed on, and their atomics, all on
+      // two cache lines of counters, went through the L2 one after the other.
+      const bool lead = too_long && gl == 0;
+      const bool to_dense = lead && (nS > P.dense_min || nS > P.list_cap);
+      const bool to_list = lead && !to_dense && nS > FX_WAVE_CAP, to_wave = lead && !to_dense && !to_list;
+      // positions [base, base + n) of counter c for the lanes of m (wave-uniform call); returns this lane's
+      auto draw = [&](unsigned long long m, bool mine, uint32_t c, uint32_t amount, uint32_t before) -> uint32_t {
+        if (!m) return 0u;
+        const uint32_t first = (uint32_t)__ffsll((long long)m) - 1u;
+        uint32_t b0 = 0;
+        if (lane == first) b0 = atomicAdd(&B.counters[c], amount);
+        b0 = (uint32_t)__shfl((int)b0, (int)first, 64);
+        return mine ? b0 + before : 0u;
+      };
+      const unsigned long long m_list = __ballot(to_list), m_wave = __ballot(to_wave), m_dense = __ballot(to_dense);
+      const uint32_t p_list = draw(m_list, to_list, 4u, (uint32_t)__popcll(m_list), lanes_below(m_list));
+      const uint32_t p_wave = draw(m_wave, to_wave, 8u, (uint32_t)__popcll(m_wave), lanes_below(m_wave));
+      if (to_list) B.list_desc[p_list] = row;
+      if (to_wave) B.wave_desc[p_wave] = row;
+      if (m_dense) {  // (wave-uniform)
         // a slot in the dense-row list and nS entries of the sorted pool (k_dense_sort fills them)
-        const uint32_t slot = atomicAdd(&B.counters[6], 1u);
-        const uint32_t off = atomicAdd(&B.counters[13], nS);
-        const bool ok = slot < P.max_dense_rows && off <= P.dense_cap && nS <= P.dense_cap - off;
-        if (slot < P.max_dense_rows) {
-          B.dense_rows[slot] = ok ? row : FX_NONE;
-          B.dense_off[slot] = off;
-          // the tier's kernels take the rows largest first (four size classes), so that the big ones do not end up alone at the tail
-          const uint32_t cls = dense_class(nS);
-          B.dense_order[cls * P.max_dense_rows + atomicAdd(&B.counters[dense_class_counter(cls)], 1u)] = slot;
+        uint32_t pre = 0, tot = 0;
+#pragma unroll
+        for (uint32_t g2 = 0; g2 < FX_GROUPS; ++g2) {
+          const uint32_t v = (uint32_t)__shfl((int)(to_dense ? nS : 0u), (int)(g2 * FX_GLANES), 64);
+          pre += g2 < g ? v : 0u;
+          tot += v;
         }
-        if (!ok) {  // pools exhausted (limits.max_dense_points): flagged, never silent
-          atomicOr(&B.flags[scan], FX_FLAG_NBR_OVERFLOW);
-          B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = FX_NONE;
-          dense_fail = 1;
+        const uint32_t slot = draw(m_dense, to_dense, 6u, (uint32_t)__popcll(m_dense), lanes_below(m_dense));
+        const uint32_t off = draw(m_dense, to_dense, 13u, tot, pre);
+        // the tier's kernels take the rows largest first (four size classes), so that the big ones do not end up alone at the tail
+        const uint32_t cls = dense_class(nS);
+        uint32_t p_cls = 0;
+#pragma unroll
+        for (uint32_t c2 = 0; c2 < 4u; ++c2) {
+          const bool in = to_dense && slot < P.max_dense_rows && cls == c2;  // (a row without a slot is in no class list)
+          const unsigned long long m_c = __ballot(in);
+          const uint32_t v = draw(m_c, in, dense_class_counter(c2), (uint32_t)__popcll(m_c), lanes_below(m_c));
+          p_cls = in ? v : p_cls;
         }
-      } else {
-        const uint32_t c = nS > FX_WAVE_CAP ? 4u : 8u;
-        (nS > FX_WAVE_CAP ? B.list_desc : B.wave_desc)[atomicAdd(&B.counters[c], 1u)] = row;
+        if (to_dense) {
+          const bool ok = slot < P.max_dense_rows && off <= P.dense_cap && nS <= P.dense_cap - off;
+          if (slot < P.max_dense_rows) {
+            B.dense_rows[slot] = ok ? row : FX_NONE;
+            B.dense_off[slot] = off;
+            B.dense_order[cls * P.max_dense_rows + p_cls] = slot;
+          }
+          if (!ok) {  // pools exhausted (limits.max_dense_points): flagged, never silent
+            atomicOr(&B.flags[scan], FX_FLAG_NBR_OVERFLOW);
+            B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = FX_NONE;
+            dense_fail = 1;
+          }
+        }
       }
     }
     dense_fail = (uint32_t)__shfl((int)dense_fail, (int)(g * FX_GLANES), 64);
