@@ -2189,6 +2189,13 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
               const float sz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vs.z), (int)e));
               const uint32_t i = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(vs.w), (int)e);
               // every pair once (j > i)
+#ifdef FX_STAMPS
+              if (B.stamps && lane == 0) atomicAdd(&B.stamps[60], 1ull);
+              if (B.stamps && j > i && dist2(sx, sy, sz, vj.x, vj.y, vj.z) < P.r2_merge) {
+                atomicAdd(&B.stamps[61], 1ull);
+                if (((volatile lds_u32 *)parent)[i] != rj) atomicAdd(&B.stamps[62], 1ull);
+              }
+#endif
               if (j > i && dist2(sx, sy, sz, vj.x, vj.y, vj.z) < P.r2_merge) {
                 if (((volatile lds_u32 *)parent)[i] != rj) {
                   uf_union(parent, j, i);
@@ -2215,7 +2222,13 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
         // every pair once (j > i)
 #pragma unroll
         for (uint32_t e = 0; e < 4; ++e)
-          if (q + e < q1 && j[e] > i && dist2(v.x, v.y, v.z, u[e].x, u[e].y, u[e].z) < P.r2_merge) uf_union(parent, j[e], i);
+          if (q + e < q1 && j[e] > i && dist2(v.x, v.y, v.z, u[e].x, u[e].y, u[e].z) < P.r2_merge) {
+            // (already under one parent — after the first few unions of a pole that many rings saw: most pairs — is two reads
+            //  instead of two finds: k_merge_big on config 3 0.208 -> 0.182 ms; not inside k_front, where a pole has a
+            //  candidate per ring of sixteen and the reads cost more than they save)
+            const volatile lds_u32 *pp = (const volatile lds_u32 *)parent;
+            if (FRONT || pp[j[e]] != pp[i]) uf_union(parent, j[e], i);
+          }
       }
     }
     __syncthreads();

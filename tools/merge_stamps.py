@@ -38,3 +38,6 @@ tot = sum(v[base + k] for k in names)
 print(f"{name}: {B} scans; cycles (100 MHz clock) summed over the workgroups' lane 0")
 for k, nm in names.items():
     print(f"   {nm:28s} {v[base + k] / max(tot, 1) * 100:6.2f} %   {v[base + k] / B:10.0f} per scan")
+if v[60]:
+    print(f"k_merge_huge pair loop: {v[60] / B:.0f} wavefront iterations (a source against 64 targets) per scan, {v[61] / B:.0f} pairs within the tolerance, "
+          f"{v[62] / B:.0f} of them not recognised as one set already (union calls)")
