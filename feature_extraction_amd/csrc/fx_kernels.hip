@@ -147,6 +147,24 @@ __device__ __forceinline__ void uf_union(uint32_t *parent, uint32_t a, uint32_t 
   }
 }
 
+// The same, from any members (or ancestors) of the two sets; returns the root of the united set as of the call's end.
+__device__ __forceinline__ uint32_t uf_union_root(uint32_t *parent, uint32_t a, uint32_t b) {
+  lds_u32 *p = (lds_u32 *)parent;
+  while (true) {
+    a = uf_find(parent, a);
+    b = uf_find(parent, b);
+    if (a == b) return a;
+    if (a < b) {
+      const uint32_t t = a;
+      a = b;
+      b = t;
+    }
+    const uint32_t old = __hip_atomic_fetch_min(p + a, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (old == a) return b;
+    a = old;  // a stopped being a root meanwhile: its former parent must join b's set too
+  }
+}
+
 // Diagnostic build only (-DFX_STAMPS): per-phase cycle shares of the ring kernel, summed by
 // thread 0 of every workgroup into B.counters-adjacent debug words.  Never in the product build.
 #ifdef FX_STAMPS
@@ -2197,10 +2215,8 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
               }
 #endif
               if (j > i && dist2(sx, sy, sz, vj.x, vj.y, vj.z) < P.r2_merge) {
-                if (((volatile lds_u32 *)parent)[i] != rj) {
-                  uf_union(parent, j, i);
-                  rj = uf_find(parent, j);
-                }
+                const uint32_t pi = ((volatile lds_u32 *)parent)[i];
+                if (pi != rj) rj = uf_union_root(parent, rj, pi);  // (from the ancestors at hand: shorter finds, and the root comes back)
               }
             }
           }
