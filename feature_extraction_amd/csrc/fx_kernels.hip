@@ -5168,6 +5168,7 @@ __device__ __forceinline__ void dense_finish_row(const FxDevParams &P, const FxB
   float *out = B.desc + (size_t)row * FX_DESC_FLOATS;
   const float4 *pts = B.dense_pts + off;
   const unsigned long long *cache = B.dens_cache + (size_t)scan * P.max_points;
+  FX_STAMP_INIT(B.stamps);
   __syncthreads();
   if (tid == 0) s_w[0] = 0, s_w[1] = 0;
   if (nM > (uint32_t)KMAX || nM > P.dense_lds_keys) {
@@ -5212,6 +5213,7 @@ __device__ __forceinline__ void dense_finish_row(const FxDevParams &P, const FxB
   __syncthreads();
   dense_keys<NT, true>(P, pts, nS, kp, xa, T, keys, bin_end, s_w);
   __syncthreads();
+  FX_STAMP(49);
   if (tid < 64) {  // counts -> exclusive starts, in place, by one wavefront
     constexpr uint32_t per = 1984 / 64;
     uint32_t sum = 0;
@@ -5231,7 +5233,24 @@ __device__ __forceinline__ void dense_finish_row(const FxDevParams &P, const FxB
   }
   __syncthreads();
   // every key's index to its bin's segment (the fill turns a bin's start into its end = the next bin's start)
+  FX_STAMP(50);
   for (uint32_t e = tid; e < nM; e += NT) ord[atomicAdd(&bin_end[(uint32_t)(keys[e] >> 52)], 1u)] = (uint16_t)e;
+  __syncthreads();
+  FX_STAMP(51);
+  // the keys into bin order, in place (through registers), so that the ranking below walks a bin's keys at consecutive
+  // addresses instead of through their indices: two dependent LDS reads a step were most of this kernel's ranking time
+  unsigned long long mykey[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const uint32_t p = tid + (uint32_t)u * NT;
+    mykey[u] = p < nM ? keys[ord[p]] : 0ull;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const uint32_t p = tid + (uint32_t)u * NT;
+    if (p < nM) keys[p] = mykey[u];
+  }
   __syncthreads();
   // rank inside the bin (keys are unique: they end in the point index), and the weight
   uint32_t dst[PER];
@@ -5241,17 +5260,26 @@ __device__ __forceinline__ void dense_finish_row(const FxDevParams &P, const FxB
     const uint32_t p = tid + (uint32_t)u * NT;
     dst[u] = FX_NONE;
     if (p < nM) {
-      const unsigned long long key = keys[ord[p]];
+      const unsigned long long key = mykey[u];
       const uint32_t bin = (uint32_t)(key >> 52);
       const uint32_t s0 = bin ? bin_end[bin - 1u] : 0u, s1 = bin_end[bin];
       uint32_t rank = 0;
 #pragma unroll 4
-      for (uint32_t qq = s0; qq < s1; ++qq) rank += keys[ord[qq]] < key ? 1u : 0u;
+      for (uint32_t qq = s0; qq < s1; ++qq) rank += keys[qq] < key ? 1u : 0u;
       dst[u] = s0 + rank;
-      wgt[u] = dense_weight(key, cache, seq, T, &s_w[1]);
     }
   }
+#ifdef FX_STAMPS
+  __syncthreads();
+  FX_STAMP(57);
+#endif
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const uint32_t p = tid + (uint32_t)u * NT;
+    if (p < nM) wgt[u] = dense_weight(mykey[u], cache, seq, T, &s_w[1]);
+  }
   __syncthreads();  // (the keys are done with: their storage takes the weights, in sorted order)
+  FX_STAMP(52);
   if (s_w[1]) {  // a density this row needs was never computed (workgroup-uniform)
     if (tid == 0) {
       atomicOr(&B.flags[scan], FX_FLAG_NBR_OVERFLOW);
@@ -5276,6 +5304,12 @@ __device__ __forceinline__ void dense_finish_row(const FxDevParams &P, const FxB
     out[bin] = acc;
   }
   __syncthreads();
+  FX_STAMP(53);
+  if (tid == 0) {
+    FX_COUNT(54, 1);
+    FX_COUNT(55, nM);
+    FX_COUNT(56, nS);
+  }
 }
 // rows of up to KS binned neighbours: 256-thread workgroups, several per CU; larger: one 1024-thread workgroup per CU
 template <int KMAX, int NT, bool LARGE>
