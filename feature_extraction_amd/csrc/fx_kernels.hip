@@ -93,6 +93,49 @@ __device__ __forceinline__ float dist2(float qx, float qy, float qz, float px, f
   return r;
 }
 
+// How many of the points sp[q0 .. q1) (LDS, x y z first in a float4) are closer to (bx, by, bz) than sqrt(r2): dist2's
+// arithmetic — FLANN's L2_Simple order, ((dx dx) + dy dy) + dz dz — two points per packed instruction, and counted without
+// a compare and an add-with-carry per test: with S a power of two, fma(d2, -S, r2 S) is the exactly scaled difference
+// rounded once — positive, zero or negative as r2 - d2 is (-inf when d2 S overflows; never a NaN for finite inputs) — at
+// least 2^76 in magnitude unless zero, so the instruction's clamp to [0, 1] gives 1.0f or 0.0f, and the counts add up
+// exactly in fp32 (below 2^24).  3DSC's local point density in every descriptor tier.  (r2 >= 1e-30: fx_create.)
+struct WithinR2 {
+  fx_f2 neg_s, r2s;
+  float r2;
+  __device__ __forceinline__ explicit WithinR2(float r2_) : r2(r2_) {
+    const float kS = __uint_as_float(min(354u - ((__float_as_uint(r2_) >> 23) & 0xffu), 254u) << 23);  // r2 S in [2^100, 2^101)
+    neg_s = fx_f2{-kS, -kS};
+    r2s = fx_f2{r2_ * kS, r2_ * kS};
+  }
+  // the two points at f and f + 4 (floats) against b
+  __device__ __forceinline__ fx_f2 pair(const float *f, float bx, float by, float bz) const {
+    const fx_f2 X = {f[0], f[4]}, Y = {f[1], f[5]}, Z = {f[2], f[6]};
+    const fx_f2 dx = bx - X, dy = by - Y, dz = bz - Z;
+    fx_f2 r = dx * dx;
+    r = r + dy * dy;
+    r = r + dz * dz;
+    fx_f2 in;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(in) : "v"(r), "v"(neg_s), "v"(r2s));
+    return in;
+  }
+  __device__ __forceinline__ uint32_t count(const float4 *sp, uint32_t q0, uint32_t q1, float bx, float by, float bz) const {
+    const float *f = reinterpret_cast<const float *>(sp);
+    fx_f2 acc0 = {0.0f, 0.0f}, acc1 = {0.0f, 0.0f};
+    uint32_t q = q0;
+    for (; q + 3u < q1; q += 4u) {  // (unrolled by hand: the pragma gives up on a loop with inline assembly)
+      acc0 = acc0 + pair(f + 4u * q, bx, by, bz);
+      acc1 = acc1 + pair(f + 4u * q + 8u, bx, by, bz);
+    }
+    if (q + 1u < q1) {
+      acc0 = acc0 + pair(f + 4u * q, bx, by, bz);
+      q += 2u;
+    }
+    uint32_t n = (uint32_t)(acc0.x + acc1.x) + (uint32_t)(acc0.y + acc1.y);
+    if (q < q1) n += dist2(bx, by, bz, f[4u * q], f[4u * q + 1u], f[4u * q + 2u]) < r2 ? 1u : 0u;
+    return n;
+  }
+};
+
 // Global memory written by one wavefront of a workgroup and re-read by another: __syncthreads() orders the stores (they
 // are written through to the L2 and acknowledged before the barrier), and an ACQUIRE at agent scope drops the lines this
 // CU's L1 may still hold from an earlier read.  (__threadfence() would also RELEASE at agent scope: on gfx950 that writes
@@ -3750,6 +3793,7 @@ template <bool FAST>
 __device__ __forceinline__ void desc_wave_body(const FxDevParams &P, const FxBuffers &B, uint32_t batch,
                                                uint32_t *smem, uint32_t bid, uint32_t nblk) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const WithinR2 within(P.r2_density);
   uint32_t *base = smem + wave * FX_WAVE_WORDS;
   // per-wave LDS: support set as float4 (x, y, z, d2) + point index, unsorted (key, weight); the
   // sorted (key, weight) arrays reuse the support-set storage once the density counts are done
@@ -3807,12 +3851,7 @@ __device__ __forceinline__ void desc_wave_body(const FxDevParams &P, const FxBuf
       if (use) {
         float lut;
         const uint32_t bin = sc3d_bin<FAST>(kp, b.x, b.y, b.z, d2, xa, T, lut, amb);
-        uint32_t dens = 0;  // support points within R/5 of this neighbour (itself included)
-#pragma unroll 8
-        for (uint32_t q = 0; q < nS; ++q) {
-          const float4 s = sp[q];
-          dens += (dist2(b.x, b.y, b.z, s.x, s.y, s.z) < P.r2_density) ? 1u : 0u;
-        }
+        const uint32_t dens = within.count(sp, 0u, nS, b.x, b.y, b.z);  // support points within R/5 of this neighbour (itself included)
         w = (1.0f / (float)dens) * lut;
         key = sc3d_key(bin, d2, sidx[e]);
       }
@@ -3889,6 +3928,7 @@ extern "C" __global__ __launch_bounds__(FX_WG, FX_GROUP_OCC) void k_desc_group(F
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t gl = lane % FX_GLANES, g = lane / FX_GLANES;
+  const WithinR2 within(P.r2_density);
   uint32_t *base = smem + (wave * FX_GROUPS + g) * FX_GROUP_WORDS;
   float4 *sp = reinterpret_cast<float4 *>(base);                                                   // 4 * CAP words
   unsigned long long *nkey = reinterpret_cast<unsigned long long *>(base + 4 * FX_GROUP_CAP);      // 2 * CAP
@@ -4040,12 +4080,7 @@ extern "C" __global__ __launch_bounds__(FX_WG, FX_GROUP_OCC) void k_desc_group(F
       float lut;
       bool amb = false;
       const uint32_t bin = sc3d_bin<true>(kp, b.x, b.y, b.z, d2, xa, T, lut, amb);
-      uint32_t dens = 0;  // support points within R/5 of this neighbour (itself included)
-#pragma unroll FX_GROUP_UNROLL
-      for (uint32_t q = 0; q < nS; ++q) {
-        const float4 s = sp[q];
-        dens += (dist2(b.x, b.y, b.z, s.x, s.y, s.z) < P.r2_density) ? 1u : 0u;
-      }
+      const uint32_t dens = within.count(sp, 0u, nS, b.x, b.y, b.z);  // support points within R/5 of this neighbour (itself included)
       const uint32_t pos = atomicAdd(&cnt[1], 1u);
       nkey[pos] = sc3d_key(bin, d2, sidx[e]);
       nw[pos] = (1.0f / (float)dens) * lut;
@@ -4146,6 +4181,7 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
   DescLds L = desc_carve(smem, cap);
   FX_STAMP_INIT(B.stamps && FAST ? B.stamps + 48 : nullptr);
   const uint32_t tid = threadIdx.x;
+  const WithinR2 within(P.r2_density);
   const FxScanMeta M = B.meta[scan];
   const float4 kp = B.keypoints[(size_t)scan * P.max_keypoints + k];
   float *out = B.desc + (size_t)row * FX_DESC_FLOATS;
@@ -4299,19 +4335,11 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
           if (yy >= G || zz >= G) continue;  // (also the wrapped -1)
           const uint32_t c0 = (zz * G + yy) * G + xa0, c1 = (zz * G + yy) * G + xa1;
           const uint32_t q0 = c0 ? cell_end[c0 - 1] : 0u, q1 = cell_end[c1];
-#pragma unroll 8
-          for (uint32_t q = q0; q < q1; ++q) {
-            const float4 sq = L.sp[q];
-            c += (dist2(bq.x, bq.y, bq.z, sq.x, sq.y, sq.z) < P.r2_density) ? 1u : 0u;
-          }
+          c += within.count(L.sp, q0, q1, bq.x, bq.y, bq.z);
         }
       } else {
         const uint32_t q0 = part * chunk, q1 = min(q0 + chunk, nS);
-#pragma unroll 8
-        for (uint32_t q = q0; q < q1; ++q) {
-          const float4 sq = L.sp[q];
-          c += (dist2(bq.x, bq.y, bq.z, sq.x, sq.y, sq.z) < P.r2_density) ? 1u : 0u;
-        }
+        c += within.count(L.sp, q0, q1, bq.x, bq.y, bq.z);
       }
       if (c) atomicAdd(&dens[2 * m], c);
     }
@@ -5168,7 +5196,11 @@ __device__ __forceinline__ void dense_finish_row(const FxDevParams &P, const FxB
   float *out = B.desc + (size_t)row * FX_DESC_FLOATS;
   const float4 *pts = B.dense_pts + off;
   const unsigned long long *cache = B.dens_cache + (size_t)scan * P.max_points;
+#ifdef FX_STAMPS_FINISH  // (-DFX_STAMPS -DFX_STAMPS_FINISH: the columns are the list tier's otherwise)
   FX_STAMP_INIT(B.stamps);
+#else
+  FX_STAMP_INIT((unsigned long long *)nullptr);
+#endif
   __syncthreads();
   if (tid == 0) s_w[0] = 0, s_w[1] = 0;
   if (nM > (uint32_t)KMAX || nM > P.dense_lds_keys) {
