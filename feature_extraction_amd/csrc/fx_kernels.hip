@@ -2023,6 +2023,9 @@ extern "C" __global__ __launch_bounds__(FX_RING_LARGE_T) void k_rings_large(FxDe
 // Three tiers share this code: coordinates in LDS (k_merge_small: <= 512 candidates, one workgroup per scan;
 // k_merge_big: what fits 160 KB), or — scans with more candidates than LDS holds as points (a 128-ring scan under the
 // launch preset has ~5000) — coordinates left in HBM (k_merge_huge: the scan's `cand` rows, L2 resident).
+#ifndef FX_MERGE_BIN_TICKET
+#define FX_MERGE_BIN_TICKET 8u  // bins a wavefront of k_merge_huge's pair loop draws at a time (a power of two)
+#endif
 #ifndef FX_MERGE_HUGE_U
 #define FX_MERGE_HUGE_U 8  // entries of a bin k_merge_huge's pair loop loads per trip
 #endif
@@ -2200,6 +2203,7 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
       sorted[pos] = (uint16_t)idx;
       if (!LDS_PTS) msort[pos] = make_float4(v.x, v.y, v.z, __uint_as_float(idx));
     }
+    if (tid == 0) s_w[152] = 0u;  // (the pair loop's bin ticket)
     __syncthreads();
     if (!LDS_PTS) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (msort is read below by other waves of this workgroup)
     FX_STAMP(2);
@@ -2217,7 +2221,13 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
       // (after the first few unions of a pole: nearly all) are recognised by their parents before any union is tried.
       const uint32_t lane = tid & 63u, wave = tid >> 6;
       const int nbm = (int)nb_mask;
-      for (uint32_t T = wave; T < NB; T += NT / 64) {
+      (void)wave;
+      while (true) {  // bins by ticket, a few at a time: a pole's bin is a hundred times an empty one
+        uint32_t T8 = 0;
+        if (lane == 0) T8 = atomicAdd(&s_w[152], FX_MERGE_BIN_TICKET);
+        T8 = (uint32_t)__builtin_amdgcn_readfirstlane((int)T8);
+        if (T8 >= NB) break;
+        for (uint32_t T = T8; T < T8 + FX_MERGE_BIN_TICKET; ++T) {
         const uint32_t t0 = T ? bin[T - 1u] : 0u, t1 = bin[T];
         if (t1 == t0) continue;
         const int cxT = (int)(T & nb_mask), cyT = (int)(T >> nb_shift);
@@ -2263,6 +2273,7 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
               }
             }
           }
+        }
         }
       }
     }
