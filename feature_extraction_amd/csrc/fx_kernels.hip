@@ -2221,15 +2221,9 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
       // (after the first few unions of a pole: nearly all) are recognised by their parents before any union is tried.
       const uint32_t lane = tid & 63u, wave = tid >> 6;
       const int nbm = (int)nb_mask;
-      (void)wave;
-      while (true) {  // bins by ticket, a few at a time: a pole's bin is a hundred times an empty one
-        uint32_t T8 = 0;
-        if (lane == 0) T8 = atomicAdd(&s_w[152], FX_MERGE_BIN_TICKET);
-        T8 = (uint32_t)__builtin_amdgcn_readfirstlane((int)T8);
-        if (T8 >= NB) break;
-        for (uint32_t T = T8; T < T8 + FX_MERGE_BIN_TICKET; ++T) {
+      auto pair_bin = [&](uint32_t T) {  // the targets of bin T against the sources of the nine bins around it
         const uint32_t t0 = T ? bin[T - 1u] : 0u, t1 = bin[T];
-        if (t1 == t0) continue;
+        if (t1 == t0) return;
         const int cxT = (int)(T & nb_mask), cyT = (int)(T >> nb_shift);
         uint32_t st[9], cum[10];  // the nine source bins: first entry, entries before it in their concatenation
         cum[0] = 0u;
@@ -2274,7 +2268,14 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
             }
           }
         }
-        }
+      };
+      (void)wave;
+      while (true) {  // bins by ticket, a few at a time: a pole's bin costs a hundred times an empty one, and behind the loop is a barrier
+        uint32_t T0 = 0;
+        if (lane == 0) T0 = atomicAdd(&s_w[152], FX_MERGE_BIN_TICKET);
+        T0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)T0);
+        if (T0 >= NB) break;  // (NB is a multiple of the ticket)
+        for (uint32_t T = T0; T < T0 + FX_MERGE_BIN_TICKET; ++T) pair_bin(T);
       }
     }
     for (uint32_t t = tid; LDS_PTS && t < 9u * C; t += NT) {
