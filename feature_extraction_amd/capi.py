@@ -105,7 +105,7 @@ EXPORTS = ("fx_version", "fx_check_abi", "fx_status_str", "fx_last_error", "fx_p
            "fx_limits_default", "fx_create", "fx_destroy", "fx_set_stream", "fx_get_stream", "fx_set_graph_batch", "fx_set_profiling", "fx_set_profiling_stages", "fx_get_timings",
            "fx_get_stage_bytes", "fx_get_limits", "fx_process_batch", "fx_synchronize", "fx_pack_features", "fx_pack_keypoint_records",
            "fx_rotation_from_roll_pitch", "fx_sc3d_tables", "fx_sc3d_xaxis", "fx_synth_cfg_vlp16",
-           "fx_synth_scan", "fx_test_sort_replay", "fx_test_sort_replay_ranked", "fx_test_sort_replay_lists", "fx_test_sort_replay_device", "fx_test_elevation_device", "fx_unpack_pointcloud2",
+           "fx_synth_scan", "fx_test_sort_replay", "fx_test_sort_replay_ranked", "fx_test_sort_replay_lists", "fx_test_sort_replay_device", "fx_test_elevation_device", "fx_test_within_device", "fx_unpack_pointcloud2",
            "fx_pack_pointxyzi")
 
 _lib = None
@@ -202,6 +202,7 @@ def load():
     lib.fx_test_sort_replay_lists.restype = None
     lib.fx_test_sort_replay_device.argtypes = [C.c_int, _U32P, C.c_uint32, C.c_uint32, _U32P]
     lib.fx_test_elevation_device.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.fx_test_within_device.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p]
     _lib = lib
     _libs[LIB_PATH] = lib
     return lib

@@ -60,6 +60,7 @@ void fxk_pack_kp_records(hipStream_t s, const FxDevParams &P, const FxBuffers &B
 void fxk_rng_ord(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
 void fxk_test_sort_replay(hipStream_t s, const uint32_t *sizes, uint32_t n_seq, uint32_t n, uint32_t *perm);
 void fxk_test_elevation(hipStream_t s, const float *xyz, uint32_t n, const double *tab, float *fast, uint8_t *ok, float *exact);
+void fxk_test_within(hipStream_t s, const float4 *sp, uint32_t n, const float4 *queries, uint32_t nq, float r2, uint32_t *packed, uint32_t *plain);
 void fxk_unpack_pc2(hipStream_t s, const void *src, uint32_t n, uint32_t point_step, uint32_t ox, uint32_t oy, uint32_t oz,
                     uint32_t oi, uint32_t big_endian, void *dst, uint32_t grid);
 void fxk_pack_xyzi32(hipStream_t s, const void *src, uint32_t n, void *dst, uint32_t grid);
@@ -1070,6 +1071,28 @@ fx_status fx_test_elevation_device(int device, const float *xyz, uint32_t n, flo
   if (e == hipSuccess) e = hipMemcpy(fast_out, d + o_fast, (size_t)n * 4, hipMemcpyDeviceToHost);
   if (e == hipSuccess) e = hipMemcpy(exact_out, d + o_exact, (size_t)n * 4, hipMemcpyDeviceToHost);
   if (e == hipSuccess) e = hipMemcpy(fast_ok_out, d + o_ok, n, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  FX_HIP(e);
+  return FX_OK;
+}
+
+// Test hook: the descriptor tiers' packed within-radius count and the plain compare it replaces.
+fx_status fx_test_within_device(int device, const float *support_xyzw, uint32_t n, const float *query_xyzw, uint32_t nq, float r2,
+                                uint32_t *packed_out, uint32_t *plain_out) {
+  if (!support_xyzw || !query_xyzw || !packed_out || !plain_out) return fail(FX_ERR_INVALID_ARG, "null argument");
+  if (!nq) return FX_OK;
+  FX_HIP(hipSetDevice(device));
+  char *d = nullptr;
+  const size_t o_q = (size_t)(n ? n : 1) * 16, o_a = o_q + (size_t)nq * 16, o_c = o_a + (size_t)nq * 4;
+  FX_HIP(hipMalloc((void **)&d, o_c + (size_t)nq * 4));
+  hipError_t e = n ? hipMemcpy(d, support_xyzw, (size_t)n * 16, hipMemcpyHostToDevice) : hipSuccess;
+  if (e == hipSuccess) e = hipMemcpy(d + o_q, query_xyzw, (size_t)nq * 16, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    fxk_test_within(nullptr, (const float4 *)d, n, (const float4 *)(d + o_q), nq, r2, (uint32_t *)(d + o_a), (uint32_t *)(d + o_c));
+    e = hipDeviceSynchronize();
+  }
+  if (e == hipSuccess) e = hipMemcpy(packed_out, d + o_a, (size_t)nq * 4, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(plain_out, d + o_c, (size_t)nq * 4, hipMemcpyDeviceToHost);
   (void)hipFree(d);
   FX_HIP(e);
   return FX_OK;

@@ -5660,6 +5660,39 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_test_elevation(const float
     exact[i] = elevation_deg(x, y, z);
   }
 }
+// Test hook: WithinR2::count (packed, fma + clamp) and the plain compare it replaces, one query per workgroup against n
+// support points staged through LDS in chunks (any range start / length parity: the chunk bounds vary with the query).
+extern "C" __global__ __launch_bounds__(FX_WG) void k_test_within(const float4 *sp, uint32_t n, const float4 *queries, float r2,
+                                                                  uint32_t *packed, uint32_t *plain) {
+  __shared__ float4 s_pts[1024];
+  __shared__ uint32_t s_cnt[2];
+  const float4 b = queries[blockIdx.x];
+  const WithinR2 within(r2);
+  if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+  for (uint32_t c0 = 0; c0 < n; c0 += 1024) {
+    const uint32_t m = min(1024u, n - c0);
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < m; t += FX_WG) s_pts[t] = sp[c0 + t];
+    __syncthreads();
+    // every thread a range of its own, odd starts and lengths included
+    const uint32_t per = (m + FX_WG - 1) / FX_WG + (blockIdx.x & 3u);
+    const uint32_t q0 = min(threadIdx.x * per, m), q1 = min(q0 + per, m);
+    uint32_t a = within.count(s_pts, q0, q1, b.x, b.y, b.z), c = 0;
+    for (uint32_t q = q0; q < q1; ++q) c += dist2(b.x, b.y, b.z, s_pts[q].x, s_pts[q].y, s_pts[q].z) < r2 ? 1u : 0u;
+    // (ranges beyond FX_WG * per are nobody's when per was rounded up by the block's offset: the tail goes to thread 0)
+    if (threadIdx.x == 0 && FX_WG * per < m) {
+      a += within.count(s_pts, FX_WG * per, m, b.x, b.y, b.z);
+      for (uint32_t q = FX_WG * per; q < m; ++q) c += dist2(b.x, b.y, b.z, s_pts[q].x, s_pts[q].y, s_pts[q].z) < r2 ? 1u : 0u;
+    }
+    if (a) atomicAdd(&s_cnt[0], a);
+    if (c) atomicAdd(&s_cnt[1], c);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) packed[blockIdx.x] = s_cnt[0], plain[blockIdx.x] = s_cnt[1];
+}
+void fxk_test_within(hipStream_t s, const float4 *sp, uint32_t n, const float4 *queries, uint32_t nq, float r2, uint32_t *packed, uint32_t *plain) {
+  hipLaunchKernelGGL(k_test_within, dim3(nq), dim3(FX_WG), 0, s, sp, n, queries, r2, packed, plain);
+}
 void fxk_test_elevation(hipStream_t s, const float *xyz, uint32_t n, const double *tab, float *fast, uint8_t *ok, float *exact) {
   hipLaunchKernelGGL(k_test_elevation, dim3(1024), dim3(FX_WG), 0, s, xyz, n, tab, fast, ok, exact);
 }

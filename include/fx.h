@@ -306,6 +306,11 @@ fx_status fx_test_sort_replay_device(int device, const uint32_t *sizes, uint32_t
  * points xyz[n][3]: the table-driven one (fast_out, and whether it vouches for its value: fast_ok_out) and the one
  * through the library's fp64 atan2 that takes the points it does not vouch for (exact_out). */
 fx_status fx_test_elevation_device(int device, const float *xyz, uint32_t n, float *fast_out, uint8_t *fast_ok_out, float *exact_out);
+/* Test hook: 3DSC's local point density count as the descriptor kernels evaluate it (two points per packed instruction, the
+ * comparison folded into a clamped fma) and as the plain `dist2 < r2` it replaces: for each of nq queries (xyzw records) the
+ * number of the n support points (xyzw records) closer than sqrt(r2), both ways. */
+fx_status fx_test_within_device(int device, const float *support_xyzw, uint32_t n, const float *query_xyzw, uint32_t nq, float r2,
+                                uint32_t *packed_out, uint32_t *plain_out);
 
 #ifdef __cplusplus
 }
