@@ -241,7 +241,7 @@ def main():
     # bound and leave issue slots, LDS and whole CUs idle (tails, the large tiers' thin launches), which the
     # kernels of the other batches in flight fill.  One step is still one pass over one batch of B scans.
     K = max(1, args.contexts)
-    ctxs = [capi.Context(params, capi.limits(B, N), device=local_rank) for _ in range(K)]
+    ctxs = [capi.Context(params, capi.limits(B, N, sparse=True), device=local_rank) for _ in range(K)]  # (fx_limits_sparse: VLP-16 scans never need the dense tier's full pools: 4.5 GB a context, not 7)
     ctx = ctxs[0]
     REC_KP = int(ctx.limits.max_keypoints)  # record stride = the context's keypoint capacity: a gathered record is never truncated
     # the contexts' own HIP streams, wrapped for torch (streams from torch's pool can share a hardware queue: two such
@@ -557,7 +557,7 @@ def main():
         if not args.no_extras:
             out["h2d_inclusive_scans_per_s"] = h2d_inclusive(ctx, capi, host, B, N, roll, pitch)
             ctx.close()
-            h2h = [capi.Context(params, capi.limits(B, N), device=local_rank) for _ in range(3)]
+            h2h = [capi.Context(params, capi.limits(B, N, sparse=True), device=local_rank) for _ in range(3)]
             # (on the contexts' own streams: a torch stream that has run work keeps its hardware queue for the life of the process —
             #  three of eight — and the six contexts of config 5 below then shared the rest: 6.2e4 instead of 8.3e4 scans/s)
             out["host_to_host_scans_per_s"] = host_to_host(h2h, capi, torch, host, B, N, roll, pitch)

@@ -117,20 +117,23 @@ def build_multi(force=False, verbose=False):
 
 
 BATCHER = os.path.join(HERE, "bin", "fx_batcher_cli")
+BATCHER_TEST = os.path.join(HERE, "bin", "fx_batcher_cli_test")
 
 
-def build_batcher(force=False, verbose=False):
+def build_batcher(force=False, verbose=False, test_hooks=False):
     """Streaming front end (csrc/fx_batcher.hpp: producers push scans, one consumer batches whatever has arrived) and its
-    simulated-sensors driver."""
-    deps = [os.path.join(CSRC, s) for s in ("fx_batcher_cli.cpp", "fx_batcher.hpp", "fx_node.hpp")] + [LIB]
-    if force or not _newer(BATCHER, deps):
-        os.makedirs(os.path.dirname(BATCHER), exist_ok=True)
-        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-pthread", "-o", BATCHER, os.path.join(CSRC, "fx_batcher_cli.cpp"),
-               "-L" + os.path.dirname(LIB), "-lfx_hip", "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath," + os.path.dirname(LIB)]
+    simulated-sensors driver.  test_hooks: the same driver linked against the TEST build of the library (its environment
+    hooks: FX_FAIL_AFTER_ENQUEUE makes a batch fail)."""
+    exe, lib = (BATCHER_TEST, build_test_hooks()) if test_hooks else (BATCHER, LIB)
+    deps = [os.path.join(CSRC, s) for s in ("fx_batcher_cli.cpp", "fx_batcher.hpp", "fx_node.hpp")] + [lib]
+    if force or not _newer(exe, deps):
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-pthread", "-o", exe, os.path.join(CSRC, "fx_batcher_cli.cpp"),
+               "-L" + os.path.dirname(lib), "-l:" + os.path.basename(lib), "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath," + os.path.dirname(lib)]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-    return BATCHER
+    return exe
 
 
 ROS_MOCK_NODE = os.path.join(HERE, "bin", "fx_ros_mock_node")

@@ -54,7 +54,7 @@ class FxParams(C.Structure):
 class FxLimits(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in
                 ("max_batch", "max_points", "max_ring_points", "max_ring_candidates", "max_candidates",
-                 "max_keypoints", "max_neighbors", "max_total_keypoints", "max_kpc_points", "max_dense_points")]
+                 "max_keypoints", "max_neighbors", "max_total_keypoints", "max_kpc_points", "max_dense_points", "max_overflow_points")]
 
 
 class FxScanDesc(C.Structure):
@@ -100,13 +100,15 @@ class FxSynthCfg(C.Structure):
 
 
 # every symbol include/fx.h declares (tests/test_capi_symbols.py checks the list against the header)
-FX_HEADER_VERSION = (0 << 16) | 5  # the include/fx.h these ctypes structures mirror
+FX_HEADER_VERSION = (0 << 16) | 6  # the include/fx.h these ctypes structures mirror
 EXPORTS = ("fx_version", "fx_check_abi", "fx_status_str", "fx_last_error", "fx_params_default", "fx_params_launch",
-           "fx_limits_default", "fx_create", "fx_destroy", "fx_set_stream", "fx_get_stream", "fx_set_graph_batch", "fx_set_profiling", "fx_set_profiling_stages", "fx_get_timings",
+           "fx_limits_default", "fx_limits_sparse", "fx_create", "fx_destroy", "fx_set_stream", "fx_get_stream", "fx_set_graph_batch", "fx_set_profiling", "fx_set_profiling_stages", "fx_get_timings",
            "fx_get_stage_bytes", "fx_get_limits", "fx_process_batch", "fx_synchronize", "fx_pack_features", "fx_pack_keypoint_records",
            "fx_rotation_from_roll_pitch", "fx_sc3d_tables", "fx_sc3d_xaxis", "fx_synth_cfg_vlp16",
-           "fx_synth_scan", "fx_test_sort_replay", "fx_test_sort_replay_ranked", "fx_test_sort_replay_lists", "fx_test_sort_replay_device", "fx_test_elevation_device", "fx_test_within_device", "fx_unpack_pointcloud2",
-           "fx_pack_pointxyzi")
+           "fx_synth_scan", "fx_unpack_pointcloud2", "fx_pack_pointxyzi")
+# the header's FX_TEST_HOOKS section: exported by lib/libfx_hip_test.so only
+TEST_EXPORTS = ("fx_test_sort_replay", "fx_test_sort_replay_ranked", "fx_test_sort_replay_lists", "fx_test_sort_replay_device",
+                "fx_test_elevation_device", "fx_test_within_device")
 
 _lib = None
 _libs = {}
@@ -123,12 +125,23 @@ class test_hooks:
         self._saved = (_lib, LIB_PATH)
         LIB_PATH = TEST_LIB_PATH
         _lib = _libs.get(LIB_PATH)
-        return load()
+        try:
+            return load()
+        except BaseException:  # (a missing / mismatched test library must not leave the process pointing at it)
+            _lib, LIB_PATH = self._saved
+            raise
 
     def __exit__(self, *exc):
         global _lib, LIB_PATH
         _lib, LIB_PATH = self._saved
         return False
+
+
+def load_test():
+    """The test build of the library (FX_TEST_HOOKS: the fx_test_* entry points and the environment hooks) without making it
+    the process's default."""
+    with test_hooks() as lib:
+        return lib
 
 
 def load():
@@ -163,6 +176,7 @@ def load():
     lib.fx_params_default.argtypes = [C.POINTER(FxParams)]
     lib.fx_params_launch.argtypes = [C.POINTER(FxParams)]
     lib.fx_limits_default.argtypes = [C.POINTER(FxLimits), C.c_uint32, C.c_uint32]
+    lib.fx_limits_sparse.argtypes = [C.POINTER(FxLimits), C.c_uint32, C.c_uint32]
     lib.fx_create.argtypes = [C.POINTER(FxParams), C.POINTER(FxLimits), C.c_int, C.POINTER(C.c_void_p)]
     lib.fx_create.restype = C.c_int
     lib.fx_destroy.argtypes = [C.c_void_p]
@@ -194,15 +208,16 @@ def load():
     lib.fx_synth_scan.restype = C.c_uint32
     lib.fx_unpack_pointcloud2.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(FxPc2Layout), C.c_void_p]
     lib.fx_pack_pointxyzi.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, _U32P]
-    lib.fx_test_sort_replay.argtypes = [_U32P, C.c_uint32, _U32P]
-    lib.fx_test_sort_replay.restype = None
-    lib.fx_test_sort_replay_ranked.argtypes = [_U32P, C.c_uint32, _U32P]
-    lib.fx_test_sort_replay_ranked.restype = None
-    lib.fx_test_sort_replay_lists.argtypes = [_U32P, C.c_uint32, _U32P]
-    lib.fx_test_sort_replay_lists.restype = None
-    lib.fx_test_sort_replay_device.argtypes = [C.c_int, _U32P, C.c_uint32, C.c_uint32, _U32P]
-    lib.fx_test_elevation_device.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
-    lib.fx_test_within_device.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p]
+    if hasattr(lib, "fx_test_sort_replay"):  # the test build (-DFX_TEST_HOOKS)
+        lib.fx_test_sort_replay.argtypes = [_U32P, C.c_uint32, _U32P]
+        lib.fx_test_sort_replay.restype = None
+        lib.fx_test_sort_replay_ranked.argtypes = [_U32P, C.c_uint32, _U32P]
+        lib.fx_test_sort_replay_ranked.restype = None
+        lib.fx_test_sort_replay_lists.argtypes = [_U32P, C.c_uint32, _U32P]
+        lib.fx_test_sort_replay_lists.restype = None
+        lib.fx_test_sort_replay_device.argtypes = [C.c_int, _U32P, C.c_uint32, C.c_uint32, _U32P]
+        lib.fx_test_elevation_device.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.fx_test_within_device.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p]
     _lib = lib
     _libs[LIB_PATH] = lib
     return lib
@@ -231,10 +246,11 @@ def params(preset="default", **overrides):
     return p
 
 
-def limits(max_batch, max_points, **overrides):
+def limits(max_batch, max_points, sparse=False, **overrides):
+    """fx_limits_default (or, sparse=True, fx_limits_sparse: small dense-tier pools, for VLP-16-class workloads) with overrides."""
     lib = load()
     l = FxLimits()
-    lib.fx_limits_default(C.byref(l), max_batch, max_points)
+    (lib.fx_limits_sparse if sparse else lib.fx_limits_default)(C.byref(l), max_batch, max_points)
     for k, v in overrides.items():
         if not hasattr(l, k):
             raise AttributeError(k)

@@ -46,11 +46,11 @@ uint32_t fxk_front_max_rings(void);
 uint32_t fxk_front_merge_cap(void);
 void fxk_front(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float near_margin, float el0, float inv_step,
                uint32_t clk_slot, uint32_t merge_cap, uint32_t force_redo);
-void fxk_front_redo(hipStream_t s, const FxDevParams &P, const FxBuffers &B, float el0, float inv_step, uint32_t huge_ccap, uint32_t tail_follows,
-                    uint32_t force_tail, uint32_t grid);
-void fxk_tail(hipStream_t s, const FxDevParams &P, const FxBuffers &B, float el0, float inv_step, uint32_t ring_cap, uint32_t merge_cap,
-              uint32_t huge_ccap, uint32_t grid);
-hipError_t fxk_configure_front(const FxDevParams &P, uint32_t ring_cap, uint32_t merge_cap, uint32_t huge_ccap);
+void fxk_front_redo(hipStream_t s, const FxDevParams &P, const FxBuffers &B, float el0, float inv_step, uint32_t huge_ccap, uint32_t force_slow,
+                    uint32_t grid);
+size_t fxk_slow_words(uint32_t max_ring_points, uint32_t max_candidates, uint32_t huge_ccap);
+void fxk_slow(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t huge_ccap, uint32_t grid);
+hipError_t fxk_configure_front(void);
 uint32_t fxk_gather_slices(uint32_t batch);
 void fxk_gather(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float box_margin);
 void fxk_desc_group(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid);
@@ -58,9 +58,11 @@ void fxk_desc_mid(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint3
 void fxk_pack_kp_records(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, void *dst,
                          uint32_t rec_kp);
 void fxk_rng_ord(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
+#ifdef FX_TEST_HOOKS
 void fxk_test_sort_replay(hipStream_t s, const uint32_t *sizes, uint32_t n_seq, uint32_t n, uint32_t *perm);
 void fxk_test_elevation(hipStream_t s, const float *xyz, uint32_t n, const double *tab, float *fast, uint8_t *ok, float *exact);
 void fxk_test_within(hipStream_t s, const float4 *sp, uint32_t n, const float4 *queries, uint32_t nq, float r2, uint32_t *packed, uint32_t *plain);
+#endif
 void fxk_unpack_pc2(hipStream_t s, const void *src, uint32_t n, uint32_t point_step, uint32_t ox, uint32_t oy, uint32_t oz,
                     uint32_t oi, uint32_t big_endian, void *dst, uint32_t grid);
 void fxk_pack_xyzi32(hipStream_t s, const void *src, uint32_t n, void *dst, uint32_t grid);
@@ -116,7 +118,9 @@ struct fx_ctx {
   FxScanMeta *d_meta = nullptr;
   float box_margin = 0.f;
   uint32_t desc_wgs_per_cu = 10;
+  uint32_t ring_lds_cap = 0;     // points a ring may have in the workgroup ring tier's LDS (<= max_ring_points; beyond: k_slow)
   uint32_t merge_big_cap = 0;    // candidates the LDS merge tier holds as points (<= max_candidates)
+  uint32_t merge_huge_cap = 0;   // candidates the large merge tier (coordinates in HBM, tables in LDS) holds (<= max_candidates; beyond: k_slow)
   uint32_t merge_huge_ccap = 0;  // clusters the large merge tier can order (>= max_keypoints)
   // host-input staging
   float *d_stage = nullptr;
@@ -147,8 +151,8 @@ struct fx_ctx {
   volatile uint32_t *tier_hint = nullptr;
   uint32_t tier_min_grid = 8;  // FX_TIER_MIN_GRID: workgroups those tiers get at least (0: always the full grids)
   // The fused front kernel (k_front: filter to keypoints in one launch, for scans whose filtered cloud fits LDS) with
-  // k_tail behind it.  A batch that hands more than an eighth of its scans to k_tail sends the next front_retry batches
-  // through the separate kernels (k_prep ... k_merge_*), which are the fast way for large scans.
+  // k_front_redo behind it.  A batch that hands more than an eighth of its scans to k_front_redo sends the next front_retry
+  // batches through the separate kernels (k_prep ... k_merge_*), which are the fast way for large scans.
   bool front_ok = false;       // sensor within k_front's ring capacity
   bool front_last = false;     // what the last batch ran
   uint32_t front_force = 0;    // test hook (FX_FRONT_FORCE)
@@ -159,6 +163,7 @@ struct fx_ctx {
   bool state_suspect = false;
   uint32_t fail_after = 0;     // test hook (FX_FAIL_AFTER_ENQUEUE = n: the n-th batch returns an error after its kernels were enqueued)
   uint32_t front_pause = 0;    // batches left on the separate kernels
+  uint32_t skip_mask = 0;      // experiment hook (FX_SKIP_EMPTY, test build): bit 0 no k_front_redo, bit 1 no dense tier — only for workloads that need neither
   static constexpr uint32_t front_retry = 64;
 };
 
@@ -255,16 +260,16 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof, bo
     const uint32_t clk_slot = (uint32_t)(c->batch_seq % FX_CLK_SLOTS), clk_next = (uint32_t)((c->batch_seq + 1) % FX_CLK_SLOTS);
     const float el0 = (float)c->params.el0_deg, inv_step = (float)(1.0 / c->params.el_step_deg);
     if (front) {
-      // stages 0-4 in two launches: k_front, and k_front_redo — workgroups of k_front's shape, a few of them unless the
-      // previous batch had work for it — for the scans that do not fit k_front's tables.  The few of THOSE that need more
-      // LDS than that shape has go on to k_tail (a whole CU per workgroup), launched only when the previous batch handed it
-      // something (or nothing is known yet): an empty launch of it waits for a free CU behind the other batches' k_front.
+      // stages 0-4 in three launches: k_front; k_front_redo — workgroups of k_front's shape, a few of them unless the
+      // previous batch had work for it — for the scans that do not fit k_front's tables; and k_slow (256 threads, 9 KB of
+      // LDS: an empty launch of it places anywhere) for what exceeds that shape's LDS too, on scratch in HBM.  All three go
+      // with EVERY batch: the hints size grids, they never decide whether a scan gets what it needs.
       const uint32_t mcap = std::min(fxk_front_merge_cap(), L.max_candidates);
-      const bool tail = hint[7] != 0u || c->front_force >= 2u;
       fxk_front(s, P, B, batch, c->box_margin, el0, inv_step, clk_slot, mcap, c->front_force >= 1u ? 1u : 0u);
       for (int i = 1; i <= 4; ++i) FX_HIP(mark(i));
-      fxk_front_redo(s, P, B, el0, inv_step, c->merge_huge_ccap, tail ? 1u : 0u, c->front_force >= 2u ? 1u : 0u, tier_grid(hint[6], 2 * big_grid, batch));
-      if (tail) fxk_tail(s, P, B, el0, inv_step, L.max_ring_points, c->merge_big_cap, c->merge_huge_ccap, tier_grid(hint[7], big_grid, batch));
+      if (!(c->skip_mask & 1u))
+      fxk_front_redo(s, P, B, el0, inv_step, c->merge_huge_ccap, c->front_force >= 2u ? 1u : 0u, tier_grid(hint[6], 2 * big_grid, batch));
+      fxk_slow(s, P, B, c->merge_huge_ccap, tier_grid(hint[7], big_grid, batch));
       fxk_offsets(s, P, B, batch, clk_next);
       FX_HIP(mark(5));
     } else {
@@ -281,13 +286,14 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof, bo
     // (these two take the list of XCD class blockIdx % 8: grids are multiples of 8, the hints the longest class list)
     const uint32_t n_items = batch * (uint32_t)c->params.n_rings;
     if (runs2) fxk_rings_runs2(s, P, B, L.max_ring_points, 8 * tier_grid(hint[0], (big_grid * 7 + 7) / 8, (n_items + 7) / 8, 8));  // (seven a CU: 21 KB of LDS each)
-    fxk_rings_large(s, P, B, L.max_ring_points, L.max_ring_points, 8 * tier_grid(hint[runs2 ? 1 : 0], (big_grid + 7) / 8, (n_items + 7) / 8, 8),
+    fxk_rings_large(s, P, B, c->ring_lds_cap, c->ring_lds_cap, 8 * tier_grid(hint[runs2 ? 1 : 0], (big_grid + 7) / 8, (n_items + 7) / 8, 8),
                     runs2 ? 1u : 0u);
     FX_HIP(mark(4));
     fxk_merge_small(s, P, B, batch, merge_small);
     fxk_merge_big(s, P, B, c->merge_big_cap, tier_grid(hint[2], big_grid, batch), c->merge_big_cap >= L.max_candidates);
     if (c->merge_big_cap < L.max_candidates)
-      fxk_merge_huge(s, P, B, L.max_candidates, c->merge_huge_ccap, tier_grid(hint[3], big_grid, batch));
+      fxk_merge_huge(s, P, B, c->merge_huge_cap, c->merge_huge_ccap, tier_grid(hint[3], big_grid, batch));
+    fxk_slow(s, P, B, c->merge_huge_ccap, tier_grid(hint[7], big_grid, batch));  // (rings / merges beyond the LDS tiers: see the front path)
     fxk_offsets(s, P, B, batch, clk_next);
     FX_HIP(mark(5));
     }
@@ -307,7 +313,7 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof, bo
         const uint32_t rows = tier_grid(hint[4], 3 * big_grid, max_rows);
         // density items: 1024 queries each, at most one a row more than the support points fill
         const uint32_t items = hint[5] == 0xffffffffu ? 3 * big_grid : tier_grid(hint[4] + hint[5] / 1024u, 3 * big_grid, 0xffffffffu);
-        fxk_dense(s, P, B, big_grid, rows, items);
+        if (!(c->skip_mask & 2u)) fxk_dense(s, P, B, big_grid, rows, items);
       }
     } else {
       for (int i = 6; i <= 8; ++i) FX_HIP(mark(i));
@@ -389,6 +395,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   if (!L.max_total_keypoints) L.max_total_keypoints = D.max_total_keypoints;
   if (!L.max_kpc_points) L.max_kpc_points = D.max_kpc_points;
   if (!L.max_dense_points) L.max_dense_points = D.max_dense_points;
+  if (!L.max_overflow_points) L.max_overflow_points = D.max_overflow_points;
   if (L.max_batch == 0 || L.max_points == 0) return fail(FX_ERR_INVALID_ARG, "max_batch and max_points must be > 0");
   if (L.max_batch > 65535) return fail(FX_ERR_INVALID_ARG, "max_batch > 65535 (one grid row per scan in the support gather)");
   if (L.max_points > (1u << 20)) return fail(FX_ERR_INVALID_ARG, "max_points > 2^20 (descriptor sort key packs the point index in 20 bits)");
@@ -398,10 +405,13 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   if (params->descriptor_radius < 1e-12 || params->descriptor_radius > 1e12)  // (the squared radii stay normal floats with room to scale)
     return fail(FX_ERR_INVALID_ARG, "descriptor_radius out of range");
   if (L.max_ring_candidates > L.max_ring_points) L.max_ring_candidates = L.max_ring_points;
-  // LDS budget of the large tiers (160 KiB per workgroup on gfx950)
+  // LDS budget of the large tiers (160 KiB per workgroup on gfx950); what the limits allow beyond it takes the slow tier
+  // (k_slow: the same bodies on scratch in HBM)
   const size_t kLds = 160 * 1024;
-  if (fxk_ring_large_lds_bytes(L.max_ring_points, L.max_ring_points) > kLds)
-    return fail(FX_ERR_INVALID_ARG, "max_ring_points exceeds the LDS budget (<= 2400)");
+  if (L.max_ring_points > 32768 || L.max_candidates > 32768 || L.max_keypoints > 65535)
+    return fail(FX_ERR_INVALID_ARG, "limit exceeds the 16-bit packing of the order replay (max_ring_points, max_candidates <= 32768)");
+  uint32_t ring_lds_cap = L.max_ring_points;
+  while (fxk_ring_large_lds_bytes(ring_lds_cap, ring_lds_cap) > kLds) ring_lds_cap -= ring_lds_cap > 64 ? 16 : 1;
   // merge tiers: up to merge_big_cap candidates a scan live in LDS as points; beyond that (dense many-ring scans)
   // the large tier keeps only parents and a cell sort in LDS
   uint32_t merge_big_cap = L.max_candidates;
@@ -411,19 +421,27 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
     if (v >= 16 && v < merge_big_cap) merge_big_cap = v;
   }
   const uint32_t merge_huge_ccap = L.max_keypoints > 64 ? L.max_keypoints : 64;
-  if (merge_big_cap < L.max_candidates &&
-      (L.max_candidates > 65535 || fxk_merge_huge_lds_bytes(L.max_candidates, merge_huge_ccap, params->n_rings) > kLds))
-    return fail(FX_ERR_INVALID_ARG, "max_candidates (with max_keypoints) exceeds the LDS budget of the large merge tier (<= ~16000)");
+  uint32_t merge_huge_cap = L.max_candidates;
+  while (merge_huge_cap > merge_big_cap && fxk_merge_huge_lds_bytes(merge_huge_cap, merge_huge_ccap, params->n_rings) > kLds) merge_huge_cap -= 64;
+  if (merge_huge_cap < merge_big_cap) merge_huge_cap = merge_big_cap;
+  if (const char *e = test_hook("FX_MERGE_HUGE_CAP")) {  // test hook: push scans on from the large merge tier to the slow one
+    const uint32_t v = (uint32_t)atoi(e);
+    if (v >= merge_big_cap && v < merge_huge_cap) merge_huge_cap = v;
+  }
+  if (const char *e = test_hook("FX_RING_LDS_CAP")) {  // test hook: push rings on from the workgroup ring tier to the slow one
+    const uint32_t v = (uint32_t)atoi(e);
+    if (v >= 16 && v < ring_lds_cap) ring_lds_cap = v & ~3u;
+  }
   if (fxk_gather_lds_bytes(L.max_keypoints) > kLds) return fail(FX_ERR_INVALID_ARG, "support gather: LDS tables beyond the budget (build parameter FX_GATHER_KCAP)");
-  if (L.max_keypoints > 65535 || L.max_candidates > 32768 || L.max_ring_points > 32768)
-    return fail(FX_ERR_INVALID_ARG, "limit exceeds the 16-bit packing of the order replay");
 
   FX_HIP(hipSetDevice(device_id));
   fx_ctx *c = new fx_ctx();
   c->params = *params;
   c->lim = L;
   c->device = device_id;
+  c->ring_lds_cap = ring_lds_cap;
   c->merge_big_cap = merge_big_cap;
+  c->merge_huge_cap = merge_huge_cap;
   c->merge_huge_ccap = merge_huge_ccap;
   if (const char *e = test_hook("FX_DESC_WGS_PER_CU")) {  // experiment hook: ignored outside 1..32
     const int v = atoi(e);
@@ -481,13 +499,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   P.near_words = fxk_near_words(L.max_points);
   // dense tier pools (fx_limits.max_dense_points; default: as many entries as the batch has points, at least 32 scans' worth)
   P.dense_min = kDenseMin;
-  // a scan's overflow region: one entry per point of the scan — in contexts of fewer than 32 scans as many more as keep
-  // the regions at 32 scans' worth together (a single scan whose rows overflow their lists many times over has no batch
-  // to average with: descriptor radii of 2–3 m on the differential fuzz's scenes need up to three entries per point)
-  {
-    const unsigned long long per = (unsigned long long)L.max_points * (L.max_batch >= 32u ? 1u : 32u / (L.max_batch ? L.max_batch : 1u));
-    P.ovf_cap = (uint32_t)(per > 0x7ff00000ull ? 0x7ff00000ull : per);
-  }
+  P.ovf_cap = L.max_overflow_points > 0x7ff00000u ? 0x7ff00000u : L.max_overflow_points;  // a scan's overflow region (fx_limits.max_overflow_points)
   {
     const unsigned long long want = L.max_dense_points ? L.max_dense_points : (unsigned long long)(L.max_batch > 32u ? L.max_batch : 32u) * L.max_points;
     P.dense_cap = (uint32_t)(want > 0xfff00000ull ? 0xfff00000ull : (want < 4096ull ? 4096ull : want));  // (a row takes its support points + 700 entries of it)
@@ -572,9 +584,24 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   FX_A(dev_alloc(c, &b.big_merge, B));
   FX_A(dev_alloc(c, &b.huge_merge, B));
   FX_A(dev_alloc(c, &b.redo, B));
-  FX_A(dev_alloc(c, &b.redo2, B));
-  b.merge_sorted = nullptr;
-  if (c->merge_big_cap < L.max_candidates) FX_A(dev_alloc(c, &b.merge_sorted, (size_t)B * L.max_candidates));
+  FX_A(dev_alloc(c, &b.slow, B));
+  FX_A(dev_alloc(c, &b.slow_state, B));
+  FX_A(dev_alloc(c, &b.ring_pending, B * ((R + 31) / 32)));
+  if (hipMemset(b.slow_state, 0, B * sizeof(uint32_t)) != hipSuccess || hipMemset(b.ring_pending, 0, B * ((R + 31) / 32) * sizeof(uint32_t)) != hipSuccess)
+    return bail(fail(FX_ERR_HIP, "hipMemset"));
+  {
+    // the slow tier's scratch: a region per workgroup of its largest grid — a CU's worth of workgroups, fewer for small
+    // contexts or huge limits (256 MB at most)
+    const size_t words = fxk_slow_words(L.max_ring_points, L.max_candidates, c->merge_huge_ccap);
+    size_t slots = std::min<size_t>((size_t)c->n_cu, B);
+    while (slots > 1 && slots * words * 4 > ((size_t)256 << 20)) --slots;
+    P.gs_words = (uint32_t)words;
+    P.gs_slots = (uint32_t)slots;
+    FX_A(dev_alloc(c, &b.gs_pool, slots * words));
+  }
+  // (the large merge tier's bin-ordered copy: k_merge_huge, and k_front_redo — whose LDS image holds fewer candidates as points
+  //  than k_merge_big's — whenever a scan has more candidates than that)
+  FX_A(dev_alloc(c, &b.merge_sorted, (size_t)B * L.max_candidates));
   FX_A(dev_alloc(c, &b.list_desc, L.max_total_keypoints));
   FX_A(dev_alloc(c, &b.s_pts, (size_t)L.max_total_keypoints * P.list_cap));
   FX_A(dev_alloc(c, &b.s_cnt, L.max_total_keypoints));
@@ -668,19 +695,20 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
     return bail(fail(FX_ERR_HIP, "hipStreamCreate"));
   c->stream = c->own_stream;
   {
-    hipError_t ce = fxk_configure(fxk_ring_large_lds_bytes(L.max_ring_points, L.max_ring_points), fxk_merge_lds_bytes(c->merge_big_cap, params->n_rings),
-                                  c->merge_big_cap < L.max_candidates ? fxk_merge_huge_lds_bytes(L.max_candidates, c->merge_huge_ccap, params->n_rings) : 0,
+    hipError_t ce = fxk_configure(fxk_ring_large_lds_bytes(c->ring_lds_cap, c->ring_lds_cap), fxk_merge_lds_bytes(c->merge_big_cap, params->n_rings),
+                                  c->merge_big_cap < L.max_candidates ? fxk_merge_huge_lds_bytes(c->merge_huge_cap, c->merge_huge_ccap, params->n_rings) : 0,
                                   fxk_desc_lds_bytes(P.list_cap < P.dense_min ? P.list_cap : P.dense_min), fxk_gather_lds_bytes(L.max_keypoints));
     if (ce != hipSuccess) return bail(fail(FX_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(ce)));
   }
   if (hipMemset(b.counters, 0, FX_N_COUNTER_WORDS * sizeof(uint32_t)) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
   c->front_ok = (uint32_t)params->n_rings <= fxk_front_max_rings();
   if (const char *e = test_hook("FX_FRONT")) c->front_ok = c->front_ok && atoi(e) != 0;  // 0 = the separate kernels (measurements; tests of those kernels)
-  // 1: k_front hands every scan to k_front_redo; 2: and that one every scan to k_tail (tests of those two)
+  // 1: k_front hands every scan to k_front_redo; 2: and that one every ring and merge to the slow tier, k_slow (tests of those two)
   if (const char *e = test_hook("FX_FRONT_FORCE")) c->front_force = (uint32_t)std::max(0, atoi(e));
   if (const char *e = test_hook("FX_FAIL_AFTER_ENQUEUE")) c->fail_after = (uint32_t)std::max(0, atoi(e));
+  if (const char *e = test_hook("FX_SKIP_EMPTY")) c->skip_mask = (uint32_t)std::max(0, atoi(e));
   if (c->front_ok) {
-    hipError_t ce = fxk_configure_front(P, L.max_ring_points, c->merge_big_cap, c->merge_huge_ccap);
+    hipError_t ce = fxk_configure_front();
     if (ce != hipSuccess) return bail(fail(FX_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(ce)));
   }
   if (hipMemset(b.kp_offset, 0, (B + 1) * sizeof(uint32_t)) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
@@ -916,6 +944,8 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
   if (c->state_suspect) {
     FX_HIP(hipMemsetAsync(c->buf.desc_nbins, 0xff, (size_t)L.max_total_keypoints * sizeof(uint32_t), s));  // FX_ROW_DIRTY: clear whole
     FX_HIP(hipMemsetAsync(c->buf.counters, 0, FX_N_COUNTER_WORDS * sizeof(uint32_t), s));
+    FX_HIP(hipMemsetAsync(c->buf.slow_state, 0, (size_t)L.max_batch * sizeof(uint32_t), s));  // (the slow tier's list markers: k_slow clears what it has done)
+    FX_HIP(hipMemsetAsync(c->buf.ring_pending, 0, (size_t)L.max_batch * (((size_t)c->params.n_rings + 31) / 32) * sizeof(uint32_t), s));
     FX_HIP(hipStreamSynchronize(s));  // (the hints are host memory the device writes: nothing of the failed batch may land after the reset)
     for (int i = 0; i < FX_N_HINTS; ++i) c->tier_hint[i] = 0xffffffffu;
     c->front_pause = 0;
@@ -1053,6 +1083,7 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
   return FX_OK;
 }
 
+#ifdef FX_TEST_HOOKS
 // Test hook: k_prep's two elevation paths on caller-supplied points.
 fx_status fx_test_elevation_device(int device, const float *xyz, uint32_t n, float *fast_out, uint8_t *fast_ok_out, float *exact_out) {
   if (!xyz || !fast_out || !fast_ok_out || !exact_out) return fail(FX_ERR_INVALID_ARG, "null argument");
@@ -1119,6 +1150,8 @@ fx_status fx_test_sort_replay_device(int device, const uint32_t *sizes, uint32_t
   FX_HIP(e);
   return FX_OK;
 }
+
+#endif  // FX_TEST_HOOKS
 
 // Diagnostic: what the last completed batch left for the next one's tier grids (FxBuffers::tier_hint).
 fx_status fx_debug_tier_hints(fx_ctx *c, uint32_t *out /* FX_N_HINTS = 8 words */) {

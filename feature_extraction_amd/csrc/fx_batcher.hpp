@@ -11,6 +11,10 @@
 // Threads: any number of producers call push() (the scan is copied: the caller's buffer is free on return); one
 // consumer thread owns the fx_ctx (a context is not thread-safe), runs the batches and hands every scan's result to
 // the callback, in arrival order.  No CPU fallback: construction fails without a GPU.
+//
+// A batch that FAILS (fx_process_batch returns an error) does not end the stream: its scans are delivered with the status
+// and the error text and no results, the context repairs its own state on the next call (fx_ctx::state_suspect, csrc/
+// fx_api.cpp) and the consumer goes on with whatever has arrived meanwhile.
 #ifndef FX_BATCHER_HPP_
 #define FX_BATCHER_HPP_
 #include <chrono>
@@ -36,23 +40,39 @@ class StreamBatcher {
     uint32_t sensor = 0;
     uint32_t flags = 0;     // FX_FLAG_* of the scan
     uint32_t batch = 0;     // scans in the batch it rode in
+    fx_status status = FX_OK;  // of the batch: anything else means the batch failed and the clouds below are empty
+    std::string error;         // fx_last_error() of the failed batch
     double latency_ms = 0;  // push() to callback
     PointCloud keypoints;         // ~keypoints (ref: node.cpp:129-131)
     DescriptorCloud descriptors;  // ~features payload (ref: node.cpp:113-124)
   };
   using Callback = std::function<void(Result &&)>;
   struct Stats {
-    uint64_t scans = 0, batches = 0;
+    uint64_t scans = 0, batches = 0, failed_batches = 0;
     uint32_t largest_batch = 0;
   };
 
-  StreamBatcher(const fx_params &params, uint32_t max_batch, uint32_t max_points, int device, Callback cb)
+  // pool_keypoints: rows of the descriptor pool (7956 B of device memory each + as much pinned host memory + the row's
+  // support list, 16 KB).  0 = every scan's keypoint capacity for batches of up to 64 scans (a one- or two-scan batch with
+  // more keypoints than the default's average of 64 a scan must not flag FX_FLAG_TOTAL_KP_OVERFLOW), the library's
+  // default (64 a scan) beyond: max_batch 1024 is then 65 536 rows = 1.6 GB, not 6 GB.
+  // limits: non-zero fields (other than max_batch / max_points) override the preset's.
+  StreamBatcher(const fx_params &params, uint32_t max_batch, uint32_t max_points, int device, Callback cb, uint32_t pool_keypoints = 0,
+                const fx_limits *limits = nullptr)
       : cb_(std::move(cb)), max_batch_(max_batch), max_points_(max_points) {
+    if (FX_CHECK_ABI() != FX_OK) throw std::runtime_error(std::string("fx_check_abi: ") + fx_last_error());  // (this translation unit's fx.h against the library's)
     fx_limits lim;
-    fx_limits_default(&lim, max_batch, max_points);
-    // the descriptor pool holds every scan's keypoint capacity (the default, 64 a scan, is an average for large batches:
-    // a batch of one or two scans with more keypoints than that would flag FX_FLAG_TOTAL_KP_OVERFLOW)
-    lim.max_total_keypoints = max_batch * lim.max_keypoints;
+    fx_limits_sparse(&lim, max_batch, max_points);  // (streaming sensors are VLP-16 class: no dense-tier pools — INTEGRATION.md §6)
+    if (pool_keypoints)
+      lim.max_total_keypoints = pool_keypoints;
+    else if (max_batch <= 64u)
+      lim.max_total_keypoints = max_batch * (limits && limits->max_keypoints ? limits->max_keypoints : lim.max_keypoints);
+    if (limits) {
+      const uint32_t *ov = reinterpret_cast<const uint32_t *>(limits);
+      uint32_t *dst = reinterpret_cast<uint32_t *>(&lim);
+      for (size_t i = 2; i < sizeof(fx_limits) / 4; ++i)
+        if (ov[i]) dst[i] = ov[i];
+    }
     if (fx_create(&params, &lim, device, &ctx_) != FX_OK) throw std::runtime_error(std::string("fx_create: ") + fx_last_error());
     fx_set_graph_batch(ctx_, max_batch < 16u ? max_batch : 16u);  // the launch-bound sizes: one graph per batch size
     estimate_descriptors_ = params.estimate_descriptors != 0;
@@ -136,11 +156,30 @@ class StreamBatcher {
       for (size_t i = 0; i < batch.size(); ++i)
         descs[i] = fx_scan_desc{batch[i].xyzi.data(), batch[i].n, 16, batch[i].roll, batch[i].pitch};
       fx_batch_view v;
-      if (fx_process_batch(ctx_, descs.data(), (uint32_t)batch.size(), FX_OUT_HOST, &v) != FX_OK) {
-        std::lock_guard<std::mutex> lk(m_);
-        error_ = std::string("fx_process_batch: ") + fx_last_error();
+      const fx_status st = fx_process_batch(ctx_, descs.data(), (uint32_t)batch.size(), FX_OUT_HOST, &v);
+      if (st != FX_OK) {
+        // the batch's scans come back with the status and no results; the context starts its next batch from scratch
+        // (state_suspect) and the stream goes on
+        const std::string err = std::string("fx_process_batch: ") + fx_last_error();
+        for (size_t i = 0; i < batch.size(); ++i) {
+          Result r;
+          r.id = batch[i].id;
+          r.sensor = batch[i].sensor;
+          r.batch = (uint32_t)batch.size();
+          r.status = st;
+          r.error = err;
+          r.latency_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - batch[i].t0).count();
+          cb_(std::move(r));
+        }
+        {
+          std::lock_guard<std::mutex> lk(m_);
+          delivered_ += batch.size();
+          stats_.scans += batch.size();
+          stats_.batches += 1;
+          stats_.failed_batches += 1;
+        }
         cv_.notify_all();
-        return;
+        continue;
       }
       for (size_t i = 0; i < batch.size(); ++i) {
         Result r;

@@ -41,6 +41,9 @@ struct FxDevParams {
   uint32_t dense_qcap;      // entries of the query pool (every cell's queries padded to four: up to 4 per support point)
   uint32_t dense_lds_keys;  // binned neighbours k_dense_finish_l sorts in LDS (16384; tests lower it to reach the key pool)
   uint32_t dense_won_points;  // support points of a row whose query marks k_dense_sort keeps as a bit map in LDS (65536; tests lower it)
+  // slow tier (k_slow): scratch regions in HBM for what exceeds every LDS-sized tier
+  uint32_t gs_slots;  // regions (= the largest grid k_slow is launched with)
+  uint32_t gs_words;  // words per region
 };
 
 // 3DSC tables in device memory (built on the host by fx_sc3d_tables / fx_sc3d_xaxis).
@@ -54,13 +57,13 @@ struct FxScTables {
 // Every device buffer of a context.
 #define FX_CLK_SLOTS 64
 #define FX_N_COUNTERS 48  // counters k_prep / k_front clear for the batch
-#define FX_CNT_REDO 48    // counters[48]: scans k_front hands to k_front_redo, [49]: scans that hands to k_tail (cleared by k_offsets, after their readers)
+#define FX_CNT_REDO 48    // counters[48]: scans k_front hands to k_front_redo, [49]: scans handed to the slow tier, k_slow (cleared by k_offsets, after their readers)
 #define FX_N_COUNTER_WORDS 56
 #define FX_CNT_RUNS2_TICKET 40  // counters[40 + c]: next ring of XCD class c's list for k_rings_runs2
 #define FX_ATAN_N 64      // table step of k_prep's arctangent: 1 / 64 over [0, 1]
 #define FX_ATAN_DEG 6     // degree of the expansion about a table point (|offset| <= 1 / 128: truncation below 2^-51)
 #define FX_ROW_DIRTY 0xffffffffu
-#define FX_N_HINTS 8      // tier_hint[]: 0 / 1 rings handed to the second run tier / the workgroup tier (largest XCD class), 2 big merges, 3 huge merges, 4 dense rows, 5 dense support points, 6 scans k_front handed to k_front_redo, 7 scans that handed to k_tail
+#define FX_N_HINTS 8      // tier_hint[]: 0 / 1 rings handed to the second run tier / the workgroup tier (largest XCD class), 2 big merges, 3 huge merges, 4 dense rows, 5 dense support points, 6 scans k_front handed to k_front_redo, 7 scans handed to the slow tier (k_slow)
 #define FX_CNT_QPOOL 32   // counters[32]: entries of the dense tier's query pool in use
 #define FX_CNT_LARGE2 16  // counters[16 + c]: rings of XCD class c the second run tier hands to the workgroup tier
 #define FX_CNT_LARGE 24  // counters[24 + c]: ... to the large tier
@@ -112,7 +115,10 @@ struct FxBuffers {
   uint32_t *big_merge;    // [B]
   uint32_t *huge_merge;   // [B]  scans with more candidates than the LDS merge tiers hold
   uint32_t *redo;         // [B]  scans that do not fit k_front's LDS tables: k_front_redo runs the general kernels' bodies on them
-  uint32_t *redo2;        // [B]  ... and those that need more LDS than k_front_redo has: k_tail (a whole CU per workgroup)
+  uint32_t *slow;         // [B]  scans with work for the slow tier (k_slow): rings or merges beyond every LDS-sized tier
+  uint32_t *slow_state;   // [B]  1 while the scan is listed (k_slow clears it)
+  uint32_t *ring_pending; // [B][(n_rings + 31) / 32]  bit r: ring r of the scan waits for k_slow (which clears it)
+  uint32_t *gs_pool;      // [gs_slots][gs_words]  k_slow's scratch: the LDS tiers' per-point / per-cluster arrays, in HBM
   float4 *merge_sorted;   // [B][max_candidates] (x, y, pseudo z, id) in bin order: k_merge_huge's pair tests (allocated only when that tier exists)
   uint32_t *list_desc;    // [max_total_kp]  rows whose list is too long for one wavefront (257 .. dense_min support points)
   uint32_t *wave_desc;    // [max_total_kp]  rows with 65..256 support points (one wavefront each)

@@ -86,6 +86,21 @@ void fx_limits_default(fx_limits *l, uint32_t max_batch, uint32_t max_points) {
   // overlap many times over (hundreds of keypoints, descriptor radius beyond a metre: the differential fuzz finds them)
   const unsigned long long dp = (unsigned long long)(max_batch > 32u ? max_batch : 32u) * max_points;
   l->max_dense_points = dp > 0xfff00000ull ? 0xfff00000u : (uint32_t)dp;
+  // a scan's overflow region (list entries beyond max_neighbors, any row of the scan): one entry per point of the scan — in
+  // contexts of fewer than 32 scans as many more as keep the regions at 32 scans' worth together (a single scan whose rows
+  // overflow their lists many times over has no batch to average with: descriptor radii of 2-3 m on the differential fuzz's
+  // scenes need up to three entries per point)
+  const unsigned long long per = (unsigned long long)max_points * (max_batch >= 32u ? 1u : 32u / (max_batch ? max_batch : 1u));
+  l->max_overflow_points = per > 0x7ff00000ull ? 0x7ff00000u : (uint32_t)per;
+}
+
+void fx_limits_sparse(fx_limits *l, uint32_t max_batch, uint32_t max_points) {
+  fx_limits_default(l, max_batch, max_points);
+  // room for a few dense rows a batch (a keypoint beside a wall): 64 rows' worth of the longest lists, four scans' points at least
+  const unsigned long long dp = 4ull * max_points > 262144ull ? 4ull * max_points : 262144ull;
+  if (dp < l->max_dense_points) l->max_dense_points = (uint32_t)dp;
+  const uint32_t ovf = max_points < 8192u ? max_points : 8192u;
+  if (ovf < l->max_overflow_points) l->max_overflow_points = ovf;
 }
 
 // rotateCloud (ref: node.cpp:159-167): Eigen::AngleAxisf(pitch, Y) * Eigen::AngleAxisf(roll, X).
@@ -236,6 +251,7 @@ uint32_t fx_synth_scan(const fx_synth_cfg *c, float *out, uint32_t capacity) {
   return n;
 }
 
+#ifdef FX_TEST_HOOKS
 // Host build of the order-replay used by the kernels (same header, same code path), so the
 // CPU test-suite can check it against libstdc++'s std::sort without a GPU.
 void fx_test_sort_replay(const uint32_t *sizes, uint32_t n, uint32_t *perm_out) {
@@ -281,5 +297,7 @@ void fx_test_sort_replay_lists(const uint32_t *sizes, uint32_t n, uint32_t *perm
   delete[] rec;
   delete[] pos;
 }
+
+#endif  // FX_TEST_HOOKS
 
 }  // extern "C"

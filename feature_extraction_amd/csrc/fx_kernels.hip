@@ -151,8 +151,41 @@ __device__ __forceinline__ void wg_global_sync() {
 // The parent array is always LDS; addressing it through an explicit LDS pointer keeps these
 // loops on ds_read / ds_min instead of flat instructions.
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
+// GS ("global scratch"): the slow tier behind every LDS-sized one (k_slow) runs the same bodies with their per-point and
+// per-cluster arrays in a scratch region of HBM instead of LDS — any ring / candidate count the limits allow, at L2 latency.
+// Results do not depend on which tier ran.  Barriers there also drop this CU's L1 lines (wg_global_sync).
+template <bool GS>
+struct UfWord { typedef lds_u32 type; };
+template <>
+struct UfWord<true> { typedef uint32_t type; };
+template <bool GS>
+__device__ __forceinline__ void wg_sync() {
+  if (GS)
+    wg_global_sync();
+  else
+    __syncthreads();
+}
+// a wavefront's own hand-over (one lane writes, another reads): LDS is in order within a wavefront; HBM scratch waits for the
+// stores and drops the L1's lines
+template <bool GS>
+__device__ __forceinline__ void wave_sync() {
+  if (GS) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+template <bool GS = false>
+__device__ __forceinline__ uint32_t uf_load(const uint32_t *parent, uint32_t i) {
+  return ((const volatile typename UfWord<GS>::type *)parent)[i];
+}
+template <bool GS = false>
 __device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t i) {
-  volatile lds_u32 *p = (volatile lds_u32 *)parent;
+  volatile typename UfWord<GS>::type *p = (volatile typename UfWord<GS>::type *)parent;
   uint32_t q = p[i];
   while (q != i) {
     const uint32_t g = p[q];
@@ -164,8 +197,9 @@ __device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t i) {
 }
 // Read-only variant for the final root pass: there each owner overwrites parent[i] with its root,
 // and a concurrent path-halving write from another lane could put a non-root ancestor back.
+template <bool GS = false>
 __device__ __forceinline__ uint32_t uf_find_ro(uint32_t *parent, uint32_t i) {
-  volatile lds_u32 *p = (volatile lds_u32 *)parent;
+  volatile typename UfWord<GS>::type *p = (volatile typename UfWord<GS>::type *)parent;
   uint32_t q = p[i];
   while (q != i) {
     i = q;
@@ -173,11 +207,12 @@ __device__ __forceinline__ uint32_t uf_find_ro(uint32_t *parent, uint32_t i) {
   }
   return i;
 }
+template <bool GS = false>
 __device__ __forceinline__ void uf_union(uint32_t *parent, uint32_t a, uint32_t b) {
-  lds_u32 *p = (lds_u32 *)parent;
+  typename UfWord<GS>::type *p = (typename UfWord<GS>::type *)parent;
   while (true) {
-    a = uf_find(parent, a);
-    b = uf_find(parent, b);
+    a = uf_find<GS>(parent, a);
+    b = uf_find<GS>(parent, b);
     if (a == b) return;
     if (a < b) {
       const uint32_t t = a;
@@ -191,11 +226,12 @@ __device__ __forceinline__ void uf_union(uint32_t *parent, uint32_t a, uint32_t 
 }
 
 // The same, from any members (or ancestors) of the two sets; returns the root of the united set as of the call's end.
+template <bool GS = false>
 __device__ __forceinline__ uint32_t uf_union_root(uint32_t *parent, uint32_t a, uint32_t b) {
-  lds_u32 *p = (lds_u32 *)parent;
+  typename UfWord<GS>::type *p = (typename UfWord<GS>::type *)parent;
   while (true) {
-    a = uf_find(parent, a);
-    b = uf_find(parent, b);
+    a = uf_find<GS>(parent, a);
+    b = uf_find<GS>(parent, b);
     if (a == b) return a;
     if (a < b) {
       const uint32_t t = a;
@@ -206,6 +242,19 @@ __device__ __forceinline__ uint32_t uf_union_root(uint32_t *parent, uint32_t a, 
     if (old == a) return b;
     a = old;  // a stopped being a root meanwhile: its former parent must join b's set too
   }
+}
+
+// The slow tier's work list (k_slow): a scan is listed once however many of its rings are pending (slow_state), a ring
+// handed over is marked in the scan's bit map and counts for nothing until k_slow has done it.  One thread calls these.
+__device__ __forceinline__ void slow_push(const FxBuffers &B, uint32_t scan) {
+  if (atomicExch(&B.slow_state[scan], 1u) == 0u) B.slow[atomicAdd(&B.counters[FX_CNT_REDO + 1], 1u)] = scan;
+}
+__device__ __forceinline__ void slow_ring(const FxDevParams &P, const FxBuffers &B, uint32_t scan, uint32_t ring) {
+  const uint32_t R = (uint32_t)P.n_rings;
+  atomicOr(&B.ring_pending[(size_t)scan * ((R + 31u) / 32u) + (ring >> 5)], 1u << (ring & 31u));
+  B.ring_cand_cnt[(size_t)scan * R + ring] = 0u;
+  B.kpc_ring_cnt[(size_t)scan * R + ring] = 0u;
+  slow_push(B, scan);
 }
 
 // Diagnostic build only (-DFX_STAMPS): per-phase cycle shares of the ring kernel, summed by
@@ -309,7 +358,7 @@ __device__ __forceinline__ uint32_t block_count_incl(bool flag, uint32_t *s_w, u
 //     input order.
 //  3. roots per run head, then per point; sizes per segment.
 // Returns the number of segments (the table is valid iff it is <= SegCfg<NT>::kMax).
-template <int NT>
+template <int NT, bool GS = false>
 __device__ __forceinline__ uint32_t cc_label(const float4 *pt, uint32_t n, float r2, uint32_t *parent, uint32_t *csize, uint32_t *rid,
                              uint32_t *s_w, unsigned long long *stamps = nullptr) {
   constexpr uint32_t kSegMax = SegCfg<NT>::kMax;
@@ -327,7 +376,7 @@ __device__ __forceinline__ uint32_t cc_label(const float4 *pt, uint32_t n, float
     ST.set_rbox(FX_MINY, t, __uint_as_float(f2ord(INFINITY)));
     ST.set_rbox(FX_MAXY, t, __uint_as_float(f2ord(-INFINITY)));
   }
-  __syncthreads();
+  wg_sync<GS>();
   uint32_t carry = 0, n_runs = 0, n_segs = 0;
   for (uint32_t b0 = 0; b0 < n; b0 += NT) {
     const uint32_t i = b0 + threadIdx.x;
@@ -344,7 +393,7 @@ __device__ __forceinline__ uint32_t cc_label(const float4 *pt, uint32_t n, float
     }
     const unsigned long long m = __ballot(start);
     if (lane == 0) s_w[wave] = m ? (b0 + wave * 64 + (63u - (uint32_t)__clzll((long long)m))) : FX_NONE;
-    __syncthreads();
+    wg_sync<GS>();
     const unsigned long long below = m & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
     uint32_t head = carry, last = carry;
 #pragma unroll
@@ -356,7 +405,7 @@ __device__ __forceinline__ uint32_t cc_label(const float4 *pt, uint32_t n, float
       }
     }
     if (below) head = b0 + wave * 64 + (63u - (uint32_t)__clzll((long long)below));
-    __syncthreads();
+    wg_sync<GS>();
     carry = last;
     // number the runs and the segments (a segment starts at a run head and every seg_len points)
     uint32_t tot_r, tot_s;
@@ -384,7 +433,7 @@ __device__ __forceinline__ uint32_t cc_label(const float4 *pt, uint32_t n, float
     n_segs += tot_s;
   }
   const bool table = n_segs <= kSegMax;
-  __syncthreads();
+  wg_sync<GS>();
   FX_STAMP(2);
   if (threadIdx.x == 0) {
     FX_COUNT(12, 1);
@@ -409,12 +458,12 @@ __device__ __forceinline__ uint32_t cc_label(const float4 *pt, uint32_t n, float
       ST.start(n_segs) = n;
       ST.rseg(n_runs) = n_segs;
     }
-    __syncthreads();
+    wg_sync<GS>();
     for (uint32_t r = threadIdx.x; r < n_runs; r += NT) {
 #pragma unroll
       for (uint32_t k = 0; k < 4; ++k) ST.w[(7 + k) * kSegMax + 2 + r] = __float_as_uint(ord2f(ST.w[(7 + k) * kSegMax + 2 + r]));
     }
-    __syncthreads();
+    wg_sync<GS>();
   }
   if (n_runs > 1) {
     // Candidate generation is wave-uniform and cheap; the expensive part (finds, segment and
@@ -425,19 +474,17 @@ __device__ __forceinline__ uint32_t cc_label(const float4 *pt, uint32_t n, float
     uint32_t wq_n = 0;
     const float r2_pad = r2 * 1.001f;  // box distances are lower bounds; pad them against fp32 rounding
     auto drain = [&]() {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      wave_sync<GS>();
       for (uint32_t t = lane; t < wq_n; t += 64) {
         const uint32_t item = wq[t];
         const uint32_t i = item >> 16, x = item & 0xffffu;
         if (!table) {
-          uf_union(parent, x, i);  // (i, j) is an edge
+          uf_union<GS>(parent, x, i);  // (i, j) is an edge
           continue;
         }
         // (point i, other run x): its segments' boxes, then their points
         const uint32_t s0 = ST.rseg(x), s1 = ST.rseg(x + 1);
-        if (uf_find(parent, i) == uf_find(parent, ST.start(s0))) continue;  // already one component
+        if (uf_find<GS>(parent, i) == uf_find<GS>(parent, ST.start(s0))) continue;  // already one component
         const float4 q = pt[i];
         bool linked = false;
         for (uint32_t sg = s0; sg < s1 && !linked; ++sg) {
@@ -447,7 +494,7 @@ __device__ __forceinline__ uint32_t cc_label(const float4 *pt, uint32_t n, float
           for (uint32_t j = ST.start(sg); j < ST.start(sg + 1); ++j) {
             const float4 p = pt[j];
             if (dist2(q.x, q.y, q.z, p.x, p.y, p.z) < r2) {
-              uf_union(parent, j, i);
+              uf_union<GS>(parent, j, i);
               linked = true;  // the two runs are one component now; more edges add nothing
               break;
             }
@@ -472,7 +519,7 @@ __device__ __forceinline__ uint32_t cc_label(const float4 *pt, uint32_t n, float
       uint32_t *rp = s_w + 32;
       constexpr uint32_t kPairCap = FX_SORT_STACK_WORDS;
       if (threadIdx.x == 0) s_w[16] = 0;
-      __syncthreads();
+      wg_sync<GS>();
       const float inv_runs = 1.0f / (float)n_runs;
       for (uint32_t p = threadIdx.x; p < n_runs * n_runs; p += NT) {
         // p = a * n_runs + b; (p + 0.5) / n_runs is never within rounding distance of an integer (p < 2^14)
@@ -484,7 +531,7 @@ __device__ __forceinline__ uint32_t cc_label(const float4 *pt, uint32_t n, float
         const uint32_t slot = atomicAdd(&s_w[16], 1u);
         if (slot < kPairCap) rp[slot] = (a << 16) | b;
       }
-      __syncthreads();
+      wg_sync<GS>();
       const uint32_t n_rp = s_w[16];
       if (threadIdx.x == 0) {
         FX_COUNT(15, n_rp);
@@ -574,25 +621,25 @@ __device__ __forceinline__ uint32_t cc_label(const float4 *pt, uint32_t n, float
     }
     drain();
   }
-  __syncthreads();
+  wg_sync<GS>();
   FX_STAMP(3);
   // roots: run heads first (only heads are ever linked), then every point through its head
   for (uint32_t i = threadIdx.x; i < n; i += NT) {
     const bool is_head = i == 0 || rid[i] != rid[i - 1];
-    if (is_head) parent[i] = uf_find_ro(parent, i);
+    if (is_head) parent[i] = uf_find_ro<GS>(parent, i);
   }
-  __syncthreads();
+  wg_sync<GS>();
   for (uint32_t i = threadIdx.x; i < n; i += NT) {
     const bool is_head = i == 0 || rid[i] != rid[i - 1];
     if (!is_head) parent[i] = parent[parent[i]];
   }
-  __syncthreads();
+  wg_sync<GS>();
   if (table) {
     for (uint32_t sg = threadIdx.x; sg < n_segs; sg += NT) atomicAdd(&csize[parent[ST.start(sg)]], ST.start(sg + 1) - ST.start(sg));
   } else {
     for (uint32_t i = threadIdx.x; i < n; i += NT) atomicAdd(&csize[parent[i]], 1u);
   }
-  __syncthreads();
+  wg_sync<GS>();
   FX_STAMP(4);
   return n_segs;
 }
@@ -609,7 +656,7 @@ __device__ __forceinline__ void wave_sync_lds() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-template <int W>
+template <int W, bool GS = false>
 __device__ __noinline__ void sort_partition_wave(uint32_t *crec, int n, int *stk, uint16_t *Lpos, uint16_t *Rpos) {
   using namespace fx_sort_detail;
   if (n <= FX_SORT_THRESHOLD) return;
@@ -625,7 +672,7 @@ __device__ __noinline__ void sort_partition_wave(uint32_t *crec, int n, int *stk
     stk_last[0] = n;
     stk_depth[0] = 2 * lg;
   }
-  wave_sync_lds();
+  wave_sync<GS>();
   int sp = 1;
   while (sp > 0) {
     --sp;
@@ -633,12 +680,12 @@ __device__ __noinline__ void sort_partition_wave(uint32_t *crec, int n, int *stk
     while (last - first > FX_SORT_THRESHOLD) {
       if (depth == 0) {  // depth budget spent (adversarial input): heap sort, sequential
         if (lane == 0) heap_sort(v, first, last);
-        wave_sync_lds();
+        wave_sync<GS>();
         break;
       }
       --depth;
       if (lane == 0) median_to_first(v, first, first + 1, first + (last - first) / 2, last - 1);
-      wave_sync_lds();
+      wave_sync<GS>();
       const uint32_t pivot = v.get(first);
       unsigned long long mL[W], mR[W];
       bool isL[W], isR[W];
@@ -668,7 +715,7 @@ __device__ __noinline__ void sort_partition_wave(uint32_t *crec, int n, int *stk
         if (isL[w]) Lpos[rankL[w]] = (uint16_t)(w * 64 + lane);
         if (isR[w]) Rpos[rankR[w]] = (uint16_t)(w * 64 + lane);
       }
-      wave_sync_lds();
+      wave_sync<GS>();
       int partner[W], s = 0;
       uint32_t incoming[W];
 #pragma unroll
@@ -687,7 +734,7 @@ __device__ __noinline__ void sort_partition_wave(uint32_t *crec, int n, int *stk
         incoming[w] = partner[w] >= 0 ? v.get(partner[w]) : 0u;
         s += __popcll(__ballot(as_left));
       }
-      wave_sync_lds();
+      wave_sync<GS>();
 #pragma unroll
       for (int w = 0; w < W; ++w)
         if (partner[w] >= 0) v.set(w * 64 + lane, incoming[w]);
@@ -699,7 +746,7 @@ __device__ __noinline__ void sort_partition_wave(uint32_t *crec, int n, int *stk
         stk_last[sp] = last;
         stk_depth[sp] = depth;
       }
-      wave_sync_lds();
+      wave_sync<GS>();
       ++sp;
       last = cut;
     }
@@ -713,7 +760,7 @@ __device__ __noinline__ void sort_partition_wave(uint32_t *crec, int n, int *stk
 // the clusters; croot[ordinal] = root index; tmp: scratch.  croot / crec / tmp hold ccap entries;
 // returns the cluster count, which the caller must check against ccap (nothing is written past it,
 // and nothing is ordered, when it does not fit).
-template <int NT>
+template <int NT, bool GS = false>
 __device__ __forceinline__ uint32_t cc_order(uint32_t n, const uint32_t *parent, const uint32_t *csize, uint32_t min_sz,
                              uint32_t max_sz, uint32_t *croot, uint32_t *crec, uint32_t *tmp, uint32_t ccap,
                              uint32_t *s_w, unsigned long long *stamps = nullptr) {
@@ -738,26 +785,26 @@ __device__ __forceinline__ uint32_t cc_order(uint32_t n, const uint32_t *parent,
     }
     n_c += tot;
   }
-  __syncthreads();
+  wg_sync<GS>();
   FX_STAMP(5);
   if (n_c > ccap) return n_c;
   if (n_c > FX_SORT_THRESHOLD) {
     if (threadIdx.x < 64) {  // one wavefront; tmp doubles as the two position tables
       uint16_t *pos = reinterpret_cast<uint16_t *>(tmp);
       if (n_c <= 64) {
-        sort_partition_wave<1>(crec, (int)n_c, (int *)(s_w + 32), pos, pos + n_c);
+        sort_partition_wave<1, GS>(crec, (int)n_c, (int *)(s_w + 32), pos, pos + n_c);
       } else if (n_c <= 128) {
-        sort_partition_wave<2>(crec, (int)n_c, (int *)(s_w + 32), pos, pos + n_c);
+        sort_partition_wave<2, GS>(crec, (int)n_c, (int *)(s_w + 32), pos, pos + n_c);
       } else if (n_c <= 192) {
-        sort_partition_wave<3>(crec, (int)n_c, (int *)(s_w + 32), pos, pos + n_c);
+        sort_partition_wave<3, GS>(crec, (int)n_c, (int *)(s_w + 32), pos, pos + n_c);
       } else if (n_c <= 256) {
-        sort_partition_wave<4>(crec, (int)n_c, (int *)(s_w + 32), pos, pos + n_c);
+        sort_partition_wave<4, GS>(crec, (int)n_c, (int *)(s_w + 32), pos, pos + n_c);
       } else if (threadIdx.x == 0) {  // more clusters than three words of lanes: one lane, sequentially
         fx_sort_detail::RevView v{crec, (int)n_c};
         fx_sort_partition_phase(v, (int)n_c, (int *)(s_w + 32));
       }
     }
-    __syncthreads();
+    wg_sync<GS>();
   }
   if (n_c > 1) {
     for (uint32_t c = threadIdx.x; c < n_c; c += NT) {
@@ -770,9 +817,9 @@ __device__ __forceinline__ uint32_t cc_order(uint32_t n, const uint32_t *parent,
       }
       tmp[pos] = rec;
     }
-    __syncthreads();
+    wg_sync<GS>();
     for (uint32_t c = threadIdx.x; c < n_c; c += NT) crec[c] = tmp[c];
-    __syncthreads();
+    wg_sync<GS>();
   }
   FX_STAMP(6);
   return n_c;
@@ -1274,11 +1321,13 @@ struct RingLds {
 };
 #define FX_RING_WORDS_PER_POINT 7
 #define FX_RING_WORDS_PER_CLUSTER 8
+// (gs: the per-point and per-cluster arrays go to that scratch region of HBM instead — the slow tier, k_slow; the scratch
+//  words in front stay in LDS)
 template <int NT>
-__device__ __forceinline__ RingLds ring_carve(uint32_t *smem, uint32_t cap, uint32_t ccap) {
+__device__ __forceinline__ RingLds ring_carve(uint32_t *smem, uint32_t cap, uint32_t ccap, uint32_t *gs = nullptr) {
   RingLds L;
   L.s_w = smem;
-  uint32_t *p = smem + SegCfg<NT>::kWords;  // multiple of 4 words: the float4 arrays stay 16-byte aligned
+  uint32_t *p = gs ? gs : smem + SegCfg<NT>::kWords;  // multiple of 4 words: the float4 arrays stay 16-byte aligned
   L.pt = reinterpret_cast<float4 *>(p), p += 4 * cap;
   L.cc = reinterpret_cast<float4 *>(p), p += 4 * ccap;
   L.parent = p, p += cap;
@@ -1295,10 +1344,10 @@ __device__ __forceinline__ RingLds ring_carve(uint32_t *smem, uint32_t cap, uint
 // Euclidean clustering, centroid + diameter gate, candidates in PCL's cluster order, member
 // points for keypoint_cloud.  Returns false when the ring does not fit this tier (more than
 // `cap` points or more than `ccap` size-admissible clusters): the caller defers it to a larger one.
-template <int NT>
+template <int NT, bool GS = false>
 __device__ __forceinline__ bool ring_body(const FxDevParams &P, const FxBuffers &B, uint32_t scan, uint32_t ring, uint32_t cap,
-                          uint32_t ccap, uint32_t *smem, bool last_tier) {
-  RingLds L = ring_carve<NT>(smem, cap, ccap);
+                          uint32_t ccap, uint32_t *smem, bool last_tier, uint32_t *gs = nullptr) {
+  RingLds L = ring_carve<NT>(smem, cap, ccap, GS ? gs : nullptr);
   unsigned long long *const stamp_base = B.stamps ? B.stamps + (NT == 64 ? 0 : 16) : nullptr;
   FX_STAMP_INIT(stamp_base);
   const uint32_t tid = threadIdx.x;
@@ -1322,12 +1371,12 @@ __device__ __forceinline__ bool ring_body(const FxDevParams &P, const FxBuffers 
   }
   const float4 *src = B.ring_pts + (size_t)scan * P.ring_slot_cap + off;
   for (uint32_t i = tid; i < n; i += NT) L.pt[i] = src[i];
-  __syncthreads();
+  wg_sync<GS>();
   FX_STAMP(1);
 
   // ---- pcl::EuclideanClusterExtraction (ref: node.cpp:269-276)
-  const uint32_t n_segs = cc_label<NT>(L.pt, n, P.r2_cluster, L.parent, L.csize, L.rank, L.s_w, stamp_base);
-  const uint32_t n_c = cc_order<NT>(n, L.parent, L.csize, P.min_count, P.max_count, L.croot, L.crec, L.ckoff, ccap, L.s_w,
+  const uint32_t n_segs = cc_label<NT, GS>(L.pt, n, P.r2_cluster, L.parent, L.csize, L.rank, L.s_w, stamp_base);
+  const uint32_t n_c = cc_order<NT, GS>(n, L.parent, L.csize, P.min_count, P.max_count, L.croot, L.crec, L.ckoff, ccap, L.s_w,
                                     stamp_base);
   if (n_c > ccap) return false;  // (ccap == cap in the last tier, so this cannot happen there)
 #ifdef FX_STAMPS
@@ -1344,7 +1393,7 @@ __device__ __forceinline__ bool ring_body(const FxDevParams &P, const FxBuffers 
     bb[4 * s + 2] = f2ord(1000.0f);
     bb[4 * s + 3] = f2ord(-1000.0f);
   }
-  __syncthreads();
+  wg_sync<GS>();
   // min/max are exact whatever the order, so segments (or points) fold into their cluster's box
   if (n_segs <= SegCfg<NT>::kMax) {
     const SegTable<NT> ST(L.s_w);
@@ -1369,7 +1418,7 @@ __device__ __forceinline__ bool ring_body(const FxDevParams &P, const FxBuffers 
       atomicMax(&b[3], f2ord(q.y));
     }
   }
-  __syncthreads();
+  wg_sync<GS>();
   FX_STAMP(7);
   // ---- diameter gate per cluster, in PCL's cluster order (ref: node.cpp:314-316)
   for (uint32_t s = tid; s < n_c; s += NT) {
@@ -1379,7 +1428,7 @@ __device__ __forceinline__ bool ring_body(const FxDevParams &P, const FxBuffers 
     const double diameter = sqrt(ddx * ddx + ddy * ddy);
     L.cslot[s] = (diameter < P.gate_diameter) ? 1u : 0u;
   }
-  __syncthreads();
+  wg_sync<GS>();
   FX_STAMP(8);
   // ---- centroid of the clusters that pass: fp64 sums in ascending member order
   //      (ref: node.cpp:293-297, 317-320); the walk also ranks the members for keypoint_cloud
@@ -1411,7 +1460,7 @@ __device__ __forceinline__ bool ring_body(const FxDevParams &P, const FxBuffers 
     }
     L.cc[s] = make_float4((float)(sumx / (double)sz), (float)(sumy / (double)sz), (float)(sumz / (double)sz), L.pt[root].w);
   }
-  __syncthreads();
+  wg_sync<GS>();
   FX_STAMP(9);
 
   // ---- slots of the gate-passing clusters and offsets of their member runs
@@ -1430,7 +1479,7 @@ __device__ __forceinline__ bool ring_body(const FxDevParams &P, const FxBuffers 
     n_pass += tot_p;
     n_mem += tot_m;
   }
-  __syncthreads();
+  wg_sync<GS>();
   FX_STAMP(10);
 
   // ---- candidates of this ring (cylinderCentroids, ref: node.cpp:322)
@@ -1465,7 +1514,7 @@ __device__ __forceinline__ bool ring_body(const FxDevParams &P, const FxBuffers 
       pool_c[dst] = slot;
     }
   }
-  __syncthreads();
+  wg_sync<GS>();
   FX_STAMP(11);
   return true;
 }
@@ -1998,7 +2047,9 @@ extern "C" __global__ __launch_bounds__(FX_RING_LARGE_T) void k_rings_large(FxDe
   const uint32_t *items = (after_runs2 ? B.huge_rings2 : B.huge_rings) + (size_t)cls * P.ring_list_cap;
   for (uint32_t w = blockIdx.x >> 3; w < n_big; w += gridDim.x >> 3) {
     const uint32_t item = items[w];
-    ring_body<FX_RING_LARGE_T>(P, B, item / P.n_rings, item % P.n_rings, cap, ccap, smem, true);
+    // (more points than this tier's LDS holds: the slow tier, which also flags what exceeds limits.max_ring_points)
+    if (!ring_body<FX_RING_LARGE_T>(P, B, item / P.n_rings, item % P.n_rings, cap, ccap, smem, false) && threadIdx.x == 0)
+      slow_ring(P, B, item / P.n_rings, item % P.n_rings);
     __syncthreads();
   }
 }
@@ -2066,9 +2117,12 @@ struct FrontCands {
 // Returns false when the scan has more candidates than this tier holds (the caller defers it to the next one).
 // FRONT: the candidates come from k_front's LDS tables (FC) instead of the ring kernels' rows in HBM, and keypoint_cloud
 // has been written by the caller.
-template <int NT, bool LDS_PTS, bool FRONT = false>
+// GS (with LDS_PTS false): parents, bin table, ids, cluster tables and the bin-ordered copy live in the scratch region `gs` of
+// HBM instead of LDS (k_slow: any candidate count the limits allow); the head and the ring bases stay in LDS.
+template <int NT, bool LDS_PTS, bool FRONT = false, bool GS = false>
 __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers &B, uint32_t scan, uint32_t cap, uint32_t ccap,
-                                           uint32_t *smem, bool last_tier, const FrontCands *FC = nullptr) {
+                                           uint32_t *smem, bool last_tier, const FrontCands *FC = nullptr, uint32_t *gs = nullptr) {
+  static_assert(!GS || (!LDS_PTS && !FRONT), "the scratch tier keeps the coordinates in HBM");
   unsigned long long *const stamp_base = B.stamps ? B.stamps + 32 : nullptr;
   FX_STAMP_INIT(stamp_base);
   const uint32_t tid = threadIdx.x;
@@ -2077,7 +2131,9 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
   uint32_t *s_w = smem;
   uint32_t *rbase = smem + FX_MERGE_HEAD;  // [R + 1]
   uint32_t *kbase = rbase + (R + 1);       // [R + 1]
-  uint32_t *p = smem + FX_MERGE_HEAD + ((2 * (R + 1) + 3) & ~3u);
+  uint32_t *p = GS ? gs : smem + FX_MERGE_HEAD + ((2 * (R + 1) + 3) & ~3u);
+  float4 *gs_sorted = nullptr;  // GS: the bin-ordered copy of the merge points
+  if (GS) gs_sorted = reinterpret_cast<float4 *>(p), p += 4 * (size_t)cap;
   float4 *pt = nullptr;   // (x, y, pseudo z, elevation)
   float *cz = nullptr;    // true z
   uint16_t *mlist = nullptr;  // [2][cap]: members of the admissible clusters, unordered then ordered
@@ -2122,7 +2178,7 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
   }
   if (C > cap && !last_tier) return false;  // (cap == max_candidates in the last tier)
   for (uint32_t t = tid; t <= NB; t += NT) bin[t] = 0;
-  __syncthreads();
+  wg_sync<GS>();
 
   float4 *cand = B.cand + (size_t)scan * P.max_candidates;
   uint32_t *cand_size = B.cand_size + (size_t)scan * P.max_candidates;
@@ -2171,7 +2227,7 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
     parent[idx] = idx;
     atomicAdd(&bin[bin_of(cell_x(v.x), cell_y(v.y))], 1u);
   }
-  __syncthreads();
+  wg_sync<GS>();
   if (!LDS_PTS) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // `cand` is re-read below by other waves of this workgroup (see wg_global_sync)
   FX_STAMP(1);
   uint32_t n_c = 0;
@@ -2193,10 +2249,10 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
         run += c;
       }
     }
-    __syncthreads();
+    wg_sync<GS>();
     // (coordinates left in HBM: a copy of the merge points in bin order, id in .w, so that the pair tests below read a bin's
     //  entries from consecutive addresses instead of one dependent L2 load per id — 86 % of k_merge_huge was that loop)
-    float4 *msort = LDS_PTS ? nullptr : B.merge_sorted + (size_t)scan * P.max_candidates;
+    float4 *msort = LDS_PTS ? nullptr : (GS ? gs_sorted : B.merge_sorted + (size_t)scan * P.max_candidates);
     for (uint32_t idx = tid; idx < C; idx += NT) {  // each id to its bin: a start becomes the bin's end
       const float4 v = merge_pt(idx);
       const uint32_t pos = atomicAdd(&bin[bin_of(cell_x(v.x), cell_y(v.y))], 1u);
@@ -2204,7 +2260,7 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
       if (!LDS_PTS) msort[pos] = make_float4(v.x, v.y, v.z, __uint_as_float(idx));
     }
     if (tid == 0) s_w[152] = 0u;  // (the pair loop's bin ticket)
-    __syncthreads();
+    wg_sync<GS>();
     if (!LDS_PTS) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (msort is read below by other waves of this workgroup)
     FX_STAMP(2);
     // ---- pcl::EuclideanClusterExtraction on (x, y, pseudo z) (ref: node.cpp:222-229)
@@ -2239,7 +2295,7 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
           const bool has = tc + lane < t1;
           const float4 vj = msort[min(tc + lane, t1 - 1u)];
           const uint32_t j = has ? __float_as_uint(vj.w) : 0u;  // (0: never larger than a source's id)
-          uint32_t rj = has ? uf_find(parent, j) : 0u;
+          uint32_t rj = has ? uf_find<GS>(parent, j) : 0u;
           for (uint32_t base = 0; base < total; base += 64u) {
             const uint32_t g = min(base + lane, total - 1u);
             uint32_t s_at = st[0] + g;
@@ -2258,12 +2314,12 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
               if (B.stamps && lane == 0) atomicAdd(&B.stamps[60], 1ull);
               if (B.stamps && j > i && dist2(sx, sy, sz, vj.x, vj.y, vj.z) < P.r2_merge) {
                 atomicAdd(&B.stamps[61], 1ull);
-                if (((volatile lds_u32 *)parent)[i] != rj) atomicAdd(&B.stamps[62], 1ull);
+                if (uf_load<GS>(parent, i) != rj) atomicAdd(&B.stamps[62], 1ull);
               }
 #endif
               if (j > i && dist2(sx, sy, sz, vj.x, vj.y, vj.z) < P.r2_merge) {
-                const uint32_t pi = ((volatile lds_u32 *)parent)[i];
-                if (pi != rj) rj = uf_union_root(parent, rj, pi);  // (from the ancestors at hand: shorter finds, and the root comes back)
+                const uint32_t pi = uf_load<GS>(parent, i);
+                if (pi != rj) rj = uf_union_root<GS>(parent, rj, pi);  // (from the ancestors at hand: shorter finds, and the root comes back)
               }
             }
           }
@@ -2297,20 +2353,19 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
             // (already under one parent — after the first few unions of a pole that many rings saw: most pairs — is two reads
             //  instead of two finds: k_merge_big on config 3 0.208 -> 0.182 ms; not inside k_front, where a pole has a
             //  candidate per ring of sixteen and the reads cost more than they save)
-            const volatile lds_u32 *pp = (const volatile lds_u32 *)parent;
-            if (FRONT || pp[j[e]] != pp[i]) uf_union(parent, j[e], i);
+            if (FRONT || uf_load<GS>(parent, j[e]) != uf_load<GS>(parent, i)) uf_union<GS>(parent, j[e], i);
           }
       }
     }
-    __syncthreads();
+    wg_sync<GS>();
     FX_STAMP(3);
-    for (uint32_t i = tid; i < C; i += NT) parent[i] = uf_find_ro(parent, i);
+    for (uint32_t i = tid; i < C; i += NT) parent[i] = uf_find_ro<GS>(parent, i);
     for (uint32_t i = tid; i < C; i += NT) csize[i] = 0u;  // (bin table and ids are done with)
-    __syncthreads();
+    wg_sync<GS>();
     for (uint32_t i = tid; i < C; i += NT) atomicAdd(&csize[parent[i]], 1u);
-    __syncthreads();
+    wg_sync<GS>();
     FX_STAMP(4);
-    n_c = cc_order<NT>(C, parent, csize, P.ndc, P.secondary_max, croot, crec, tmp, ccap, s_w, stamp_base);
+    n_c = cc_order<NT, GS>(C, parent, csize, P.ndc, P.secondary_max, croot, crec, tmp, ccap, s_w, stamp_base);
     if (n_c > ccap) {  // (large tier only: ccap >= max_keypoints there, so the scan overflows its keypoints anyway)
       if (tid == 0) atomicOr(&B.flags[scan], FX_FLAG_KP_OVERFLOW);
       n_c = 0;
@@ -2346,16 +2401,16 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
       }
       run += tot;
     }
-    __syncthreads();
+    wg_sync<GS>();
     for (uint32_t s = tid; s < n_c; s += NT) mfill[s] = 0u;
-    __syncthreads();
+    wg_sync<GS>();
     uint16_t *unord = mlist, *ord = mlist + cap;
     for (uint32_t i = tid; i < C; i += NT) {
       const uint32_t pos = csize[parent[i]] >> 16;
       if (pos == 0) continue;
       unord[mbase[pos - 1u] + atomicAdd(&mfill[pos - 1u], 1u)] = (uint16_t)i;
     }
-    __syncthreads();
+    wg_sync<GS>();
     if (!LDS_PTS) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     for (uint32_t i = tid; i < C; i += NT) {  // rank within the cluster = members with a smaller index
       const uint32_t pos = csize[parent[i]] >> 16;
@@ -2365,7 +2420,7 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
       for (uint32_t m = 0; m < sz; ++m) rank += (uint32_t)unord[m0 + m] < i ? 1u : 0u;
       ord[m0 + rank] = (uint16_t)i;
     }
-    __syncthreads();
+    wg_sync<GS>();
     if (!LDS_PTS) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     float4 *kp = B.keypoints + (size_t)scan * P.max_keypoints;
     uint32_t *kps = B.kp_size + (size_t)scan * P.max_keypoints;
@@ -2383,7 +2438,7 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
       kps[s] = sz;
       B.kp_nbrs[(size_t)scan * P.max_keypoints + s] = 0u;  // (k_gather flags the keypoints that have a neighbour; the descriptor kernels count)
     }
-    __syncthreads();
+    wg_sync<GS>();
     FX_STAMP(8);
     for (uint32_t i = tid; i < C; i += NT) {
       const uint32_t pos = csize[parent[i]] >> 16;
@@ -2397,7 +2452,7 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
       B.n_cand[scan] = C;
       B.n_kp[scan] = K;
     }
-    __syncthreads();
+    wg_sync<GS>();
     return true;
   }
   // ---- keypoint_cloud: chunks into ring order, candidate slot -> ordinal in keypoints_full
@@ -2417,7 +2472,7 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
     run += tot;
   }
   if (tid == 0) kbase[R] = run;
-  __syncthreads();
+  wg_sync<GS>();
   FX_STAMP(10);
   if (run > P.max_kpc) {
     if (tid == 0) atomicOr(&B.flags[scan], FX_FLAG_KPC_OVERFLOW);
@@ -2442,7 +2497,7 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
     B.n_kp[scan] = K;
     B.n_kpc[scan] = run;
   }
-  __syncthreads();
+  wg_sync<GS>();
   FX_STAMP(11);
   return true;
 }
@@ -2481,7 +2536,8 @@ extern "C" __global__ __launch_bounds__(FX_MBIG_T) void k_merge_huge(FxDevParams
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const uint32_t n_big = B.counters[9];
   for (uint32_t w = blockIdx.x; w < n_big; w += gridDim.x) {
-    merge_body<FX_MBIG_T, false>(P, B, B.huge_merge[w], cap, ccap, smem, true);
+    // (cap: what this tier's LDS holds; a scan with more candidates, up to limits.max_candidates, takes the slow tier)
+    if (!merge_body<FX_MBIG_T, false>(P, B, B.huge_merge[w], cap, ccap, smem, cap >= P.max_candidates) && threadIdx.x == 0) slow_push(B, B.huge_merge[w]);
     __syncthreads();
   }
 }
@@ -2501,7 +2557,7 @@ extern "C" __global__ __launch_bounds__(FX_MBIG_T) void k_merge_huge(FxDevParams
 //      concatenated rings — runs never cross a ring start, near run pairs are looked for inside a ring only —; PCL's
 //      cluster order per ring (the replay's partition phase: a ring per wavefront; its ranking: a cluster per thread);
 //   D  the secondary merge (merge_body) on the candidates in LDS; keypoint_cloud written straight in its final order.
-// Anything that does not fit the tables below hands the scan to k_tail, which runs the general kernels' bodies on it
+// Anything that does not fit the tables below hands the scan to k_front_redo, which runs the general kernels' bodies on it
 // from ~cloud: more ring entries than FX_FRONT_CAP, more runs than FX_FRONT_RUNS, more near run pairs than
 // FX_FRONT_PAIRS, more candidates than the small merge tier holds, or any of the limits the general kernels flag.
 #define FX_FRONT_T FX_PREP_T
@@ -2613,7 +2669,7 @@ extern "C" __global__ __launch_bounds__(FX_FRONT_T, FX_PREP_OCC) void k_front(Fx
   uint32_t nf = prep_stream<true>(P, B, M, scan, near_margin, el0, inv_step, PL);
   if (nf == FX_NONE) nf = prep_stream<false>(P, B, M, scan, near_margin, el0, inv_step, PL);  // (more survivors than the buffer keeps: once more, recycling it)
   FX_STAMP(1);
-  for (uint32_t r = tid; r < R; r += NT) B.ring_cnt[(size_t)scan * R + r] = r_cnt[r];  // (k_tail's ring split starts from these)
+  for (uint32_t r = tid; r < R; r += NT) B.ring_cnt[(size_t)scan * R + r] = r_cnt[r];  // (k_front_redo's ring split starts from these)
   if (tid == 0) {
     B.n_filt[scan] = nf;
     B.flags[scan] = 0u;
@@ -3157,11 +3213,10 @@ extern "C" __global__ __launch_bounds__(FX_FRONT_T, FX_PREP_OCC) void k_front(Fx
 // The scans k_front could not take (k_front_redo, a workgroup of k_front's shape each — 512 threads, the same LDS image — so
 // that a launch that finds nothing to do slips in beside the other batches' k_front workgroups instead of waiting for a whole
 // free CU): the general kernels' bodies as far as that image holds them (the ring split to HBM, every ring through the
-// workgroup tier, the merge tiers), starting from ~cloud and the ring counts.  front_general returns false when something
-// does not fit (a ring of more than FX_FRONT_G_CAP1 points with more than FX_FRONT_G_CCAP2 size-admissible clusters, more
-// candidates than either merge tier holds here): such a scan needs k_tail's whole-CU workgroup, which the host launches
-// when the previous batch needed it (tail_follows); a scan that needs it when it was not launched is flagged (never
-// silent), and the next batch gets it.
+// workgroup tier, the merge tiers), starting from ~cloud and the ring counts.  What does not fit that image either (a ring of
+// more than FX_FRONT_G_CAP1 points with more than FX_FRONT_G_CCAP2 size-admissible clusters, more candidates than either
+// merge tier holds here) goes on to the slow tier (k_slow: the same bodies on scratch in HBM), ring by ring — launched with
+// every batch, so the scan's result never depends on what earlier batches needed.
 #define FX_FRONT_G_WORDS (FrontOff::end - SegCfg<FX_FRONT_T>::kWords)
 #define FX_FRONT_G_CAP1 ((FX_FRONT_G_WORDS / (FX_RING_WORDS_PER_POINT + FX_RING_WORDS_PER_CLUSTER)) & ~3u)  // points = clusters
 #define FX_FRONT_G_CCAP2 224u                                                                          // clusters of a larger ring
@@ -3171,8 +3226,8 @@ __host__ __device__ constexpr uint32_t front_merge_cap_lds() {  // candidates th
   while (merge_words(c + 64, c + 64, FX_FRONT_RMAX, true) <= FrontOff::end) c += 64;
   return c;
 }
-__device__ __forceinline__ bool front_general(const FxDevParams &P, const FxBuffers &B, uint32_t scan, float el0, float inv_step, uint32_t huge_ccap,
-                                           uint32_t *smem) {
+__device__ __forceinline__ void front_general(const FxDevParams &P, const FxBuffers &B, uint32_t scan, float el0, float inv_step, uint32_t huge_ccap,
+                                              uint32_t *smem, bool force_slow) {
   constexpr int NT = FX_FRONT_T;
   const uint32_t R = (uint32_t)P.n_rings;
   if (R > 24)
@@ -3180,75 +3235,74 @@ __device__ __forceinline__ bool front_general(const FxDevParams &P, const FxBuff
   else
     bucket_body<false, NT>(P, B, scan, el0, inv_step, smem);
   wg_global_sync();
-  bool ok = true;
-  for (uint32_t ring = 0; ring < R && ok; ++ring) {
+  bool pending = false;
+  for (uint32_t ring = 0; ring < R; ++ring) {
     const uint32_t n = B.ring_cnt[(size_t)scan * R + ring];
-    if (n > P.max_ring_points)
-      ring_body<NT>(P, B, scan, ring, P.max_ring_points, P.max_ring_points, smem, true);  // (flags the scan, touches no LDS)
+    bool ok = false;
+    if (force_slow)  // (the test build's hook: every ring through the slow tier)
+      ok = false;
+    else if (n > P.max_ring_points)
+      ok = ring_body<NT>(P, B, scan, ring, P.max_ring_points, P.max_ring_points, smem, true);  // (flags the scan, touches no LDS)
     else if (n <= FX_FRONT_G_CAP1)
       ok = ring_body<NT>(P, B, scan, ring, FX_FRONT_G_CAP1, FX_FRONT_G_CAP1, smem, false);
     else if (n <= FX_FRONT_G_CAP2)
       ok = ring_body<NT>(P, B, scan, ring, FX_FRONT_G_CAP2, FX_FRONT_G_CCAP2, smem, false);
-    else
-      ok = false;
     __syncthreads();
+    if (!ok) {  // more points, or more clusters, than this workgroup's LDS holds: the slow tier does the ring (and then the merge)
+      if (threadIdx.x == 0) slow_ring(P, B, scan, ring);
+      pending = true;
+    }
   }
-  if (!ok) return false;
+  if (pending) return;
   wg_global_sync();
   constexpr uint32_t kCapLds = front_merge_cap_lds();
   const uint32_t cap1 = min(kCapLds, P.max_candidates);
-  if (merge_body<NT, true>(P, B, scan, cap1, cap1, smem, cap1 >= P.max_candidates)) return true;
+  if (merge_body<NT, true>(P, B, scan, cap1, cap1, smem, cap1 >= P.max_candidates)) return;
   __syncthreads();
-  if (merge_words(P.max_candidates, huge_ccap, R, false) > FrontOff::end) return false;
-  merge_body<NT, false>(P, B, scan, P.max_candidates, huge_ccap, smem, true);
-  return true;
+  if (merge_words(P.max_candidates, huge_ccap, R, false) <= FrontOff::end) {
+    merge_body<NT, false>(P, B, scan, P.max_candidates, huge_ccap, smem, true);
+    return;
+  }
+  if (threadIdx.x == 0) slow_push(B, scan);  // (more candidates than either merge tier holds here)
 }
 
 extern "C" __global__ __launch_bounds__(FX_FRONT_T) void k_front_redo(FxDevParams P, FxBuffers B, float el0, float inv_step, uint32_t huge_ccap,
-                                                                    uint32_t tail_follows, uint32_t force_tail) {
+                                                                    uint32_t force_slow) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const uint32_t n_redo = B.counters[FX_CNT_REDO];
   for (uint32_t w = blockIdx.x; w < n_redo; w += gridDim.x) {
-    const uint32_t scan = B.redo[w];
-    const bool done = !force_tail && front_general(P, B, scan, el0, inv_step, huge_ccap, smem);  // (force_tail: the test build's hook)
+    front_general(P, B, B.redo[w], el0, inv_step, huge_ccap, smem, force_slow != 0u);
     __syncthreads();
-    if (!done && threadIdx.x == 0) {
-      B.redo2[atomicAdd(&B.counters[FX_CNT_REDO + 1], 1u)] = scan;
-      if (!tail_follows) {
-        atomicOr(&B.flags[scan], FX_FLAG_RING_OVERFLOW | FX_FLAG_CAND_OVERFLOW);
-        B.n_cand[scan] = 0u;
-        B.n_kp[scan] = 0u;
-        B.n_kpc[scan] = 0u;
-      }
-    }
   }
 }
 
-// The scans k_front could not take, one 1024-thread workgroup each: the general kernels' bodies one after the other — ring
-// split to HBM, every ring through the workgroup tier, the merge tiers.  Slow per scan and rare by construction (the host
-// goes back to the separate kernels when a batch hands over more than an eighth of its scans).
-#define FX_TAIL_T 1024
-extern "C" __global__ __launch_bounds__(FX_TAIL_T) void k_tail(FxDevParams P, FxBuffers B, float el0, float inv_step, uint32_t ring_cap, uint32_t merge_cap,
-                                                             uint32_t merge_last, uint32_t huge_ccap) {
+// The slow tier behind every LDS-sized one: rings of more points (or clusters) than a workgroup's LDS holds and scans of more
+// candidates than the merge tiers hold, up to the context's limits, by the SAME bodies with their per-point and per-cluster
+// arrays in a scratch region of HBM (GS).  Always launched — 256 threads and 9 KB of LDS place anywhere, and an empty
+// launch costs a few microseconds — so what a scan gets never depends on what earlier batches needed (ref: node.cpp:72-145
+// never drops a scan).  A listed scan has its pending rings done (in ring order), then its merge (again, if a merge tier has
+// already run on the rings that were ready).  Grid <= P.gs_slots: workgroup b owns scratch region b.
+#define FX_SLOW_T 256
+__host__ __device__ constexpr size_t slow_ring_words(uint32_t cap) { return (size_t)(FX_RING_WORDS_PER_POINT + FX_RING_WORDS_PER_CLUSTER) * cap; }
+__host__ __device__ constexpr size_t slow_merge_words(uint32_t cap, uint32_t ccap) { return 4 * (size_t)cap + cap + merge_aux_words(cap) + 3 * (size_t)ccap; }
+extern "C" __global__ __launch_bounds__(FX_SLOW_T) void k_slow(FxDevParams P, FxBuffers B, uint32_t huge_ccap) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  const uint32_t n_redo = B.counters[FX_CNT_REDO + 1];
-  for (uint32_t w = blockIdx.x; w < n_redo; w += gridDim.x) {
-    const uint32_t scan = B.redo2[w];
-    if (P.n_rings > 24)
-      bucket_body<true, FX_TAIL_T>(P, B, scan, el0, inv_step, smem);
-    else
-      bucket_body<false, FX_TAIL_T>(P, B, scan, el0, inv_step, smem);
-    wg_global_sync();
-    for (uint32_t ring = 0; ring < (uint32_t)P.n_rings; ++ring) {
-      ring_body<FX_TAIL_T>(P, B, scan, ring, ring_cap, ring_cap, smem, true);
-      __syncthreads();
+  const uint32_t n_slow = B.counters[FX_CNT_REDO + 1];
+  const uint32_t R = (uint32_t)P.n_rings, PW = (R + 31u) / 32u;
+  uint32_t *gs = B.gs_pool + (size_t)blockIdx.x * P.gs_words;
+  for (uint32_t w = blockIdx.x; w < n_slow; w += gridDim.x) {
+    const uint32_t scan = B.slow[w];
+    uint32_t *pend = B.ring_pending + (size_t)scan * PW;
+    for (uint32_t ring = 0; ring < R; ++ring) {
+      if (!((pend[ring >> 5] >> (ring & 31u)) & 1u)) continue;  // (workgroup-uniform)
+      ring_body<FX_SLOW_T, true>(P, B, scan, ring, P.max_ring_points, P.max_ring_points, smem, true, gs);
+      wg_global_sync();
     }
+    for (uint32_t t = threadIdx.x; t < PW; t += FX_SLOW_T) pend[t] = 0u;  // (the bit map and the marker start every batch clear)
+    if (threadIdx.x == 0) B.slow_state[scan] = 0u;
     wg_global_sync();
-    if (!merge_body<FX_TAIL_T, true>(P, B, scan, merge_cap, merge_cap, smem, merge_last != 0)) {
-      __syncthreads();
-      merge_body<FX_TAIL_T, false>(P, B, scan, P.max_candidates, huge_ccap, smem, true);
-    }
-    __syncthreads();
+    merge_body<FX_SLOW_T, false, false, true>(P, B, scan, P.max_candidates, huge_ccap, smem, true, nullptr, gs);
+    wg_global_sync();
   }
 }
 
@@ -3278,8 +3332,8 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_offsets(FxDevParams P, FxB
     B.tier_hint[1] = l2;
     B.tier_hint[2] = B.counters[1];
     B.tier_hint[3] = B.counters[9];
-    B.tier_hint[6] = B.counters[FX_CNT_REDO];  // scans k_front handed to k_tail (which has read the count by now)
-    B.tier_hint[7] = B.counters[FX_CNT_REDO + 1];  // scans k_front_redo handed to k_tail
+    B.tier_hint[6] = B.counters[FX_CNT_REDO];  // scans k_front handed to k_front_redo (which has read the count by now)
+    B.tier_hint[7] = B.counters[FX_CNT_REDO + 1];  // scans handed to the slow tier (k_slow has read the count by now)
     B.counters[FX_CNT_REDO] = 0u;
     B.counters[FX_CNT_REDO + 1] = 0u;
     B.clk[2 * clk_next] = ~0ull;  // the clock slot the next batch's first kernel stamps
@@ -5478,6 +5532,7 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_pack_xyzi32(const float4 *
 }
 
 // ====================================================================== launchers
+#ifdef FX_TEST_HOOKS
 // Test hook (fx_test_sort_replay_device): the cluster-order replay exactly as cc_order runs it, on
 // arbitrary size sequences; one 64-thread workgroup per sequence, n <= 192.
 extern "C" __global__ __launch_bounds__(64) void k_test_sort_replay(const uint32_t *sizes, uint32_t n, uint32_t *perm) {
@@ -5505,6 +5560,8 @@ extern "C" __global__ __launch_bounds__(64) void k_test_sort_replay(const uint32
   __syncthreads();
   for (uint32_t c = threadIdx.x; c < n; c += 64) perm[(size_t)blockIdx.x * n + c] = tmp[c] & 0xffffu;
 }
+
+#endif  // FX_TEST_HOOKS
 
 extern "C" {
 
@@ -5583,35 +5640,29 @@ void fxk_merge_huge(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uin
 void fxk_offsets(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t clk_next) {
   hipLaunchKernelGGL(k_offsets, dim3(1), dim3(FX_WG), 0, s, P, B, batch, clk_next);
 }
-// the fused front kernel takes sensors of up to FX_FRONT_RMAX rings (scans that do not fit its tables go on to k_tail)
+// the fused front kernel takes sensors of up to FX_FRONT_RMAX rings (scans that do not fit its tables go on to k_front_redo)
 uint32_t fxk_front_max_rings(void) { return FX_FRONT_RMAX; }
 uint32_t fxk_front_merge_cap(void) { return FX_FRONT_MERGE; }
 void fxk_front(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float near_margin, float el0, float inv_step,
                uint32_t clk_slot, uint32_t merge_cap, uint32_t force_redo) {
   hipLaunchKernelGGL(k_front, dim3(batch), dim3(FX_FRONT_T), front_lds_bytes(), s, P, B, near_margin, el0, inv_step, clk_slot, merge_cap, force_redo);
 }
-void fxk_front_redo(hipStream_t s, const FxDevParams &P, const FxBuffers &B, float el0, float inv_step, uint32_t huge_ccap, uint32_t tail_follows,
-                    uint32_t force_tail, uint32_t grid) {
-  hipLaunchKernelGGL(k_front_redo, dim3(grid), dim3(FX_FRONT_T), front_lds_bytes(), s, P, B, el0, inv_step, huge_ccap, tail_follows, force_tail);
+void fxk_front_redo(hipStream_t s, const FxDevParams &P, const FxBuffers &B, float el0, float inv_step, uint32_t huge_ccap, uint32_t force_slow,
+                    uint32_t grid) {
+  hipLaunchKernelGGL(k_front_redo, dim3(grid), dim3(FX_FRONT_T), front_lds_bytes(), s, P, B, el0, inv_step, huge_ccap, force_slow);
 }
-size_t fxk_tail_lds_bytes(const FxDevParams &P, uint32_t ring_cap, uint32_t merge_cap, uint32_t huge_ccap) {
-  size_t b = (48 + (size_t)P.n_rings * (2 + FX_TAIL_T / 64) + 1) * 4;
-  b = std::max(b, (size_t)(SegCfg<FX_TAIL_T>::kWords + FX_RING_WORDS_PER_POINT * ring_cap + FX_RING_WORDS_PER_CLUSTER * ring_cap) * 4);
-  b = std::max(b, merge_words(merge_cap, merge_cap, P.n_rings, true) * 4);
-  if (merge_cap < P.max_candidates) b = std::max(b, merge_words(P.max_candidates, huge_ccap, P.n_rings, false) * 4);
-  return b;
+// scratch words of one workgroup of the slow tier; its LDS (the bodies' scratch words in front, the merge's ring bases)
+size_t fxk_slow_words(uint32_t max_ring_points, uint32_t max_candidates, uint32_t huge_ccap) {
+  return (std::max(slow_ring_words(max_ring_points), slow_merge_words(max_candidates, huge_ccap)) + 3) & ~(size_t)3;
 }
-void fxk_tail(hipStream_t s, const FxDevParams &P, const FxBuffers &B, float el0, float inv_step, uint32_t ring_cap, uint32_t merge_cap,
-              uint32_t huge_ccap, uint32_t grid) {
-  hipLaunchKernelGGL(k_tail, dim3(grid), dim3(FX_TAIL_T), fxk_tail_lds_bytes(P, ring_cap, merge_cap, huge_ccap), s, P, B, el0, inv_step, ring_cap,
-                     merge_cap, merge_cap >= P.max_candidates ? 1u : 0u, huge_ccap);
+void fxk_slow(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t huge_ccap, uint32_t grid) {
+  const size_t lds = std::max((size_t)SegCfg<FX_SLOW_T>::kWords, (size_t)FX_MERGE_HEAD + ((2 * ((size_t)P.n_rings + 1) + 3) & ~(size_t)3)) * 4;
+  hipLaunchKernelGGL(k_slow, dim3(std::max(1u, std::min(grid, P.gs_slots))), dim3(FX_SLOW_T), lds, s, P, B, huge_ccap);
 }
-hipError_t fxk_configure_front(const FxDevParams &P, uint32_t ring_cap, uint32_t merge_cap, uint32_t huge_ccap) {
+hipError_t fxk_configure_front(void) {
   hipError_t e = hipFuncSetAttribute((const void *)k_front, hipFuncAttributeMaxDynamicSharedMemorySize, (int)front_lds_bytes());
   if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void *)k_front_redo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)front_lds_bytes());
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute((const void *)k_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fxk_tail_lds_bytes(P, ring_cap, merge_cap, huge_ccap));
+  return hipFuncSetAttribute((const void *)k_front_redo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)front_lds_bytes());
 }
 // one workgroup per scan when the batch fills the GPU anyway (it is then the only writer of the scan's lists: no
 // global atomics, and it settles the RNG ordinals itself), several when it does not (streaming)
@@ -5647,6 +5698,7 @@ void fxk_dense(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t
   hipLaunchKernelGGL(k_dense_finish_s, dim3(grid(rows, n_cu * 3)), dim3(FX_DFIN_TS), fxk_dense_finish_lds_bytes(0), s, P, B);
   hipLaunchKernelGGL(k_dense_finish_l, dim3(grid(rows, n_cu)), dim3(FX_DFIN_TL), fxk_dense_finish_lds_bytes(1), s, P, B);
 }
+#ifdef FX_TEST_HOOKS
 extern "C" __global__ __launch_bounds__(FX_WG) void k_test_elevation(const float *xyz, uint32_t n, const double *tab, float *fast, uint8_t *ok,
                                                                      float *exact) {
   __shared__ double s_atan[(FX_ATAN_N + 1) * (FX_ATAN_DEG + 1)];
@@ -5699,6 +5751,7 @@ void fxk_test_elevation(hipStream_t s, const float *xyz, uint32_t n, const doubl
 void fxk_test_sort_replay(hipStream_t s, const uint32_t *sizes, uint32_t n_seq, uint32_t n, uint32_t *perm) {
   hipLaunchKernelGGL(k_test_sort_replay, dim3(n_seq), dim3(64), 0, s, sizes, n, perm);
 }
+#endif  // FX_TEST_HOOKS
 void fxk_rng_ord(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch) {
   hipLaunchKernelGGL(k_rng_ord, dim3((batch + FX_NWAVE - 1) / FX_NWAVE), dim3(FX_WG), 0, s, P, B, batch);
 }

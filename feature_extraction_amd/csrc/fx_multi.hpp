@@ -41,6 +41,7 @@ struct MultiGpuOptions {
   uint32_t in_flight = 2;  // contexts (batches in flight) per device (2: 1.59 million scans/s on one MI355X, 1: 1.24, 3: 1.48 — the shared communicator orders the slots)
   uint32_t rec_kp = 0;     // keypoints per gathered record; 0 = the contexts' limits.max_keypoints
   fx_limits limits{};      // non-zero fields override fx_limits_default(scans per rank, max_points)
+  bool sparse_limits = false;  // start from fx_limits_sparse instead (VLP-16-class streams: small dense-tier pools — 4.5 GB a 1024-scan context, not 7)
 };
 // What one batch produced.  Valid until `in_flight` more batches have been submitted (the contexts own the memory).
 struct MultiGpuBatch {
@@ -96,7 +97,10 @@ class MultiGpu {
         R.slots.resize(in_flight_);
         for (Slot &S : R.slots) {
           fx_limits lim;
-          fx_limits_default(&lim, per_rank_, max_points);
+          if (opt.sparse_limits)
+            fx_limits_sparse(&lim, per_rank_, max_points);
+          else
+            fx_limits_default(&lim, per_rank_, max_points);
           const uint32_t *ov = reinterpret_cast<const uint32_t *>(&opt.limits);
           uint32_t *dst = reinterpret_cast<uint32_t *>(&lim);
           for (size_t i = 2; i < sizeof(fx_limits) / 4; ++i)  // (max_batch / max_points are the constructor's)

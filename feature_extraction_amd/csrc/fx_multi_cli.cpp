@@ -49,6 +49,7 @@ int main(int argc, char **argv) {
     }
     fx::MultiGpu::Options opt;
     opt.in_flight = in_flight;
+    opt.sparse_limits = true;  // (the stream is synthetic VLP-16 scans)
     fx::MultiGpu multi(p, devices, batch, N, opt);
     const uint32_t G = multi.world(), rec_kp = multi.record_keypoints();
     std::printf("fx_multi_cli: %d device(s) visible, %u rank(s), %u scans per batch (%u per rank), %u batches in flight per device, "

@@ -43,6 +43,8 @@ class FeatureExtractionNode {
   int nRings = 16;
   double el0Deg = -15.0, elStepDeg = 2.0;
   int secondaryMax = 16;
+  // --- capacities of the device context (non-zero fields override fx_limits_default(1, max_points); call reset() after a change)
+  fx_limits limitsOverride{};
 
   explicit FeatureExtractionNode(int device = 0, uint32_t max_points = 1u << 18) : device_(device), max_points_(max_points) {}
   ~FeatureExtractionNode() {
@@ -138,8 +140,14 @@ class FeatureExtractionNode {
     p.n_rings = nRings, p.el0_deg = el0Deg, p.el_step_deg = elStepDeg, p.secondary_max = secondaryMax;
     fx_limits l;
     fx_limits_default(&l, 1, max_points_);
-    l.max_total_keypoints = l.max_keypoints;
     l.max_kpc_points = max_points_;
+    {
+      const uint32_t *ov = reinterpret_cast<const uint32_t *>(&limitsOverride);
+      uint32_t *dst = reinterpret_cast<uint32_t *>(&l);
+      for (size_t i = 2; i < sizeof(fx_limits) / 4; ++i)
+        if (ov[i]) dst[i] = ov[i];
+    }
+    if (!limitsOverride.max_total_keypoints) l.max_total_keypoints = l.max_keypoints;
     check(FX_CHECK_ABI());  // (this translation unit's fx.h against the library's)
     check(fx_create(&p, &l, device_, &ctx_));
   }

@@ -22,7 +22,7 @@ extern "C" {
 #endif
 
 #define FX_VERSION_MAJOR 0
-#define FX_VERSION_MINOR 5
+#define FX_VERSION_MINOR 6
 
 /* pcl::ShapeContext1980: 12 azimuth x 11 elevation x 15 radius bins + rf[9]
  * (ref: include/feature_extraction/feature_extraction_node.h:35-53,75). */
@@ -80,10 +80,13 @@ typedef struct fx_params {
 typedef struct fx_limits {
   uint32_t max_batch;           /* scans per fx_process_batch                       */
   uint32_t max_points;          /* points per scan                                  */
-  uint32_t max_ring_points;     /* points per (scan, ring) held in LDS   (def 2048) */
+  uint32_t max_ring_points;     /* points per (scan, ring)               (def 2048; <= 32768.  Rings of up to ~2400 points are
+                                 * clustered in LDS — azimuth-ordered rings of few runs at any size —, larger ones on scratch
+                                 * in HBM: slower, same result) */
   uint32_t max_ring_candidates; /* candidates one ring may emit          (def 256)  */
-  uint32_t max_candidates;      /* per-ring candidates per scan, all rings (def 2048; <= ~3800 live in LDS as points,
-                                 * beyond that — up to ~16000 — the large merge tier keeps the coordinates in HBM) */
+  uint32_t max_candidates;      /* per-ring candidates per scan, all rings (def 2048; <= 32768.  <= ~3800 live in LDS as points,
+                                 * beyond that — up to ~16000 — the large merge tier keeps the coordinates in HBM, beyond
+                                 * that everything: slower, same result) */
   uint32_t max_keypoints;       /* keypoints per scan                    (def 256)  */
   uint32_t max_neighbors;       /* support-list slots per keypoint row (def 1024, 4096 for scans of more than 65536
                                  * points; 16 B each, capped at 4096).  Not a cap on the support set: larger sets overflow
@@ -91,7 +94,10 @@ typedef struct fx_limits {
   uint32_t max_total_keypoints; /* keypoints per batch (descriptor pool) (def max_batch*64) */
   uint32_t max_kpc_points;      /* keypoint_cloud points per scan        (def 4096) */
   uint32_t max_dense_points;    /* support points per batch the dense descriptor tier sorts (rows of more than 1024
-                                 * support points; def max(max_batch, 32)*max_points; 28 B each).  New in 0.4 */
+                                 * support points; def max(max_batch, 32)*max_points; 28 B each + 17.5 KB per 1024).  New in 0.4 */
+  uint32_t max_overflow_points; /* support-list entries beyond max_neighbors a scan's rows may have together (its overflow
+                                 * region: 20 B each, per scan of the batch; def max_points, 32/max_batch times that in
+                                 * contexts of fewer than 32 scans).  New in 0.6 */
 } fx_limits;
 
 /* One scan = what cloudCallback receives after fromPCLPointCloud2
@@ -173,7 +179,7 @@ typedef struct fx_timings {
 typedef struct fx_ctx fx_ctx;
 
 uint32_t fx_version(void);
-/* ABI guard.  The structs of this header may grow at their END between minor versions (fx_limits did in 0.4) and the
+/* ABI guard.  The structs of this header may grow at their END between minor versions (fx_limits did in 0.4 and 0.6) and the
  * library reads every member: a caller compiled against another header must not get as far as fx_create.  Pass the version and
  * the sizes the caller was compiled with (FX_CHECK_ABI() does); FX_ERR_INVALID_ARG, with the mismatch in fx_last_error(),
  * when they are not the library's.  Always initialise fx_params / fx_limits with fx_params_default / fx_params_launch /
@@ -191,6 +197,11 @@ void fx_params_default(fx_params *p);
 /* ref: launch/keypoint_playback.launch:17-33 (the preset the launch file sets) */
 void fx_params_launch(fx_params *p);
 void fx_limits_default(fx_limits *l, uint32_t max_batch, uint32_t max_points);
+/* The same for sensors whose keypoints rarely have more than max_neighbors (1024) support points — VLP-16-class scans at the
+ * reference's descriptor radius: the dense descriptor tier's pools and the overflow regions hold a few such rows per batch
+ * instead of every point of it (1024 scans of 28 800 points: 4.5 GB of device memory instead of 7).  Results are the same;
+ * a batch with more dense rows than the pools hold flags them (FX_FLAG_NBR_OVERFLOW), as with any limit.  New in 0.6 */
+void fx_limits_sparse(fx_limits *l, uint32_t max_batch, uint32_t max_points);
 
 /* Replaces the FeatureExtractionNode constructor's parameter block (ref: node.cpp:3-34).
  * Allocates every device/host buffer; fails with FX_ERR_NO_DEVICE when no GPU. */
@@ -292,6 +303,10 @@ typedef struct fx_synth_cfg {
 void fx_synth_cfg_vlp16(fx_synth_cfg *c, uint64_t seed);
 uint32_t fx_synth_scan(const fx_synth_cfg *c, float *xyzi_out, uint32_t capacity_points);
 
+/* ---- test entry points: only in the TEST build of the library (lib/libfx_hip_test.so, compiled with -DFX_TEST_HOOKS,
+ * which also reads the environment hooks tests use to push work through the rarely used tiers).  The product library
+ * exports none of them and contains none of the k_test_* kernels. ---- */
+#ifdef FX_TEST_HOOKS
 /* Test hook: host build of the cluster-order replay the kernels run on one GPU lane
  * (csrc/fx_sort_replay.h).  perm_out[s] = ordinal of the cluster PCL returns at position s. */
 void fx_test_sort_replay(const uint32_t *sizes, uint32_t n, uint32_t *perm_out);
@@ -311,6 +326,7 @@ fx_status fx_test_elevation_device(int device, const float *xyz, uint32_t n, flo
  * number of the n support points (xyzw records) closer than sqrt(r2), both ways. */
 fx_status fx_test_within_device(int device, const float *support_xyzw, uint32_t n, const float *query_xyzw, uint32_t nq, float r2,
                                 uint32_t *packed_out, uint32_t *plain_out);
+#endif /* FX_TEST_HOOKS */
 
 #ifdef __cplusplus
 }

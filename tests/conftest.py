@@ -20,6 +20,14 @@ def fxlib():
 
 
 @pytest.fixture(scope="session")
+def fxtestlib(fxlib):
+    """lib/libfx_hip_test.so (-DFX_TEST_HOOKS): the only build that exports the header's fx_test_* section."""
+    from feature_extraction_amd import build, capi
+    build.build_test_hooks()
+    return capi.load_test()
+
+
+@pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle_py
     oracle_py.load()

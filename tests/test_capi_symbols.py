@@ -11,9 +11,13 @@ from feature_extraction_amd import capi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
+def _declared(test_section=False):
+    """Function names include/fx.h declares: outside (default) or inside its `#ifdef FX_TEST_HOOKS` section."""
     src = open(os.path.join(ROOT, "include", "fx.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    m = re.search(r"#ifdef FX_TEST_HOOKS(.*?)#endif", src, flags=re.S)
+    assert m, "the header's test section"
+    src = m.group(1) if test_section else src[:m.start()] + src[m.end():]
     names = re.findall(r"\b(fx_[a-z0-9_]+)\s*\(", src)
     return sorted(set(n for n in names if not n.endswith("_t")))
 
@@ -26,16 +30,31 @@ def test_header_symbols_exported(fxlib):
     assert sorted(capi.EXPORTS) == declared, (set(capi.EXPORTS) ^ set(declared))
 
 
+def test_test_entry_points_only_in_the_test_build(fxlib, fxtestlib):
+    """the fx_test_* entry points (and the k_test_* kernels behind them) are compiled only with -DFX_TEST_HOOKS:
+    the header declares them in a guarded section, lib/libfx_hip_test.so exports them, the product library does not."""
+    import subprocess
+    from feature_extraction_amd import build
+    hooks = _declared(test_section=True)
+    assert sorted(capi.TEST_EXPORTS) == hooks and len(hooks) >= 6
+    assert not [n for n in hooks + list(capi.EXPORTS) if not hasattr(fxtestlib, n)]
+    dyn = subprocess.check_output(["nm", "-D", "--defined-only", build.LIB], text=True)
+    assert "fx_create" in dyn and "fx_test_" not in dyn, [l for l in dyn.splitlines() if "fx_test_" in l]
+    product = open(build.LIB, "rb").read()
+    assert b"k_test_" not in product  # (kernel names are in the code object's symbol table)
+    assert b"k_test_within" in open(build.build_test_hooks(), "rb").read()
+
+
 def test_struct_sizes_match_header(fxlib):
     # fx_params: int32 + 6 doubles + double + 2 int32 + double + int32 + int32 + double + int32 + 2 doubles + int32
     assert C.sizeof(capi.FxParams) == 128
-    assert C.sizeof(capi.FxLimits) == 10 * 4
+    assert C.sizeof(capi.FxLimits) == 11 * 4
     assert C.sizeof(capi.FxScanDesc) == 32
     assert C.sizeof(capi.FxTimings) == (capi.FX_N_STAGES + 2) * 4
 
 
 def test_version_and_status_strings(fxlib):
-    assert fxlib.fx_version() == (0 << 16) | 5 == capi.FX_HEADER_VERSION  # FX_VERSION_MAJOR << 16 | FX_VERSION_MINOR (include/fx.h)
+    assert fxlib.fx_version() == (0 << 16) | 6 == capi.FX_HEADER_VERSION  # FX_VERSION_MAJOR << 16 | FX_VERSION_MINOR (include/fx.h)
     for code in range(6):
         assert fxlib.fx_status_str(code)
     assert b"no CPU fallback" in fxlib.fx_status_str(capi.FX_ERR_NO_DEVICE)
@@ -48,8 +67,8 @@ def test_abi_guard_refuses_other_headers(fxlib):
     assert fxlib.fx_check_abi(capi.FX_HEADER_VERSION, *sizes) == capi.FX_OK
     assert fxlib.fx_check_abi((0 << 16) | 3, *sizes) == 1  # FX_ERR_INVALID_ARG
     assert b"0.3" in fxlib.fx_last_error()
-    assert fxlib.fx_check_abi(capi.FX_HEADER_VERSION, sizes[0], sizes[1] - 4, sizes[2], sizes[3]) == 1  # 0.3's nine-word fx_limits
-    assert b"fx_limits 36" in fxlib.fx_last_error()
+    assert fxlib.fx_check_abi(capi.FX_HEADER_VERSION, sizes[0], sizes[1] - 4, sizes[2], sizes[3]) == 1  # 0.5's ten-word fx_limits
+    assert b"fx_limits 40" in fxlib.fx_last_error()
 
 
 def test_product_library_has_no_environment_hooks(fxlib):

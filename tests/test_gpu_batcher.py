@@ -77,3 +77,62 @@ def test_scans_with_more_keypoints_than_the_pool_average(fxlib, oracle, tmp_path
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     _check(_read(out), oracle, 1, 3, poles=256, min_k=65)
+
+
+def test_a_failed_batch_does_not_end_the_stream(fxlib, oracle, tmp_path, monkeypatch):
+    """VERDICT r4 (weak #12): a failing fx_process_batch used to end the stream for every sensor.  The batch's scans now come
+    back with the status and no results, the context repairs its own state on the next call (fx_ctx::state_suspect) and
+    every later scan is exact.  The driver linked against the TEST build fails its third batch (FX_FAIL_AFTER_ENQUEUE: after
+    the kernels were enqueued — the worst case, the context's rows and counters are mid-update)."""
+    exe = build.build_batcher(test_hooks=True)
+    out = tmp_path / "fail.bin"
+    monkeypatch.setenv("FX_FAIL_AFTER_ENQUEUE", "3")  # (batch 1 is the driver's warm-up scan)
+    r = subprocess.run([exe, "--sensors", "2", "--burst", "8", "--max-batch", "4", "--out", str(out)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    print(r.stdout.strip())
+    m = re.search(r"(\d+) scans in (\d+) batches \(largest (\d+)\), (\d+) failed", r.stdout)
+    assert m and int(m.group(1)) == 16 and int(m.group(4)) == 1, r.stdout
+    got = _read(out)
+    failed = {k: v for k, v in got.items() if v[0] & 0x80000000}
+    assert 1 <= len(failed) <= 4 and all(v[0] == 0x80000003 and len(v[1]) == 0 for v in failed.values()), {k: hex(v[0]) for k, v in failed.items()}
+    ok = {k: v for k, v in got.items() if k not in failed}
+    p = capi.params("launch")
+    for (s, q), (flags, kp, desc) in sorted(ok.items()):
+        ora = oracle.run(p, util.vlp16_scan(1000 + 1000 * s + q), roll=0.02, pitch=-0.015)
+        assert flags == 0
+        util.assert_bit_equal(kp, ora["keypoints"], f"after the failed batch: sensor {s} scan {q} keypoints")
+        o = ora["descriptors"]
+        assert desc.shape == o.shape and np.abs(np.where(np.isnan(o), 0, desc) - np.where(np.isnan(o), 0, o)).max(initial=0.0) <= util.DESC_TOL
+
+
+@pytest.mark.parametrize("host", ["batcher", "node"])
+def test_a_scan_beyond_the_lds_tiers_through_the_cpp_hosts(fxlib, oracle, tmp_path, host):
+    """the scan that needs the slow tier (tests/test_gpu_front.py) is exact the first time a warm context sees
+    it through fx::StreamBatcher and through fx::FeatureExtractionNode::cloudCallback too — small, big, small, big, one scan
+    per batch."""
+    from tests.test_gpu_front import shells_ring
+    from tests.test_gpu_ring_run_tier import long_ring_with_late_poles
+    big = np.concatenate([shells_ring(), long_ring_with_late_poles()]).astype(np.float32)
+    small = util.vlp16_scan(1000)
+    seq = [small, small, big, small, big]
+    paths = []
+    for i, s in enumerate(seq):
+        paths.append(str(tmp_path / f"scan{i}.bin"))
+        np.ascontiguousarray(s, np.float32).tofile(paths[-1])
+    out = tmp_path / "seq.bin"
+    exe = build.build_batcher()
+    r = subprocess.run([exe, "--files", ",".join(paths), "--big-limits", "--out", str(out)] + (["--node"] if host == "node" else []),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = _read(out)
+    p = capi.params("launch")
+    ora = {id(s): oracle.run(p, s) for s in (small, big)}
+    assert len(got) == len(seq)
+    for i, s in enumerate(seq):
+        flags, kp, desc = got[(0, i)]
+        o = ora[id(s)]
+        assert flags == 0, (host, i, hex(flags))
+        util.assert_bit_equal(kp, o["keypoints"], f"{host} scan {i} keypoints")
+        assert desc.shape == o["descriptors"].shape
+        assert np.abs(np.where(np.isnan(o["descriptors"]), 0, desc) - np.where(np.isnan(o["descriptors"]), 0, o["descriptors"])).max(initial=0.0) <= util.DESC_TOL
+    assert len(got[(0, 2)][1]) == ora[id(big)]["n_keypoints"]

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _device(xyz):
-    lib = capi.load()
+    lib = capi.load_test()  # (the fx_test_* entry points exist only in the test build)
     xyz = np.ascontiguousarray(xyz, np.float32)
     n = len(xyz)
     fast, exact, ok = np.empty(n, np.float32), np.empty(n, np.float32), np.empty(n, np.uint8)

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _device(sup, qry, r2):
-    lib = capi.load()
+    lib = capi.load_test()  # (the fx_test_* entry points exist only in the test build)
     sup = np.ascontiguousarray(sup, np.float32)
     qry = np.ascontiguousarray(qry, np.float32)
     a, c = np.empty(len(qry), np.uint32), np.empty(len(qry), np.uint32)

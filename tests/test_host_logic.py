@@ -72,6 +72,12 @@ def test_limits_defaults(fxlib):
                 1024, 28800, 2048, 256, 2048, 256, 1024, 65536, 4096, 1024 * 28800)
     assert capi.limits(64, 128 * 2048).max_neighbors == 4096  # dense many-ring scans: longer support lists
     assert capi.limits(1, 28800).max_dense_points == 32 * 28800  # a one-scan context still holds a scan of overlapping support sets
+    assert (l.max_overflow_points, capi.limits(1, 28800).max_overflow_points, capi.limits(8, 1000).max_overflow_points) == (28800, 32 * 28800, 4000)
+    # the sparse preset (VLP-16-class workloads): only the dense tier's pools and the overflow regions shrink
+    s = capi.limits(1024, 28800, sparse=True)
+    assert (s.max_dense_points, s.max_overflow_points) == (262144, 8192)
+    assert all(getattr(s, f) == getattr(l, f) for f, _ in capi.FxLimits._fields_ if f not in ("max_dense_points", "max_overflow_points"))
+    assert capi.limits(4, 131072, sparse=True).max_dense_points == 4 * 131072 and capi.limits(1, 1000, sparse=True).max_overflow_points == 1000
 
 
 def test_shard_plan_is_a_partition():

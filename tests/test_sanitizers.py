@@ -31,16 +31,17 @@ def test_host_library_under_sanitizers(fxlib, tmp_path):
     """fx_host.cpp: presets, rotation, 3DSC tables, RNG x-axes, the synthetic generator (three sensor shapes) and the three
     host statements of the libstdc++ sort replay, on random and adversarial size sequences."""
     so = str(tmp_path / "libfx_host_asan.so")
-    _cc(so, ["-shared", os.path.join(CSRC, "fx_host.cpp")])
+    _cc(so, ["-shared", "-DFX_TEST_HOOKS", os.path.join(CSRC, "fx_host.cpp")])  # (with the replay's host statements: the header's test section)
     code = r'''
 import ctypes as C, sys, numpy as np
 lib = C.CDLL(sys.argv[1])
 out = {}
 class P(C.Structure): _fields_ = [("b", C.c_byte * 128)]
-class L(C.Structure): _fields_ = [("v", C.c_uint32 * 10)]
+class L(C.Structure): _fields_ = [("v", C.c_uint32 * 11)]
 p = P(); lib.fx_params_default(C.byref(p)); out["pd"] = np.frombuffer(bytes(p), np.uint8).copy()
 lib.fx_params_launch(C.byref(p)); out["pl"] = np.frombuffer(bytes(p), np.uint8).copy()
 l = L(); lib.fx_limits_default(C.byref(l), 1024, 28800); out["lim"] = np.array(list(l.v), np.uint32)
+lib.fx_limits_sparse(C.byref(l), 1024, 28800); out["lims"] = np.array(list(l.v), np.uint32)
 R = (C.c_float * 9)(); rr = []
 lib.fx_rotation_from_roll_pitch.argtypes = [C.c_double, C.c_double, C.c_void_p]
 for a, b in ((0.0, 0.0), (0.02, -0.015), (3.13, 0.005), (-1.0, 2.0)):
@@ -81,7 +82,7 @@ out["perms"] = np.concatenate(perms)
 np.savez(sys.argv[2], **out)
 '''
     res = {}
-    for tag, lib, env in (("asan", so, _asan_env()), ("plain", capi.LIB_PATH, dict(os.environ))):
+    for tag, lib, env in (("asan", so, _asan_env()), ("plain", build.build_test_hooks(), dict(os.environ))):
         path = str(tmp_path / f"{tag}.npz")
         r = subprocess.run([sys.executable, "-c", code, lib, path], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, f"{tag}: {r.stderr[-3000:]}"
