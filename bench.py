@@ -199,22 +199,17 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from feature_extraction_amd import build, capi, sharding
+    from feature_extraction_amd import bench_dist, build, capi, sharding
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    # one rank builds (a stale library would otherwise be rewritten by every rank at once); the others wait for it
-    if local_rank == 0:
-        build.build()
-    else:  # (build.py links to a temporary name and renames: a library that is there is whole)
-        t_wait = time.time()
-        while build.stale():
-            if time.time() - t_wait > 900:
-                raise SystemExit(f"[bench] rank {rank}: libfx_hip.so still stale after 900 s (did local rank 0's build fail?)")
-            time.sleep(0.5)
+    # one rank builds (a stale library would otherwise be rewritten by every rank at once); the others wait for it.  The
+    # distributed scaffolding — this handshake, the agreement on RCCL's C API, the kernel every rank times, the timed region
+    # and its repeat count, the step loop — lives in feature_extraction_amd/bench_dist.py, where a gloo world-2 test runs it.
+    bench_dist.wait_for_library(local_rank, build.build, build.stale, log=lambda m: print(m, file=sys.stderr))
     capi.load()  # raises if the HIP library is missing
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
@@ -227,12 +222,13 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         if rank == 0:
             print(f"[bench] torch.distributed backend {dist.get_backend()} (RCCL), world {dist.get_world_size()}", file=sys.stderr)
+    coll = bench_dist.Collectives(torch, dist, dev, rank, world, use_dist)
 
     B, N = args.batch, N_RINGS * N_AZ
     roll, pitch = 0.02, -0.015
     threads = os.cpu_count() or 1
     # ---- synthetic input (SURVEY.md Appendix C / BASELINE.md config 2), seed 1000 + global scan index
-    seeds = [1000 + rank * B + b for b in range(B)]
+    seeds = bench_dist.rank_seeds(rank, world, B)
     scans = make_scans(capi, seeds, max(1, threads // max(1, min(world, 8))))
     host = np.stack(scans)  # [B, N, 4]
     d_in = torch.from_numpy(host).to(dev)  # resident in HBM before the timed region
@@ -257,7 +253,7 @@ def main():
     # A second batch of different scans: the steps alternate between the two, so no context ever sees the batch it
     # processed last time (descriptor rows keep their content between batches — k_desc_group clears a row by un-writing
     # what it wrote — and a repeated batch would clear and rewrite the very same bins).
-    scans_b = make_scans(capi, [1000 + (world + rank) * B + b for b in range(B)], max(1, threads // max(1, min(world, 8))))
+    scans_b = make_scans(capi, bench_dist.rank_seeds(rank, world, B, second=True), max(1, threads // max(1, min(world, 8))))
     d_in_b = torch.from_numpy(np.stack(scans_b)).to(dev)
     descs_b = ctx.make_descs([d_in_b.data_ptr() + b * N * 16 for b in range(B)], [N] * B, 16, roll, pitch)
     del scans_b
@@ -265,8 +261,6 @@ def main():
     # kernels of the batches behind it; a buffer is reused only after its collective has completed
     recs = [torch.zeros((B, 1 + REC_KP, 4), dtype=torch.float32, device=dev) for _ in range(K)]
     gathered = [torch.zeros((world * B, 1 + REC_KP, 4), dtype=torch.float32, device=dev) for _ in range(K)] if use_dist else None
-    pending = [None] * K
-    counter = [0]
     # the collective goes straight on the context's stream through RCCL's C API (sharding.RcclGather);
     # FX_BENCH_TORCH_GATHER=1 takes torch.distributed's all_gather_into_tensor instead (sharding.all_gather_records, the
     # function the gloo test runs)
@@ -279,39 +273,24 @@ def main():
         # ranks can hold each other's kernels back, but that has never run on more than one GPU) and a dedicated gather
         # stream fed through events (1.30: cross-stream waits are dear on this stack) were measured too.
         # Every rank first proves it can load RCCL's C API; only then are ids exchanged.
-        ok = 1 if sharding.RcclGather.available() else 0
-        if world > 1:
-            t = torch.tensor([ok], dtype=torch.int64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            ok = int(t.item())
-        if ok:
+        if coll.agree(sharding.RcclGather.available()):
             rccl_comms = K if os.environ.get("FX_BENCH_MULTI_COMM") == "1" else 1
             rccl = sharding.RcclGather(world, rank, dev, n_comms=rccl_comms)
         elif rank == 0:
             print("[bench] direct RCCL gather unavailable on some rank; using torch.distributed's all_gather", file=sys.stderr)
     torch.cuda.synchronize(dev)  # inputs and zeroed buffers are in place before any side stream starts
 
-    def step():
-        j = counter[0] % K
-        batch_descs = descs_b if (counter[0] // K) % 2 else descs
-        counter[0] += 1
-        with torch.cuda.stream(streams[j]):
-            if pending[j] is not None:
-                pending[j].wait()  # stream-level wait: rec[j] / gathered[j] are free again
-                pending[j] = None
-            ctxs[j].process_raw(batch_descs, B, capi.FX_IN_DEVICE)
-            ctxs[j].pack_keypoint_records(recs[j].data_ptr(), REC_KP)
-            if rccl is not None:  # the path's one collective, an ordinary kernel of this context's stream
-                rccl.all_gather(recs[j], gathered[j], streams[j].cuda_stream, comm=j % rccl_comms)
-            elif use_dist:
-                _tab, pending[j] = sharding.all_gather_records(recs[j], world, out=gathered[j], async_op=True)
+    def run_slot(j, which):
+        ctxs[j].process_raw(descs_b if which else descs, B, capi.FX_IN_DEVICE)
+        ctxs[j].pack_keypoint_records(recs[j].data_ptr(), REC_KP)
+        if rccl is not None:  # the path's one collective, an ordinary kernel of this context's stream
+            rccl.all_gather(recs[j], gathered[j], streams[j].cuda_stream, comm=j % rccl_comms)
+        elif use_dist:
+            return sharding.all_gather_records(recs[j], world, out=gathered[j], async_op=True)[1]
+        return None
 
-    def drain():
-        for j in range(K):
-            if pending[j] is not None:
-                with torch.cuda.stream(streams[j]):
-                    pending[j].wait()
-                pending[j] = None
+    loop = bench_dist.StepLoop(K, run_slot, enter=lambda j: torch.cuda.stream(streams[j]))
+    step, drain = loop.step, loop.drain
 
     def profile_all(depth, stages=None):
         for c in ctxs:
@@ -364,41 +343,17 @@ def main():
     dom_rule = (f"of the single-launch stages within 10 % of the longest ({longest}: HIP-event mean over {n_sel} profiled steps per "
                 f"context, {K} batches in flight, measured in this run before the timed region) the one with the most "
                 "algorithmic bytes per launch")
-    if use_dist:  # every rank times the same kernel
-        names = list(capi.STAGE_NAMES)
-        t = torch.tensor([names.index(dom)], dtype=torch.int64, device=dev)
-        dist.broadcast(t, 0)
-        dom = names[int(t.item())]
+    dom = capi.STAGE_NAMES[coll.broadcast_index(capi.STAGE_NAMES.index(dom))]  # every rank times the same kernel
     per_ctx_steps = max(1, args.steps // K)
     profile_all(per_ctx_steps, stages=[dom])  # on the launch streams, inside the timed region
 
-    def timed_region():
-        """EXACTLY args.steps steps between barrier + synchronize on both sides; the MAX over the ranks."""
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        drain()
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
-
+    # EXACTLY args.steps steps between barrier + synchronize on both sides, the MAX over the ranks (bench_dist.timed_region).
     # A region of a few dozen steps lasts ~10 ms, of which filling and draining the batches in flight is a sixth, and a
     # driver that samples GPU activity never sees it: the region is repeated for about a second (the same count on every
     # rank: it follows from the first region's all-reduced time) and the MEDIAN region is reported (SURVEY.md 8d); `steps`
     # stays the unit.
-    regions = [timed_region()]
-    repeats = args.repeats if args.repeats > 0 else max(1, min(200, int(np.ceil(args.target_seconds / regions[0]))))
-    while len(regions) < repeats:
-        regions.append(timed_region())
+    regions = bench_dist.measure(args.steps, step, drain, lambda: torch.cuda.synchronize(dev), coll, repeats=args.repeats,
+                                 target_seconds=args.target_seconds)
     elapsed = float(np.median(regions))
 
     # ---- the dominant kernel's duration over the timed steps (HIP events recorded inside the timed region)
@@ -437,15 +392,10 @@ def main():
     if n_chk:
         v2 = ctx.process_raw(descs, n_chk, capi.FX_IN_DEVICE | capi.FX_OUT_HOST | capi.FX_OUT_CLOUDS | capi.FX_OUT_DEBUG)
         res = ctx.unpack(v2)
-    if world > 1:
-        kt = torch.tensor([k_total], dtype=torch.float64, device=dev)
-        dist.all_reduce(kt)
-        k_all = float(kt.item())
-    else:
-        k_all = k_total
+    k_all = coll.sum(k_total)
     if use_dist and rank == 0:
         # the gathered table holds every rank's records in stream order: check this rank's block
-        last = (counter[0] - 1) % K
+        last = loop.last_slot
         g = gathered[last][rank * B:(rank + 1) * B]
         assert torch.equal(g, recs[last]), "gathered keypoint records differ from the local ones"
         print(f"[bench] all-gather of keypoint records over {'RCCL (ncclAllGather on the context stream)' if rccl is not None else dist.get_backend()}: table {tuple(gathered[last].shape)}, "
@@ -475,7 +425,7 @@ def main():
         dom_kernel = "k_front" if (dom == "k_prep" and front) else dom
         own_r, own_w = stage_bytes[dom]
         own_bytes = own_r + own_w
-        achieved = own_bytes / (dom_ms * 1e-3) / 1e9
+        achieved = own_bytes / (dom_alone_ms * 1e-3) / 1e9  # (one batch on the chip: the reading a kernel trace reproduces)
         ms_per_step = elapsed / args.steps * 1e3
         traffic = traffic_total = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -489,7 +439,7 @@ def main():
                 traffic = traffic_total = None
         flag_msg = None
         if use_dist:  # the gathered records carry every scan's flags: a truncated record (more keypoints than the stride) shows here
-            last = (counter[0] - 1) % K
+            last = loop.last_slot
             hdr = gathered[last].view(torch.int32)[:, 0, :2].cpu().numpy()
             flag_msg = int(np.bitwise_or.reduce(hdr[:, 1])) if len(hdr) else 0
             assert flag_msg == 0, f"gathered keypoint records carry flags 0x{flag_msg:x} (0x4: more keypoints than the record stride)"
@@ -506,31 +456,37 @@ def main():
                        "parallelism": f"frame-sharded x{world}" + (", all-gather of keypoint records (RCCL)" if world > 1 else ""),
                        "keypoints_per_scan": k_all / (world * B), "flags_or": flags_or, "batches_in_flight": K,
                        "gathered_record_flags_or": flag_msg},
+            # frac = the dominant kernel's own algorithmic bytes / its duration with ONE batch on the chip (HIP events, 20
+            # launches after the timed region): the reading a kernel trace of `bench.py --contexts 1` reproduces
+            # (profiles/*_c1_kernel_stats.csv).  frac_exec = the same bytes / the kernel's execution span (device clock, first
+            # workgroup's start to last workgroup's end) INSIDE the timed region, the other batches in flight sharing the chip:
+            # what rocprofv3 reports for the headline run (profiles/*_kernel_stats.csv).
             "roofline": {"bound": "hbm", "kernel": dom_kernel, "stage": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "definition": "achieved = this kernel's own algorithmic bytes per launch (alg_bytes_read + alg_bytes_written, "
-                                       "fx_get_stage_bytes) / kernel_ms; path_frac = the whole path's algorithmic bytes per step "
-                                       "(SURVEY.md 8d) / ms_per_step / peak: the figure to hold against north_star's 0.40",
+                                       "fx_get_stage_bytes) / kernel_ms, its duration with one batch on the chip; frac_exec: the same "
+                                       "over its execution span with the other batches in flight; path_frac = the whole path's "
+                                       "algorithmic bytes per step (SURVEY.md 8d) / ms_per_step / peak: the figure to hold against "
+                                       "north_star's 0.40",
                          "alg_bytes_per_launch": own_bytes, "alg_bytes_read": own_r, "alg_bytes_written": own_w,
-                         "kernel_ms": dom_ms,
-                         # one batch on the chip at a time (20 steps after the timed region): the figure a kernel trace of
-                         # `bench.py --contexts 1` reproduces (profiles/*_c1_kernel_stats.csv)
-                         "kernel_ms_one_at_a_time": dom_alone_ms,
-                         "frac_one_at_a_time": own_bytes / (dom_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "kernel_ms_source": f"HIP events around this kernel on the launch stream, inside the timed region, {K} batches in flight "
-                                             "(also counts the launch's wait for free CUs behind the other batches)",
+                         "kernel_ms": dom_alone_ms,
+                         "kernel_ms_source": f"HIP events around this kernel on the launch stream, {n_alone} launches of one context after the "
+                                             "timed region, nothing else on the chip",
+                         # inside the timed region, K batches in flight
+                         "kernel_exec_ms": dom_exec_ms,
+                         "kernel_exec_ms_source": f"device clock, first workgroup's start to last workgroup's end, inside the timed region ({K} batches in flight): what rocprofv3 reports",
+                         "frac_exec": (own_bytes / (dom_exec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if dom_exec_ms else None,
+                         # (the HIP-event span of a launch with batches in flight also counts its wait for free CUs behind the
+                         #  other batches: a queueing figure, kept as a diagnostic only)
+                         "kernel_event_span_ms_in_flight": dom_ms,
                          "selected_by": dom_rule,
                          "longest_stage": max(stage_ms, key=stage_ms.get),
-                         # the kernel's execution span on the device clock (what rocprofv3 calls its duration)
-                         "kernel_exec_ms": dom_exec_ms,
-                         "kernel_exec_ms_source": "device clock, first workgroup's start to last workgroup's end (k_prep only): what rocprofv3 reports",
-                         "frac_exec": (own_bytes / (dom_exec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if dom_exec_ms else None,
-                         "kernel_traffic_gbs": (traffic / (dom_ms * 1e-3) / 1e9) if traffic else None,
+                         "kernel_traffic_gbs": (traffic / (dom_alone_ms * 1e-3) / 1e9) if traffic else None,
                          "path_alg_bytes_per_step": path_bytes,
                          "path_frac": path_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          # the task statement's literal reading (the per-scan figure x scans / ONE kernel's time): kept for
                          # comparison with earlier rounds, not a bandwidth statement about any kernel
-                         "path_bytes_over_kernel_ms_frac": path_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "path_bytes_over_kernel_ms_frac": path_bytes / (dom_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "traffic_total": traffic_total,
                          "traffic_over_path_alg_bytes": (traffic_total / path_bytes) if traffic_total else None,
                          # what physically has to move: the input once; every output the boundary exposes once (~cloud, near bits,
