@@ -886,7 +886,8 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
     const fx_scan_desc &d = scans[i];
     if (d.n_points > L.max_points) return fail(FX_ERR_TOO_LARGE, "scan has more points than max_points");
     if (d.n_points && !d.points) return fail(FX_ERR_INVALID_ARG, "scan with null points");
-    if (d.stride_bytes < 16 || (d.stride_bytes % 16) != 0) return fail(FX_ERR_INVALID_ARG, "stride_bytes must be a multiple of 16");
+    if (d.stride_bytes < 16 || (d.stride_bytes % 16) != 0 || d.stride_bytes > 256)
+      return fail(FX_ERR_INVALID_ARG, "stride_bytes must be a multiple of 16 in [16, 256]");
     if (((uintptr_t)d.points % 16) != 0) return fail(FX_ERR_INVALID_ARG, "points must be 16-byte aligned");
     hm[i].n = d.n_points;
     hm[i].pad_ = 0;
@@ -923,8 +924,9 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
       hm[i].stride_f = d.stride_bytes / 4;
       if (!d.n_points) continue;
       // full-size scans that follow one another in host memory (a stacked batch) go over in one copy
+      // (up to the last record's x y z i: nothing behind it is read, on the host or on the device)
       uint32_t j = i;
-      size_t bytes = (size_t)d.n_points * d.stride_bytes;
+      size_t bytes = (size_t)(d.n_points - 1u) * d.stride_bytes + 16u;
       while (d.n_points == L.max_points && d.stride_bytes == c->stage_stride && j + 1 < batch && scans[j + 1].stride_bytes == d.stride_bytes &&
              scans[j + 1].n_points == L.max_points && (const uint8_t *)scans[j + 1].points == (const uint8_t *)scans[j].points + slot_bytes) {
         ++j;
@@ -963,7 +965,9 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
   const FxDevParams &P = c->dp;
   const FxBuffers &B = c->buf;
   const bool prof = c->profiling;
-  // front kernel or separate kernels (see fx_ctx::front_pause): tier_hint[6] is what the last COMPLETED batch handed to k_tail
+  // front kernel or separate kernels (see fx_ctx::front_pause): tier_hint[6] is what the last COMPLETED batch of this context
+  // handed to k_front_redo (with batches in flight: an older batch's count, possibly of another size — this decides speed
+  // only, never a result)
   bool front = c->front_ok;
   if (front && c->front_pause) {
     --c->front_pause;

@@ -41,6 +41,11 @@ struct MultiGpuOptions {
   uint32_t in_flight = 2;  // contexts (batches in flight) per device (2: 1.59 million scans/s on one MI355X, 1: 1.24, 3: 1.48 — the shared communicator orders the slots)
   uint32_t rec_kp = 0;     // keypoints per gathered record; 0 = the contexts' limits.max_keypoints
   fx_limits limits{};      // non-zero fields override fx_limits_default(scans per rank, max_points)
+  // SELF-TEST: the ranks' collective is replaced by a gather through host memory (every rank downloads its block, all ranks
+  // meet, every rank uploads the whole table) and no RCCL communicator is made — RCCL refuses a communicator with the same
+  // device twice, so this is how G > 1 ranks (worker threads, tickets, the error barrier, slots in flight, uneven blocks)
+  // run on the ONE GPU a test box has: devices = {0, 0, ..., 0}.  Never the product path.
+  bool host_gather = false;
   bool sparse_limits = false;  // start from fx_limits_sparse instead (VLP-16-class streams: small dense-tier pools — 4.5 GB a 1024-scan context, not 7)
 };
 // What one batch produced.  Valid until `in_flight` more batches have been submitted (the contexts own the memory).
@@ -61,6 +66,8 @@ struct MultiGpuJob {
   std::condition_variable cv;
   uint32_t arrived = 0;    // ranks that finished the local part (the barrier before the collective)
   uint32_t enqueued = 0;   // ranks that finished enqueuing (or gave up): wait() may look at the events
+  uint32_t gathered = 0;   // (host_gather) ranks whose block is in host_table
+  std::vector<float> host_table;  // (host_gather) the table on its way through host memory
 };
 
 
@@ -81,7 +88,7 @@ class MultiGpu {
 
   // devices: HIP device ids, one rank each; max_batch: scans of one batch over all devices together
   MultiGpu(const fx_params &params, const std::vector<int> &devices, uint32_t max_batch, uint32_t max_points, const Options &opt = Options())
-      : devices_(devices), max_batch_(max_batch), in_flight_(opt.in_flight ? opt.in_flight : 1u) {
+      : devices_(devices), max_batch_(max_batch), in_flight_(opt.in_flight ? opt.in_flight : 1u), host_gather_(opt.host_gather) {
     const uint32_t G = (uint32_t)devices.size();
     if (!G) throw std::invalid_argument("fx::MultiGpu: no devices");
     per_rank_ = (max_batch + G - 1) / G;
@@ -90,7 +97,7 @@ class MultiGpu {
     try {
       // one communicator per device of this process (ncclCommInitAll: single-process, multi-device); the slots of a device
       // share it and issue their collectives in ticket order, which is RCCL's ordering contract
-      nccl(ncclCommInitAll(comms_.data(), (int)G, devices_.data()), "ncclCommInitAll");
+      if (!host_gather_) nccl(ncclCommInitAll(comms_.data(), (int)G, devices_.data()), "ncclCommInitAll");
       for (uint32_t r = 0; r < G; ++r) {
         Rank &R = *ranks_[r];
         hip(hipSetDevice(devices_[r]), "hipSetDevice");
@@ -147,6 +154,7 @@ class MultiGpu {
     job->out.views.resize(world());
     job->out.tables.resize(world());
     job->local_error.resize(world());
+    if (host_gather_) job->host_table.assign((size_t)per_rank_ * world() * record_floats(rec_kp_), 0.0f);
     for (auto &rp : ranks_) {
       Rank &R = *rp;
       {
@@ -231,6 +239,7 @@ class MultiGpu {
   std::vector<std::unique_ptr<Rank>> ranks_;  // (a Rank holds a mutex: it never moves)
   std::vector<ncclComm_t> comms_;
   uint32_t rec_kp_ = kRecKeypoints, max_batch_, per_rank_ = 0, in_flight_;
+  bool host_gather_ = false;
   uint64_t next_ticket_ = 0;
 };
 
@@ -296,7 +305,21 @@ inline void MultiGpu::work(uint32_t r) {
         }
     }
     std::string late;
-    if (all_ok) {
+    if (all_ok && host_gather_) {
+      // (self-test: the all-gather through host memory — every rank has passed the error barrier, so every rank gets here)
+      const size_t block = (size_t)per_rank_ * record_floats(rec_kp_);
+      hipError_t ge = hipMemcpyAsync(job->host_table.data() + (size_t)r * block, S.rec, block * sizeof(float), hipMemcpyDeviceToHost, S.stream);
+      if (ge == hipSuccess) ge = hipStreamSynchronize(S.stream);
+      {
+        std::unique_lock<std::mutex> lk(job->m);
+        ++job->gathered;
+        job->cv.notify_all();
+        job->cv.wait(lk, [&] { return job->gathered == G; });
+      }
+      if (ge == hipSuccess) ge = hipMemcpyAsync(S.table, job->host_table.data(), block * G * sizeof(float), hipMemcpyHostToDevice, S.stream);
+      if (ge == hipSuccess) ge = hipStreamSynchronize(S.stream);  // (the job's host table may go away with the last ticket)
+      if (ge != hipSuccess) late = std::string("rank ") + std::to_string(r) + ": host gather: " + hipGetErrorString(ge);
+    } else if (all_ok) {
       // the path's one collective, an ordinary kernel of the slot's stream
       const ncclResult_t ce = ncclAllGather(S.rec, S.table, (size_t)per_rank_ * record_floats(rec_kp_), ncclFloat, comms_[r], S.stream);
       if (ce != ncclSuccess) late = std::string("rank ") + std::to_string(r) + ": ncclAllGather: " + ncclGetErrorString(ce);

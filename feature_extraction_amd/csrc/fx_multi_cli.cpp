@@ -2,7 +2,11 @@
 // visible GPUs (or --devices N of them), gathers the keypoint records over RCCL, checks the gathered table against the
 // per-rank results and prints scans/s with the inputs resident in device memory (--host-input: handed over as host
 // buffers).  On a 1-GPU box it runs with one rank: RCCL initialises and the collective runs.
-//   fx_multi_cli [--devices N] [--batch B] [--steps K] [--inflight F] [--default] [--host-input]
+//   fx_multi_cli [--devices N] [--batch B] [--steps K] [--inflight F] [--default] [--host-input] [--selftest G] [--bad-scan I]
+// --selftest G: G ranks on device 0 with the collective replaced by a gather through host memory (fx::MultiGpuOptions::
+// host_gather: RCCL refuses the same device twice) — worker threads, tickets, the error barrier, slots in flight and
+// uneven blocks with G > 1 on a one-GPU box.  --bad-scan I: scan I of one submitted batch claims more points than the
+// contexts hold: that batch must fail on every rank (no rank may wait in a collective for ever) and the next one be right.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -24,6 +28,7 @@ int main(int argc, char **argv) {
     int want = n_dev;
     uint32_t batch = 256, steps = 20, in_flight = 4;
     bool launch = true, host_input = false;
+    int selftest = 0, bad_scan = -1;
     for (int i = 1; i < argc; ++i) {
       if (!std::strcmp(argv[i], "--devices") && i + 1 < argc) want = std::atoi(argv[++i]);
       else if (!std::strcmp(argv[i], "--batch") && i + 1 < argc) batch = (uint32_t)std::atoi(argv[++i]);
@@ -31,10 +36,13 @@ int main(int argc, char **argv) {
       else if (!std::strcmp(argv[i], "--inflight") && i + 1 < argc) in_flight = (uint32_t)std::atoi(argv[++i]);
       else if (!std::strcmp(argv[i], "--default")) launch = false;
       else if (!std::strcmp(argv[i], "--host-input")) host_input = true;
+      else if (!std::strcmp(argv[i], "--selftest") && i + 1 < argc) selftest = std::atoi(argv[++i]);
+      else if (!std::strcmp(argv[i], "--bad-scan") && i + 1 < argc) bad_scan = std::atoi(argv[++i]);
     }
     if (want < 1 || want > n_dev) want = n_dev;
     std::vector<int> devices;
     for (int d = 0; d < want; ++d) devices.push_back(d);
+    if (selftest > 0) devices.assign((size_t)selftest, 0);
     fx_params p;
     if (launch) fx_params_launch(&p); else fx_params_default(&p);
     fx_synth_cfg cfg;
@@ -50,10 +58,12 @@ int main(int argc, char **argv) {
     fx::MultiGpu::Options opt;
     opt.in_flight = in_flight;
     opt.sparse_limits = true;  // (the stream is synthetic VLP-16 scans)
+    opt.host_gather = selftest > 0;
     fx::MultiGpu multi(p, devices, batch, N, opt);
     const uint32_t G = multi.world(), rec_kp = multi.record_keypoints();
     std::printf("fx_multi_cli: %d device(s) visible, %u rank(s), %u scans per batch (%u per rank), %u batches in flight per device, "
-                "records of %u keypoints, RCCL communicators up\n", n_dev, G, batch, multi.scans_per_rank(), multi.in_flight(), rec_kp);
+                "records of %u keypoints, %s\n", n_dev, G, batch, multi.scans_per_rank(), multi.in_flight(), rec_kp,
+                selftest > 0 ? "SELF-TEST: all ranks on device 0, gather through host memory" : "RCCL communicators up");
     // ---- a checked batch (host input, results back on the host): the gathered table against every rank's own results
     std::vector<float> table;
     std::vector<fx_batch_view> views;
@@ -85,6 +95,25 @@ int main(int argc, char **argv) {
       if (std::memcmp(t0.data(), table.data(), table.size() * sizeof(float)) != 0)
         throw std::runtime_error("the same batch gave a different table the second time");
     }
+    if (bad_scan >= 0 && (uint32_t)bad_scan < batch) {
+      // ---- a batch one rank cannot run: every rank must come back with the error (the barrier before the collective), the
+      //      ticket throws, and the next batch is right again
+      std::vector<fx_scan_desc> bad = scans;
+      bad[(size_t)bad_scan].n_points = N + 1;  // more points than the contexts hold: FX_ERR_TOO_LARGE on the owning rank
+      bool threw = false;
+      try {
+        multi.submit(bad.data(), batch, 0).wait();
+      } catch (const std::exception &e) {
+        threw = true;
+        std::printf("fx_multi_cli: the bad batch failed on every rank as it must: %s\n", e.what());
+      }
+      if (!threw) throw std::runtime_error("a batch with an oversized scan did not fail");
+      std::vector<float> again;
+      multi.process(scans.data(), batch, 0, &again);
+      if (again.size() != table.size() || std::memcmp(again.data(), table.data(), table.size() * sizeof(float)) != 0)
+        throw std::runtime_error("the batch after a failed one gave a different table");
+      std::printf("fx_multi_cli: the batch after the failed one equals the reference table\n");
+    }
     // ---- throughput: tickets kept in flight; inputs resident on the devices unless --host-input
     std::vector<void *> d_in(G, nullptr);
     std::vector<fx_scan_desc> dscans = scans;
@@ -95,7 +124,7 @@ int main(int argc, char **argv) {
         const auto span = fx::shard_range(batch, G, r);
         const size_t n = (size_t)(span.second - span.first);
         if (!n) continue;
-        if (hipSetDevice(devices[r]) != hipSuccess || hipMalloc(&d_in[r], n * N * 16) != hipSuccess ||
+        if (hipSetDevice(devices[r]) != hipSuccess || hipMalloc(&d_in[r], n * N * 16) != hipSuccess ||  // (self-test: every block on device 0)
             hipMemcpy(d_in[r], &host[(size_t)span.first * N * 4], n * N * 16, hipMemcpyHostToDevice) != hipSuccess)
           throw std::runtime_error("upload of a rank's block failed");
         for (size_t i = 0; i < n; ++i) dscans[span.first + i].points = (const char *)d_in[r] + i * N * 16;

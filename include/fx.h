@@ -109,7 +109,7 @@ typedef struct fx_limits {
 typedef struct fx_scan_desc {
   const void *points; /* host or device pointer (see FX_IN_DEVICE), 16-byte aligned */
   uint32_t n_points;
-  uint32_t stride_bytes; /* multiple of 16, >= 16 */
+  uint32_t stride_bytes; /* multiple of 16 in [16, 256] */
   double roll, pitch;    /* radians; narrowed to float like Eigen::AngleAxisf (ref: node.cpp:163-164) */
 } fx_scan_desc;
 

@@ -321,9 +321,9 @@ struct V3 {
 };
 static inline float dot3(const V3 &a, const V3 &b) { return a.v[0] * b.v[0] + (a.v[1] * b.v[1] + a.v[2] * b.v[2]); }
 static inline float sqnorm3(const V3 &a) { return dot3(a, a); }
-static inline void normalize3(V3 &a) { /* Eigen 3.3: z = squaredNorm(); if (z > 0) *this /= sqrt(z) */
+static inline void normalize3(V3 &a, bool eigen32 = false) { /* Eigen 3.3: z = squaredNorm(); if (z > 0) *this /= sqrt(z); 3.2: *this /= norm() */
   float z = sqnorm3(a);
-  if (z > 0.0f) {
+  if (z > 0.0f || eigen32) {
     float s = std::sqrt(z);
     a.v[0] /= s;
     a.v[1] /= s;
@@ -460,7 +460,10 @@ static void estimate_keypoints(Result &R, int search_kind) {
 }
 
 /* ref: node.cpp:329-355 estimateDescriptors == pcl::ShapeContext3DEstimation::compute (A.8) */
-static void estimate_descriptors(Result &R, int search_kind, int trig_kind) {
+static void estimate_descriptors(Result &R, int search_kind, int trig_policy) {
+  const int trig_kind = trig_policy & 0xf;
+  const bool skip_epsilon = (trig_policy & FXO_POLICY_SKIP_EPSILON) != 0, eigen32 = (trig_policy & FXO_POLICY_EIGEN32_NORMALIZE) != 0,
+             std_uniform = (trig_policy & FXO_POLICY_STD_UNIFORM_FLOAT) != 0;
   const fx_params &P = R.p;
   const Cloud &surface = R.rotated; /* cloud_full: unfiltered, rotated (ref: :115) */
   const Cloud &input = R.keypoints;
@@ -475,7 +478,11 @@ static void estimate_descriptors(Result &R, int search_kind, int trig_kind) {
   Sc3dTables T;
   sc3d_tables(search_radius, min_radius, T);
   std::mt19937 rng(12345u); /* boost::mt19937 seeded 12345u, fresh per compute() (ref: :343) */
-  auto rnd = [&]() -> double { return (double)rng() * (1.0 / 4294967296.0); }; /* boost::uniform_01 */
+  std::uniform_real_distribution<float> uni01(0.0f, 1.0f); /* (FXO_POLICY_STD_UNIFORM_FLOAT: PCL >= 1.10) */
+  auto rnd = [&]() -> double {
+    if (std_uniform) return (double)uni01(rng);
+    return (double)rng() * (1.0 / 4294967296.0); /* boost::uniform_01 */
+  };
 
   std::unique_ptr<Searcher> tree = make_searcher(surface, search_kind);
   const float r2_search = radius2(search_radius);
@@ -507,12 +514,12 @@ static void estimate_descriptors(Result &R, int search_kind, int trig_kind) {
     x_axis.v[2] = static_cast<float>(rnd());
     /* !equal(normal[2], 0) branch */
     x_axis.v[2] = -(normal.v[0] * x_axis.v[0] + normal.v[1] * x_axis.v[1]) / normal.v[2];
-    normalize3(x_axis);
+    normalize3(x_axis, eigen32);
 
     for (size_t ne = 0; ne < neighb_cnt; ne++) {
       /* pcl::utils::equal(nn_dists[ne], 0.0f): default tolerance std::numeric_limits<float>::min()
        * (pcl/common/utils.h) — only the point the keypoint sits on is skipped */
-      if (std::fabs(nn[ne].d - 0.0f) < std::numeric_limits<float>::min()) continue;
+      if (std::fabs(nn[ne].d - 0.0f) < (skip_epsilon ? std::numeric_limits<float>::epsilon() : std::numeric_limits<float>::min())) continue;
       const P4 &nbp = surface[nn[ne].idx];
       V3 neighbour = {{nbp.x, nbp.y, nbp.z}};
       float r = sqrtf(nn[ne].d);
@@ -524,7 +531,7 @@ static void estimate_descriptors(Result &R, int search_kind, int trig_kind) {
       proj.v[0] -= origin.v[0];
       proj.v[1] -= origin.v[1];
       proj.v[2] -= origin.v[2];
-      normalize3(proj);
+      normalize3(proj, eigen32);
       V3 cross = cross3(x_axis, proj);
       float cn = std::sqrt(sqnorm3(cross));
       float xd = dot3(x_axis, proj);
@@ -535,7 +542,7 @@ static void estimate_descriptors(Result &R, int search_kind, int trig_kind) {
         phi = rad2deg_f((float)atan2((double)cn, (double)xd));
       phi = dot3(cross, normal) < 0.f ? (360.0f - phi) : phi;
       V3 no = po;
-      normalize3(no);
+      normalize3(no, eigen32);
       float theta = dot3(normal, no);
       float tc = std::min(1.0f, std::max(-1.0f, theta));
       if (trig_kind == FXO_TRIG_LIBM_F32)

@@ -26,6 +26,15 @@ typedef struct fxo_result fxo_result;
 #define FXO_SEARCH_KDTREE 1 /* own exact kd-tree (leaf 15): the timed CPU baseline */
 #define FXO_TRIG_F64_ROUNDED 0 /* phi/theta via fp64 atan2/acos rounded once to fp32 */
 #define FXO_TRIG_LIBM_F32 1    /* literal atan2f/acosf of this glibc (diagnostic mode) */
+/* Switchable policies, OR-ed into trig_kind: where the restatement had to pick ONE reading of an un-vendored dependency
+ * (PARITY UNPINNED: none of PCL / Eigen / Boost is in this image).  Whoever runs tools/pcl_crosscheck against a real PCL
+ * flips the switch that matches the installed versions; tests/test_oracle_policies.py counts what each one moves. */
+#define FXO_POLICY_SKIP_EPSILON 0x10     /* 3DSC skips a neighbour when d2 < FLT_EPSILON (SURVEY.md A.8-6's reading) instead of
+                                          * pcl::utils::equal's default tolerance numeric_limits<float>::min() */
+#define FXO_POLICY_EIGEN32_NORMALIZE 0x20 /* Eigen 3.2: normalize() divides by the norm unguarded (a zero vector becomes NaN);
+                                          * Eigen 3.3 leaves a zero vector alone */
+#define FXO_POLICY_STD_UNIFORM_FLOAT 0x40 /* PCL >= 1.10: std::mt19937 + std::uniform_real_distribution<float>(0, 1) for the
+                                          * x-axis draws instead of boost::mt19937 + boost::uniform_01 (double, narrowed) */
 
 /* Runs cloudCallback's body (ref: node.cpp:83-115) on one scan.
  * points: n records of stride_floats floats, x,y,z at 0,1,2. */

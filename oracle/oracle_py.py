@@ -73,14 +73,19 @@ def _i(a):
     return a.ctypes.data_as(_I32P)
 
 
+# switchable readings of the un-vendored dependencies (oracle/fx_oracle.h FXO_POLICY_*), OR-ed together
+POLICY_SKIP_EPSILON, POLICY_EIGEN32_NORMALIZE, POLICY_STD_UNIFORM_FLOAT = 0x10, 0x20, 0x40
+
+
 def run(params, points, roll=0.0, pitch=0.0, search=SEARCH_KDTREE, trig=TRIG_F64_ROUNDED, want_rotated=False,
-        want_labels=False):
+        want_labels=False, policy=0):
     """Run the oracle on one scan.  params: the same ctypes fx_params the product takes.
-    points: [N, >=3] float32.  Returns a dict shaped like feature_extraction_amd.capi.Context.unpack()."""
+    points: [N, >=3] float32.  Returns a dict shaped like feature_extraction_amd.capi.Context.unpack().
+    policy: POLICY_* switches (0 = the readings the product follows)."""
     lib = load()
     pts = np.ascontiguousarray(points, dtype=np.float32)
     n, stride = pts.shape
-    h = lib.fxo_run(C.byref(params), _f(pts), n, stride, roll, pitch, search, trig)
+    h = lib.fxo_run(C.byref(params), _f(pts), n, stride, roll, pitch, search, trig | policy)
     try:
         nf, nc, nk, nkpc = lib.fxo_n_filtered(h), lib.fxo_n_candidates(h), lib.fxo_n_keypoints(h), lib.fxo_n_kpc(h)
         out = {"n_keypoints": nk}
