@@ -30,7 +30,7 @@ SINGLE_LAUNCH_STAGES = ("k_prep", "k_bucket", "k_rings_runs", "k_gather", "k_des
 STAGE_KERNELS = {"k_prep": ("k_prep", "k_front"),  # (k_front: stages 0-4 of scans that fit its LDS tables, in one launch)
                  "k_bucket": ("k_bucket", "k_bucket_many"),  # (k_bucket_many: sensors of more than 24 rings)
                  "k_rings_large": ("k_rings_runs2", "k_rings_large"),  # (k_rings_runs2: sensors of more than 16 rings)
-                 "k_merge": ("k_merge_small", "k_merge_big", "k_merge_huge", "k_front_redo", "k_tail", "k_offsets"),
+                 "k_merge": ("k_merge_small", "k_merge_big", "k_merge_huge", "k_front_redo", "k_slow", "k_offsets"),
                  "k_desc_mid": ("k_desc_mid",),
                  "k_gather": ("k_gather", "k_rng_ord"),  # (k_rng_ord only when several workgroups share a scan: small batches)
                  "k_desc_rare": ("k_dense_sort", "k_dense_density", "k_dense_finish_s", "k_dense_finish_l")}

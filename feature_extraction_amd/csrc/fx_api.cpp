@@ -891,7 +891,12 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
     if (((uintptr_t)d.points % 16) != 0) return fail(FX_ERR_INVALID_ARG, "points must be 16-byte aligned");
     hm[i].n = d.n_points;
     hm[i].pad_ = 0;
-    fx_rotation_from_roll_pitch(d.roll, d.pitch, hm[i].R);
+    // (scans of one sensor and instant share their attitude: the matrix — four trigonometric calls — is built once per run of
+    //  equal angles; a 1024-scan batch spent 0.25 ms of host time here, most of the enqueue)
+    if (i && d.roll == scans[i - 1].roll && d.pitch == scans[i - 1].pitch)
+      std::memcpy(hm[i].R, hm[i - 1].R, sizeof(hm[i].R));
+    else
+      fx_rotation_from_roll_pitch(d.roll, d.pitch, hm[i].R);
     if (in_dev) {
       hm[i].pts = (const float *)d.points;
       hm[i].stride_f = d.stride_bytes / 4;

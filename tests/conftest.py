@@ -38,7 +38,7 @@ def oracle():
 def fx_hooks(fxlib, monkeypatch):
     """The test build of the library (lib/libfx_hip_test.so, -DFX_TEST_HOOKS) for the duration of a test: contexts created
     inside read the environment hooks the returned function sets (FX_FRONT=0: the separate front kernels, FX_FRONT_FORCE=1 / 2:
-    every scan through k_front_redo / k_tail, FX_MERGE_BIG_CAP, FX_DENSE_LDS_KEYS, FX_DENSE_WON_POINTS, FX_TIER_MIN_GRID, ...).  The product
+    every scan through k_front_redo / k_slow, FX_MERGE_BIG_CAP, FX_DENSE_LDS_KEYS, FX_DENSE_WON_POINTS, FX_TIER_MIN_GRID, ...).  The product
     library has none of them."""
     from feature_extraction_amd import capi
     with capi.test_hooks():

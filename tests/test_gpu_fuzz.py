@@ -45,7 +45,7 @@ def _case(seed):
 def test_random_scenes_parameters_and_perturbations(fx_hooks, oracle, block, path):
     """Every case through the fused front kernel (the default), through the separate kernels, through those with the LDS merge
     tier's capacity lowered (scans with more than 16 candidates take the large merge tier), and through the two kernels behind
-    k_front (k_front_redo: the general bodies in k_front's shape; k_tail: in a whole CU)."""
+    k_front (k_front_redo: the general bodies in k_front's shape; k_slow: the same on scratch in HBM)."""
     if path in ("front-redo", "front-tail") and block >= 4:
         pytest.skip("half of the blocks are enough for the rarely used kernels")
     fx_hooks(**{"front": {}, "separate": dict(FX_FRONT=0), "separate-large-merge": dict(FX_FRONT=0, FX_MERGE_BIG_CAP=16),

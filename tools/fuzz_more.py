@@ -1,6 +1,6 @@
 """Diagnostic: the differential fuzz of tests/test_gpu_fuzz.py over an arbitrary seed range, through every front path: the
 fused front kernel (product library), and — test build — the separate kernels, those with the large merge tier, every scan
-through k_front_redo, every scan through k_tail.
+through k_front_redo, every scan through k_slow.
   python tools/fuzz_more.py FIRST LAST [paths=front,separate,separate-large-merge,front-redo,front-tail]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
