@@ -30,6 +30,8 @@ uint32_t fxk_dense_cells(void);
 uint32_t fxk_group_cap(void);
 uint32_t fxk_dfin_kl(void);
 void fxk_dense(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t n_cu, uint32_t rows, uint32_t items);
+size_t fxk_dense_slow_words(uint32_t max_points);
+void fxk_dense_slow(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t grid);
 size_t fxk_merge_huge_lds_bytes(uint32_t cap, uint32_t ccap, uint32_t n_rings);
 hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t merge_huge, size_t desc_big, size_t gather);
 uint32_t fxk_near_words(uint32_t max_points);
@@ -163,6 +165,11 @@ struct fx_ctx {
   bool state_suspect = false;
   uint32_t fail_after = 0;     // test hook (FX_FAIL_AFTER_ENQUEUE = n: the n-th batch returns an error after its kernels were enqueued)
   uint32_t front_pause = 0;    // batches left on the separate kernels
+  // The dense descriptor tier: its four kernels when a recent batch had rows for it (or nothing is known), else ONE small
+  // launch (k_dense_slow) that computes whatever does turn up, slower — the same results either way.
+  uint32_t dense_fast_left = 0;            // batches that still get the four kernels after the last one that needed them
+  static constexpr uint32_t dense_linger = 64;
+  int dense_force = -1;                    // test hook (FX_DENSE_SLOW): 1 always the one launch, 0 always the four kernels
   uint32_t skip_mask = 0;      // experiment hook (FX_SKIP_EMPTY, test build): bit 0 no k_front_redo, bit 1 no dense tier — only for workloads that need neither
   static constexpr uint32_t front_retry = 64;
 };
@@ -313,7 +320,17 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof, bo
         const uint32_t rows = tier_grid(hint[4], 3 * big_grid, max_rows);
         // density items: 1024 queries each, at most one a row more than the support points fill
         const uint32_t items = hint[5] == 0xffffffffu ? 3 * big_grid : tier_grid(hint[4] + hint[5] / 1024u, 3 * big_grid, 0xffffffffu);
-        if (!(c->skip_mask & 2u)) fxk_dense(s, P, B, big_grid, rows, items);
+        // four kernels, or the one small launch: the previous batches decide speed, never results
+        bool fast = capture || hint[4] != 0u;  // (0xffffffff: nothing known yet)
+        if (fast && !capture && hint[4] != 0xffffffffu) c->dense_fast_left = fx_ctx::dense_linger;
+        if (!fast && c->dense_fast_left) --c->dense_fast_left, fast = true;
+        if (c->dense_force >= 0) fast = c->dense_force == 0;
+        if (c->skip_mask & 2u) {
+        } else if (fast) {
+          fxk_dense(s, P, B, big_grid, rows, items);
+        } else {
+          fxk_dense_slow(s, P, B, c->tier_min_grid ? c->tier_min_grid : 8u);
+        }
       }
     } else {
       for (int i = 6; i <= 8; ++i) FX_HIP(mark(i));
@@ -599,6 +616,15 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
     P.gs_slots = (uint32_t)slots;
     FX_A(dev_alloc(c, &b.gs_pool, slots * words));
   }
+  {
+    // k_dense_slow's scratch: a region per workgroup (a handful of them: the launch exists to be small), 128 MB at most
+    const size_t words = fxk_dense_slow_words(L.max_points);
+    size_t slots = 32;
+    while (slots > 1 && slots * words * 4 > ((size_t)128 << 20)) --slots;
+    P.gsd_words = (uint32_t)words;
+    P.gsd_slots = (uint32_t)slots;
+    FX_A(dev_alloc(c, &b.gsd_pool, slots * words));
+  }
   // (the large merge tier's bin-ordered copy: k_merge_huge, and k_front_redo — whose LDS image holds fewer candidates as points
   //  than k_merge_big's — whenever a scan has more candidates than that)
   FX_A(dev_alloc(c, &b.merge_sorted, (size_t)B * L.max_candidates));
@@ -707,6 +733,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   if (const char *e = test_hook("FX_FRONT_FORCE")) c->front_force = (uint32_t)std::max(0, atoi(e));
   if (const char *e = test_hook("FX_FAIL_AFTER_ENQUEUE")) c->fail_after = (uint32_t)std::max(0, atoi(e));
   if (const char *e = test_hook("FX_SKIP_EMPTY")) c->skip_mask = (uint32_t)std::max(0, atoi(e));
+  if (const char *e = test_hook("FX_DENSE_SLOW")) c->dense_force = atoi(e) != 0 ? 1 : 0;
   if (c->front_ok) {
     hipError_t ce = fxk_configure_front();
     if (ce != hipSuccess) return bail(fail(FX_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(ce)));

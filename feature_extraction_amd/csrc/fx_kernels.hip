@@ -4238,13 +4238,27 @@ __device__ __forceinline__ DescLds desc_carve(uint32_t *smem, uint32_t cap) {
   return L;
 }
 
+__device__ __forceinline__ DescLds desc_carve_gs(uint32_t *smem, uint32_t *gs, uint32_t cap) {
+  DescLds L;
+  L.s_w = smem;  // 16 words
+  L.img = (float *)(smem + 16);  // FX_DESC_BINS floats
+  uint32_t *p = gs;  // (16-byte aligned)
+  L.sp = (float4 *)p, p += 4 * (size_t)cap;
+  L.nkey = (unsigned long long *)p, p += 2 * (size_t)cap;
+  L.nw = (float *)p, p += cap;
+  L.sidx = p;
+  return L;
+}
+
 // One keypoint by a whole workgroup.  from_list: the support set comes from k_gather's list;
 // otherwise it is re-gathered from the scan (lists that overflowed P.list_cap).
 // Returns false if the support set does not fit `cap` (only possible when !from_list).
-template <bool FAST, int NT>
+// GS (k_dense_slow): the per-point arrays live in the scratch region `gs` of HBM (8 words a point: any support set), the
+// scratch words and the image stay in LDS.
+template <bool FAST, int NT, bool GS = false>
 __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers &B, uint32_t row, uint32_t scan, uint32_t k,
-                          uint32_t cap, uint32_t *smem, bool from_list) {
-  DescLds L = desc_carve(smem, cap);
+                          uint32_t cap, uint32_t *smem, bool from_list, uint32_t *gs = nullptr) {
+  DescLds L = GS ? desc_carve_gs(smem, gs, cap) : desc_carve(smem, cap);
   FX_STAMP_INIT(B.stamps && FAST ? B.stamps + 48 : nullptr);
   const uint32_t tid = threadIdx.x;
   const WithinR2 within(P.r2_density);
@@ -4256,7 +4270,7 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
   // the 3DSC tables ride in the image until the bins are known (the image is cleared after that)
   uint32_t *tl = reinterpret_cast<uint32_t *>(L.img) + FX_DGRID3 * FX_DGRID3 * FX_DGRID3;  // behind the cell table
   for (uint32_t t = tid; t < sizeof(FxScTables) / 4; t += NT) tl[t] = __float_as_uint(reinterpret_cast<const float *>(B.tables)[t]);
-  __syncthreads();
+  wg_sync<GS>();
   uint32_t nS;
   // Density grid: a list-fed support set is stored sorted by cell (12 x 12 x 12 cells of width >= R/5
   // over the support sphere's box), so the density query of a neighbour only scans the nine rows of
@@ -4276,12 +4290,12 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
     if (grid) {
       const float4 *lst = B.s_pts + (size_t)row * P.list_cap;
       for (uint32_t t = tid; t < kCells; t += NT) cell_end[t] = 0;
-      __syncthreads();
+      wg_sync<GS>();
       for (uint32_t e = tid; e < nS; e += NT) {
         const float4 v = lst[e];
         atomicAdd(&cell_end[cell_of(v.x, v.y, v.z)], 1u);
       }
-      __syncthreads();
+      wg_sync<GS>();
       if (tid < 64) {  // counts -> exclusive starts, in place, by one wavefront
         constexpr uint32_t per = (kCells + 63) / 64;
         uint32_t sum = 0;
@@ -4305,7 +4319,7 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
           }
         }
       }
-      __syncthreads();
+      wg_sync<GS>();
       for (uint32_t e = tid; e < nS; e += NT) {  // second read of the list (cache-resident): each entry to its cell
         const float4 v = lst[e];
         const uint32_t slot = atomicAdd(&cell_end[cell_of(v.x, v.y, v.z)], 1u);
@@ -4319,7 +4333,7 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
         L.sidx[e] = __float_as_uint(v.w);
       }
     }
-    __syncthreads();
+    wg_sync<GS>();
   } else {
     const uint32_t n = M.n;
     for (uint32_t i0 = 0; i0 < n; i0 += NT * 4) {
@@ -4345,7 +4359,7 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
         }
       }
     }
-    __syncthreads();
+    wg_sync<GS>();
     nS = L.s_w[0];
     if (nS > cap) return false;  // the caller hands the keypoint to the spill tier
   }
@@ -4380,7 +4394,7 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
     }
     if (tid == 0) L.s_w[1] = n_use;
   }
-  __syncthreads();
+  wg_sync<GS>();
   FX_STAMP(6);
   {
     // ---- local point density = support points within R/5 of the neighbour (itself included): every
@@ -4409,7 +4423,7 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
       }
       if (c) atomicAdd(&dens[2 * m], c);
     }
-    __syncthreads();
+    wg_sync<GS>();
     FX_STAMP(7);
     // ---- bins and weights, one neighbour per lane
     for (uint32_t m = tid; m < nMq; m += NT) {
@@ -4423,7 +4437,7 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
       L.nw[m] = (1.0f / (float)d) * lut;
     }
   }
-  __syncthreads();
+  wg_sync<GS>();
   FX_STAMP(2);
   for (uint32_t t = tid; t < FX_DESC_BINS; t += NT) L.img[t] = 0.0f;  // (cell table and 3DSC tables are done with)
   const uint32_t nM = L.s_w[1], nAll = L.s_w[2];
@@ -4435,7 +4449,7 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
   if (tid == 0) B.kp_nbrs[(size_t)scan * P.max_keypoints + k] = nAll;
   if (nAll == 0) {  // no neighbours: NaN descriptor, no RNG draw (A.8-3)
     desc_fill_nan(out, tid, NT);
-    __syncthreads();
+    wg_sync<GS>();
     return true;
   }
   // ---- PCL adds a bin's contributions in the order of its sorted radius search, (d2, index) ascending: counting sort by
@@ -4446,9 +4460,9 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
   unsigned long long *skey = reinterpret_cast<unsigned long long *>(L.sp);  // the support set is done with: [cap] keys by bin,
   float *sw = reinterpret_cast<float *>(L.sp) + 2 * cap;                    // [cap] their weights,
   float *sorted_w = reinterpret_cast<float *>(L.sp) + 3 * cap;              // [cap] the weights in (bin, d2, index) order
-  __syncthreads();
+  wg_sync<GS>();
   for (uint32_t m = tid; m < nM; m += NT) atomicAdd(&bin_end[(uint32_t)(L.nkey[m] >> 52)], 1u);
-  __syncthreads();
+  wg_sync<GS>();
   if (tid < 64) {  // counts -> exclusive starts, in place, by one wavefront
     constexpr uint32_t per = (FX_DESC_BINS + 63) / 64;
     uint32_t sum = 0;
@@ -4472,14 +4486,14 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
       }
     }
   }
-  __syncthreads();
+  wg_sync<GS>();
   for (uint32_t m = tid; m < nM; m += NT) {  // (the fill turns a bin's start into its end = the next bin's start)
     const unsigned long long key = L.nkey[m];
     const uint32_t pos = atomicAdd(&bin_end[(uint32_t)(key >> 52)], 1u);
     skey[pos] = key;
     sw[pos] = L.nw[m];
   }
-  __syncthreads();
+  wg_sync<GS>();
   for (uint32_t p = tid; p < nM; p += NT) {
     const unsigned long long key = skey[p];
     const uint32_t bin = (uint32_t)(key >> 52);
@@ -4488,7 +4502,7 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
     for (uint32_t q = s0; q < s1; ++q) rank += skey[q] < key ? 1u : 0u;
     sorted_w[s0 + rank] = sw[p];
   }
-  __syncthreads();
+  wg_sync<GS>();
   FX_STAMP(3);
   // ---- sequential fp32 accumulation per bin, in sorted order; the row was cleared by k_desc_group (rf stays zero)
   for (uint32_t bin = tid; bin < FX_DESC_BINS; bin += NT) {
@@ -4498,7 +4512,7 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
     for (uint32_t q = s0; q < s1; ++q) acc += sorted_w[q];
     out[bin] = acc;
   }
-  __syncthreads();
+  wg_sync<GS>();
   FX_STAMP(4);
   FX_STAMP(5);
   return true;
@@ -4537,6 +4551,26 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_mid(FxDevParams P, Fx
     desc_wg_loop<true, FX_DESC_WG_FAST_T>(P, B, batch, cap, smem, blockIdx.x, n_wg);
   else
     desc_wave_body<true>(P, B, batch, smem, blockIdx.x - n_wg, gridDim.x - n_wg);
+}
+
+// The dense tier's rows WITHOUT its four launches: a batch whose predecessor had no dense row (every VLP-16-class batch) gets
+// this one launch instead — 256 threads and 8 KB of LDS place anywhere, where the four kernels' workgroups each wait for a
+// large LDS slot behind the other batches' kernels (+3.7 % on the headline with them gone, profiles/r05_experiments.md).
+// A row that does turn up is computed here by the list tier's body on scratch in HBM, its support set re-gathered from the
+// scan: slower, the same result (each row counts its neighbours' densities itself: what the tier's per-scan cache shares).
+// Which of the two runs never changes a result — the host's memory of earlier batches chooses speed only.
+#define FX_DSLOW_T 256
+extern "C" __global__ __launch_bounds__(FX_DSLOW_T) void k_dense_slow(FxDevParams P, FxBuffers B) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const uint32_t n_rows = min(B.counters[6], P.max_dense_rows);
+  uint32_t *gs = B.gsd_pool + (size_t)blockIdx.x * P.gsd_words;
+  for (uint32_t slot = blockIdx.x; slot < n_rows; slot += gridDim.x) {
+    const uint32_t row = B.dense_rows[slot];
+    if (row == FX_NONE) continue;  // (no room in the pools: flagged by k_desc_group, as for the fast kernels)
+    const uint2 rm = B.row_map[row];
+    desc_body<true, FX_DSLOW_T, true>(P, B, row, rm.x, rm.y, P.max_points, smem, false, gs);
+    wg_global_sync();
+  }
 }
 
 // ---------------------------------------------------------------- dense tier
@@ -5689,6 +5723,10 @@ void fxk_desc_mid(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint3
                   uint32_t n_wave) {
   const size_t lds_wave = (size_t)(FX_NWAVE * FX_WAVE_WORDS + FX_TABLE_WORDS) * 4, lds_wg = fxk_desc_lds_bytes(cap);
   hipLaunchKernelGGL(k_desc_mid, dim3(n_wg + n_wave), dim3(FX_WG), lds_wave > lds_wg ? lds_wave : lds_wg, s, P, B, batch, cap, n_wg);
+}
+size_t fxk_dense_slow_words(uint32_t max_points) { return ((size_t)FX_DESC_WORDS_PER_POINT * max_points + 3) & ~(size_t)3; }
+void fxk_dense_slow(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t grid) {
+  hipLaunchKernelGGL(k_dense_slow, dim3(std::max(1u, std::min(grid, P.gsd_slots))), dim3(FX_DSLOW_T), (size_t)(16 + FX_DESC_BINS + 16) * 4, s, P, B);
 }
 // (rows and items are taken by ticket: any grid is correct; the full ones are what is resident at once)
 void fxk_dense(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t n_cu, uint32_t rows, uint32_t items) {

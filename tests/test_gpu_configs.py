@@ -56,6 +56,22 @@ def test_dense_128_ring_scan_radius_2m(fxlib, oracle, preset):
     ctx.close()
 
 
+def test_dense_128_ring_scan_through_the_one_small_dense_launch(fx_hooks, oracle):
+    """The same scan with every dense row — support sets of up to ~10 000 points — computed by k_dense_slow instead of the
+    dense tier's four kernels (what a batch gets whose predecessors had no dense row): the same result."""
+    fx_hooks(FX_DENSE_SLOW=1)
+    s = capi.synth_scan(capi.synth_cfg(50, n_poles=256, **DENSE))
+    p = _dense_params("launch")
+    ctx = capi.Context(p, capi.limits(1, 128 * 2048, max_candidates=8192, max_kpc_points=65536, max_keypoints=512, max_total_keypoints=512))
+    got = ctx.process_host([s], roll=0.02, pitch=-0.015)[0]
+    h = (C.c_uint32 * 8)()
+    ctx.lib.fx_debug_tier_hints.argtypes = [C.c_void_p, C.c_void_p]
+    capi.check(ctx.lib.fx_debug_tier_hints(ctx.handle, h))
+    st = util.compare_scan(got, oracle.run(p, s, roll=0.02, pitch=-0.015), tag="128 rings, dense rows by k_dense_slow")
+    assert st["K"] > 0 and h[4] > 20  # (dense rows there were)
+    ctx.close()
+
+
 def test_128_rings_by_4096_azimuths(fxlib, oracle):
     """A sensor beyond BASELINE's largest: 128 x 4096 = 524 288 points a scan, R = 2 m, launch preset (≈ 5000 per-ring
     candidates, support sets of more than 11 000 points).  Must run unflagged and match the oracle."""
