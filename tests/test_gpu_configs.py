@@ -68,7 +68,7 @@ def test_dense_128_ring_scan_through_the_one_small_dense_launch(fx_hooks, oracle
     ctx.lib.fx_debug_tier_hints.argtypes = [C.c_void_p, C.c_void_p]
     capi.check(ctx.lib.fx_debug_tier_hints(ctx.handle, h))
     st = util.compare_scan(got, oracle.run(p, s, roll=0.02, pitch=-0.015), tag="128 rings, dense rows by k_dense_slow")
-    assert st["K"] > 0 and h[4] > 20  # (dense rows there were)
+    assert st["K"] > 0 and h[4] > 0  # (dense rows there were: support sets beyond the 4096-entry lists of a 262 144-point scan)
     ctx.close()
 
 
