@@ -68,6 +68,15 @@ def build_trig_literal(force=False, verbose=False):
     return LIB_TRIG
 
 
+def build_variant(name, defines, force=False, verbose=False):
+    """A measurement build lib/libfx_hip_<name>.so with extra -D flags (tools/bench_lib.py, tools/*_stamps.py): diagnostic, never
+    the product."""
+    lib = os.path.join(HERE, "lib", f"libfx_hip_{name}.so")
+    if force or stale(lib):
+        _link(lib, list(defines), verbose)
+    return lib
+
+
 CLI = os.path.join(HERE, "bin", "fx_cli")
 CLI_SOURCES = ["fx_cli.cpp", "fx_node.hpp", "fx_pcd.hpp"]
 

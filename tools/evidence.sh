@@ -3,11 +3,12 @@
 # usage: tools/evidence.sh TAG        -> gpurun_out/evidence_TAG/* and gpurun_out/prof_TAG*/ (summarised afterwards with
 #        tools/summarize_profile.py TAG, TAG_c1 and tools/summarize_config_profile.py TAG 3|5)
 set -u
-TAG=${1:-r04i}
+TAG=${1:-r05a}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 E=$R/gpurun_out/evidence_$TAG
 mkdir -p "$E"
 cd "$R"
+bash tools/kernel_info.sh > "$E/kernel_info.txt" 2>&1   # registers, spills, scratch, LDS and code size of every kernel of the product library
 python3 bench.py > "$E/bench_default_run.json" 2> "$E/bench_default_run.err"
 FX_BENCH_FORCE_DIST=1 python3 bench.py --no-extras --no-cpu-baseline > "$E/force_dist.json" 2> "$E/force_dist.err"
 python3 bench.py --contexts 1 --no-extras --no-cpu-baseline > "$E/bench_one_at_a_time.json" 2> /dev/null
@@ -24,4 +25,8 @@ bash tools/profile.sh $TAG > "$E/profile.log" 2>&1
 bash tools/profile.sh ${TAG}_c1 --contexts 1 > "$E/profile_c1.log" 2>&1
 FX_PROFILE_PMC=1 bash tools/profile_config.sh $TAG 3 > "$E/profile_cfg3.log" 2>&1
 FX_PROFILE_PMC=1 bash tools/profile_config.sh $TAG 5 > "$E/profile_cfg5.log" 2>&1
+# parity beyond the suite, on this binary: the VLP-16 fuzz through five front paths, the dense fuzz, determinism
+timeout 1500 python3 tools/fuzz_more.py 0 1500 > "$E/fuzz_more.log" 2>&1
+timeout 900 python3 tools/fuzz_dense.py 0 300 > "$E/fuzz_dense.log" 2>&1
+feature_extraction_amd/bin/fx_multi_cli --selftest 8 --batch 61 --steps 6 --inflight 3 --bad-scan 60 > "$E/fx_multi_selftest8.log" 2>&1
 ls "$E"

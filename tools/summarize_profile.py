@@ -88,10 +88,10 @@ try:
     own = rf.get("kernel_exec_ms") or rf["kernel_ms"]
     ratio = avg_ms / own
     check_lines.append(f"{named}: rocprofv3 average {avg_ms:.4f} ms; the same run's own clock {rf.get('kernel_exec_ms')} ms (device span), "
-                       f"{rf['kernel_ms']:.4f} ms (HIP events): ratio to the run's own {ratio:.2f}")
+                       f"{rf['kernel_ms']:.4f} ms (HIP events, one batch on the chip, after the timed region): ratio to the run's own {ratio:.2f}")
     check_lines.append(f"own algorithmic bytes {rf['alg_bytes_per_launch']:.0f} / rocprofv3 average = {rf['alg_bytes_per_launch'] / (avg_ms * 1e-3) / 1e9:.0f} GB/s "
-                       f"= {rf['alg_bytes_per_launch'] / (avg_ms * 1e-3) / 1e9 / 8000:.3f} of the HBM peak (the line of that run says {rf['frac']:.3f} by HIP events, "
-                       f"{rf.get('frac_exec')} by the device span)")
+                       f"= {rf['alg_bytes_per_launch'] / (avg_ms * 1e-3) / 1e9 / 8000:.3f} of the HBM peak (the line of that run says frac {rf['frac']:.3f} = one batch on the chip, "
+                       f"frac_exec {rf.get('frac_exec')} = the device span with the other batches in flight)")
     check_lines.append(f"sum of kernel durations per batch {per_batch_ms:.3f} ms / {k_ctx} in flight = {per_batch_ms / k_ctx:.3f} ms; the run's ms_per_step "
                        f"{bj['ms_per_step']:.3f}; the profiled run made {bj['value']:.0f} scans/s")
     consistent = 0.85 <= ratio <= 1.15
