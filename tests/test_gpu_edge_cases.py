@@ -242,9 +242,12 @@ def test_dense_tier_query_marks_in_the_sorted_region(fx_hooks, oracle):
     _cmp(oracle, capi.params("default", descriptor_radius=4.0), capi.limits(1, 28800), [s], tag="dense neighbourhoods, marks in the sorted region")
 
 
-def test_dense_tier_pool_exhaustion_is_flagged(fxlib, oracle):
+@pytest.mark.parametrize("dense_slow", [0, 1])
+def test_dense_tier_pool_exhaustion_is_flagged(fx_hooks, oracle, dense_slow):
     """A sorted pool too small for the batch's dense rows: FX_FLAG_NBR_OVERFLOW on the scan, NaN descriptors for the rows
-    that did not fit, every other row still exact."""
+    that did not fit, every other row still exact — whether the tier's four kernels run or the one small launch that stands
+    in for them (the pool accounting is k_desc_group's, before either)."""
+    fx_hooks(FX_DENSE_SLOW=dense_slow)
     s = util.vlp16_scan(1000, n_poles=8, x_lo=3.0, x_hi=8.0, y_lo=-4.0, y_hi=4.0)
     p = capi.params("default", descriptor_radius=4.0)
     ora = oracle.run(p, s)
@@ -260,6 +263,24 @@ def test_dense_tier_pool_exhaustion_is_flagged(fxlib, oracle):
     for k in range(K):
         if k not in bad:
             np.testing.assert_allclose(got["descriptors"][k], ora["descriptors"][k], rtol=0, atol=util.DESC_TOL)
+
+
+def test_sparse_limits_preset_gives_the_same_results_and_flags_what_it_cannot_hold(fxlib, oracle):
+    """fx_limits_sparse (new in 0.6: small dense-tier pools and overflow regions, for VLP-16-class workloads — 4.5 GB a
+    1024-scan context instead of 7): the bench scans and a scan with a few dense rows come back exactly as with the default
+    limits; a scan whose rows overflow their lists by more than the preset's regions hold is FLAGGED, never silently short."""
+    p = capi.params("launch")
+    scans = [util.vlp16_scan(1000 + b) for b in range(3)]
+    _cmp(oracle, p, capi.limits(3, 28800, sparse=True), scans, 0.02, -0.015, "sparse preset, bench scans")
+    dense = util.vlp16_scan(1000, n_poles=8, x_lo=3.0, x_hi=8.0, y_lo=-4.0, y_hi=4.0)
+    pd = capi.params("default", descriptor_radius=4.0)
+    assert oracle.run(pd, dense)["kp_neighbors"].max() > 1100
+    _cmp(oracle, pd, capi.limits(2, 28800, sparse=True), [dense, scans[0]], tag="sparse preset, a few dense rows")
+    # support lists of 64 slots: every row overflows into the scan's region, which the preset sizes at 8192 entries
+    ctx = capi.Context(p, capi.limits(1, 28800, sparse=True, max_neighbors=64, max_overflow_points=256))
+    got = ctx.process_host([scans[0]], roll=0.02, pitch=-0.015)[0]
+    ctx.close()
+    assert got["flags"] & 0x8 and got["n_keypoints"] == oracle.run(p, scans[0], roll=0.02, pitch=-0.015)["n_keypoints"]
 
 
 def test_long_support_lists_use_the_workgroup_tiers(fxlib, oracle):
