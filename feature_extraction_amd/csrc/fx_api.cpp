@@ -38,6 +38,11 @@ uint32_t fxk_near_words(uint32_t max_points);
 void fxk_prep(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float near_margin, float el0, float inv_step,
               uint32_t clk_slot);
 void fxk_bucket(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float el0, float inv_step, uint32_t clk_next);
+uint32_t fxk_prep_slices_max(void);
+void fxk_prep_sliced(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t slices, float near_margin, float el0, float inv_step,
+                     uint32_t clk_slot);
+void fxk_bucket_sliced(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t slices, float el0, float inv_step,
+                       uint32_t clk_next);
 size_t fxk_ring_runs_lds_bytes(void);
 void fxk_rings_runs(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t max_pts, uint32_t grid);
 void fxk_merge_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap);
@@ -169,6 +174,7 @@ struct fx_ctx {
   // launch (k_dense_slow) that computes whatever does turn up, slower — the same results either way.
   uint32_t dense_fast_left = 0;            // batches that still get the four kernels after the last one that needed them
   static constexpr uint32_t dense_linger = 64;
+  int prep_slices = -1;                    // test hook (FX_PREP_SLICES): workgroups a scan in the separate kernels' streaming pass and ring split
   int dense_force = -1;                    // test hook (FX_DENSE_SLOW): 1 always the one launch, 0 always the four kernels
   uint32_t skip_mask = 0;      // experiment hook (FX_SKIP_EMPTY, test build): bit 0 no k_front_redo, bit 1 no dense tier — only for workloads that need neither
   static constexpr uint32_t front_retry = 64;
@@ -280,9 +286,24 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof, bo
       fxk_offsets(s, P, B, batch, clk_next);
       FX_HIP(mark(5));
     } else {
-    fxk_prep(s, P, B, batch, c->box_margin, el0, inv_step, clk_slot);
-    FX_HIP(mark(1));
-    fxk_bucket(s, P, B, batch, el0, inv_step, clk_next);
+    // one workgroup a scan when the batch fills the chip with that, several (a counting pass first) when it does not and the
+    // scans are big enough to be worth a second read: 64 scans of 262 144 points are 64 workgroups on 256 CUs
+    uint32_t slices = 1;
+    if (c->prep_slices >= 0) {
+      slices = (uint32_t)c->prep_slices;  // (test hook)
+    } else if (batch < 2u * big_grid && L.max_points >= 65536u) {
+      slices = (2u * big_grid + batch - 1u) / batch;
+    }
+    slices = std::max(1u, std::min(slices, fxk_prep_slices_max()));
+    if (slices > 1) {
+      fxk_prep_sliced(s, P, B, batch, slices, c->box_margin, el0, inv_step, clk_slot);
+      FX_HIP(mark(1));
+      fxk_bucket_sliced(s, P, B, batch, slices, el0, inv_step, clk_next);
+    } else {
+      fxk_prep(s, P, B, batch, c->box_margin, el0, inv_step, clk_slot);
+      FX_HIP(mark(1));
+      fxk_bucket(s, P, B, batch, el0, inv_step, clk_next);
+    }
     FX_HIP(mark(2));
     // one wavefront per (scan, ring): the hardware dispatcher balances the rings, whose costs differ a lot
     // (persistent wavefronts striding over the items: 0.18 ms instead of 0.14)
@@ -567,6 +588,8 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   FX_A(dev_alloc(c, &b.filt, B * L.max_points));
   FX_A(dev_alloc(c, &b.n_filt, B));
   FX_A(dev_alloc(c, &b.near_bits, B * P.near_words));
+  FX_A(dev_alloc(c, &b.prep_cnt, B * fxk_prep_slices_max()));
+  FX_A(dev_alloc(c, &b.prep_ring_cnt, B * fxk_prep_slices_max() * R));
   FX_A(dev_alloc(c, &b.ring_cand, B * R * L.max_ring_candidates));
   FX_A(dev_alloc(c, &b.ring_cand_size, B * R * L.max_ring_candidates));
   FX_A(dev_alloc(c, &b.ring_cand_cnt, B * R));
@@ -734,6 +757,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   if (const char *e = test_hook("FX_FAIL_AFTER_ENQUEUE")) c->fail_after = (uint32_t)std::max(0, atoi(e));
   if (const char *e = test_hook("FX_SKIP_EMPTY")) c->skip_mask = (uint32_t)std::max(0, atoi(e));
   if (const char *e = test_hook("FX_DENSE_SLOW")) c->dense_force = atoi(e) != 0 ? 1 : 0;
+  if (const char *e = test_hook("FX_PREP_SLICES")) c->prep_slices = std::max(1, atoi(e));
   if (c->front_ok) {
     hipError_t ce = fxk_configure_front();
     if (ce != hipSuccess) return bail(fail(FX_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(ce)));

@@ -78,6 +78,8 @@ struct FxBuffers {
   float4 *filt;          // [B][max_points]
   uint32_t *n_filt;      // [B]
   uint32_t *near_bits;   // [B][near_words]  bit: some point of that sector (4 points) is within the descriptor stage's reach of the filter box
+  uint32_t *prep_cnt;       // [B][S]     survivors of slice s of the scan (k_prep_count; S workgroups a scan: small batches of big scans)
+  uint32_t *prep_ring_cnt;  // [B][S][n_rings]  their ring counts (k_prep_sliced -> k_bucket_sliced)
   // stage 2a: ring-major copy of the filtered cloud
   float4 *ring_pts;         // [B][ring_slot_cap]
   uint32_t *ring_off;       // [B][n_rings]

@@ -949,9 +949,12 @@ struct PrepLds {
 // 50 MB of HBM traffic a batch).  A scan with more survivors than L.keep_cap makes the pass return FX_NONE at the tile that
 // no longer fits (the caller runs the recycling instance over the whole scan again: rare, and such a scan is
 // k_front_redo's anyway).
+// (t_begin, t_end, base0: the points [t_begin, t_end) of the scan only — t_begin a multiple of the tile —, their survivors
+//  written from position base0 of the filtered cloud on: one of several workgroups of a scan, k_prep_sliced)
 template <bool KEEP = false>
 __device__ __forceinline__ uint32_t prep_stream(const FxDevParams &P, const FxBuffers &B, const FxScanMeta &M, uint32_t scan,
-                                                float near_margin, float el0, float inv_step, const PrepLds &L) {
+                                                float near_margin, float el0, float inv_step, const PrepLds &L, uint32_t t_begin = 0u,
+                                                uint32_t t_end = 0xffffffffu, uint32_t base0 = 0u) {
   constexpr int NW = FX_PREP_T / 64;
   constexpr uint32_t kTile = FX_PREP_TILE;           // points per tile; wave w owns [256 w, 256 w + 256) of it
   constexpr uint32_t kKeep = FX_PREP_KEEP;
@@ -964,8 +967,8 @@ __device__ __forceinline__ uint32_t prep_stream(const FxDevParams &P, const FxBu
   float4 *out = B.filt + (size_t)scan * P.max_points;
   uint32_t *near_bits = B.near_bits + (size_t)scan * P.near_words;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  uint32_t base = 0, buffered = 0, parity = 0;
-  const uint32_t n = M.n;
+  uint32_t base = base0, buffered = 0, parity = 0;
+  const uint32_t n = min(M.n, t_end);
   // (global address space stated: a generic-pointer load would be a flat load, which also counts as an
   //  LDS access and gets waited for at the next LDS instruction)
   const gfloat *gpts = (const gfloat *)M.pts;
@@ -1028,9 +1031,9 @@ __device__ __forceinline__ uint32_t prep_stream(const FxDevParams &P, const FxBu
   //  not waiting for them: a second tile of loads in flight, tile buffers that take turns without the register copies below
   //  (a copy waits for the copied register's load) and 16-byte loads all left the kernel's time where it was.)
   float4 v[FX_PREP_U], nv[FX_PREP_U];
-  load_tile(0, v);
+  load_tile(t_begin, v);
   FX_STAMP(24);
-  for (uint32_t t0 = 0; t0 < n; t0 += kTile) {
+  for (uint32_t t0 = t_begin; t0 < n; t0 += kTile) {
     load_tile(t0 + kTile, nv);
     FX_STAMP(30);
     bool keep[FX_PREP_U];
@@ -1158,6 +1161,89 @@ __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, 
   if (tid == 0) atomicMax(&B.clk[2 * clk_slot + 1], (unsigned long long)wall_clock64());
 }
 
+// ---- several workgroups a scan (batches that leave most of the chip idle with one: 64 scans of 262 144 points are 64
+// workgroups on 256 CUs, each streaming at what ONE CU's memory pipe gives).  Slice s of S takes the tiles
+// [s per, (s + 1) per) of the scan.  Its survivors must land behind those of the slices before it: a counting pass first
+// (k_prep_count: rotate, test, count — nothing stored), then the streaming pass proper with every slice's base known
+// (k_prep_sliced).  The scan is read twice, by eight times as many workgroups; nothing waits on another workgroup.
+__device__ __forceinline__ uint32_t prep_slice_tiles(uint32_t n, uint32_t S) {
+  const uint32_t tiles = (n + FX_PREP_TILE - 1u) / FX_PREP_TILE;
+  return (tiles + S - 1u) / S;
+}
+extern "C" __global__ __launch_bounds__(FX_PREP_T) void k_prep_count(FxDevParams P, FxBuffers B) {
+  const uint32_t slice = blockIdx.x, S = gridDim.x, scan = blockIdx.y, tid = threadIdx.x;
+  const FxScanMeta M = B.meta[scan];
+  __shared__ uint32_t s_tot[FX_PREP_T / 64];
+  uint32_t cnt = 0;
+  if (M.n) {
+    const uint32_t per = prep_slice_tiles(M.n, S) * FX_PREP_TILE;
+    const uint32_t lo = slice * per, hi = min(M.n, lo + per);
+    const gfloat *gpts = (const gfloat *)M.pts;
+    auto lo_lim = [](float v) { return fmaxf(v, -FLT_MAX); };
+    auto hi_lim = [](float v) { return fminf(v, FLT_MAX); };
+    const float fx0 = lo_lim(P.x_min), fx1 = hi_lim(P.x_max), fy0 = lo_lim(P.y_min), fy1 = hi_lim(P.y_max), fz0 = lo_lim(P.z_min), fz1 = hi_lim(P.z_max);
+    for (uint32_t i0 = lo; i0 < hi; i0 += 4u * FX_PREP_T) {  // (four loads in flight a lane)
+      float x[4], y[4], z[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t i = i0 + u * FX_PREP_T + tid;
+        const gfloat *q = gpts + (size_t)min(i, hi - 1u) * M.stride_f;
+        x[u] = i < hi ? q[0] : NAN, y[u] = q[1], z[u] = q[2];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {  // prep_stream's predicate: the same arithmetic, the same clamped limits
+        const float rx = (M.R[0] * x[u] + M.R[1] * y[u]) + M.R[2] * z[u];
+        const float ry = (M.R[3] * x[u] + M.R[4] * y[u]) + M.R[5] * z[u];
+        const float rz = (M.R[6] * x[u] + M.R[7] * y[u]) + M.R[8] * z[u];
+        cnt += (rx >= fx0 && rx <= fx1 && ry >= fy0 && ry <= fy1 && rz >= fz0 && rz <= fz1) ? 1u : 0u;
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, d, 64);
+  if ((tid & 63u) == 0) s_tot[tid >> 6] = cnt;
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t t = 0;
+    for (int w = 0; w < FX_PREP_T / 64; ++w) t += s_tot[w];
+    B.prep_cnt[(size_t)scan * S + slice] = t;
+  }
+}
+extern "C" __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep_sliced(FxDevParams P, FxBuffers B, float near_margin, float el0, float inv_step,
+                                                                                 uint32_t clk_slot) {
+  constexpr int NW = FX_PREP_T / 64;
+  const uint32_t slice = blockIdx.x, S = gridDim.x, scan = blockIdx.y, tid = threadIdx.x;
+  const FxScanMeta M = B.meta[scan];
+  __shared__ uint32_t s_cnt[2 * NW];
+  __shared__ float s_keep[3 * FX_PREP_KEEP];
+  __shared__ uint32_t s_ring[FX_MAX_RINGS];
+  __shared__ double s_atan[(FX_ATAN_N + 1) * (FX_ATAN_DEG + 1)];
+  __shared__ float2 s_win[FX_MAX_RINGS];
+  if (tid == 0) atomicMin(&B.clk[2 * clk_slot], (unsigned long long)wall_clock64());
+  const uint32_t R = (uint32_t)P.n_rings;
+  uint32_t *prc = B.prep_ring_cnt + ((size_t)scan * S + slice) * R;
+  if (scan == 0 && slice == 0 && tid < FX_N_COUNTERS) B.counters[tid] = 0u;  // work-list counters of the batch (used from k_rings_runs on)
+  if (M.n == 0) {  // empty scan: its pointer may be null — nothing is loaded
+    if (tid == 0 && slice == 0) {
+      B.n_filt[scan] = 0u;
+      B.flags[scan] = 0u;
+    }
+    for (uint32_t r = tid; r < R; r += FX_PREP_T) prc[r] = 0u;
+    return;
+  }
+  uint32_t base0 = 0;
+  for (uint32_t j = 0; j < slice; ++j) base0 += B.prep_cnt[(size_t)scan * S + j];  // (workgroup-uniform)
+  const uint32_t per = prep_slice_tiles(M.n, S) * FX_PREP_TILE;
+  const PrepLds L{s_cnt, s_keep, s_ring, s_atan, s_win, nullptr, 0u};
+  const uint32_t end = prep_stream<false>(P, B, M, scan, near_margin, el0, inv_step, L, slice * per, slice * per + per, base0);
+  for (uint32_t r = tid; r < R; r += FX_PREP_T) prc[r] = s_ring[r];
+  if (tid == 0) {
+    if (slice == 0) B.flags[scan] = 0u;
+    if (slice == S - 1u) B.n_filt[scan] = end;
+  }
+  if (tid == 0) atomicMax(&B.clk[2 * clk_slot + 1], (unsigned long long)wall_clock64());
+}
+
 // ====================================================================== stage 2a: ring buckets
 // estimateKeypoints' ring loop (ref: node.cpp:195-202) runs 16 PassThrough filters over the
 // filtered cloud.  Here one workgroup per scan deals the filtered points to their rings in
@@ -1168,8 +1254,13 @@ __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep(FxDevParams P, 
 #endif
 #define FX_BUCKET_NW (FX_BUCKET_T / 64)
 // MANY: sensors of more than 24 rings (the sort-based ranking below is compiled only into that instance)
+// (prc: the scan is split over S workgroups — k_bucket_sliced —, this one takes the survivors [f_begin, f_end) that workgroup
+//  `slice` of k_prep_sliced wrote, whose per-ring counts are prc[(scan S + j) R + r]: a ring's total is their sum, this
+//  slice's first place in the ring the sum over the slices before it)
 template <bool MANY, int NT>
-__device__ __forceinline__ void bucket_body(const FxDevParams &P, const FxBuffers &B, uint32_t scan, float el0, float inv_step, uint32_t *smem) {
+__device__ __forceinline__ void bucket_body(const FxDevParams &P, const FxBuffers &B, uint32_t scan, float el0, float inv_step, uint32_t *smem,
+                                            const uint32_t *prc = nullptr, uint32_t S = 1u, uint32_t slice = 0u, uint32_t f_begin = 0u,
+                                            uint32_t f_end = 0xffffffffu) {
   constexpr int NWV = NT / 64;
   const uint32_t R = (uint32_t)P.n_rings;
   uint32_t *s_w = smem;            // 48: block helpers, per-wave ring ranges
@@ -1177,9 +1268,22 @@ __device__ __forceinline__ void bucket_body(const FxDevParams &P, const FxBuffer
   uint32_t *off = cnt + R;         // [R + 1]
   uint32_t *cw = off + R + 1;      // [NT / 64][R] per-wave counts of the current chunk
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t nf = B.n_filt[scan];
+  const uint32_t nf = min(B.n_filt[scan], f_end);
   const float4 *f = B.filt + (size_t)scan * P.max_points;
-  for (uint32_t r = tid; r < R; r += NT) cnt[r] = B.ring_cnt[(size_t)scan * R + r];  // counted by k_prep's sweep
+  for (uint32_t r = tid; r < R; r += NT) {
+    uint32_t c = 0, fill = 0;  // the ring's points in all slices / in the slices before this one
+    if (prc) {
+      for (uint32_t j = 0; j < S; ++j) {
+        const uint32_t v = prc[((size_t)scan * S + j) * R + r];
+        c += v;
+        fill += j < slice ? v : 0u;
+      }
+    } else {
+      c = B.ring_cnt[(size_t)scan * R + r];  // counted by k_prep's sweep
+    }
+    cnt[r] = c;
+    cw[r] = fill;  // (cw is free until the chunk loop: parked here until cnt becomes the running fill)
+  }
   __syncthreads();
   uint32_t total = 0;
   for (uint32_t b0 = 0; b0 < R; b0 += NT) {
@@ -1194,17 +1298,19 @@ __device__ __forceinline__ void bucket_body(const FxDevParams &P, const FxBuffer
   const bool overflow = total > P.ring_slot_cap;
   uint32_t *g_off = B.ring_off + (size_t)scan * R, *g_cnt = B.ring_cnt + (size_t)scan * R;
   for (uint32_t r = tid; r < R; r += NT) {
-    g_off[r] = overflow ? 0u : off[r];
-    g_cnt[r] = overflow ? 0u : cnt[r];
-    cnt[r] = 0;  // becomes the running fill
+    if (slice == 0) {
+      g_off[r] = overflow ? 0u : off[r];
+      g_cnt[r] = overflow ? 0u : cnt[r];
+    }
+    cnt[r] = cw[r];  // becomes the running fill (from the slices before this one)
   }
   if (overflow) {
-    if (tid == 0) atomicOr(&B.flags[scan], FX_FLAG_RING_OVERFLOW);
+    if (tid == 0 && slice == 0) atomicOr(&B.flags[scan], FX_FLAG_RING_OVERFLOW);
     return;
   }
   __syncthreads();
   float4 *dst = B.ring_pts + (size_t)scan * P.ring_slot_cap;
-  for (uint32_t b0 = 0; b0 < nf; b0 += NT) {
+  for (uint32_t b0 = f_begin; b0 < nf; b0 += NT) {
     const uint32_t i = b0 + tid;
     float4 v = make_float4(0, 0, 0, 0);
     int r_first = 0;
@@ -1310,6 +1416,23 @@ extern "C" __global__ __launch_bounds__(FX_BUCKET_T) void k_bucket_many(FxDevPar
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   clk_reset(B, clk_next);
   bucket_body<true, FX_BUCKET_T>(P, B, blockIdx.x, el0, inv_step, smem);
+}
+
+// the ring split of a scan by S workgroups: workgroup `slice` deals the survivors slice `slice` of k_prep_sliced wrote
+extern "C" __global__ __launch_bounds__(FX_BUCKET_T) void k_bucket_sliced(FxDevParams P, FxBuffers B, float el0, float inv_step, uint32_t clk_next) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const uint32_t slice = blockIdx.x, S = gridDim.x, scan = blockIdx.y;
+  if (scan == 0 && slice == 0 && threadIdx.x == 0) {
+    B.clk[2 * clk_next] = ~0ull;
+    B.clk[2 * clk_next + 1] = 0ull;
+  }
+  uint32_t f_begin = 0;
+  for (uint32_t j = 0; j < slice; ++j) f_begin += B.prep_cnt[(size_t)scan * S + j];
+  const uint32_t f_end = f_begin + B.prep_cnt[(size_t)scan * S + slice];
+  if (P.n_rings > 24)
+    bucket_body<true, FX_BUCKET_T>(P, B, scan, el0, inv_step, smem, B.prep_ring_cnt, S, slice, f_begin, f_end);
+  else
+    bucket_body<false, FX_BUCKET_T>(P, B, scan, el0, inv_step, smem, B.prep_ring_cnt, S, slice, f_begin, f_end);
 }
 
 // ====================================================================== stage 2b: rings
@@ -5643,6 +5766,19 @@ uint32_t fxk_near_words(uint32_t max_points) { return (max_points + FX_PREP_TILE
 void fxk_prep(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float near_margin, float el0, float inv_step,
               uint32_t clk_slot) {
   hipLaunchKernelGGL(k_prep, dim3(batch), dim3(FX_PREP_T), 0, s, P, B, near_margin, el0, inv_step, clk_slot);
+}
+// several workgroups a scan for batches that would otherwise leave most of the chip idle (see k_prep_count)
+#define FX_PREP_SLICES_MAX 16u
+uint32_t fxk_prep_slices_max(void) { return FX_PREP_SLICES_MAX; }
+void fxk_prep_sliced(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t slices, float near_margin, float el0, float inv_step,
+                     uint32_t clk_slot) {
+  hipLaunchKernelGGL(k_prep_count, dim3(slices, batch), dim3(FX_PREP_T), 0, s, P, B);
+  hipLaunchKernelGGL(k_prep_sliced, dim3(slices, batch), dim3(FX_PREP_T), 0, s, P, B, near_margin, el0, inv_step, clk_slot);
+}
+void fxk_bucket_sliced(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t slices, float el0, float inv_step,
+                       uint32_t clk_next) {
+  const size_t lds = (48 + (size_t)P.n_rings * (2 + FX_BUCKET_NW) + 1) * 4;
+  hipLaunchKernelGGL(k_bucket_sliced, dim3(slices, batch), dim3(FX_BUCKET_T), lds, s, P, B, el0, inv_step, clk_next);
 }
 void fxk_bucket(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float el0, float inv_step,
                 uint32_t clk_next) {
