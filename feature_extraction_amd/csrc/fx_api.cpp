@@ -291,7 +291,9 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof, bo
     uint32_t slices = 1;
     if (c->prep_slices >= 0) {
       slices = (uint32_t)c->prep_slices;  // (test hook)
-    } else if (batch < 2u * big_grid && L.max_points >= 65536u) {
+    } else if (4u * batch <= 2u * big_grid && L.max_points >= 65536u) {
+      // (from four workgroups a scan on: with two — 256 scans of 131 072 points — the second read of the scan costs more
+      //  than the wider grid gains: k_prep 0.15 -> 0.23 ms; with eight — 64 scans of 262 144 points — 0.23 -> 0.125 ms)
       slices = (2u * big_grid + batch - 1u) / batch;
     }
     slices = std::max(1u, std::min(slices, fxk_prep_slices_max()));
