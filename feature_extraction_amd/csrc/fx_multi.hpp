@@ -91,6 +91,7 @@ class MultiGpu {
       : devices_(devices), max_batch_(max_batch), in_flight_(opt.in_flight ? opt.in_flight : 1u), host_gather_(opt.host_gather) {
     const uint32_t G = (uint32_t)devices.size();
     if (!G) throw std::invalid_argument("fx::MultiGpu: no devices");
+    if (FX_CHECK_ABI() != FX_OK) throw std::runtime_error(std::string("fx_check_abi: ") + fx_last_error());  // (this translation unit's fx.h against the library's)
     per_rank_ = (max_batch + G - 1) / G;
     for (uint32_t r = 0; r < G; ++r) ranks_.emplace_back(new Rank());
     comms_.assign(G, nullptr);
