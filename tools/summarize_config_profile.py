@@ -46,7 +46,7 @@ def counter(pattern, cname):
 if glob.glob(os.path.join(src, "fetch/**/*_counter_collection.csv"), recursive=True):
     fetch, dur, calls = counter("fetch/**/*_counter_collection.csv", "FETCH_SIZE")
     write, _, _ = counter("write/**/*_counter_collection.csv", "WRITE_SIZE")
-    nb = calls["k_prep"]
+    nb = calls.get("k_prep") or calls.get("k_prep_sliced") or calls["k_offsets"]  # launches per batch: one (k_prep_sliced: small batches of big scans)
     rows = []
     for k in sorted(fetch, key=lambda k: -dur[k]):
         if not k.startswith("k_"):
@@ -63,5 +63,5 @@ if glob.glob(os.path.join(src, "fetch/**/*_counter_collection.csv"), recursive=T
         print(r)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import sq_summary  # noqa: E402
-sq_summary.write_table(src, os.path.join(dst, f"{tag}_cfg{cfg}_sq_counters.csv"), counter, "k_prep")
+sq_summary.write_table(src, os.path.join(dst, f"{tag}_cfg{cfg}_sq_counters.csv"), counter, "k_prep" if calls.get("k_prep") else "k_prep_sliced")
 print(open(os.path.join(dst, f"{tag}_cfg{cfg}_run.txt")).read())
