@@ -2636,6 +2636,9 @@ extern "C" __global__ __launch_bounds__(FX_MSMALL_T) void k_merge_small(FxDevPar
     for (uint32_t t = z0 + threadIdx.x; t < z1; t += FX_MSMALL_T) B.s_cnt[t] = 0u;
     if (threadIdx.x == 0) B.ovf_cnt[blockIdx.x] = 0u;  // entries in the scan's overflow region (k_gather)
   }
+  // (a scan with a ring still waiting for the slow tier is merged there, once, from all its rings: a merge of the rings that
+  //  are ready could split a cluster in two and flag a keypoint overflow the whole scan does not have)
+  if (B.slow_state[blockIdx.x] != 0u) return;
   if (!merge_body<FX_MSMALL_T, true>(P, B, blockIdx.x, cap, cap, smem, false)) {
     if (threadIdx.x == 0) {
       const uint32_t pos = atomicAdd(&B.counters[1], 1u);
