@@ -52,7 +52,8 @@ OTHER_CONFIGS = {
         batch=64, n_uniq=8, synth=dict(n_rings=128, n_az=2048, el0_deg=-25.0, el_step_deg=40.0 / 127, n_poles=256),
         preset="launch", params=dict(n_rings=128, el0_deg=-25.0, el_step_deg=40.0 / 127, secondary_max=128, descriptor_radius=2.0),
         limits=dict(max_candidates=8192, max_kpc_points=65536, max_keypoints=512, max_total_keypoints=64 * 256),
-        in_flight=6),  # (64-scan batches: several kernels are one workgroup a scan; measured 2 / 4 / 6 / 8 in flight: 4.4 / 7.5 / 8.1 / 6.1e4)
+        in_flight=4),  # (measured 2 / 3 / 4 / 5 / 6 / 8 in flight: 5.9 / 7.5 / 8.5 / 8.1 / 8.5 / 7.5e4 — four since the streaming pass and the ring split
+                       #  take several workgroups a scan; before that six were needed for 8.1e4)
 }
 
 
