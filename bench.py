@@ -214,16 +214,25 @@ def main():
     capi.load()  # raises if the HIP library is missing
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # FX_BENCH_ONE_DEVICE=1 (TEST mode, tests/test_gpu_bench_multi.py): every rank on device 0 over gloo, the gather through
+    # host memory — the N > 1 control flow of this script (launch environment, build handshake, seeds, agreement, the timed
+    # regions, rank 0's checks and its one JSON line) on a box with ONE GPU.  Never a measurement: RCCL refuses two ranks
+    # on one device, and the ranks share the chip.
+    one_device = os.environ.get("FX_BENCH_ONE_DEVICE") == "1"
+    dev_index = 0 if one_device else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     use_dist = world > 1 or os.environ.get("FX_BENCH_FORCE_DIST") == "1"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         if rank == 0:
             print(f"[bench] torch.distributed backend {dist.get_backend()} (RCCL), world {dist.get_world_size()}", file=sys.stderr)
-    coll = bench_dist.Collectives(torch, dist, dev, rank, world, use_dist)
+    coll = bench_dist.Collectives(torch, dist, "cpu" if one_device else dev, rank, world, use_dist)
 
     B, N = args.batch, N_RINGS * N_AZ
     roll, pitch = 0.02, -0.015
@@ -238,7 +247,7 @@ def main():
     # bound and leave issue slots, LDS and whole CUs idle (tails, the large tiers' thin launches), which the
     # kernels of the other batches in flight fill.  One step is still one pass over one batch of B scans.
     K = max(1, args.contexts)
-    ctxs = [capi.Context(params, capi.limits(B, N, sparse=True), device=local_rank) for _ in range(K)]  # (fx_limits_sparse: VLP-16 scans never need the dense tier's full pools: 4.5 GB a context, not 7)
+    ctxs = [capi.Context(params, capi.limits(B, N, sparse=True), device=dev_index) for _ in range(K)]  # (fx_limits_sparse: VLP-16 scans never need the dense tier's full pools: 4.5 GB a context, not 7)
     ctx = ctxs[0]
     REC_KP = int(ctx.limits.max_keypoints)  # record stride = the context's keypoint capacity: a gathered record is never truncated
     # the contexts' own HIP streams, wrapped for torch (streams from torch's pool can share a hardware queue: two such
@@ -266,7 +275,7 @@ def main():
     # FX_BENCH_TORCH_GATHER=1 takes torch.distributed's all_gather_into_tensor instead (sharding.all_gather_records, the
     # function the gloo test runs)
     rccl, rccl_comms = None, 1
-    if use_dist and os.environ.get("FX_BENCH_TORCH_GATHER") != "1":
+    if use_dist and os.environ.get("FX_BENCH_TORCH_GATHER") != "1" and not one_device:
         # ONE communicator for all contexts, its collectives issued in step order on every rank: RCCL's ordering contract,
         # whatever the streams do.  Measured on one rank with the collective forced: 1.50 million scans/s against 1.68
         # without a collective — the shared communicator orders the contexts' streams against each other.  One
@@ -286,6 +295,9 @@ def main():
         ctxs[j].pack_keypoint_records(recs[j].data_ptr(), REC_KP)
         if rccl is not None:  # the path's one collective, an ordinary kernel of this context's stream
             rccl.all_gather(recs[j], gathered[j], streams[j].cuda_stream, comm=j % rccl_comms)
+        elif use_dist and one_device:  # (test mode: gloo has no device all-gather — through host memory, synchronously)
+            streams[j].synchronize()
+            gathered[j].copy_(sharding.all_gather_records(recs[j].cpu(), world))
         elif use_dist:
             return sharding.all_gather_records(recs[j], world, out=gathered[j], async_op=True)[1]
         return None
@@ -454,7 +466,8 @@ def main():
             "config": {"workload": f"batch of {B} synthetic VLP-16 scans (16x1800 pts, 64 uniform poles) per GPU, "
                                    f"device-resident, preset '{args.preset}', roll/pitch 0.02/-0.015",
                        "scans_per_gpu": B, "points_per_scan": N, "preset": args.preset,
-                       "parallelism": f"frame-sharded x{world}" + (", all-gather of keypoint records (RCCL)" if world > 1 else ""),
+                       "parallelism": f"frame-sharded x{world}" + (", all-gather of keypoint records (RCCL)" if world > 1 else "")
+                                      + (" — TEST MODE: all ranks on one device over gloo, not a measurement" if one_device else ""),
                        "keypoints_per_scan": k_all / (world * B), "flags_or": flags_or, "batches_in_flight": K,
                        "gathered_record_flags_or": flag_msg},
             # frac = the dominant kernel's own algorithmic bytes / its duration with ONE batch on the chip (HIP events, 20
@@ -514,7 +527,7 @@ def main():
         if not args.no_extras:
             out["h2d_inclusive_scans_per_s"] = h2d_inclusive(ctx, capi, host, B, N, roll, pitch)
             ctx.close()
-            h2h = [capi.Context(params, capi.limits(B, N, sparse=True), device=local_rank) for _ in range(3)]
+            h2h = [capi.Context(params, capi.limits(B, N, sparse=True), device=dev_index) for _ in range(3)]
             # (on the contexts' own streams: a torch stream that has run work keeps its hardware queue for the life of the process —
             #  three of eight — and the six contexts of config 5 below then shared the rest: 6.2e4 instead of 8.3e4 scans/s)
             out["host_to_host_scans_per_s"] = host_to_host(h2h, capi, torch, host, B, N, roll, pitch)
