@@ -249,6 +249,8 @@ def main():
     K = max(1, args.contexts)
     ctxs = [capi.Context(params, capi.limits(B, N, sparse=True), device=dev_index) for _ in range(K)]  # (fx_limits_sparse: VLP-16 scans never need the dense tier's full pools: 4.5 GB a context, not 7)
     ctx = ctxs[0]
+    for c in ctxs:
+        c.set_batches_in_flight(K)  # (launch-policy hint: the grid-stride kernels share the chip with the other batches' kernels)
     REC_KP = int(ctx.limits.max_keypoints)  # record stride = the context's keypoint capacity: a gathered record is never truncated
     # the contexts' own HIP streams, wrapped for torch (streams from torch's pool can share a hardware queue: two such
     # contexts then do not overlap at all; FX_BENCH_TORCH_STREAMS=1 brings them back)

@@ -102,7 +102,7 @@ class FxSynthCfg(C.Structure):
 # every symbol include/fx.h declares (tests/test_capi_symbols.py checks the list against the header)
 FX_HEADER_VERSION = (0 << 16) | 6  # the include/fx.h these ctypes structures mirror
 EXPORTS = ("fx_version", "fx_check_abi", "fx_status_str", "fx_last_error", "fx_params_default", "fx_params_launch",
-           "fx_limits_default", "fx_limits_sparse", "fx_create", "fx_destroy", "fx_set_stream", "fx_get_stream", "fx_set_graph_batch", "fx_set_profiling", "fx_set_profiling_stages", "fx_get_timings",
+           "fx_limits_default", "fx_limits_sparse", "fx_create", "fx_destroy", "fx_set_stream", "fx_get_stream", "fx_set_graph_batch", "fx_set_batches_in_flight", "fx_set_profiling", "fx_set_profiling_stages", "fx_get_timings",
            "fx_get_stage_bytes", "fx_get_limits", "fx_process_batch", "fx_synchronize", "fx_pack_features", "fx_pack_keypoint_records",
            "fx_rotation_from_roll_pitch", "fx_sc3d_tables", "fx_sc3d_xaxis", "fx_synth_cfg_vlp16",
            "fx_synth_scan", "fx_unpack_pointcloud2", "fx_pack_pointxyzi")
@@ -185,6 +185,7 @@ def load():
     lib.fx_set_profiling.argtypes = [C.c_void_p, C.c_int]
     lib.fx_set_profiling_stages.argtypes = [C.c_void_p, C.c_uint32]
     lib.fx_set_graph_batch.argtypes = [C.c_void_p, C.c_uint32]
+    lib.fx_set_batches_in_flight.argtypes = [C.c_void_p, C.c_uint32]
     lib.fx_get_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     lib.fx_get_stream.restype = C.c_int
     lib.fx_get_timings.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(FxTimings)]
@@ -317,6 +318,10 @@ class Context:
         p = C.c_void_p()
         check(self.lib.fx_get_stream(self.handle, C.byref(p)))
         return p.value or 0
+
+    def set_batches_in_flight(self, n):
+        """Launch-policy hint: how many contexts the caller keeps busy on this device at a time (results never depend on it)."""
+        check(self.lib.fx_set_batches_in_flight(self.handle, int(n)))
 
     def set_graph_batch(self, max_batch):
         check(self.lib.fx_set_graph_batch(self.handle, int(max_batch)))

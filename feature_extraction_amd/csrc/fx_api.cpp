@@ -124,7 +124,8 @@ struct fx_ctx {
   int meta_next = 0;
   FxScanMeta *d_meta = nullptr;
   float box_margin = 0.f;
-  uint32_t desc_wgs_per_cu = 10;
+  uint32_t desc_wgs_per_cu = 0;  // k_desc_group's workgroups a CU (0: by batches_in_flight; FX_DESC_WGS_PER_CU in the test build)
+  uint32_t batches_in_flight = 1;  // fx_set_batches_in_flight: the caller's contexts busy on this device at a time
   uint32_t ring_lds_cap = 0;     // points a ring may have in the workgroup ring tier's LDS (<= max_ring_points; beyond: k_slow)
   uint32_t merge_big_cap = 0;    // candidates the LDS merge tier holds as points (<= max_candidates)
   uint32_t merge_huge_cap = 0;   // candidates the large merge tier (coordinates in HBM, tables in LDS) holds (<= max_candidates; beyond: k_slow)
@@ -269,7 +270,11 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof, bo
   if (!batch) FX_HIP(hipMemsetAsync(B.counters, 0, FX_N_COUNTERS * sizeof(uint32_t), s));  // (k_prep clears them otherwise)
   if (batch) {
     const uint32_t merge_small = L.max_candidates < kMergeCapSmall ? L.max_candidates : kMergeCapSmall;
-    const uint32_t desc_grid = (uint32_t)c->n_cu * c->desc_wgs_per_cu;  // resident all at once (32 KB LDS each)
+    // k_desc_group strides over the rows: ten workgroups a CU (resident all at once, 32 KB of LDS each) when the batch has the
+    // chip to itself; with batches in flight fewer, longer-lived ones (measured, 1 / 2 / 3 / 4 batches in flight, scans/s with
+    // 10 against 1 a CU: 1.64 / 1.47, 2.11 / 2.04, 2.25 / 2.27 — 2.29 with 3 —, 2.32 / 2.38e6: profiles/r05_experiments.md)
+    const uint32_t desc_per_cu = c->desc_wgs_per_cu ? c->desc_wgs_per_cu : (c->batches_in_flight >= 4u ? 1u : (c->batches_in_flight == 3u ? 3u : 10u));
+    const uint32_t desc_grid = (uint32_t)c->n_cu * desc_per_cu;
     const uint32_t clk_slot = (uint32_t)(c->batch_seq % FX_CLK_SLOTS), clk_next = (uint32_t)((c->batch_seq + 1) % FX_CLK_SLOTS);
     const float el0 = (float)c->params.el0_deg, inv_step = (float)(1.0 / c->params.el_step_deg);
     if (front) {
@@ -795,6 +800,13 @@ fx_status fx_set_stream(fx_ctx *c, void *hip_stream) {
 fx_status fx_get_stream(fx_ctx *c, void **hip_stream) {
   if (!c || !hip_stream) return fail(FX_ERR_INVALID_ARG, "null argument");
   *hip_stream = (void *)c->stream;
+  return FX_OK;
+}
+fx_status fx_set_batches_in_flight(fx_ctx *c, uint32_t n) {
+  if (!c) return fail(FX_ERR_INVALID_ARG, "null ctx");
+  c->batches_in_flight = n ? n : 1u;
+  for (auto &g : c->graphs) (void)hipGraphExecDestroy(g.second);  // (captured grids are fixed: graphs are rebuilt with the new ones)
+  c->graphs.clear();
   return FX_OK;
 }
 fx_status fx_set_graph_batch(fx_ctx *c, uint32_t max_batch) {

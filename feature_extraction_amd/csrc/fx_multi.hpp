@@ -117,6 +117,7 @@ class MultiGpu {
           fx_limits got;
           fx_get_limits(S.ctx, &got);
           rec_kp_ = opt.rec_kp ? opt.rec_kp : got.max_keypoints;
+          fx_set_batches_in_flight(S.ctx, in_flight_);  // (launch-policy hint: the slots of a device share its chip)
           hip(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking), "hipStreamCreate");
           fx_set_stream(S.ctx, S.stream);
           hip(hipEventCreateWithFlags(&S.done, hipEventDisableTiming), "hipEventCreate");

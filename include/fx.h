@@ -216,6 +216,11 @@ fx_status fx_get_stream(fx_ctx *ctx, void **hip_stream);
  * batch size instead of ~30 separate launches (0 = never).  Needs a non-NULL stream; ignored while
  * profiling is on.  Results are identical either way. */
 fx_status fx_set_graph_batch(fx_ctx *ctx, uint32_t max_batch);
+/* How many contexts the caller keeps busy on this device at a time (default 1; bench.py and fx::MultiGpu run four).  A
+ * launch-policy hint only — results never depend on it: with several batches in flight the grid-stride kernels take
+ * smaller grids, so that the batches share the chip instead of each claiming all of it (k_desc_group: one workgroup a CU
+ * instead of ten is +2 % on four batches in flight and -10 % on a batch alone).  New in 0.6 */
+fx_status fx_set_batches_in_flight(fx_ctx *ctx, uint32_t n);
 /* depth > 0: record HIP events around every stage kernel for the next batches, keeping the
  * last `depth` batches; 0 disables.  fx_get_timings reads the batch `back` calls ago
  * (0 = most recent) and waits for it to finish. */

@@ -347,3 +347,26 @@ def test_neighbour_a_tenth_of_a_millimetre_from_the_keypoint_counts(fxlib, oracl
     got = ctx.process_host([s2])[0]
     util.compare_scan(got, ora, tag="near-origin neighbour")
     ctx.close()
+
+
+def test_batches_in_flight_hint_changes_no_result(fxlib, oracle):
+    """fx_set_batches_in_flight is a launch-policy hint (the grid-stride kernels take smaller grids when the caller keeps
+    several contexts busy): every value gives the same bits, through plain launches and through the graph replay of small batches."""
+    p = capi.params("launch")
+    scans = [util.vlp16_scan(1000 + b) for b in range(5)] + [np.zeros((0, 4), np.float32)]
+    ctx = capi.Context(p, capi.limits(len(scans), 28800))
+    ref = None
+    for n, graph in ((1, 0), (3, 0), (4, 0), (8, 0), (4, 16), (1, 16)):
+        ctx.set_graph_batch(graph)
+        ctx.set_batches_in_flight(n)
+        got = ctx.process_host(scans, roll=0.02, pitch=-0.015)
+        if ref is None:
+            ref = got
+            for b, s in enumerate(scans):
+                util.compare_scan(got[b], oracle.run(p, s, roll=0.02, pitch=-0.015), tag=f"in-flight hint scan {b}")
+        for b in range(len(scans)):
+            for key in ("flags", "n_keypoints"):
+                assert got[b][key] == ref[b][key]
+            for key in ("filtered", "candidates", "kpc", "keypoints", "kp_neighbors", "descriptors"):
+                util.assert_bit_equal(got[b][key], ref[b][key], f"hint {n} graph {graph} scan {b} {key}")
+    ctx.close()
