@@ -158,6 +158,10 @@ struct fx_ctx {
   // the previous batch's work for the rarely used tiers (pinned; written by the device: FxBuffers::tier_hint)
   volatile uint32_t *tier_hint = nullptr;
   uint32_t tier_min_grid = 8;  // FX_TIER_MIN_GRID: workgroups those tiers get at least (0: always the full grids)
+  // what the tiers were handed lately: the largest count of the last hint_hold_batches batches (a workload that alternates
+  // between batches with and without work for a tier keeps the tier's grid)
+  uint32_t hint_hold[FX_N_HINTS] = {}, hint_age[FX_N_HINTS] = {};
+  static constexpr uint32_t hint_hold_batches = 64;
   // The fused front kernel (k_front: filter to keypoints in one launch, for scans whose filtered cloud fits LDS) with
   // k_front_redo behind it.  A batch that hands more than an eighth of its scans to k_front_redo sends the next front_retry
   // batches through the separate kernels (k_prep ... k_merge_*), which are the fast way for large scans.
@@ -243,10 +247,19 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof, bo
   // that, at least tier_min_grid, at most the full grid; the full grid while nothing is known): a sparse batch costs
   // eight workgroups a tier instead of 256, and a batch that is suddenly dense runs its tiers narrow once.
   uint32_t hint[FX_N_HINTS];
-  for (int i = 0; i < FX_N_HINTS; ++i) hint[i] = (capture || !c->tier_min_grid) ? 0xffffffffu : c->tier_hint[i];
-  auto tier_grid = [&](uint32_t work, uint32_t full, uint32_t bound, uint32_t per = 1) -> uint32_t {
+  for (int i = 0; i < FX_N_HINTS; ++i) {
+    hint[i] = (capture || !c->tier_min_grid) ? 0xffffffffu : c->tier_hint[i];
+    if (capture || !c->tier_min_grid) continue;
+    // (held: the largest count of the last hint_hold_batches batches; "nothing known yet" stays that)
+    if (hint[i] == 0xffffffffu || hint[i] >= c->hint_hold[i] || ++c->hint_age[i] > fx_ctx::hint_hold_batches) c->hint_hold[i] = hint[i], c->hint_age[i] = 0;
+    hint[i] = c->hint_hold[i];
+  }
+  // (min_wg: the scans k_front hands on — k_front_redo, k_slow — get ONE workgroup when the last 64 batches handed on
+  //  nothing: an empty launch of eight k_front-shaped workgroups instead costs the headline 1 %, profiles/r05_experiments.md §9)
+  auto tier_grid = [&](uint32_t work, uint32_t full, uint32_t bound, uint32_t per = 1, uint32_t min_wg = 0) -> uint32_t {
     uint32_t g = work > full / 2 ? full : 2 * work;  // (also: unknown)
-    if (g < (c->tier_min_grid + per - 1) / per) g = (c->tier_min_grid + per - 1) / per;
+    const uint32_t floor_wg = min_wg ? std::min(min_wg, c->tier_min_grid) : c->tier_min_grid;
+    if (g < (floor_wg + per - 1) / per) g = (floor_wg + per - 1) / per;
     if (g > bound) g = bound ? bound : 1;            // never more workgroups than the batch could have items for
     return g < full ? g : full;
   };
@@ -286,8 +299,8 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof, bo
       fxk_front(s, P, B, batch, c->box_margin, el0, inv_step, clk_slot, mcap, c->front_force >= 1u ? 1u : 0u);
       for (int i = 1; i <= 4; ++i) FX_HIP(mark(i));
       if (!(c->skip_mask & 1u))
-      fxk_front_redo(s, P, B, el0, inv_step, c->merge_huge_ccap, c->front_force >= 2u ? 1u : 0u, tier_grid(hint[6], 2 * big_grid, batch));
-      fxk_slow(s, P, B, c->merge_huge_ccap, tier_grid(hint[7], big_grid, batch));
+      fxk_front_redo(s, P, B, el0, inv_step, c->merge_huge_ccap, c->front_force >= 2u ? 1u : 0u, tier_grid(hint[6], 2 * big_grid, batch, 1, 1));
+      fxk_slow(s, P, B, c->merge_huge_ccap, tier_grid(hint[7], big_grid, batch, 1, 1));
       fxk_offsets(s, P, B, batch, clk_next);
       FX_HIP(mark(5));
     } else {
@@ -1019,7 +1032,7 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
     FX_HIP(hipMemsetAsync(c->buf.slow_state, 0, (size_t)L.max_batch * sizeof(uint32_t), s));  // (the slow tier's list markers: k_slow clears what it has done)
     FX_HIP(hipMemsetAsync(c->buf.ring_pending, 0, (size_t)L.max_batch * (((size_t)c->params.n_rings + 31) / 32) * sizeof(uint32_t), s));
     FX_HIP(hipStreamSynchronize(s));  // (the hints are host memory the device writes: nothing of the failed batch may land after the reset)
-    for (int i = 0; i < FX_N_HINTS; ++i) c->tier_hint[i] = 0xffffffffu;
+    for (int i = 0; i < FX_N_HINTS; ++i) c->tier_hint[i] = 0xffffffffu, c->hint_hold[i] = 0xffffffffu, c->hint_age[i] = 0;
     c->front_pause = 0;
     c->state_suspect = false;
   }
