@@ -6,7 +6,7 @@
 // scan (0.38 ms for one, 0.63 ms for eight), so the policy here is: never wait for a batch to fill —
 // whenever the GPU is free, take WHATEVER HAS ARRIVED (up to max_batch scans) as one batch.  Under light load that is
 // one scan at a time at the single-scan latency; when scans arrive faster than batches finish, the batches grow by
-// themselves and the throughput follows.  Small batch sizes are replayed as one HIP graph each (fx_set_graph_batch).
+// themselves and the throughput follows.
 //
 // Threads: any number of producers call push() (the scan is copied: the caller's buffer is free on return); one
 // consumer thread owns the fx_ctx (a context is not thread-safe), runs the batches and hands every scan's result to
@@ -74,7 +74,9 @@ class StreamBatcher {
         if (ov[i]) dst[i] = ov[i];
     }
     if (fx_create(&params, &lim, device, &ctx_) != FX_OK) throw std::runtime_error(std::string("fx_create: ") + fx_last_error());
-    fx_set_graph_batch(ctx_, max_batch < 16u ? max_batch : 16u);  // the launch-bound sizes: one graph per batch size
+    // (no HIP-graph replay of the small batch sizes any more: since the launches behind the common kernels are one small
+    //  workgroup each and the dense tier's four kernels one small launch, plain launches are as fast or faster — one scan per
+    //  call 0.271 ms against 0.282 with the graph, two 0.301 / 0.316, eight and sixteen level: profiles/r05_experiments.md §10)
     estimate_descriptors_ = params.estimate_descriptors != 0;
     consumer_ = std::thread([this] { run(); });
   }
