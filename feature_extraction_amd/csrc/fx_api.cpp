@@ -56,7 +56,7 @@ void fxk_front(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t
 void fxk_front_redo(hipStream_t s, const FxDevParams &P, const FxBuffers &B, float el0, float inv_step, uint32_t huge_ccap, uint32_t force_slow,
                     uint32_t grid);
 size_t fxk_slow_words(uint32_t max_ring_points, uint32_t max_candidates, uint32_t huge_ccap);
-void fxk_slow(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t huge_ccap, uint32_t grid);
+uint32_t fxk_slow(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t huge_ccap, uint32_t grid, uint32_t batch, uint32_t clk_next);
 hipError_t fxk_configure_front(void);
 uint32_t fxk_gather_slices(uint32_t batch);
 void fxk_gather(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float box_margin);
@@ -300,8 +300,8 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof, bo
       for (int i = 1; i <= 4; ++i) FX_HIP(mark(i));
       if (!(c->skip_mask & 1u))
       fxk_front_redo(s, P, B, el0, inv_step, c->merge_huge_ccap, c->front_force >= 2u ? 1u : 0u, tier_grid(hint[6], 2 * big_grid, batch, 1, 1));
-      fxk_slow(s, P, B, c->merge_huge_ccap, tier_grid(hint[7], big_grid, batch, 1, 1));
-      fxk_offsets(s, P, B, batch, clk_next);
+      if (!fxk_slow(s, P, B, c->merge_huge_ccap, tier_grid(hint[7], big_grid, batch, 1, 1), batch, clk_next))  // (one workgroup: it does the offsets too)
+        fxk_offsets(s, P, B, batch, clk_next);
       FX_HIP(mark(5));
     } else {
     // one workgroup a scan when the batch fills the chip with that, several (a counting pass first) when it does not and the
@@ -341,8 +341,8 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof, bo
     fxk_merge_big(s, P, B, c->merge_big_cap, tier_grid(hint[2], big_grid, batch), c->merge_big_cap >= L.max_candidates);
     if (c->merge_big_cap < L.max_candidates)
       fxk_merge_huge(s, P, B, c->merge_huge_cap, c->merge_huge_ccap, tier_grid(hint[3], big_grid, batch));
-    fxk_slow(s, P, B, c->merge_huge_ccap, tier_grid(hint[7], big_grid, batch));  // (rings / merges beyond the LDS tiers: see the front path)
-    fxk_offsets(s, P, B, batch, clk_next);
+    if (!fxk_slow(s, P, B, c->merge_huge_ccap, tier_grid(hint[7], big_grid, batch), batch, clk_next))  // (rings / merges beyond the LDS tiers: see the front path)
+      fxk_offsets(s, P, B, batch, clk_next);
     FX_HIP(mark(5));
     }
     if (P.estimate_descriptors) {

@@ -3411,7 +3411,12 @@ extern "C" __global__ __launch_bounds__(FX_FRONT_T) void k_front_redo(FxDevParam
 #define FX_SLOW_T 256
 __host__ __device__ constexpr size_t slow_ring_words(uint32_t cap) { return (size_t)(FX_RING_WORDS_PER_POINT + FX_RING_WORDS_PER_CLUSTER) * cap; }
 __host__ __device__ constexpr size_t slow_merge_words(uint32_t cap, uint32_t ccap) { return 4 * (size_t)cap + cap + merge_aux_words(cap) + 3 * (size_t)ccap; }
-extern "C" __global__ __launch_bounds__(FX_SLOW_T) void k_slow(FxDevParams P, FxBuffers B, uint32_t huge_ccap) {
+__device__ __forceinline__ void offsets_body(const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t clk_next, uint32_t *s_w);
+// (offsets: launched as ONE workgroup — the last 64 batches handed it nothing — it also does k_offsets' work, the batch-wide
+//  keypoint offsets, and that launch is left out: one launch less in every batch's chain of dependent launches)
+extern "C" __global__ __launch_bounds__(FX_SLOW_T) void k_slow(FxDevParams P, FxBuffers B, uint32_t huge_ccap, uint32_t offsets, uint32_t batch,
+                                                             uint32_t clk_next) {
+  static_assert(FX_SLOW_T == FX_WG, "k_slow stands in for k_offsets");
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const uint32_t n_slow = B.counters[FX_CNT_REDO + 1];
   const uint32_t R = (uint32_t)P.n_rings, PW = (R + 31u) / 32u;
@@ -3430,11 +3435,15 @@ extern "C" __global__ __launch_bounds__(FX_SLOW_T) void k_slow(FxDevParams P, Fx
     merge_body<FX_SLOW_T, false, false, true>(P, B, scan, P.max_candidates, huge_ccap, smem, true, nullptr, gs);
     wg_global_sync();
   }
+  if (offsets) {  // (the only workgroup of the launch: everything the offsets need has been written, by earlier launches or above)
+    wg_global_sync();
+    offsets_body(P, B, batch, clk_next, smem);
+  }
 }
 
 // ====================================================================== stage 4: offsets
-extern "C" __global__ __launch_bounds__(FX_WG) void k_offsets(FxDevParams P, FxBuffers B, uint32_t batch, uint32_t clk_next) {
-  __shared__ uint32_t s_w[FX_NWAVE];
+// (by one FX_WG-thread workgroup; s_w: FX_NWAVE words of LDS)
+__device__ __forceinline__ void offsets_body(const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t clk_next, uint32_t *s_w) {
   uint32_t run = 0;
   for (uint32_t b0 = 0; b0 < batch; b0 += FX_WG) {
     const uint32_t b = b0 + threadIdx.x;
@@ -3467,6 +3476,11 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_offsets(FxDevParams P, FxB
     B.kp_offset[batch] = run;
     B.seq[0] += 1ull;  // batch tag of the dense tier's density cache (device side: a replayed HIP graph advances it too)
   }
+}
+
+extern "C" __global__ __launch_bounds__(FX_WG) void k_offsets(FxDevParams P, FxBuffers B, uint32_t batch, uint32_t clk_next) {
+  __shared__ uint32_t s_w[FX_NWAVE];
+  offsets_body(P, B, batch, clk_next, s_w);
 }
 
 // ====================================================================== stage 5: descriptors
@@ -5828,9 +5842,12 @@ void fxk_front_redo(hipStream_t s, const FxDevParams &P, const FxBuffers &B, flo
 size_t fxk_slow_words(uint32_t max_ring_points, uint32_t max_candidates, uint32_t huge_ccap) {
   return (std::max(slow_ring_words(max_ring_points), slow_merge_words(max_candidates, huge_ccap)) + 3) & ~(size_t)3;
 }
-void fxk_slow(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t huge_ccap, uint32_t grid) {
+// returns 1 when the launch also did k_offsets' work (a single workgroup): the caller then leaves that launch out
+uint32_t fxk_slow(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t huge_ccap, uint32_t grid, uint32_t batch, uint32_t clk_next) {
   const size_t lds = std::max((size_t)SegCfg<FX_SLOW_T>::kWords, (size_t)FX_MERGE_HEAD + ((2 * ((size_t)P.n_rings + 1) + 3) & ~(size_t)3)) * 4;
-  hipLaunchKernelGGL(k_slow, dim3(std::max(1u, std::min(grid, P.gs_slots))), dim3(FX_SLOW_T), lds, s, P, B, huge_ccap);
+  const uint32_t g = std::max(1u, std::min(grid, P.gs_slots));
+  hipLaunchKernelGGL(k_slow, dim3(g), dim3(FX_SLOW_T), lds, s, P, B, huge_ccap, g == 1u ? 1u : 0u, batch, clk_next);
+  return g == 1u ? 1u : 0u;
 }
 hipError_t fxk_configure_front(void) {
   hipError_t e = hipFuncSetAttribute((const void *)k_front, hipFuncAttributeMaxDynamicSharedMemorySize, (int)front_lds_bytes());
