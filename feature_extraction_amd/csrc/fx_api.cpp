@@ -287,7 +287,10 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof, bo
     // chip to itself; with batches in flight fewer, longer-lived ones (measured, 1 / 2 / 3 / 4 batches in flight, scans/s with
     // 10 against 1 a CU: 1.64 / 1.47, 2.11 / 2.04, 2.25 / 2.27 — 2.29 with 3 —, 2.32 / 2.38e6: profiles/r05_experiments.md)
     const uint32_t desc_per_cu = c->desc_wgs_per_cu ? c->desc_wgs_per_cu : (c->batches_in_flight >= 4u ? 1u : (c->batches_in_flight == 3u ? 3u : 10u));
-    const uint32_t desc_grid = (uint32_t)c->n_cu * desc_per_cu;
+    // (never more workgroups than the batch can have rows for: sixteen rows a workgroup and trip — one scan per call launched
+    //  2560 workgroups for its fifty rows)
+    const uint32_t rows_bound = std::min<uint64_t>((uint64_t)batch * L.max_keypoints, L.max_total_keypoints);
+    const uint32_t desc_grid = std::max(1u, std::min((uint32_t)c->n_cu * desc_per_cu, (rows_bound + 15u) / 16u));
     const uint32_t clk_slot = (uint32_t)(c->batch_seq % FX_CLK_SLOTS), clk_next = (uint32_t)((c->batch_seq + 1) % FX_CLK_SLOTS);
     const float el0 = (float)c->params.el0_deg, inv_step = (float)(1.0 / c->params.el_step_deg);
     if (front) {
@@ -352,7 +355,8 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof, bo
       fxk_desc_group(s, P, B, batch, desc_grid);
       FX_HIP(mark(7));
       // wave rows and list rows (lists of up to dense_min entries, four keypoints per CU in flight) share a launch
-      fxk_desc_mid(s, P, B, batch, P.list_cap < P.dense_min ? P.list_cap : P.dense_min, big_grid * 4, big_grid * 4);
+      fxk_desc_mid(s, P, B, batch, P.list_cap < P.dense_min ? P.list_cap : P.dense_min, std::max(1u, std::min(big_grid * 4, rows_bound)),
+                   std::max(1u, std::min(big_grid * 4, (rows_bound + 3u) / 4u)));
       FX_HIP(mark(8));
       // the dense tier: larger support sets and overflowed lists (empty launches on sparse scans)
       // (beside k_desc_mid on a second stream of the context: measured and dropped, profiles/r04_front_experiments.md)
