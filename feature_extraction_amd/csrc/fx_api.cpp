@@ -125,6 +125,7 @@ struct fx_ctx {
   FxScanMeta *d_meta = nullptr;
   float box_margin = 0.f;
   uint32_t desc_wgs_per_cu = 0;  // k_desc_group's workgroups a CU (0: by batches_in_flight; FX_DESC_WGS_PER_CU in the test build)
+  uint32_t desc_grid_abs = 0;      // test hook (FX_DESC_GRID): k_desc_group's grid, absolute
   uint32_t batches_in_flight = 1;  // fx_set_batches_in_flight: the caller's contexts busy on this device at a time
   uint32_t ring_lds_cap = 0;     // points a ring may have in the workgroup ring tier's LDS (<= max_ring_points; beyond: k_slow)
   uint32_t merge_big_cap = 0;    // candidates the LDS merge tier holds as points (<= max_candidates)
@@ -290,7 +291,8 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof, bo
     // (never more workgroups than the batch can have rows for: sixteen rows a workgroup and trip — one scan per call launched
     //  2560 workgroups for its fifty rows)
     const uint32_t rows_bound = std::min<uint64_t>((uint64_t)batch * L.max_keypoints, L.max_total_keypoints);
-    const uint32_t desc_grid = std::max(1u, std::min((uint32_t)c->n_cu * desc_per_cu, (rows_bound + 15u) / 16u));
+    uint32_t desc_grid = std::max(1u, std::min((uint32_t)c->n_cu * desc_per_cu, (rows_bound + 15u) / 16u));
+    if (c->desc_grid_abs) desc_grid = c->desc_grid_abs;  // (test hook)
     const uint32_t clk_slot = (uint32_t)(c->batch_seq % FX_CLK_SLOTS), clk_next = (uint32_t)((c->batch_seq + 1) % FX_CLK_SLOTS);
     const float el0 = (float)c->params.el0_deg, inv_step = (float)(1.0 / c->params.el_step_deg);
     if (front) {
@@ -509,6 +511,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
     const int v = atoi(e);
     if (v >= 1 && v <= 32) c->desc_wgs_per_cu = (uint32_t)v;
   }
+  if (const char *e = test_hook("FX_DESC_GRID")) c->desc_grid_abs = (uint32_t)std::max(0, atoi(e));
   if (const char *e = test_hook("FX_DEBUG_SYNC")) c->debug_sync = atoi(e) != 0;
   if (const char *e = test_hook("FX_GRAPH_MAX_BATCH")) {
     const int v = atoi(e);
