@@ -2820,6 +2820,11 @@ extern "C" __global__ __launch_bounds__(FX_FRONT_T, FX_PREP_OCC) void k_front(Fx
     stamp_end();
     return;
   }
+#if defined(FX_FRONT_STOP) && FX_FRONT_STOP == 1  // measurement build: the kernel's phases one at a time (tools/front_phases.sh)
+  no_keypoints();
+  stamp_end();
+  return;
+#endif
   // ---------------------------------------------------------------- B: ring split into LDS (ref: node.cpp:195-202)
   // A stable counting sort by ring with three barriers and nothing from HBM: the survivors are still in LDS (un-rotated, in
   // input order: the streaming pass's buffer) with their elevations.  Every wavefront owns a contiguous slice, ranks its
@@ -2915,6 +2920,11 @@ extern "C" __global__ __launch_bounds__(FX_FRONT_T, FX_PREP_OCC) void k_front(Fx
     wg_global_sync();  // (the ring-major points are in; ~cloud, written by the sweeps, is read below: cluster intensities, member copies)
     FX_STAMP(19);
   }
+#if defined(FX_FRONT_STOP) && FX_FRONT_STOP == 2
+  no_keypoints();
+  stamp_end();
+  return;
+#endif
   // ---------------------------------------------------------------- C: getCylinderSegments, all rings (ref: node.cpp:261-327)
   FX_STAMP(2);
   const float r2 = P.r2_cluster;
@@ -3329,6 +3339,11 @@ extern "C" __global__ __launch_bounds__(FX_FRONT_T, FX_PREP_OCC) void k_front(Fx
     if (tid == 0) B.n_kpc[scan] = n_mem;
   }
   FX_STAMP(14);
+#if defined(FX_FRONT_STOP) && FX_FRONT_STOP == 3
+  no_keypoints();
+  stamp_end();
+  return;
+#endif
   // ---------------------------------------------------------------- D: secondary merge (ref: node.cpp:209-257)
   const FrontCands FC{crec, ctmp, rbox4, n_c, C};
   merge_body<NT, true, true>(P, B, scan, merge_cap, merge_cap, smem, true, &FC);

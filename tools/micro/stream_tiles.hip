@@ -54,21 +54,22 @@ __global__ __launch_bounds__(T) void k_tiles(const float *p, unsigned n, unsigne
 }
 
 int main() {
-  const unsigned n = 28800, B = 1024;
+  const unsigned n = 28800, BMAX = 1024;
   const int W = 6;
   float *d;
   unsigned *o;
-  hipMalloc(&d, (size_t)B * n * 16 * W);
-  hipMalloc(&o, B * 4);
-  hipMemset(d, 0, (size_t)B * n * 16 * W);
+  hipMalloc(&d, (size_t)BMAX * n * 16 * W);
+  hipMalloc(&o, BMAX * 4);
+  hipMemset(d, 0, (size_t)BMAX * n * 16 * W);
   hipEvent_t a, b;
   hipEventCreate(&a);
   hipEventCreate(&b);
-  for (int lds_kb : {80, 52, 16})
+  for (unsigned B : {1u, 8u, 256u, 512u, 1024u})
+  for (int lds_kb : {80, 16})
     for (int mode = 0; mode < 3; ++mode) {
       const int R = 12;
       auto launch = [&](int rep) {
-        const float *src = d + (size_t)(rep % W) * B * n * 4;
+        const float *src = d + (size_t)(rep % W) * BMAX * n * 4;
         const size_t lds = (size_t)lds_kb * 1024;
         if (mode == 0) {
           hipFuncSetAttribute((const void *)k_tiles<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -88,7 +89,7 @@ int main() {
       hipEventSynchronize(b);
       float ms;
       hipEventElapsedTime(&ms, a, b);
-      printf("LDS %2d KB a workgroup (%s a CU), loads %s: %.3f ms for 1024 scans, %.2f TB/s\n", lds_kb, lds_kb == 80 ? "two" : lds_kb == 52 ? "three" : "five+",
+      printf("%4u scans, LDS %2d KB a workgroup (%s a CU), loads %s: %.4f ms, %.3f TB/s\n", B, lds_kb, lds_kb == 80 ? "two" : lds_kb == 52 ? "three" : "five+",
              mode == 0 ? "dword + dwordx2, conditional" : mode == 1 ? "dwordx3" : "dwordx4", ms / R, (double)B * n * 16 / (ms / R * 1e-3) / 1e12);
     }
   return 0;
