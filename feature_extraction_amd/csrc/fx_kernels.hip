@@ -1026,10 +1026,10 @@ __device__ __forceinline__ uint32_t prep_stream(const FxDevParams &P, const FxBu
               ny1 = hi_lim(P.y_max + near_margin), nz0 = lo_lim(P.z_min - near_margin), nz1 = hi_lim(P.z_max + near_margin);
   const float fx0 = lo_lim(P.x_min), fx1 = hi_lim(P.x_max), fy0 = lo_lim(P.y_min), fy1 = hi_lim(P.y_max), fz0 = lo_lim(P.z_min),
               fz1 = hi_lim(P.z_max);
-  // (Measured in round 4, profiles/r04_front_experiments.md: what a tile costs is ISSUING its loads — 4000 of a tile's 9000
-  //  cycles pass between the first and the last of a wavefront's eight load instructions, the memory pipeline being full —,
-  //  not waiting for them: a second tile of loads in flight, tile buffers that take turns without the register copies below
-  //  (a copy waits for the copied register's load) and 16-byte loads all left the kernel's time where it was.)
+  // (Measured, profiles/r05_experiments.md 12: a second tile of loads in flight, tile buffers that take turns without the register
+  //  copies below, 16-byte loads and touching the tile after the next a period early all left the kernel's time where it was —
+  //  the pass waits for its own instruction stream between the loads, not for the loads.  Round 4's "issuing the loads costs
+  //  half a tile" was an artefact of the stamped build: its spilled offsets are reloaded behind s_waitcnt vmcnt(0).)
   float4 v[FX_PREP_U], nv[FX_PREP_U];
   load_tile(t_begin, v);
   FX_STAMP(24);
