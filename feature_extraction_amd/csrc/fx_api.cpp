@@ -31,7 +31,6 @@ uint32_t fxk_group_cap(void);
 uint32_t fxk_dfin_kl(void);
 void fxk_dense(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t n_cu, uint32_t rows, uint32_t items);
 size_t fxk_dense_slow_words(uint32_t max_points);
-void fxk_dense_slow(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t grid);
 size_t fxk_merge_huge_lds_bytes(uint32_t cap, uint32_t ccap, uint32_t n_rings);
 hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t merge_huge, size_t desc_big, size_t gather);
 uint32_t fxk_near_words(uint32_t max_points);
@@ -61,7 +60,8 @@ hipError_t fxk_configure_front(void);
 uint32_t fxk_gather_slices(uint32_t batch);
 void fxk_gather(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float box_margin);
 void fxk_desc_group(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid);
-void fxk_desc_mid(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t n_wg, uint32_t n_wave);
+void fxk_desc_mid(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t n_wg, uint32_t n_wave,
+                  uint32_t n_dslow);
 void fxk_pack_kp_records(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, void *dst,
                          uint32_t rec_kp);
 void fxk_rng_ord(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
@@ -176,12 +176,12 @@ struct fx_ctx {
   bool state_suspect = false;
   uint32_t fail_after = 0;     // test hook (FX_FAIL_AFTER_ENQUEUE = n: the n-th batch returns an error after its kernels were enqueued)
   uint32_t front_pause = 0;    // batches left on the separate kernels
-  // The dense descriptor tier: its four kernels when a recent batch had rows for it (or nothing is known), else ONE small
-  // launch (k_dense_slow) that computes whatever does turn up, slower — the same results either way.
+  // The dense descriptor tier: its four kernels when a recent batch had rows for it (or nothing is known), else a handful of
+  // workgroups in k_desc_mid's launch (dense_slow_loop) that compute whatever does turn up, slower — the same results either way.
   uint32_t dense_fast_left = 0;            // batches that still get the four kernels after the last one that needed them
   static constexpr uint32_t dense_linger = 64;
   int prep_slices = -1;                    // test hook (FX_PREP_SLICES): workgroups a scan in the separate kernels' streaming pass and ring split
-  int dense_force = -1;                    // test hook (FX_DENSE_SLOW): 1 always the one launch, 0 always the four kernels
+  int dense_force = -1;                    // test hook (FX_DENSE_SLOW): 1 always k_desc_mid's workgroups, 0 always the four kernels
   uint32_t skip_mask = 0;      // experiment hook (FX_SKIP_EMPTY, test build): bit 0 no k_front_redo, bit 1 no dense tier — only for workloads that need neither
   static constexpr uint32_t front_retry = 64;
 };
@@ -356,28 +356,24 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof, bo
       FX_HIP(mark(6));
       fxk_desc_group(s, P, B, batch, desc_grid);
       FX_HIP(mark(7));
+      // The dense tier (larger support sets and overflowed lists; nothing on sparse scans): its four kernels, or a handful of
+      // workgroups of k_desc_mid's launch — the previous batches decide speed, never results.
+      // (beside k_desc_mid on a second stream of the context: measured and dropped, profiles/r04_front_experiments.md)
+      bool fast = capture || hint[4] != 0u;  // (0xffffffff: nothing known yet)
+      if (fast && !capture && hint[4] != 0xffffffffu) c->dense_fast_left = fx_ctx::dense_linger;
+      if (!fast && c->dense_fast_left) --c->dense_fast_left, fast = true;
+      if (c->dense_force >= 0) fast = c->dense_force == 0;
+      const bool skip_dense = (c->skip_mask & 2u) != 0u;
       // wave rows and list rows (lists of up to dense_min entries, four keypoints per CU in flight) share a launch
       fxk_desc_mid(s, P, B, batch, P.list_cap < P.dense_min ? P.list_cap : P.dense_min, std::max(1u, std::min(big_grid * 4, rows_bound)),
-                   std::max(1u, std::min(big_grid * 4, (rows_bound + 3u) / 4u)));
+                   std::max(1u, std::min(big_grid * 4, (rows_bound + 3u) / 4u)), fast || skip_dense ? 0u : (c->tier_min_grid ? c->tier_min_grid : 8u));
       FX_HIP(mark(8));
-      // the dense tier: larger support sets and overflowed lists (empty launches on sparse scans)
-      // (beside k_desc_mid on a second stream of the context: measured and dropped, profiles/r04_front_experiments.md)
-      {
+      if (fast && !skip_dense) {
         const uint32_t max_rows = batch * L.max_keypoints < L.max_total_keypoints ? batch * L.max_keypoints : L.max_total_keypoints;
         const uint32_t rows = tier_grid(hint[4], 3 * big_grid, max_rows);
         // density items: 1024 queries each, at most one a row more than the support points fill
         const uint32_t items = hint[5] == 0xffffffffu ? 3 * big_grid : tier_grid(hint[4] + hint[5] / 1024u, 3 * big_grid, 0xffffffffu);
-        // four kernels, or the one small launch: the previous batches decide speed, never results
-        bool fast = capture || hint[4] != 0u;  // (0xffffffff: nothing known yet)
-        if (fast && !capture && hint[4] != 0xffffffffu) c->dense_fast_left = fx_ctx::dense_linger;
-        if (!fast && c->dense_fast_left) --c->dense_fast_left, fast = true;
-        if (c->dense_force >= 0) fast = c->dense_force == 0;
-        if (c->skip_mask & 2u) {
-        } else if (fast) {
-          fxk_dense(s, P, B, big_grid, rows, items);
-        } else {
-          fxk_dense_slow(s, P, B, c->tier_min_grid ? c->tier_min_grid : 8u);
-        }
+        fxk_dense(s, P, B, big_grid, rows, items);
       }
     } else {
       for (int i = 6; i <= 8; ++i) FX_HIP(mark(i));
@@ -667,7 +663,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
     FX_A(dev_alloc(c, &b.gs_pool, slots * words));
   }
   {
-    // k_dense_slow's scratch: a region per workgroup (a handful of them: the launch exists to be small), 128 MB at most
+    // dense_slow_loop's scratch: a region per workgroup (a handful of them), 128 MB at most
     const size_t words = fxk_dense_slow_words(L.max_points);
     size_t slots = 32;
     while (slots > 1 && slots * words * 4 > ((size_t)128 << 20)) --slots;

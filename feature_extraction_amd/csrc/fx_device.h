@@ -44,7 +44,7 @@ struct FxDevParams {
   // slow tier (k_slow): scratch regions in HBM for what exceeds every LDS-sized tier
   uint32_t gs_slots;  // regions (= the largest grid k_slow is launched with)
   uint32_t gs_words;  // words per region
-  uint32_t gsd_slots, gsd_words;  // the same for k_dense_slow (the dense descriptor tier's rows without its four launches)
+  uint32_t gsd_slots, gsd_words;  // the same for dense_slow_loop (the dense descriptor tier's rows without its four launches)
 };
 
 // 3DSC tables in device memory (built on the host by fx_sc3d_tables / fx_sc3d_xaxis).
@@ -122,7 +122,7 @@ struct FxBuffers {
   uint32_t *slow_state;   // [B]  1 while the scan is listed (k_slow clears it)
   uint32_t *ring_pending; // [B][(n_rings + 31) / 32]  bit r: ring r of the scan waits for k_slow (which clears it)
   uint32_t *gs_pool;      // [gs_slots][gs_words]  k_slow's scratch: the LDS tiers' per-point / per-cluster arrays, in HBM
-  uint32_t *gsd_pool;     // [gsd_slots][gsd_words]  k_dense_slow's scratch: a support set of up to max_points points
+  uint32_t *gsd_pool;     // [gsd_slots][gsd_words]  dense_slow_loop's scratch: a support set of up to max_points points
   float4 *merge_sorted;   // [B][max_candidates] (x, y, pseudo z, id) in bin order: k_merge_huge's pair tests (allocated only when that tier exists)
   uint32_t *list_desc;    // [max_total_kp]  rows whose list is too long for one wavefront (257 .. dense_min support points)
   uint32_t *wave_desc;    // [max_total_kp]  rows with 65..256 support points (one wavefront each)

@@ -4408,7 +4408,7 @@ __device__ __forceinline__ DescLds desc_carve_gs(uint32_t *smem, uint32_t *gs, u
 // One keypoint by a whole workgroup.  from_list: the support set comes from k_gather's list;
 // otherwise it is re-gathered from the scan (lists that overflowed P.list_cap).
 // Returns false if the support set does not fit `cap` (only possible when !from_list).
-// GS (k_dense_slow): the per-point arrays live in the scratch region `gs` of HBM (8 words a point: any support set), the
+// GS (dense_slow_loop): the per-point arrays live in the scratch region `gs` of HBM (8 words a point: any support set), the
 // scratch words and the image stay in LDS.
 template <bool FAST, int NT, bool GS = false>
 __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers &B, uint32_t row, uint32_t scan, uint32_t k,
@@ -4691,41 +4691,45 @@ __device__ __forceinline__ void desc_wg_loop(const FxDevParams &P, const FxBuffe
 // The fp32 pass runs 256-thread workgroups, four keypoints per CU at a time (most phases of a keypoint are
 // latency chains that leave lanes idle, so concurrency beats width).
 #define FX_DESC_WG_FAST_T 256
-// Both middle tiers in one launch: the first n_wg workgroups take list rows (193..cap support points, one keypoint per
-// workgroup at a time), the others take wave rows (65..192, one keypoint per wavefront).  Neither tier fills the chip
-// alone (1600 and 900 of the 8192 wave slots on the VLP-16 bench) and neither depends on the other: one after the
-// other they cost 0.135 + 0.075 ms, together about the longer of the two.
-extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_mid(FxDevParams P, FxBuffers B, uint32_t batch, uint32_t cap,
-                                                                uint32_t n_wg) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {  // (k_desc_group, which fills the dense tier's row list, has completed)
-    B.tier_hint[4] = B.counters[6];
-    B.tier_hint[5] = B.counters[13];
-  }
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  if (blockIdx.x < n_wg)
-    desc_wg_loop<true, FX_DESC_WG_FAST_T>(P, B, batch, cap, smem, blockIdx.x, n_wg);
-  else
-    desc_wave_body<true>(P, B, batch, smem, blockIdx.x - n_wg, gridDim.x - n_wg);
-}
-
-// The dense tier's rows WITHOUT its four launches: a batch whose predecessor had no dense row (every VLP-16-class batch) gets
-// this one launch instead — 256 threads and 8 KB of LDS place anywhere, where the four kernels' workgroups each wait for a
-// large LDS slot behind the other batches' kernels (+3.7 % on the headline with them gone, profiles/r05_experiments.md).
-// A row that does turn up is computed here by the list tier's body on scratch in HBM, its support set re-gathered from the
-// scan: slower, the same result (each row counts its neighbours' densities itself: what the tier's per-scan cache shares).
-// Which of the two runs never changes a result — the host's memory of earlier batches chooses speed only.
+// The dense tier's rows WITHOUT its four launches: a batch whose predecessors had no dense row (every VLP-16-class batch) gets
+// a handful of workgroups of k_desc_mid's launch instead — 256 threads and 8 KB of LDS place anywhere, where the four kernels'
+// workgroups each wait for a large LDS slot behind the other batches' kernels (+3.7 % on the headline with them gone,
+// profiles/r05_experiments.md).  A row that does turn up is computed here by the list tier's body on scratch in HBM, its
+// support set re-gathered from the scan: slower, the same result (each row counts its neighbours' densities itself: what the
+// tier's per-scan cache shares).  Which of the two runs never changes a result — the host's memory of earlier batches chooses
+// speed only.
 #define FX_DSLOW_T 256
-extern "C" __global__ __launch_bounds__(FX_DSLOW_T) void k_dense_slow(FxDevParams P, FxBuffers B) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+__device__ __forceinline__ void dense_slow_loop(const FxDevParams &P, const FxBuffers &B, uint32_t *smem, uint32_t bid, uint32_t nblk) {
   const uint32_t n_rows = min(B.counters[6], P.max_dense_rows);
-  uint32_t *gs = B.gsd_pool + (size_t)blockIdx.x * P.gsd_words;
-  for (uint32_t slot = blockIdx.x; slot < n_rows; slot += gridDim.x) {
+  uint32_t *gs = B.gsd_pool + (size_t)bid * P.gsd_words;
+  for (uint32_t slot = bid; slot < n_rows; slot += nblk) {
     const uint32_t row = B.dense_rows[slot];
     if (row == FX_NONE) continue;  // (no room in the pools: flagged by k_desc_group, as for the fast kernels)
     const uint2 rm = B.row_map[row];
     desc_body<true, FX_DSLOW_T, true>(P, B, row, rm.x, rm.y, P.max_points, smem, false, gs);
     wg_global_sync();
   }
+}
+// Both middle tiers in one launch: the first n_wg workgroups take list rows (193..cap support points, one keypoint per
+// workgroup at a time), the others take wave rows (65..192, one keypoint per wavefront).  Neither tier fills the chip
+// alone (1600 and 900 of the 8192 wave slots on the VLP-16 bench) and neither depends on the other: one after the
+// other they cost 0.135 + 0.075 ms, together about the longer of the two.  The last n_dslow workgroups (when the dense
+// tier's four kernels are not launched) take the dense tier's rows: k_desc_group, which lists them, has completed.
+static_assert(FX_DSLOW_T == FX_WG && FX_DESC_WG_FAST_T == FX_WG, "k_desc_mid's three kinds of workgroups");
+extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_mid(FxDevParams P, FxBuffers B, uint32_t batch, uint32_t cap,
+                                                                uint32_t n_wg, uint32_t n_dslow) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // (k_desc_group, which fills the dense tier's row list, has completed)
+    B.tier_hint[4] = B.counters[6];
+    B.tier_hint[5] = B.counters[13];
+  }
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const uint32_t n_mid = gridDim.x - n_dslow;
+  if (blockIdx.x >= n_mid)
+    dense_slow_loop(P, B, smem, blockIdx.x - n_mid, n_dslow);
+  else if (blockIdx.x < n_wg)
+    desc_wg_loop<true, FX_DESC_WG_FAST_T>(P, B, batch, cap, smem, blockIdx.x, n_wg);
+  else
+    desc_wave_body<true>(P, B, batch, smem, blockIdx.x - n_wg, n_mid - n_wg);
 }
 
 // ---------------------------------------------------------------- dense tier
@@ -5891,14 +5895,13 @@ void fxk_desc_group(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uin
   hipLaunchKernelGGL(k_desc_group, dim3(grid), dim3(FX_WG), (size_t)(FX_NWAVE * FX_GROUPS * FX_GROUP_WORDS + FX_TABLE_WORDS) * 4, s, P, B, batch);
 }
 void fxk_desc_mid(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t n_wg,
-                  uint32_t n_wave) {
+                  uint32_t n_wave, uint32_t n_dslow) {
   const size_t lds_wave = (size_t)(FX_NWAVE * FX_WAVE_WORDS + FX_TABLE_WORDS) * 4, lds_wg = fxk_desc_lds_bytes(cap);
-  hipLaunchKernelGGL(k_desc_mid, dim3(n_wg + n_wave), dim3(FX_WG), lds_wave > lds_wg ? lds_wave : lds_wg, s, P, B, batch, cap, n_wg);
+  static_assert((16 + FX_DESC_BINS + 16) * 4 <= (FX_NWAVE * FX_WAVE_WORDS + FX_TABLE_WORDS) * 4, "the dense tier's rows in k_desc_mid's LDS");
+  n_dslow = std::min(n_dslow, P.gsd_slots);  // (a scratch region each)
+  hipLaunchKernelGGL(k_desc_mid, dim3(n_wg + n_wave + n_dslow), dim3(FX_WG), lds_wave > lds_wg ? lds_wave : lds_wg, s, P, B, batch, cap, n_wg, n_dslow);
 }
 size_t fxk_dense_slow_words(uint32_t max_points) { return ((size_t)FX_DESC_WORDS_PER_POINT * max_points + 3) & ~(size_t)3; }
-void fxk_dense_slow(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t grid) {
-  hipLaunchKernelGGL(k_dense_slow, dim3(std::max(1u, std::min(grid, P.gsd_slots))), dim3(FX_DSLOW_T), (size_t)(16 + FX_DESC_BINS + 16) * 4, s, P, B);
-}
 // (rows and items are taken by ticket: any grid is correct; the full ones are what is resident at once)
 void fxk_dense(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t n_cu, uint32_t rows, uint32_t items) {
   auto grid = [](uint32_t want, uint32_t full) { return want < full ? (want ? want : 1u) : full; };

@@ -57,7 +57,7 @@ def test_dense_128_ring_scan_radius_2m(fxlib, oracle, preset):
 
 
 def test_dense_128_ring_scan_through_the_one_small_dense_launch(fx_hooks, oracle):
-    """The same scan with every dense row — support sets of up to ~10 000 points — computed by k_dense_slow instead of the
+    """The same scan with every dense row — support sets of up to ~10 000 points — computed by dense_slow_loop (k_desc_mid's last workgroups) instead of the
     dense tier's four kernels (what a batch gets whose predecessors had no dense row): the same result."""
     fx_hooks(FX_DENSE_SLOW=1)
     s = capi.synth_scan(capi.synth_cfg(50, n_poles=256, **DENSE))
@@ -67,7 +67,7 @@ def test_dense_128_ring_scan_through_the_one_small_dense_launch(fx_hooks, oracle
     h = (C.c_uint32 * 8)()
     ctx.lib.fx_debug_tier_hints.argtypes = [C.c_void_p, C.c_void_p]
     capi.check(ctx.lib.fx_debug_tier_hints(ctx.handle, h))
-    st = util.compare_scan(got, oracle.run(p, s, roll=0.02, pitch=-0.015), tag="128 rings, dense rows by k_dense_slow")
+    st = util.compare_scan(got, oracle.run(p, s, roll=0.02, pitch=-0.015), tag="128 rings, dense rows by dense_slow_loop")
     assert st["K"] > 0 and h[4] > 0  # (dense rows there were: support sets beyond the 4096-entry lists of a 262 144-point scan)
     ctx.close()
 

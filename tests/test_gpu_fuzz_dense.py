@@ -59,7 +59,7 @@ def test_dense_many_ring_scans(fxlib, oracle, block):
 
 @pytest.mark.parametrize("block", range(2))
 def test_dense_rows_through_the_one_small_launch(fx_hooks, oracle, block):
-    """The dense tier's rows computed by k_dense_slow (the list tier's body on scratch in HBM, what a batch gets whose
+    """The dense tier's rows computed by dense_slow_loop, k_desc_mid's last workgroups (the list tier's body on scratch in HBM, what a batch gets whose
     predecessors had no dense row) instead of the tier's four kernels: forced by the test build's hook, the same scans, the
     same results — the choice between the two is the host's memory of earlier batches and may only ever decide speed."""
     fx_hooks(FX_DENSE_SLOW=1)
@@ -82,7 +82,7 @@ def test_dense_rows_through_the_one_small_launch(fx_hooks, oracle, block):
 
 def test_a_dense_row_after_sparse_batches_and_back(fxlib, oracle):
     """The product library's own choice: a context that has seen only VLP-16 scans (no dense row: the one small launch) gets
-    a scan whose keypoints have thousands of support points — exact at once (k_dense_slow computes it) —, then keeps the four
+    a scan whose keypoints have thousands of support points — exact at once (dense_slow_loop computes it) —, then keeps the four
     kernels for the batches after it; every result equals the oracle's and a fresh context's."""
     s_d, p, roll, pitch, lim, what = None, None, 0.0, 0.0, None, None
     for seed in range(7000, 7100):  # the first case with dense rows and no capacity flag

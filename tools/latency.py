@@ -14,6 +14,8 @@ calls = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 preset = sys.argv[3] if len(sys.argv) > 3 else "launch"
 graph = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 stride = int(sys.argv[5]) if len(sys.argv) > 5 else 16
+if os.environ.get("FX_LIB"):  # (an alternative build under feature_extraction_amd/lib: A/B runs)
+    capi.LIB_PATH = os.path.join(os.path.dirname(capi.LIB_PATH), os.environ["FX_LIB"])
 capi.load()
 scans = [capi.synth_scan(capi.synth_cfg(1000 + b)) for b in range(max(B, 16))]
 if stride == 32:
