@@ -31,13 +31,19 @@ sets = []
 for j in range(len(scans) // B):
     part = scans[j * B:(j + 1) * B]
     sets.append(ctx.make_descs([s.ctypes.data for s in part], [len(s) for s in part], stride, 0.02, -0.015))
-for mode, flags in (("host->host (keypoints + descriptors)", capi.FX_OUT_HOST),):
+modes = [("host->host (keypoints + descriptors)", capi.FX_OUT_HOST)]
+if os.environ.get("FX_LATENCY_SPLIT"):  # (what the copies back cost: the same call with its results left on the device, then a stream sync)
+    modes.append(("host->device (results stay in HBM) + sync", 0))
+for mode, flags in modes:
     for w in range(20):
         ctx.process_raw(sets[w % len(sets)], B, flags)
+    ctx.synchronize()
     t = np.empty(calls)
     for i in range(calls):
         t0 = time.perf_counter()
         v = ctx.process_raw(sets[i % len(sets)], B, flags)
+        if not flags:
+            ctx.synchronize()
         t[i] = time.perf_counter() - t0
     t *= 1e3
     print(json.dumps({"mode": mode, "batch": B, "calls": calls, "preset": preset, "graph": graph, "stride_bytes": stride, "ms_median": float(np.median(t)),
