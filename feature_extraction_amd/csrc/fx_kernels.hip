@@ -280,6 +280,32 @@ __device__ __forceinline__ void slow_ring(const FxDevParams &P, const FxBuffers 
 #define FX_STAMP(slot)
 #define FX_STAMP_INIT(ptr)
 #endif
+// Diagnostic build only (-DFX_SSTAMPS): the streaming pass's steps on SCALAR registers — s_memtime differences summed in
+// uniform variables and written out once at the pass's end.  (The vector-register stamps above make the compiler spill
+// the pass's load offsets, and every reload waits for ALL outstanding loads: their split of the pass is an artefact.)
+#ifdef FX_SSTAMPS
+#define FX_SS_INIT                                                                   \
+  unsigned long long ss0_ = 0, ss1_ = 0, ss2_ = 0, ss3_ = 0, ss4_ = 0, ss5_ = 0, ss6_ = 0; \
+  unsigned long long ssp_ = __builtin_amdgcn_s_memtime()
+#define FX_SS(k)                                                       \
+  do {                                                                 \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();      \
+    ss##k##_ += now_ - ssp_;                                           \
+    ssp_ = now_;                                                       \
+  } while (0)
+#define FX_SS_FLUSH(ptr)                                                                       \
+  do {                                                                                         \
+    if (threadIdx.x == 0 && (ptr)) {                                                           \
+      unsigned long long *q_ = (ptr) + ((blockIdx.x & 63u) << 6);                              \
+      atomicAdd(&q_[24], ss0_), atomicAdd(&q_[30], ss1_), atomicAdd(&q_[25], ss2_), atomicAdd(&q_[26], ss3_); \
+      atomicAdd(&q_[27], ss4_), atomicAdd(&q_[28], ss5_), atomicAdd(&q_[29], ss6_);            \
+    }                                                                                          \
+  } while (0)
+#else
+#define FX_SS_INIT
+#define FX_SS(k)
+#define FX_SS_FLUSH(ptr)
+#endif
 
 // Scratch words in front of the per-point arrays (NT = workgroup size of the tier):
 // [0..15] block helpers, [16..31] broadcast slots, [32..151] sort stack, [160..] segment table
@@ -974,20 +1000,53 @@ __device__ __forceinline__ uint32_t prep_stream(const FxDevParams &P, const FxBu
   const gfloat *gpts = (const gfloat *)M.pts;
   const uint32_t R = (uint32_t)P.n_rings;
   FX_STAMP_INIT(B.stamps);
+  FX_SS_INIT;
   for (uint32_t r = tid; r < R; r += FX_PREP_T) s_ring[r] = 0u;  // (ordered before the first sweep by the tile barriers)
   for (uint32_t r = tid; r < (FX_ATAN_N + 1) * (FX_ATAN_DEG + 1); r += FX_PREP_T) s_atan[r] = B.atan_tab[r];
   for (uint32_t r = tid; r < R; r += FX_PREP_T) s_win[r] = B.ring_win[r];
   // the loads of the next tile are issued before this tile's barrier, so the memory pipe stays full
   // while the tile is compacted
-  auto load_tile = [&](uint32_t t0, float4 (&v)[FX_PREP_U]) {
+  // A tile's loads: a uniform base (the tile's first record: scalar registers) plus a 32-bit byte offset per lane, clamped to
+  // the scan's last record (no branch around the load; only the last tile's lanes past the end are clamped) — one 12-byte
+  // load a point, no 64-bit address arithmetic per load.  (The scan's table entry comes in through vector loads — the
+  // compiler cannot know nothing writes it —: its fields are made scalar by hand.)
+  typedef float gf3 __attribute__((ext_vector_type(3), aligned(4)));
+  typedef float gf2 __attribute__((ext_vector_type(2), aligned(4)));
+  typedef float gf4 __attribute__((ext_vector_type(4), aligned(4)));
+  typedef const __attribute__((address_space(1))) char *gbytes;
+  const uint32_t stride_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(M.stride_f * 4u));  // (a scan is < 2^28 bytes: fx_create's limits)
+  const gbytes gbase = (gbytes)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)((unsigned long long)gpts >> 32)) << 32) |
+                                (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(unsigned long long)gpts));
+  const uint32_t n_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
+  const uint32_t lane_byte = (wave * (64 * FX_PREP_U) + lane) * stride_b;
+  auto load_tile = [&](uint32_t t0, float4 (&v)[FX_PREP_U], int u_begin = 0, int u_end = FX_PREP_U) {
+    // (the tile after the last is loaded ahead and never used: every lane of it re-reads the scan's last record — one path,
+    //  so that the loads land in the registers the tile is computed from: two paths meet in copies, which wait for the loads)
+    const uint32_t t0c = min(t0, n_s - 1u);
+    const gbytes tb = gbase + (size_t)t0c * stride_b;
+    const uint32_t last = (n_s - 1u - t0c) * stride_b;  // the scan's last record, from the tile's first
 #pragma unroll
     for (int u = 0; u < FX_PREP_U; ++u) {
-      const uint32_t i = t0 + wave * (64 * FX_PREP_U) + u * 64 + lane;
-      const gfloat *q = gpts + (size_t)min(i, n - 1u) * M.stride_f;  // clamped: no branch around the load
-      // (the record's fourth word is never used and the compiler narrows the load to 12 bytes a lane — measured faster
-      //  than the full 16-byte load in round 1, 0.17 against 0.20 ms; level in round 4, 0.128 against 0.133)
+      if (u < u_begin || u >= u_end) continue;
+      const uint32_t off = lane_byte + (uint32_t)(u * 64) * stride_b;
+#if defined(FX_TILE_X4)  // (experiment: the whole 16-byte record)
+      const gf4 w = *(const __attribute__((address_space(1))) gf4 *)(tb + min(off, last));
+      v[u] = make_float4(off <= last && t0 < n_s ? w.x : NAN, w.y, w.z, 0.f);
+#elif !defined(FX_TILE_PAIR)
+      // ONE 12-byte load a point: the memory pipeline takes a wavefront's strided load in ~50 cycles whatever its width —
+      // the 4 + 8-byte pair the compiler makes of a conditional x costs two (k_front alone 0.305 -> 0.297 ms, one scan
+      // 0.106 -> 0.101, headline +2 %; round 1's "12 against 16 bytes" compared the pair, not this)
+      const gf3 w = *(const __attribute__((address_space(1))) gf3 *)(tb + min(off, last));
       // past the end: a NaN x makes all three rotated coordinates NaN, which fail every range test below
-      v[u] = make_float4(i < n ? q[0] : NAN, q[1], q[2], 0.f);
+      v[u] = make_float4(off <= last && t0 < n_s ? w.x : NAN, w.y, w.z, 0.f);
+#else
+      //  (the x load under its own condition: unconditional, the compiler fuses the pair into the 12-byte load)
+      const gbytes q = tb + min(off, last);
+      float x = NAN;
+      if (off <= last && t0 < n_s) x = *(const gfloat *)q;
+      const gf2 yz = *(const __attribute__((address_space(1))) gf2 *)(q + 4);
+      v[u] = make_float4(x, yz.x, yz.y, 0.f);
+#endif
     }
   };
   // The fp64 elevation is a long dependent chain: it runs over the buffered survivors only when the buffer could
@@ -1016,6 +1075,7 @@ __device__ __forceinline__ uint32_t prep_stream(const FxDevParams &P, const FxBu
     }
     swept = buffered;
     FX_STAMP(28);
+    FX_SS(5);
   };
   // Range tests with both ends clamped to the finite floats: a NaN or an infinite coordinate fails them (PassThrough drops
   // non-finite points first, ref: SURVEY.md A.2), a finite one compares as in PCL's !(v < min || v > max); an infinite or
@@ -1031,11 +1091,18 @@ __device__ __forceinline__ uint32_t prep_stream(const FxDevParams &P, const FxBu
   //  the pass waits for its own instruction stream between the loads, not for the loads.  Round 4's "issuing the loads costs
   //  half a tile" was an artefact of the stamped build: its spilled offsets are reloaded behind s_waitcnt vmcnt(0).)
   float4 v[FX_PREP_U], nv[FX_PREP_U];
-  load_tile(t_begin, v);
+  const uint32_t t_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)t_begin);
+  load_tile(t_first, v);
   FX_STAMP(24);
-  for (uint32_t t0 = t_begin; t0 < n; t0 += kTile) {
+  FX_SS(0);
+  for (uint32_t t0 = t_first; t0 < n_s; t0 += kTile) {
+#ifdef FX_TILE_SPLIT  // (experiment: half of the next tile's loads now, half behind the barrier)
+    load_tile(t0 + kTile, nv, 0, FX_PREP_U / 2);
+#else
     load_tile(t0 + kTile, nv);
+#endif
     FX_STAMP(30);
+    FX_SS(1);
     bool keep[FX_PREP_U];
     unsigned long long mask[FX_PREP_U];
     uint32_t wave_cnt = 0;
@@ -1083,8 +1150,13 @@ __device__ __forceinline__ uint32_t prep_stream(const FxDevParams &P, const FxBu
     // reads of s_keep before this tile's writes, and (a wave cannot be two tiles ahead of another) the
     // readers of the other parity's counts before they are overwritten next tile.
     FX_STAMP(25);
+    FX_SS(2);
     __syncthreads();
+#ifdef FX_TILE_SPLIT
+    load_tile(t0 + kTile, nv, FX_PREP_U / 2, FX_PREP_U);
+#endif
     FX_STAMP(26);
+    FX_SS(3);
     // buffer slot = survivors already buffered + those of earlier waves + of earlier slices of my wave
     //               + of earlier lanes of my slice: input order is kept
     uint32_t before = 0, tile_total = 0;
@@ -1112,6 +1184,7 @@ __device__ __forceinline__ uint32_t prep_stream(const FxDevParams &P, const FxBu
     buffered += tile_total;
     parity ^= 1u;
     FX_STAMP(27);
+    FX_SS(4);
     // recycling: the next tile might not fit; KEEP: enough survivors wait for the sweep to keep every lane busy (workgroup-uniform)
     if (KEEP ? buffered - swept >= 2u * FX_PREP_T : buffered > kKeep - kTile) {
       __syncthreads();
@@ -1120,10 +1193,13 @@ __device__ __forceinline__ uint32_t prep_stream(const FxDevParams &P, const FxBu
 #pragma unroll
     for (int u = 0; u < FX_PREP_U; ++u) v[u] = nv[u];
     FX_STAMP(29);
+    FX_SS(6);
   }
   __syncthreads();
   sweep();
   __syncthreads();
+  FX_SS(5);
+  FX_SS_FLUSH(B.stamps);
   return base + buffered;
 }
 
@@ -1187,8 +1263,9 @@ extern "C" __global__ __launch_bounds__(FX_PREP_T) void k_prep_count(FxDevParams
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const uint32_t i = i0 + u * FX_PREP_T + tid;
-        const gfloat *q = gpts + (size_t)min(i, hi - 1u) * M.stride_f;
-        x[u] = i < hi ? q[0] : NAN, y[u] = q[1], z[u] = q[2];
+        typedef float gf3 __attribute__((ext_vector_type(3), aligned(4)));
+        const gf3 w = *(const __attribute__((address_space(1))) gf3 *)(gpts + (size_t)min(i, hi - 1u) * M.stride_f);  // (one 12-byte load: see prep_stream)
+        x[u] = i < hi ? w.x : NAN, y[u] = w.y, z[u] = w.z;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {  // prep_stream's predicate: the same arithmetic, the same clamped limits

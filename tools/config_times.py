@@ -20,7 +20,7 @@ import bench  # the configurations bench.py reports as other_configs
 
 name = [n for n in bench.OTHER_CONFIGS if n.startswith(f"config{which}")][0]
 C = bench.OTHER_CONFIGS[name]
-B = int(sys.argv[2]) if len(sys.argv) > 2 else C["batch"]
+B = int(sys.argv[2]) if len(sys.argv) > 2 and int(sys.argv[2]) else C["batch"]
 cfg = C["synth"]
 p = capi.params(C["preset"], **C["params"])
 lim = capi.limits(B, cfg["n_rings"] * cfg["n_az"], **dict(C["limits"], max_total_keypoints=B * 256))

@@ -12,13 +12,14 @@ from tests.test_gpu_fuzz import _case
 PATHS = {"front": None, "separate": dict(FX_FRONT="0"), "separate-large-merge": dict(FX_FRONT="0", FX_MERGE_BIG_CAP="16"),
          "front-redo": dict(FX_FRONT_FORCE="1"), "front-tail": dict(FX_FRONT_FORCE="2")}
 HOOKS = ("FX_FRONT", "FX_MERGE_BIG_CAP", "FX_FRONT_FORCE")
-t0 = time.time(); bad = 0; total_k = 0
+t0 = time.time(); bad = 0; total_k = 0; n_over = 0
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 paths = sys.argv[3].split(",") if len(sys.argv) > 3 else list(PATHS)
 lim = dict(max_candidates=3500, max_kpc_points=57600, max_keypoints=1024, max_total_keypoints=1024, max_ring_candidates=512)
 for seed in range(lo, hi):
     s, p, roll, pitch, what = _case(seed)
     ora = O.run(p, s, roll=roll, pitch=pitch)
+    over = ora["n_keypoints"] > lim["max_keypoints"] or len(ora["candidates"]) > lim["max_candidates"]  # (the scene exceeds THIS tool's limits: every path must say so)
     for path in paths:
         for h in HOOKS:
             os.environ.pop(h, None)
@@ -31,10 +32,16 @@ for seed in range(lo, hi):
                 ctx = capi.Context(p, capi.limits(1, 28800, **lim))
         got = ctx.process_host([s], roll=roll, pitch=pitch)[0]
         ctx.close()
+        if over:
+            n_over += 1
+            if not (got["flags"] & (capi.FX_FLAG_KP_OVERFLOW | capi.FX_FLAG_CAND_OVERFLOW)):
+                bad += 1
+                print("MISSING FLAG", seed, path, hex(got["flags"]), what)
+            continue
         try:
             st = util.compare_scan(got, ora, tag=f"seed {seed} {path}")
             total_k += st["K"]
         except AssertionError as e:
             bad += 1
             print("MISMATCH", seed, path, str(e)[:300], what)
-print(f"seeds {lo}..{hi} x {paths}: {bad} mismatches, {total_k} keypoints, {time.time() - t0:.0f} s")
+print(f"seeds {lo}..{hi} x {paths}: {bad} mismatches, {total_k} keypoints, {n_over} runs over this tool's limits (flagged), {time.time() - t0:.0f} s")
