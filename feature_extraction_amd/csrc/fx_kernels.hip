@@ -2942,6 +2942,37 @@ extern "C" __global__ __launch_bounds__(FX_FRONT_T, FX_PREP_OCC) void k_front(Fx
       const int ra = mask ? r_first + (__ffs((int)mask) - 1) : -1;
       const bool two = (mask & (mask - 1u)) != 0u;
       if (mask) ring_a[u] = (uint32_t)ra | (two ? 0x100u : 0u);
+#ifndef FX_SPLIT_BALLOTS
+      // Ranks by a PACKED prefix sum: a lane's memberships as a one in the 8-bit field of its ring (four rings a word: at most
+      // 64 points a piece, no field overflows), the words prefix-summed across the wavefront (six DPP steps each) — the rank
+      // among the piece's points of every ring at once.  (A ballot per ring present: sixteen dependent trips a piece.)
+      const uint32_t rb = (uint32_t)ra + 1u;
+      const uint32_t one_a = mask ? 1u << (8u * ((uint32_t)ra & 3u)) : 0u, one_b = two ? 1u << (8u * (rb & 3u)) : 0u;
+      const uint32_t ka = (uint32_t)ra >> 2, kb = rb >> 2;
+      uint32_t mine_a = 0, mine_b = 0, tot = 0;  // the words of this lane's rings; lane r: the word of ring r's totals
+#pragma nounroll
+      for (uint32_t k = 0; 4u * k < R; ++k) {  // (a word of four rings a trip)
+        uint32_t x = (ka == k ? one_a : 0u) + (kb == k ? one_b : 0u);
+        x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
+        x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
+        x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
+        x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8
+        x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15
+        x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31
+        if (ka == k) mine_a = x;
+        if (kb == k) mine_b = x;
+        const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+        if ((lane >> 2) == k) tot = t;
+      }
+      // (this lane's points of ring r so far: lane r's run_cnt — fetched by the ring's number)
+      const uint32_t before_a = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)ra & 63u) << 2), (int)run_cnt);
+      if (mask) ring_a[u] |= (before_a + ((mine_a >> (8u * ((uint32_t)ra & 3u))) & 0xffu) - 1u) << 16;
+      if (__ballot(two)) {  // (wave-uniform; a point exactly on a window's edge: rare)
+        const uint32_t before_b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((rb & 63u) << 2), (int)run_cnt);
+        if (two) place_b[u] = before_b + ((mine_b >> (8u * (rb & 3u))) & 0xffu) - 1u;
+      }
+      if (lane < R) run_cnt += (tot >> (8u * (lane & 3u))) & 0xffu;
+#else
       int lo = mask ? ra : 0x7fffffff, hi = mask ? ra + (two ? 2 : 1) : -1;  // rings present in these 64 points: [lo, hi)
 #pragma unroll
       for (int d = 32; d > 0; d >>= 1) {
@@ -2959,6 +2990,7 @@ extern "C" __global__ __launch_bounds__(FX_FRONT_T, FX_PREP_OCC) void k_front(Fx
         if (in_b) place_b[u] = at;
         if ((int)lane == r) run_cnt += (uint32_t)__popcll(m);
       }
+#endif
     }
     if (lane < R) cw[wave * R + lane] = run_cnt;
     FX_STAMP(17);
