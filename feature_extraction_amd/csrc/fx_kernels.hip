@@ -42,6 +42,18 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
 
 // Stable rank of the threads whose pred is true (order = thread index); total = number of them.
 // s_w: FX_NWAVE words of LDS scratch.  Contains two barriers.
+// Inclusive prefix sum across a wavefront whose 64 lanes are all active: six DPP adds (row shifts, then the row broadcasts
+// of gfx9) — a __shfl_up is a ds_bpermute, an LDS round trip a step, and these scans sit between barriers with the other
+// wavefronts waiting.
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31
+  return x;
+}
 template <int NT>
 __device__ __forceinline__ uint32_t block_rank(bool pred, uint32_t *s_w, uint32_t &total) {
   const unsigned long long m = __ballot(pred);
@@ -65,11 +77,7 @@ template <int NT>
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_w, uint32_t &total) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t inc = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t t = __shfl_up(inc, d, 64);
-    if ((int)lane >= d) inc += t;
-  }
+  inc = wave_incl_scan(inc);
   if (lane == 63) s_w[wave] = inc;
   __syncthreads();
   uint32_t base = 0, tot = 0;
@@ -2437,11 +2445,7 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
       uint32_t sum = 0;
       for (uint32_t u = 0; u < per; ++u) sum += bin[tid * per + u];
       uint32_t incl = sum;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
-        if ((int)tid >= d) incl += o;
-      }
+      incl = wave_incl_scan(incl);
       uint32_t run = incl - sum;
       for (uint32_t u = 0; u < per; ++u) {
         const uint32_t c = bin[tid * per + u];
@@ -2915,11 +2919,7 @@ extern "C" __global__ __launch_bounds__(FX_FRONT_T, FX_PREP_OCC) void k_front(Fx
     if (tid < 64) {
       const uint32_t c = tid < R ? r_cnt[tid] : 0u;
       uint32_t inc = c;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(inc, d, 64);
-        if ((int)lane >= d) inc += t;
-      }
+      inc = wave_incl_scan(inc);
       if (tid <= R) r_off[tid] = inc - c;  // (r_off[R] = n)
     }
     FX_STAMP(16);
@@ -2953,12 +2953,7 @@ extern "C" __global__ __launch_bounds__(FX_FRONT_T, FX_PREP_OCC) void k_front(Fx
 #pragma nounroll
       for (uint32_t k = 0; 4u * k < R; ++k) {  // (a word of four rings a trip)
         uint32_t x = (ka == k ? one_a : 0u) + (kb == k ? one_b : 0u);
-        x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
-        x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
-        x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
-        x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8
-        x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15
-        x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31
+        x = wave_incl_scan(x);
         if (ka == k) mine_a = x;
         if (kb == k) mine_b = x;
         const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
@@ -3064,11 +3059,7 @@ extern "C" __global__ __launch_bounds__(FX_FRONT_T, FX_PREP_OCC) void k_front(Fx
     if (tid < 64) {
       const uint32_t rc = tid < nblk ? (uint32_t)__popcll(smask[tid]) : 0u, sc = tid < nblk ? (uint32_t)__popcll(gmask[tid]) : 0u;
       uint32_t ir = rc, is = sc;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t tr = __shfl_up(ir, d, 64), ts = __shfl_up(is, d, 64);
-        if ((int)lane >= d) ir += tr, is += ts;
-      }
+      ir = wave_incl_scan(ir), is = wave_incl_scan(is);
       if (tid < FX_FRONT_BLOCKS) run_base[tid] = ir - rc, seg_base[tid] = is - sc;
       if (tid == 63) s_w[20] = ir, s_w[21] = is;
     }
@@ -3861,11 +3852,7 @@ __device__ __forceinline__ void gather_body(const FxDevParams &P, const FxBuffer
       sum += ci < n_cells ? s_cell[ci] : 0u;
     }
     uint32_t incl = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
-      if ((int)tid >= d) incl += o;
-    }
+    incl = wave_incl_scan(incl);
     uint32_t run = incl - sum;
     for (uint32_t u = 0; u < per; ++u) {
       const uint32_t ci = tid * per + u;
@@ -4568,11 +4555,7 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
           sum += ci < kCells ? cell_end[ci] : 0u;
         }
         uint32_t incl = sum;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
-          if ((int)tid >= d) incl += o;
-        }
+        incl = wave_incl_scan(incl);
         uint32_t run = incl - sum;
         for (uint32_t u = 0; u < per; ++u) {
           const uint32_t ci = tid * per + u;
@@ -4735,11 +4718,7 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
       sum += bi < FX_DESC_BINS ? bin_end[bi] : 0u;
     }
     uint32_t incl = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
-      if ((int)tid >= d) incl += o;
-    }
+    incl = wave_incl_scan(incl);
     uint32_t run = incl - sum;
     for (uint32_t u = 0; u < per; ++u) {
       const uint32_t bi = tid * per + u;
@@ -4937,11 +4916,7 @@ __device__ __forceinline__ uint32_t dense_cells_prefix(uint32_t *cells, uint32_t
     sum += PAD ? (c + 3u) & ~3u : c;
   }
   uint32_t incl = sum;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
-    if ((int)lane >= d) incl += o;
-  }
+  incl = wave_incl_scan(incl);
   if (lane == 63u) tmp[wave] = incl;
   __syncthreads();
   uint32_t run = incl - sum, total = 0;
@@ -5221,11 +5196,7 @@ __device__ __forceinline__ uint32_t ddens_bin(uint32_t len) {  // len in [1, 204
 __device__ __forceinline__ uint32_t wg256_prefix(uint32_t v, uint32_t *tmp, uint32_t &total) {
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint32_t incl = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
-    if ((int)lane >= d) incl += o;
-  }
+  incl = wave_incl_scan(incl);
   if (lane == 63u) tmp[wave] = incl;
   __syncthreads();
   uint32_t before = 0;
@@ -5619,11 +5590,7 @@ __device__ __forceinline__ void dense_finish_row(const FxDevParams &P, const FxB
     uint32_t sum = 0;
     for (uint32_t u = 0; u < per; ++u) sum += bin_end[tid * per + u];
     uint32_t incl = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
-      if ((int)tid >= d) incl += o;
-    }
+    incl = wave_incl_scan(incl);
     uint32_t run = incl - sum;
     for (uint32_t u = 0; u < per; ++u) {
       const uint32_t c = bin_end[tid * per + u];
