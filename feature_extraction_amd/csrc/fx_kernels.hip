@@ -3220,18 +3220,23 @@ extern "C" __global__ __launch_bounds__(FX_FRONT_T, FX_PREP_OCC) void k_front(Fx
       wave_sync_lds();
       wq_n = 0;
     };
+    // In an azimuth-ordered ring the edge between two near runs, when there is one, is mostly between the end of the earlier
+    // and the start of the later (an arc behind a pole's shadow): found at once, the pair needs nothing else.  That test a pair
+    // a LANE (it is a chain of dependent LDS reads: a pair a wavefront spent most of this step waiting on them 64 lanes wide);
+    // what it does not settle, a pair a wavefront.
+    for (uint32_t t = tid; t < n_rp; t += NT) {
+      const uint32_t pr = pairs[t], a = pr >> 16, b = pr & 0xffffu;
+      const uint32_t ia = run_first(a + 1u) - 1u, ib = run_first(b);
+      if (dist2(px[ib], py[ib], pz[ib], px[ia], py[ia], pz[ia]) < r2) {
+        uf_union(rparent, b, a);
+        pairs[t] = FX_NONE;
+      }
+    }
+    __syncthreads();
     for (uint32_t t = wave; t < n_rp; t += NW) {
       const uint32_t pr = pairs[t], a = pr >> 16, b = pr & 0xffffu;
+      if (pr == FX_NONE) continue;  // (wave-uniform)
       const uint32_t i_end = run_first(a + 1u);
-      {
-        // In an azimuth-ordered ring the edge between two near runs, when there is one, is mostly between the end of the
-        // earlier and the start of the later (an arc behind a pole's shadow): found at once, the pair needs nothing else.
-        const uint32_t ia = i_end - 1u, ib = run_first(b);
-        if (dist2(px[ib], py[ib], pz[ib], px[ia], py[ia], pz[ia]) < r2) {
-          if (lane == 0) uf_union(rparent, b, a);
-          continue;
-        }
-      }
       const float4 bb = rbox4[b];
       for (uint32_t i0 = run_first(a); i0 < i_end; i0 += 64) {
         const uint32_t i = i0 + lane;
