@@ -3978,10 +3978,27 @@ __device__ __forceinline__ void gather_body(const FxDevParams &P, const FxBuffer
   };
   // the 64-byte sectors (four points) of a tile that hold a point within reach of the filter box (k_prep): this
   // wavefront's 256 points = the 64 sector bits one wavefront of k_prep wrote (its tiles are two of these)
+  // (The wavefront's sector words of 64 tiles at a time, lane t those of tile t — ONE load, then a readlane per tile: fetched
+  //  tile by tile, the two words were a global round trip in front of every tile's loads, which they predicate.)
+  uint2 nb_words = make_uint2(0u, 0u);
+  uint32_t nb_first = lo;  // the tile lane 0 holds
+  auto nb_fill = [&](uint32_t i_first) {
+    nb_first = i_first;
+    const uint32_t i = i_first + lane * kTile;
+    nb_words = make_uint2(0u, 0u);
+    if (i < hi) {
+      const uint32_t w = (i + wave * 256u) / 128u;  // (sector order: this wavefront's 256 points are 64 sectors = two words; w is even)
+      nb_words = *reinterpret_cast<const uint2 *>(near_bits + w);
+    }
+  };
+  nb_fill(lo);
   auto near_sectors = [&](uint32_t i0) -> unsigned long long {
     if (i0 >= hi) return 0ull;
-    const uint32_t w = (i0 + wave * 256u) / 128u;  // (sector order: this wavefront's 256 points are 64 sectors = two words)
-    return (unsigned long long)near_bits[w] | ((unsigned long long)near_bits[w + 1] << 32);
+    uint32_t t = (i0 - nb_first) / kTile;  // (workgroup-uniform)
+    if (t >= 64u) nb_fill(i0), t = 0u;
+    const uint32_t ts = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    return (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)nb_words.x, (int)ts) |
+           ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)nb_words.y, (int)ts) << 32);
   };
   auto load_tile = [&](uint32_t i0, unsigned long long sect, float4 (&v)[4]) {
 #pragma unroll
