@@ -4538,6 +4538,21 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
   const FxScanMeta M = B.meta[scan];
   const float4 kp = B.keypoints[(size_t)scan * P.max_keypoints + k];
   float *out = B.desc + (size_t)row * FX_DESC_FLOATS;
+  // A list row's entries (up to four a thread: lists of up to 4 NT entries), its length and its x-axis are fetched HERE, with
+  // the keypoint, before the length is known (slots past it hold stale data and are ignored): fetched where they are used
+  // they were three more global round trips in a row's chain — keypoint, list (counting pass), list (fill pass), x-axis.
+  constexpr uint32_t kPre = 4;
+  const bool pre = from_list && !GS;
+  float4 lv[kPre];
+  uint32_t nS_pre = 0;
+  float2 xa_pre = make_float2(1.f, 0.f);
+  if (pre) {
+    nS_pre = B.s_cnt[row];
+    xa_pre = B.row_xa[row];
+#pragma unroll
+    for (uint32_t u = 0; u < kPre; ++u)
+      if (tid + u * NT < P.list_cap) lv[u] = B.s_pts[(size_t)row * P.list_cap + tid + u * NT];
+  }
 
   if (tid < 4) L.s_w[tid] = 0;  // 0: support count, 1: binned neighbours, 2: all neighbours
   // the 3DSC tables ride in the image until the bins are known (the image is cleared after that)
@@ -4558,15 +4573,22 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
   auto cell_of = [&](float x, float y, float z) { return (cell_1d(z, gz0) * G + cell_1d(y, gy0)) * G + cell_1d(x, gx0); };
   bool grid = false;
   if (from_list) {
-    nS = B.s_cnt[row];
+    nS = pre ? nS_pre : B.s_cnt[row];
     grid = nS <= cap;
+    const bool in_regs = pre && nS <= kPre * NT;  // (workgroup-uniform)
     if (grid) {
       const float4 *lst = B.s_pts + (size_t)row * P.list_cap;
       for (uint32_t t = tid; t < kCells; t += NT) cell_end[t] = 0;
       wg_sync<GS>();
-      for (uint32_t e = tid; e < nS; e += NT) {
-        const float4 v = lst[e];
-        atomicAdd(&cell_end[cell_of(v.x, v.y, v.z)], 1u);
+      if (in_regs) {
+#pragma unroll
+        for (uint32_t u = 0; u < kPre; ++u)
+          if (tid + u * NT < nS) atomicAdd(&cell_end[cell_of(lv[u].x, lv[u].y, lv[u].z)], 1u);
+      } else {
+        for (uint32_t e = tid; e < nS; e += NT) {
+          const float4 v = lst[e];
+          atomicAdd(&cell_end[cell_of(v.x, v.y, v.z)], 1u);
+        }
       }
       wg_sync<GS>();
       if (tid < 64) {  // counts -> exclusive starts, in place, by one wavefront
@@ -4589,11 +4611,22 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
         }
       }
       wg_sync<GS>();
-      for (uint32_t e = tid; e < nS; e += NT) {  // second read of the list (cache-resident): each entry to its cell
-        const float4 v = lst[e];
-        const uint32_t slot = atomicAdd(&cell_end[cell_of(v.x, v.y, v.z)], 1u);
-        L.sp[slot] = make_float4(v.x, v.y, v.z, dist2(kp.x, kp.y, kp.z, v.x, v.y, v.z));
-        L.sidx[slot] = __float_as_uint(v.w);
+      if (in_regs) {
+#pragma unroll
+        for (uint32_t u = 0; u < kPre; ++u)
+          if (tid + u * NT < nS) {
+            const float4 v = lv[u];
+            const uint32_t slot = atomicAdd(&cell_end[cell_of(v.x, v.y, v.z)], 1u);
+            L.sp[slot] = make_float4(v.x, v.y, v.z, dist2(kp.x, kp.y, kp.z, v.x, v.y, v.z));
+            L.sidx[slot] = __float_as_uint(v.w);
+          }
+      } else {
+        for (uint32_t e = tid; e < nS; e += NT) {  // second read of the list (cache-resident): each entry to its cell
+          const float4 v = lst[e];
+          const uint32_t slot = atomicAdd(&cell_end[cell_of(v.x, v.y, v.z)], 1u);
+          L.sp[slot] = make_float4(v.x, v.y, v.z, dist2(kp.x, kp.y, kp.z, v.x, v.y, v.z));
+          L.sidx[slot] = __float_as_uint(v.w);
+        }
       }
     } else {
       for (uint32_t e = tid; e < nS; e += NT) {
@@ -4635,7 +4668,7 @@ __device__ __forceinline__ bool desc_body(const FxDevParams &P, const FxBuffers 
   FX_STAMP(1);
 
   const FxScTables *T = reinterpret_cast<const FxScTables *>(tl);
-  const float2 xa = B.row_xa[row];
+  const float2 xa = pre ? xa_pre : B.row_xa[row];
   // ---- neighbours (d2 < R^2, not the keypoint itself) packed densely: nlist[m] = support position.
   //      The list lives in the weight array and the density counters in the key array until the
   //      per-neighbour pass below overwrites slot m with the real key and weight.
