@@ -4281,32 +4281,44 @@ extern "C" __global__ __launch_bounds__(FX_WG, FX_GROUP_OCC) void k_desc_group(F
   uint32_t total = B.kp_offset[batch];
   if (total > P.max_total_kp) total = P.max_total_kp;
   const uint32_t stride = gridDim.x * FX_NWAVE * FX_GROUPS;
+  // Everything a row needs is fetched in one round trip — keypoint, x-axis, the list entries before the list length is known
+  // (slots past the length hold stale data and are ignored), and what the row holds from last time (its bin count and all 64
+  // slots of its bin list, four per lane) — and a TRIP AHEAD: the next trip's loads go out before this trip's last step (few
+  // registers are live there) and are taken at the top of the next trip.  (With one workgroup a CU a wavefront has a SIMD to
+  // itself, and every trip began with that round trip.)
+  static_assert(FX_GROUP_CAP == 4 * FX_GLANES, "a lane fetches four slots of the row's bin list");
+  uint2 f_rm = make_uint2(0u, 0u), f_pb = make_uint2(0u, 0u);
+  uint32_t f_nS = 0, f_nb = 0;
+  float4 f_kp = make_float4(0, 0, 0, 0), f_lv[FX_GROUP_CAP / FX_GLANES];
+  float2 f_xa = make_float2(1.f, 0.f);
+  auto fetch = [&](uint32_t row) {
+    if (row < total) {
+      f_rm = B.row_map[row];
+      f_nS = B.s_cnt[row];
+      f_kp = B.row_kp[row];
+      f_xa = B.row_xa[row];
+#pragma unroll
+      for (uint32_t u = 0; u < FX_GROUP_CAP / FX_GLANES; ++u)
+        if (gl + u * FX_GLANES < P.list_cap) f_lv[u] = B.s_pts[(size_t)row * P.list_cap + gl + u * FX_GLANES];
+      f_nb = B.desc_nbins[row];
+      f_pb = *reinterpret_cast<const uint2 *>(B.desc_bins + (size_t)row * FX_GROUP_CAP + 4u * gl);
+    }
+  };
+  fetch((blockIdx.x * FX_NWAVE + wave) * FX_GROUPS + g);
   // all groups of a wavefront make the same number of trips (wave-level fences inside)
   for (uint32_t r0 = (blockIdx.x * FX_NWAVE + wave) * FX_GROUPS; r0 < total; r0 += stride) {
     const uint32_t row = r0 + g;
     bool live = row < total;
     uint32_t scan = 0, k = 0, nS = 0;
-    // everything the row needs is fetched in one round trip: keypoint, x-axis, and the list entries
-    // before the list length is known (slots past the length hold stale data and are ignored)
     float4 kp = make_float4(0, 0, 0, 0);
     float2 xa = make_float2(1.f, 0.f);
     float4 lv[FX_GROUP_CAP / FX_GLANES];
     uint32_t nb_prev = 0;
     uint2 pb = make_uint2(0u, 0u);
-    static_assert(FX_GROUP_CAP == 4 * FX_GLANES, "a lane fetches four slots of the row's bin list");
     if (live) {
-      const uint2 rm = B.row_map[row];
-      nS = B.s_cnt[row];
-      kp = B.row_kp[row];
-      xa = B.row_xa[row];
+      scan = f_rm.x, k = f_rm.y, nS = f_nS, kp = f_kp, xa = f_xa, nb_prev = f_nb, pb = f_pb;
 #pragma unroll
-      for (uint32_t u = 0; u < FX_GROUP_CAP / FX_GLANES; ++u)
-        if (gl + u * FX_GLANES < P.list_cap) lv[u] = B.s_pts[(size_t)row * P.list_cap + gl + u * FX_GLANES];
-      scan = rm.x, k = rm.y;
-      // (what the row holds from last time, fetched in the same round trip: its bin count and all 64 slots of its bin list —
-      //  four per lane, the unused ones ignored — instead of the count first and then that many bins)
-      nb_prev = B.desc_nbins[row];
-      pb = *reinterpret_cast<const uint2 *>(B.desc_bins + (size_t)row * FX_GROUP_CAP + 4u * gl);
+      for (uint32_t u = 0; u < FX_GROUP_CAP / FX_GLANES; ++u) lv[u] = f_lv[u];
     }
     float *out = B.desc + (size_t)row * FX_DESC_FLOATS;
     // Every descriptor row is cleared here, whichever tier ends up computing it (the keypoint kernels write
@@ -4470,6 +4482,7 @@ extern "C" __global__ __launch_bounds__(FX_WG, FX_GROUP_OCC) void k_desc_group(F
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    fetch(r0 + stride + g);  // (the next trip's rows: see the top)
     // one lane per bin run adds its weights in sorted order (the row was cleared at the top of this trip)
     for (uint32_t e = gl; e < nM; e += FX_GLANES) {
       const uint32_t bin = (uint32_t)(skey[e] >> 52);
