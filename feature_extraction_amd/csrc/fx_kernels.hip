@@ -4292,6 +4292,10 @@ extern "C" __global__ __launch_bounds__(FX_WG, FX_GROUP_OCC) void k_desc_group(F
   float4 f_kp = make_float4(0, 0, 0, 0), f_lv[FX_GROUP_CAP / FX_GLANES];
   float2 f_xa = make_float2(1.f, 0.f);
   auto fetch = [&](uint32_t row) {
+    // (every value is defined anew on both paths: nothing of the previous fetch stays live across a trip)
+    f_rm = make_uint2(0u, 0u), f_pb = make_uint2(0u, 0u), f_nS = 0, f_nb = 0, f_kp = make_float4(0, 0, 0, 0), f_xa = make_float2(1.f, 0.f);
+#pragma unroll
+    for (uint32_t u = 0; u < FX_GROUP_CAP / FX_GLANES; ++u) f_lv[u] = make_float4(0, 0, 0, 0);
     if (row < total) {
       f_rm = B.row_map[row];
       f_nS = B.s_cnt[row];
