@@ -192,6 +192,7 @@ def main():
     ap.add_argument("--contexts", type=int, default=4,
                     help="batches in flight per GPU: contexts (each on its own HIP stream) taking the steps in turn")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-descriptors", action="store_true", help="diagnostic: estimate_descriptors = 0 (the detector alone; not the headline metric)")
     ap.add_argument("--no-extras", action="store_true", help="skip other_configs and the host-to-host measurement")
     ap.add_argument("--check", type=int, default=16, help="scans of rank 0 checked against the oracle after timing")
     ap.add_argument("--repeats", type=int, default=0, help="timed regions of --steps steps (0: as many as fill --target-seconds); the median is reported")
@@ -242,7 +243,7 @@ def main():
     scans = make_scans(capi, seeds, max(1, threads // max(1, min(world, 8))))
     host = np.stack(scans)  # [B, N, 4]
     d_in = torch.from_numpy(host).to(dev)  # resident in HBM before the timed region
-    params = capi.params(args.preset)
+    params = capi.params(args.preset, estimate_descriptors=0) if args.no_descriptors else capi.params(args.preset)
     # K contexts, each on its own HIP stream, take the steps in turn: the stage kernels of a batch are latency
     # bound and leave issue slots, LDS and whole CUs idle (tails, the large tiers' thin launches), which the
     # kernels of the other batches in flight fill.  One step is still one pass over one batch of B scans.

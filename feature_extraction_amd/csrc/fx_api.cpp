@@ -52,6 +52,9 @@ uint32_t fxk_front_max_rings(void);
 uint32_t fxk_front_merge_cap(void);
 void fxk_front(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float near_margin, float el0, float inv_step,
                uint32_t clk_slot, uint32_t merge_cap, uint32_t force_redo);
+void fxk_front_ab(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float near_margin, float el0, float inv_step,
+                  uint32_t clk_slot, uint32_t force_redo);
+void fxk_front_cd(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t clk_slot, uint32_t merge_cap);
 void fxk_front_redo(hipStream_t s, const FxDevParams &P, const FxBuffers &B, float el0, float inv_step, uint32_t huge_ccap, uint32_t force_slow,
                     uint32_t grid);
 size_t fxk_slow_words(uint32_t max_ring_points, uint32_t max_candidates, uint32_t huge_ccap);
@@ -169,6 +172,11 @@ struct fx_ctx {
   bool front_ok = false;       // sensor within k_front's ring capacity
   bool front_last = false;     // what the last batch ran
   uint32_t front_force = 0;    // test hook (FX_FRONT_FORCE)
+  // k_front as TWO launches (k_front_ab: streaming pass + ring split, the ring-major records through HBM; k_front_cd:
+  // clustering + merge).  Built, parity-green, and NOT the default: alone the two take what the one takes
+  // (0.134 + 0.156 against 0.286 ms), with four batches in flight the headline is 3 % lower (profiles/r06_experiments.md §1).
+  // The test build's FX_FRONT_SPLIT=1 runs it (tests/test_gpu_front_split.py, the fuzz's front-split path).
+  int front_split = 0;         // 1: the two launches; 0: the one fused launch
   // A batch that failed after its kernels were enqueued leaves state the next batch would build on: descriptor rows are
   // cleared by un-writing what the last batch recorded for them (desc_nbins / desc_bins), the work-list counters are
   // cleared by the batch's first kernel, the tier hints size the next grids.  The next batch then starts from scratch:
@@ -251,8 +259,11 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof, bo
   for (int i = 0; i < FX_N_HINTS; ++i) {
     hint[i] = (capture || !c->tier_min_grid) ? 0xffffffffu : c->tier_hint[i];
     if (capture || !c->tier_min_grid) continue;
-    // (held: the largest count of the last hint_hold_batches batches; "nothing known yet" stays that)
-    if (hint[i] == 0xffffffffu || hint[i] >= c->hint_hold[i] || ++c->hint_age[i] > fx_ctx::hint_hold_batches) c->hint_hold[i] = hint[i], c->hint_age[i] = 0;
+    // (held: the largest count of the last hint_hold_batches batches; "nothing known yet" stays that only until something
+    //  is known — held like a count it kept every rare tier at its full grid for the first 64 batches of a context, and
+    //  after every reset)
+    if (hint[i] == 0xffffffffu || c->hint_hold[i] == 0xffffffffu || hint[i] >= c->hint_hold[i] || ++c->hint_age[i] > fx_ctx::hint_hold_batches)
+      c->hint_hold[i] = hint[i], c->hint_age[i] = 0;
     hint[i] = c->hint_hold[i];
   }
   // (min_wg: the scans k_front hands on — k_front_redo, k_slow — get ONE workgroup when the last 64 batches handed on
@@ -301,8 +312,16 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof, bo
       // LDS: an empty launch of it places anywhere) for what exceeds that shape's LDS too, on scratch in HBM.  All three go
       // with EVERY batch: the hints size grids, they never decide whether a scan gets what it needs.
       const uint32_t mcap = std::min(fxk_front_merge_cap(), L.max_candidates);
-      fxk_front(s, P, B, batch, c->box_margin, el0, inv_step, clk_slot, mcap, c->front_force >= 1u ? 1u : 0u);
-      for (int i = 1; i <= 4; ++i) FX_HIP(mark(i));
+      const bool split = c->front_split != 0;
+      if (split) {  // (stage 0: k_front_ab, stage 1: k_front_cd)
+        fxk_front_ab(s, P, B, batch, c->box_margin, el0, inv_step, clk_slot, c->front_force >= 1u ? 1u : 0u);
+        FX_HIP(mark(1));
+        fxk_front_cd(s, P, B, batch, clk_slot, mcap);
+      } else {
+        fxk_front(s, P, B, batch, c->box_margin, el0, inv_step, clk_slot, mcap, c->front_force >= 1u ? 1u : 0u);
+        FX_HIP(mark(1));
+      }
+      for (int i = 2; i <= 4; ++i) FX_HIP(mark(i));
       if (!(c->skip_mask & 1u))
       fxk_front_redo(s, P, B, el0, inv_step, c->merge_huge_ccap, c->front_force >= 2u ? 1u : 0u, tier_grid(hint[6], 2 * big_grid, batch, 1, 1));
       if (!fxk_slow(s, P, B, c->merge_huge_ccap, tier_grid(hint[7], big_grid, batch, 1, 1), batch, clk_next))  // (one workgroup: it does the offsets too)
@@ -647,6 +666,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   FX_A(dev_alloc(c, &b.big_merge, B));
   FX_A(dev_alloc(c, &b.huge_merge, B));
   FX_A(dev_alloc(c, &b.redo, B));
+  FX_A(dev_alloc(c, &b.front_n, B));
   FX_A(dev_alloc(c, &b.slow, B));
   FX_A(dev_alloc(c, &b.slow_state, B));
   FX_A(dev_alloc(c, &b.ring_pending, B * ((R + 31) / 32)));
@@ -777,6 +797,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   if (const char *e = test_hook("FX_FRONT")) c->front_ok = c->front_ok && atoi(e) != 0;  // 0 = the separate kernels (measurements; tests of those kernels)
   // 1: k_front hands every scan to k_front_redo; 2: and that one every ring and merge to the slow tier, k_slow (tests of those two)
   if (const char *e = test_hook("FX_FRONT_FORCE")) c->front_force = (uint32_t)std::max(0, atoi(e));
+  if (const char *e = test_hook("FX_FRONT_SPLIT")) c->front_split = atoi(e) != 0 ? 1 : 0;
   if (const char *e = test_hook("FX_FAIL_AFTER_ENQUEUE")) c->fail_after = (uint32_t)std::max(0, atoi(e));
   if (const char *e = test_hook("FX_SKIP_EMPTY")) c->skip_mask = (uint32_t)std::max(0, atoi(e));
   if (const char *e = test_hook("FX_DENSE_SLOW")) c->dense_force = atoi(e) != 0 ? 1 : 0;
@@ -821,8 +842,12 @@ fx_status fx_get_stream(fx_ctx *c, void **hip_stream) {
 fx_status fx_set_batches_in_flight(fx_ctx *c, uint32_t n) {
   if (!c) return fail(FX_ERR_INVALID_ARG, "null ctx");
   c->batches_in_flight = n ? n : 1u;
-  for (auto &g : c->graphs) (void)hipGraphExecDestroy(g.second);  // (captured grids are fixed: graphs are rebuilt with the new ones)
-  c->graphs.clear();
+  if (!c->graphs.empty()) {  // (captured grids are fixed: graphs are rebuilt with the new ones — once no replay of an old one is still running)
+    FX_HIP(hipSetDevice(c->device));
+    FX_HIP(hipStreamSynchronize(c->stream));
+    for (auto &g : c->graphs) (void)hipGraphExecDestroy(g.second);
+    c->graphs.clear();
+  }
   return FX_OK;
 }
 fx_status fx_set_graph_batch(fx_ctx *c, uint32_t max_batch) {

@@ -117,6 +117,7 @@ struct FxBuffers {
   uint32_t *huge_rings2;  // [B*n_rings]  rings the second run tier hands to the workgroup tier, by XCD class
   uint32_t *big_merge;    // [B]
   uint32_t *huge_merge;   // [B]  scans with more candidates than the LDS merge tiers hold
+  uint32_t *front_n;      // [B]  k_front_ab -> k_front_cd: the scan's ring-major entries; 0: none (empty results written); FX_NONE: handed to k_front_redo
   uint32_t *redo;         // [B]  scans that do not fit k_front's LDS tables: k_front_redo runs the general kernels' bodies on them
   uint32_t *slow;         // [B]  scans with work for the slow tier (k_slow): rings or merges beyond every LDS-sized tier
   uint32_t *slow_state;   // [B]  1 while the scan is listed (k_slow clears it)

@@ -1088,8 +1088,24 @@ __device__ __forceinline__ uint32_t prep_stream(const FxDevParams &P, const FxBu
   // Range tests with both ends clamped to the finite floats: a NaN or an infinite coordinate fails them (PassThrough drops
   // non-finite points first, ref: SURVEY.md A.2), a finite one compares as in PCL's !(v < min || v > max); an infinite or
   // NaN limit (no limit on that side; a NaN limit compares false in PCL too) becomes +-FLT_MAX.
-  auto lo_lim = [](float v) { return fmaxf(v, -FLT_MAX); };
-  auto hi_lim = [](float v) { return fminf(v, FLT_MAX); };
+  // (Measured and not taken, profiles/r06_experiments.md §1: the twelve limits and the rotation made SCALAR by hand — the device
+  //  has no scalar float arithmetic, so what the compiler computes or loads per lane stays in vector registers, 21 of them —
+  //  -DFX_SCALAR_LIM / -DFX_SCALAR_R: k_prep 84 -> 72 registers, k_front 127 -> 109, and the headline 1 % lower either way.)
+  auto sgpr = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+#ifdef FX_SCALAR_LIM
+  auto lo_lim = [&](float v) { return sgpr(fmaxf(v, -FLT_MAX)); };
+  auto hi_lim = [&](float v) { return sgpr(fminf(v, FLT_MAX)); };
+#else
+  auto lo_lim = [&](float v) { return fmaxf(v, -FLT_MAX); };
+  auto hi_lim = [&](float v) { return fminf(v, FLT_MAX); };
+#endif
+#ifdef FX_SCALAR_R
+  const float R0 = sgpr(M.R[0]), R1 = sgpr(M.R[1]), R2 = sgpr(M.R[2]), R3 = sgpr(M.R[3]), R4 = sgpr(M.R[4]), R5 = sgpr(M.R[5]), R6 = sgpr(M.R[6]),
+              R7 = sgpr(M.R[7]), R8 = sgpr(M.R[8]);
+#else
+  const float R0 = M.R[0], R1 = M.R[1], R2 = M.R[2], R3 = M.R[3], R4 = M.R[4], R5 = M.R[5], R6 = M.R[6], R7 = M.R[7], R8 = M.R[8];
+#endif
+  (void)sgpr;
   const float nx0 = lo_lim(P.x_min - near_margin), nx1 = hi_lim(P.x_max + near_margin), ny0 = lo_lim(P.y_min - near_margin),
               ny1 = hi_lim(P.y_max + near_margin), nz0 = lo_lim(P.z_min - near_margin), nz1 = hi_lim(P.z_max + near_margin);
   const float fx0 = lo_lim(P.x_min), fx1 = hi_lim(P.x_max), fy0 = lo_lim(P.y_min), fy1 = hi_lim(P.y_max), fz0 = lo_lim(P.z_min),
@@ -1122,9 +1138,9 @@ __device__ __forceinline__ uint32_t prep_stream(const FxDevParams &P, const FxBu
 #pragma unroll
     for (int u = 0; u < FX_PREP_U; u += 2) {
       const fx_f2 X = {v[u].x, v[u + 1].x}, Y = {v[u].y, v[u + 1].y}, Z = {v[u].z, v[u + 1].z};
-      const fx_f2 a = (M.R[0] * X + M.R[1] * Y) + M.R[2] * Z;
-      const fx_f2 b = (M.R[3] * X + M.R[4] * Y) + M.R[5] * Z;
-      const fx_f2 c = (M.R[6] * X + M.R[7] * Y) + M.R[8] * Z;
+      const fx_f2 a = (R0 * X + R1 * Y) + R2 * Z;
+      const fx_f2 b = (R3 * X + R4 * Y) + R5 * Z;
+      const fx_f2 c = (R6 * X + R7 * Y) + R8 * Z;
       rxs[u] = a.x, rxs[u + 1] = a.y, rys[u] = b.x, rys[u + 1] = b.y, rzs[u] = c.x, rzs[u + 1] = c.y;
     }
 #pragma unroll
@@ -2823,16 +2839,20 @@ __host__ __device__ inline size_t front_lds_bytes() { return (size_t)FrontOff::e
 
 __device__ __forceinline__ unsigned long long le_mask64(uint32_t lane) { return lane == 63u ? ~0ull : ((2ull << lane) - 1ull); }
 
-extern "C" __global__ __launch_bounds__(FX_FRONT_T, FX_PREP_OCC) void k_front(FxDevParams P, FxBuffers B, float near_margin, float el0, float inv_step,
-                                                                           uint32_t clk_slot, uint32_t merge_cap, uint32_t force_redo) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+// Phases C and D of the fused front kernel — getCylinderSegments for all rings of the scan at once, then the secondary merge —
+// on the LDS image FrontOff describes: the ring-major points in px / py / pz, r_off / r_cnt set, n entries in all.  Shared by
+// k_front (the scan never left the workgroup; RM = false: a member's record is ~cloud's, through the survivor index sidx) and
+// k_front_cd (RM = true: the ring-major records k_front_ab wrote to B.ring_pts, entry i = record i).  Ends the workgroup's
+// work for the scan: results written, or the scan handed to k_front_redo.
+template <bool RM>
+__device__ __forceinline__ void front_cluster_merge(const FxDevParams &P, const FxBuffers &B, uint32_t scan, uint32_t *smem, uint32_t n,
+                                                    uint32_t clk_slot, uint32_t merge_cap) {
   using O = FrontOff;
-  constexpr uint32_t NT = FX_FRONT_T, NW = FX_FRONT_NW, CAP = FX_FRONT_CAP, RUNS = FX_FRONT_RUNS, SEGS = FX_FRONT_SEGS;
-  static_assert(merge_words(FX_FRONT_MERGE, FX_FRONT_MERGE, FX_FRONT_RMAX, true) <= 3 * FX_FRONT_CAP, "the merge's image borrows the points");
-  const uint32_t scan = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr uint32_t NT = FX_FRONT_T, NW = FX_FRONT_NW, RUNS = FX_FRONT_RUNS, SEGS = FX_FRONT_SEGS;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t R = (uint32_t)P.n_rings;
   float *px = reinterpret_cast<float *>(smem + O::px), *py = reinterpret_cast<float *>(smem + O::py), *pz = reinterpret_cast<float *>(smem + O::pz);
-  uint16_t *sidx = reinterpret_cast<uint16_t *>(smem + O::sidx);
+  const uint16_t *sidx = reinterpret_cast<const uint16_t *>(smem + O::sidx);
   uint32_t *s_w = smem + O::s_w, *r_off = smem + O::r_off, *r_cnt = smem + O::r_cnt, *r_run0 = smem + O::r_run0, *r_cb = smem + O::r_cb;
   unsigned long long *smask = reinterpret_cast<unsigned long long *>(smem + O::smask), *gmask = reinterpret_cast<unsigned long long *>(smem + O::gmask);
   uint32_t *run_base = smem + O::run_base, *seg_base = smem + O::seg_base;
@@ -2841,15 +2861,7 @@ extern "C" __global__ __launch_bounds__(FX_FRONT_T, FX_PREP_OCC) void k_front(Fx
   uint32_t *seg_box = smem + O::seg_box, *rbox = smem + O::rbox, *rparent = smem + O::rparent, *rsize = smem + O::rsize;
   uint16_t *croot = reinterpret_cast<uint16_t *>(smem + O::croot);
   uint32_t *crec = smem + O::crec, *ctmp = smem + O::ctmp;
-  {  // the support-list counters of the batch are cleared here, a slice per scan (k_gather fills them)
-    const uint32_t per = (P.max_total_kp + gridDim.x - 1) / gridDim.x;
-    const uint32_t z0 = scan * per, z1 = min(z0 + per, P.max_total_kp);
-    for (uint32_t t = z0 + tid; t < z1; t += NT) B.s_cnt[t] = 0u;
-    if (tid == 0) B.ovf_cnt[scan] = 0u;  // entries in the scan's overflow region (k_gather)
-  }
-  const FxScanMeta M = B.meta[scan];
   FX_STAMP_INIT(B.stamps);
-  if (tid == 0) atomicMin(&B.clk[2 * clk_slot], (unsigned long long)wall_clock64());
   auto stamp_end = [&]() {
     if (tid == 0) atomicMax(&B.clk[2 * clk_slot + 1], (unsigned long long)wall_clock64());
   };
@@ -2860,175 +2872,16 @@ extern "C" __global__ __launch_bounds__(FX_FRONT_T, FX_PREP_OCC) void k_front(Fx
       B.n_kpc[scan] = 0u;
     }
   };
-  if (M.n == 0) {  // empty scan: its pointer may be null — nothing is loaded
-    if (tid == 0) {
-      B.n_filt[scan] = 0u;
-      B.flags[scan] = 0u;
-    }
-    no_keypoints();
-    for (uint32_t r = tid; r < R; r += NT) B.ring_cnt[(size_t)scan * R + r] = 0u;
-    if (scan == 0 && tid < FX_N_COUNTERS) B.counters[tid] = 0u;
-    return;
-  }
-  // ---------------------------------------------------------------- A: the streaming pass
-  float *s_el = reinterpret_cast<float *>(smem + O::el);
-  const PrepLds PL{smem + O::cnt, px, r_cnt, reinterpret_cast<double *>(smem + O::atan), reinterpret_cast<float2 *>(smem + O::win), s_el, CAP};
-  uint32_t nf = prep_stream<true>(P, B, M, scan, near_margin, el0, inv_step, PL);
-  if (nf == FX_NONE) nf = prep_stream<false>(P, B, M, scan, near_margin, el0, inv_step, PL);  // (more survivors than the buffer keeps: once more, recycling it)
-  FX_STAMP(1);
-  for (uint32_t r = tid; r < R; r += NT) B.ring_cnt[(size_t)scan * R + r] = r_cnt[r];  // (k_front_redo's ring split starts from these)
-  if (tid == 0) {
-    B.n_filt[scan] = nf;
-    B.flags[scan] = 0u;
-  }
-  if (scan == 0 && tid < FX_N_COUNTERS) B.counters[tid] = 0u;  // work-list counters of the batch (not the one k_front itself adds to)
-  uint32_t n = 0, ring_max = 0;
-  for (uint32_t r = 0; r < R; ++r) {
-    const uint32_t c = r_cnt[r];
-    n += c;
-    ring_max = max(ring_max, c);
-  }
   auto redo = [&]() {  // (workgroup-uniform) the general kernels' bodies take the scan from ~cloud: k_front_redo
     if (tid == 0) B.redo[atomicAdd(&B.counters[FX_CNT_REDO], 1u)] = scan;
     stamp_end();
   };
-  if (n > CAP || nf > CAP || ring_max > P.max_ring_points || force_redo) {  // (force_redo: the test build's hook)
-    redo();
-    return;
-  }
-  if (n == 0) {
-    no_keypoints();
-    stamp_end();
-    return;
-  }
-#if defined(FX_FRONT_STOP) && FX_FRONT_STOP == 1  // measurement build: the kernel's phases one at a time (tools/front_phases.sh)
-  no_keypoints();
-  stamp_end();
-  return;
-#endif
-  // ---------------------------------------------------------------- B: ring split into LDS (ref: node.cpp:195-202)
-  // A stable counting sort by ring with three barriers and nothing from HBM: the survivors are still in LDS (un-rotated, in
-  // input order: the streaming pass's buffer) with their elevations.  Every wavefront owns a contiguous slice, ranks its
-  // points ring by ring (a ballot per ring present in 64 points, running counts in registers), the counts of the wavefronts
-  // before it make the slice's base in every ring; every lane then rotates its points (registers), and — once every lane has
-  // read its points: the ring-major arrays take the buffer's place — the points go to their places.
-  const float4 *f = B.filt + (size_t)scan * P.max_points;
-  {
-    const float2 *s_win = PL.win;
-    uint32_t *cw = smem + O::cw, *cbase = cw + NW * FX_FRONT_RMAX;  // [NW][R] points of the wavefront's slice per ring; its first place per ring
-    if (tid < 64) {
-      const uint32_t c = tid < R ? r_cnt[tid] : 0u;
-      uint32_t inc = c;
-      inc = wave_incl_scan(inc);
-      if (tid <= R) r_off[tid] = inc - c;  // (r_off[R] = n)
-    }
-    FX_STAMP(16);
-    constexpr uint32_t kSub = (CAP + 64 * NW - 1) / (64 * NW);   // 64-point pieces of a wavefront's slice at most
-    const uint32_t S = ((nf + 64u * NW - 1u) / (64u * NW)) * 64u;  // slice length
-    // per point: its first ring (a point is in one ring, or — exactly on a window's edge — in that one and the next) and its
-    // place among the wavefront's points of that ring; the second ring's place in a register of its own
-    uint32_t ring_a[kSub], place_b[kSub];  // ring_a: ring | 0x100: also in ring + 1 | place in the ring << 16; FX_NONE: in no ring
-    uint32_t run_cnt = 0;  // lane r: points of ring r in this wavefront's slice so far (no LDS round trip per ring in the loop below)
-#pragma unroll
-    for (uint32_t u = 0; u < kSub; ++u) {
-      ring_a[u] = FX_NONE, place_b[u] = 0;
-      if (u * 64u >= S) continue;  // (workgroup-uniform)
-      const uint32_t i = wave * S + u * 64u + lane;
-      const float el = i < nf ? s_el[i] : NAN;
-      uint32_t mask = 0;
-      int r_first = 0;
-      if (isfinite(el)) mask = ring_membership(el, s_win, P.n_rings, el0, inv_step, r_first);
-      // (windows of neighbouring rings share their edge only: at most two memberships, in consecutive rings)
-      const int ra = mask ? r_first + (__ffs((int)mask) - 1) : -1;
-      const bool two = (mask & (mask - 1u)) != 0u;
-      if (mask) ring_a[u] = (uint32_t)ra | (two ? 0x100u : 0u);
-#ifndef FX_SPLIT_BALLOTS
-      // Ranks by a PACKED prefix sum: a lane's memberships as a one in the 8-bit field of its ring (four rings a word: at most
-      // 64 points a piece, no field overflows), the words prefix-summed across the wavefront (six DPP steps each) — the rank
-      // among the piece's points of every ring at once.  (A ballot per ring present: sixteen dependent trips a piece.)
-      const uint32_t rb = (uint32_t)ra + 1u;
-      const uint32_t one_a = mask ? 1u << (8u * ((uint32_t)ra & 3u)) : 0u, one_b = two ? 1u << (8u * (rb & 3u)) : 0u;
-      const uint32_t ka = (uint32_t)ra >> 2, kb = rb >> 2;
-      uint32_t mine_a = 0, mine_b = 0, tot = 0;  // the words of this lane's rings; lane r: the word of ring r's totals
-#pragma nounroll
-      for (uint32_t k = 0; 4u * k < R; ++k) {  // (a word of four rings a trip)
-        uint32_t x = (ka == k ? one_a : 0u) + (kb == k ? one_b : 0u);
-        x = wave_incl_scan(x);
-        if (ka == k) mine_a = x;
-        if (kb == k) mine_b = x;
-        const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
-        if ((lane >> 2) == k) tot = t;
-      }
-      // (this lane's points of ring r so far: lane r's run_cnt — fetched by the ring's number)
-      const uint32_t before_a = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)ra & 63u) << 2), (int)run_cnt);
-      if (mask) ring_a[u] |= (before_a + ((mine_a >> (8u * ((uint32_t)ra & 3u))) & 0xffu) - 1u) << 16;
-      if (__ballot(two)) {  // (wave-uniform; a point exactly on a window's edge: rare)
-        const uint32_t before_b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((rb & 63u) << 2), (int)run_cnt);
-        if (two) place_b[u] = before_b + ((mine_b >> (8u * (rb & 3u))) & 0xffu) - 1u;
-      }
-      if (lane < R) run_cnt += (tot >> (8u * (lane & 3u))) & 0xffu;
-#else
-      int lo = mask ? ra : 0x7fffffff, hi = mask ? ra + (two ? 2 : 1) : -1;  // rings present in these 64 points: [lo, hi)
-#pragma unroll
-      for (int d = 32; d > 0; d >>= 1) {
-        lo = min(lo, __shfl_xor(lo, d, 64));
-        hi = max(hi, __shfl_xor(hi, d, 64));
-      }
-      lo = __builtin_amdgcn_readfirstlane(max(lo, 0));
-      hi = __builtin_amdgcn_readfirstlane(min(hi, (int)R));
-      for (int r = lo; r < hi; ++r) {
-        const bool in_a = r == ra, in_b = two && r == ra + 1;
-        const unsigned long long m = __ballot(in_a || in_b);
-        if (!m) continue;
-        const uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)run_cnt, r) + lanes_below(m);
-        if (in_a) ring_a[u] |= at << 16;
-        if (in_b) place_b[u] = at;
-        if ((int)lane == r) run_cnt += (uint32_t)__popcll(m);
-      }
-#endif
-    }
-    if (lane < R) cw[wave * R + lane] = run_cnt;
-    FX_STAMP(17);
-    // this lane's points, rotated as the sweep rotated them for ~cloud (pcl::transformPointCloud's order, ref: node.cpp:161-166)
-    float rx[kSub], ry[kSub], rz[kSub];
-#pragma unroll
-    for (uint32_t u = 0; u < kSub; ++u) {
-      const uint32_t i = min(wave * S + u * 64u + lane, nf - 1u);
-      const float x = px[3 * i], y = px[3 * i + 1], z = px[3 * i + 2];  // (the buffer: x y z per survivor, where px / py / pz will be)
-      rx[u] = ((M.R[0] * x + M.R[1] * y) + M.R[2] * z) + 0.0f;
-      ry[u] = ((M.R[3] * x + M.R[4] * y) + M.R[5] * z) + 0.0f;
-      rz[u] = ((M.R[6] * x + M.R[7] * y) + M.R[8] * z) + 0.0f;
-    }
-    FX_STAMP(18);
-    __syncthreads();  // (every count is in; every lane has read its points)
-    for (uint32_t t = tid; t < NW * R; t += NT) {
-      const uint32_t w = t / R, r = t - w * R;
-      uint32_t before = r_off[r];
-      for (uint32_t x = 0; x < w; ++x) before += cw[x * R + r];
-      cbase[t] = before;
-    }
-    __syncthreads();
-#pragma unroll
-    for (uint32_t u = 0; u < kSub; ++u) {
-      if (ring_a[u] == FX_NONE) continue;
-      const uint32_t ra = ring_a[u] & 0xffu;
-      uint32_t pos = cbase[wave * R + ra] + (ring_a[u] >> 16);
-      px[pos] = rx[u], py[pos] = ry[u], pz[pos] = rz[u];
-      sidx[pos] = (uint16_t)(wave * S + u * 64u + lane);
-      if (ring_a[u] & 0x100u) {
-        pos = cbase[wave * R + ra + 1u] + place_b[u];
-        px[pos] = rx[u], py[pos] = ry[u], pz[pos] = rz[u];
-        sidx[pos] = (uint16_t)(wave * S + u * 64u + lane);
-      }
-    }
-    wg_global_sync();  // (the ring-major points are in; ~cloud, written by the sweeps, is read below: cluster intensities, member copies)
-    FX_STAMP(19);
-  }
-#if defined(FX_FRONT_STOP) && FX_FRONT_STOP == 2
-  no_keypoints();
-  stamp_end();
-  return;
-#endif
+  // a ring-major entry's record (rotated x y z, elevation)
+  const float4 *src = RM ? B.ring_pts + (size_t)scan * P.ring_slot_cap : B.filt + (size_t)scan * P.max_points;
+  auto member = [&](uint32_t i) -> float4 { return RM ? src[i] : src[sidx[i]]; };
+  (void)no_keypoints;
+  (void)r_cnt;
+  (void)NW;
   // ---------------------------------------------------------------- C: getCylinderSegments, all rings (ref: node.cpp:261-327)
   FX_STAMP(2);
   const float r2 = P.r2_cluster;
@@ -3372,7 +3225,7 @@ extern "C" __global__ __launch_bounds__(FX_FRONT_T, FX_PREP_OCC) void k_front(Fx
   for (uint32_t g = tid; g < n_c; g += NT) {
     if (ctmp[g] == 0u) continue;
     const uint32_t rec = crec[g], sz = rec >> 16, root = rec & 0xffffu;
-    const float el = f[sidx[run_first(root)]].w;
+    const float el = member(run_first(root)).w;
     const uint32_t r_end = r_run0[prefix_owner(r_cb, R, g) + 1u];
     double sumx = 0.0, sumy = 0.0, sumz = 0.0;
     uint32_t cnt = 0;
@@ -3438,7 +3291,7 @@ extern "C" __global__ __launch_bounds__(FX_FRONT_T, FX_PREP_OCC) void k_front(Fx
       const uint32_t w = ctmp[g1 - 1u];
       if (!(w >> 31)) continue;
       const uint32_t dst = ckoff[g1 - 1u] + roff[r] + (i - run_first(r));
-      kpc[dst] = f[sidx[i]];
+      kpc[dst] = member(i);
       kpc_c[dst] = w & 0x7fffffffu;
     }
     if (tid == 0) B.n_kpc[scan] = n_mem;
@@ -3454,6 +3307,417 @@ extern "C" __global__ __launch_bounds__(FX_FRONT_T, FX_PREP_OCC) void k_front(Fx
   merge_body<NT, true, true>(P, B, scan, merge_cap, merge_cap, smem, true, &FC);
   FX_STAMP(15);
   stamp_end();
+}
+
+
+extern "C" __global__ __launch_bounds__(FX_FRONT_T, FX_PREP_OCC) void k_front(FxDevParams P, FxBuffers B, float near_margin, float el0, float inv_step,
+                                                                           uint32_t clk_slot, uint32_t merge_cap, uint32_t force_redo) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  using O = FrontOff;
+  constexpr uint32_t NT = FX_FRONT_T, NW = FX_FRONT_NW, CAP = FX_FRONT_CAP, RUNS = FX_FRONT_RUNS, SEGS = FX_FRONT_SEGS;
+  static_assert(merge_words(FX_FRONT_MERGE, FX_FRONT_MERGE, FX_FRONT_RMAX, true) <= 3 * FX_FRONT_CAP, "the merge's image borrows the points");
+  const uint32_t scan = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t R = (uint32_t)P.n_rings;
+  float *px = reinterpret_cast<float *>(smem + O::px), *py = reinterpret_cast<float *>(smem + O::py), *pz = reinterpret_cast<float *>(smem + O::pz);
+  uint16_t *sidx = reinterpret_cast<uint16_t *>(smem + O::sidx);
+  uint32_t *s_w = smem + O::s_w, *r_off = smem + O::r_off, *r_cnt = smem + O::r_cnt, *r_run0 = smem + O::r_run0, *r_cb = smem + O::r_cb;
+  unsigned long long *smask = reinterpret_cast<unsigned long long *>(smem + O::smask), *gmask = reinterpret_cast<unsigned long long *>(smem + O::gmask);
+  uint32_t *run_base = smem + O::run_base, *seg_base = smem + O::seg_base;
+  uint16_t *seg_start = reinterpret_cast<uint16_t *>(smem + O::seg_start), *rseg = reinterpret_cast<uint16_t *>(smem + O::rseg),
+           *roff = reinterpret_cast<uint16_t *>(smem + O::roff);
+  uint32_t *seg_box = smem + O::seg_box, *rbox = smem + O::rbox, *rparent = smem + O::rparent, *rsize = smem + O::rsize;
+  uint16_t *croot = reinterpret_cast<uint16_t *>(smem + O::croot);
+  uint32_t *crec = smem + O::crec, *ctmp = smem + O::ctmp;
+  {  // the support-list counters of the batch are cleared here, a slice per scan (k_gather fills them)
+    const uint32_t per = (P.max_total_kp + gridDim.x - 1) / gridDim.x;
+    const uint32_t z0 = scan * per, z1 = min(z0 + per, P.max_total_kp);
+    for (uint32_t t = z0 + tid; t < z1; t += NT) B.s_cnt[t] = 0u;
+    if (tid == 0) B.ovf_cnt[scan] = 0u;  // entries in the scan's overflow region (k_gather)
+  }
+  const FxScanMeta M = B.meta[scan];
+  FX_STAMP_INIT(B.stamps);
+  if (tid == 0) atomicMin(&B.clk[2 * clk_slot], (unsigned long long)wall_clock64());
+  auto stamp_end = [&]() {
+    if (tid == 0) atomicMax(&B.clk[2 * clk_slot + 1], (unsigned long long)wall_clock64());
+  };
+  auto no_keypoints = [&]() {  // ref: node.cpp:209-210, 263-264
+    if (tid == 0) {
+      B.n_cand[scan] = 0u;
+      B.n_kp[scan] = 0u;
+      B.n_kpc[scan] = 0u;
+    }
+  };
+  if (M.n == 0) {  // empty scan: its pointer may be null — nothing is loaded
+    if (tid == 0) {
+      B.n_filt[scan] = 0u;
+      B.flags[scan] = 0u;
+    }
+    no_keypoints();
+    for (uint32_t r = tid; r < R; r += NT) B.ring_cnt[(size_t)scan * R + r] = 0u;
+    if (scan == 0 && tid < FX_N_COUNTERS) B.counters[tid] = 0u;
+    return;
+  }
+  // ---------------------------------------------------------------- A: the streaming pass
+  float *s_el = reinterpret_cast<float *>(smem + O::el);
+  const PrepLds PL{smem + O::cnt, px, r_cnt, reinterpret_cast<double *>(smem + O::atan), reinterpret_cast<float2 *>(smem + O::win), s_el, CAP};
+  uint32_t nf = prep_stream<true>(P, B, M, scan, near_margin, el0, inv_step, PL);
+  if (nf == FX_NONE) nf = prep_stream<false>(P, B, M, scan, near_margin, el0, inv_step, PL);  // (more survivors than the buffer keeps: once more, recycling it)
+  FX_STAMP(1);
+  for (uint32_t r = tid; r < R; r += NT) B.ring_cnt[(size_t)scan * R + r] = r_cnt[r];  // (k_front_redo's ring split starts from these)
+  if (tid == 0) {
+    B.n_filt[scan] = nf;
+    B.flags[scan] = 0u;
+  }
+  if (scan == 0 && tid < FX_N_COUNTERS) B.counters[tid] = 0u;  // work-list counters of the batch (not the one k_front itself adds to)
+  uint32_t n = 0, ring_max = 0;
+  for (uint32_t r = 0; r < R; ++r) {
+    const uint32_t c = r_cnt[r];
+    n += c;
+    ring_max = max(ring_max, c);
+  }
+  auto redo = [&]() {  // (workgroup-uniform) the general kernels' bodies take the scan from ~cloud: k_front_redo
+    if (tid == 0) B.redo[atomicAdd(&B.counters[FX_CNT_REDO], 1u)] = scan;
+    stamp_end();
+  };
+  if (n > CAP || nf > CAP || ring_max > P.max_ring_points || force_redo) {  // (force_redo: the test build's hook)
+    redo();
+    return;
+  }
+  if (n == 0) {
+    no_keypoints();
+    stamp_end();
+    return;
+  }
+#if defined(FX_FRONT_STOP) && FX_FRONT_STOP == 1  // measurement build: the kernel's phases one at a time (tools/front_phases.sh)
+  no_keypoints();
+  stamp_end();
+  return;
+#endif
+  // ---------------------------------------------------------------- B: ring split into LDS (ref: node.cpp:195-202)
+  // A stable counting sort by ring with three barriers and nothing from HBM: the survivors are still in LDS (un-rotated, in
+  // input order: the streaming pass's buffer) with their elevations.  Every wavefront owns a contiguous slice, ranks its
+  // points ring by ring (a ballot per ring present in 64 points, running counts in registers), the counts of the wavefronts
+  // before it make the slice's base in every ring; every lane then rotates its points (registers), and — once every lane has
+  // read its points: the ring-major arrays take the buffer's place — the points go to their places.
+  const float4 *f = B.filt + (size_t)scan * P.max_points;
+  {
+    const float2 *s_win = PL.win;
+    uint32_t *cw = smem + O::cw, *cbase = cw + NW * FX_FRONT_RMAX;  // [NW][R] points of the wavefront's slice per ring; its first place per ring
+    if (tid < 64) {
+      const uint32_t c = tid < R ? r_cnt[tid] : 0u;
+      uint32_t inc = c;
+      inc = wave_incl_scan(inc);
+      if (tid <= R) r_off[tid] = inc - c;  // (r_off[R] = n)
+    }
+    FX_STAMP(16);
+    constexpr uint32_t kSub = (CAP + 64 * NW - 1) / (64 * NW);   // 64-point pieces of a wavefront's slice at most
+    const uint32_t S = ((nf + 64u * NW - 1u) / (64u * NW)) * 64u;  // slice length
+    // per point: its first ring (a point is in one ring, or — exactly on a window's edge — in that one and the next) and its
+    // place among the wavefront's points of that ring; the second ring's place in a register of its own
+    uint32_t ring_a[kSub], place_b[kSub];  // ring_a: ring | 0x100: also in ring + 1 | place in the ring << 16; FX_NONE: in no ring
+    uint32_t run_cnt = 0;  // lane r: points of ring r in this wavefront's slice so far (no LDS round trip per ring in the loop below)
+#pragma unroll
+    for (uint32_t u = 0; u < kSub; ++u) {
+      ring_a[u] = FX_NONE, place_b[u] = 0;
+      if (u * 64u >= S) continue;  // (workgroup-uniform)
+      const uint32_t i = wave * S + u * 64u + lane;
+      const float el = i < nf ? s_el[i] : NAN;
+      uint32_t mask = 0;
+      int r_first = 0;
+      if (isfinite(el)) mask = ring_membership(el, s_win, P.n_rings, el0, inv_step, r_first);
+      // (windows of neighbouring rings share their edge only: at most two memberships, in consecutive rings)
+      const int ra = mask ? r_first + (__ffs((int)mask) - 1) : -1;
+      const bool two = (mask & (mask - 1u)) != 0u;
+      if (mask) ring_a[u] = (uint32_t)ra | (two ? 0x100u : 0u);
+#ifndef FX_SPLIT_BALLOTS
+      // Ranks by a PACKED prefix sum: a lane's memberships as a one in the 8-bit field of its ring (four rings a word: at most
+      // 64 points a piece, no field overflows), the words prefix-summed across the wavefront (six DPP steps each) — the rank
+      // among the piece's points of every ring at once.  (A ballot per ring present: sixteen dependent trips a piece.)
+      const uint32_t rb = (uint32_t)ra + 1u;
+      const uint32_t one_a = mask ? 1u << (8u * ((uint32_t)ra & 3u)) : 0u, one_b = two ? 1u << (8u * (rb & 3u)) : 0u;
+      const uint32_t ka = (uint32_t)ra >> 2, kb = rb >> 2;
+      uint32_t mine_a = 0, mine_b = 0, tot = 0;  // the words of this lane's rings; lane r: the word of ring r's totals
+#pragma nounroll
+      for (uint32_t k = 0; 4u * k < R; ++k) {  // (a word of four rings a trip)
+        uint32_t x = (ka == k ? one_a : 0u) + (kb == k ? one_b : 0u);
+        x = wave_incl_scan(x);
+        if (ka == k) mine_a = x;
+        if (kb == k) mine_b = x;
+        const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+        if ((lane >> 2) == k) tot = t;
+      }
+      // (this lane's points of ring r so far: lane r's run_cnt — fetched by the ring's number)
+      const uint32_t before_a = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)ra & 63u) << 2), (int)run_cnt);
+      if (mask) ring_a[u] |= (before_a + ((mine_a >> (8u * ((uint32_t)ra & 3u))) & 0xffu) - 1u) << 16;
+      if (__ballot(two)) {  // (wave-uniform; a point exactly on a window's edge: rare)
+        const uint32_t before_b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((rb & 63u) << 2), (int)run_cnt);
+        if (two) place_b[u] = before_b + ((mine_b >> (8u * (rb & 3u))) & 0xffu) - 1u;
+      }
+      if (lane < R) run_cnt += (tot >> (8u * (lane & 3u))) & 0xffu;
+#else
+      int lo = mask ? ra : 0x7fffffff, hi = mask ? ra + (two ? 2 : 1) : -1;  // rings present in these 64 points: [lo, hi)
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) {
+        lo = min(lo, __shfl_xor(lo, d, 64));
+        hi = max(hi, __shfl_xor(hi, d, 64));
+      }
+      lo = __builtin_amdgcn_readfirstlane(max(lo, 0));
+      hi = __builtin_amdgcn_readfirstlane(min(hi, (int)R));
+      for (int r = lo; r < hi; ++r) {
+        const bool in_a = r == ra, in_b = two && r == ra + 1;
+        const unsigned long long m = __ballot(in_a || in_b);
+        if (!m) continue;
+        const uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)run_cnt, r) + lanes_below(m);
+        if (in_a) ring_a[u] |= at << 16;
+        if (in_b) place_b[u] = at;
+        if ((int)lane == r) run_cnt += (uint32_t)__popcll(m);
+      }
+#endif
+    }
+    if (lane < R) cw[wave * R + lane] = run_cnt;
+    FX_STAMP(17);
+    // this lane's points, rotated as the sweep rotated them for ~cloud (pcl::transformPointCloud's order, ref: node.cpp:161-166)
+    float rx[kSub], ry[kSub], rz[kSub];
+#pragma unroll
+    for (uint32_t u = 0; u < kSub; ++u) {
+      const uint32_t i = min(wave * S + u * 64u + lane, nf - 1u);
+      const float x = px[3 * i], y = px[3 * i + 1], z = px[3 * i + 2];  // (the buffer: x y z per survivor, where px / py / pz will be)
+      rx[u] = ((M.R[0] * x + M.R[1] * y) + M.R[2] * z) + 0.0f;
+      ry[u] = ((M.R[3] * x + M.R[4] * y) + M.R[5] * z) + 0.0f;
+      rz[u] = ((M.R[6] * x + M.R[7] * y) + M.R[8] * z) + 0.0f;
+    }
+    FX_STAMP(18);
+    __syncthreads();  // (every count is in; every lane has read its points)
+    for (uint32_t t = tid; t < NW * R; t += NT) {
+      const uint32_t w = t / R, r = t - w * R;
+      uint32_t before = r_off[r];
+      for (uint32_t x = 0; x < w; ++x) before += cw[x * R + r];
+      cbase[t] = before;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < kSub; ++u) {
+      if (ring_a[u] == FX_NONE) continue;
+      const uint32_t ra = ring_a[u] & 0xffu;
+      uint32_t pos = cbase[wave * R + ra] + (ring_a[u] >> 16);
+      px[pos] = rx[u], py[pos] = ry[u], pz[pos] = rz[u];
+      sidx[pos] = (uint16_t)(wave * S + u * 64u + lane);
+      if (ring_a[u] & 0x100u) {
+        pos = cbase[wave * R + ra + 1u] + place_b[u];
+        px[pos] = rx[u], py[pos] = ry[u], pz[pos] = rz[u];
+        sidx[pos] = (uint16_t)(wave * S + u * 64u + lane);
+      }
+    }
+    wg_global_sync();  // (the ring-major points are in; ~cloud, written by the sweeps, is read below: cluster intensities, member copies)
+    FX_STAMP(19);
+  }
+#if defined(FX_FRONT_STOP) && FX_FRONT_STOP == 2
+  no_keypoints();
+  stamp_end();
+  return;
+#endif
+  front_cluster_merge<false>(P, B, scan, smem, n, clk_slot, merge_cap);
+}
+
+// ---- the fused kernel as TWO launches (batches that fill the chip: VERDICT r5 #1).  k_front's two workgroups own a CU — 2 x 79 KB of
+// LDS, 16 wavefronts x 128 registers — for the kernel's whole 0.28 ms, and its halves want opposite things: A (+ B) is
+// bandwidth-shaped, C + D are latency chains.  k_front_ab: the streaming pass and the ring split in k_prep's register
+// budget, the ring-major records (rotated x y z, elevation: ~cloud's record) written to B.ring_pts as k_bucket writes them —
+// 41 KB a scan, read back once by k_front_cd from the L2 / infinity cache —; k_front_cd: loads them into the image and runs
+// phases C and D (front_cluster_merge<true>: a member's record is its ring-major one, no survivor index).  A scan's state
+// between the two: B.front_n[scan] = its ring-major entries, 0 when it has none (k_front_ab wrote the empty results),
+// FX_NONE when k_front_ab handed it to k_front_redo itself.
+struct FrontAbOff {  // word offsets into k_front_ab's LDS image
+  static constexpr uint32_t keep = 0;                                       // [3 CAP] the streaming pass's survivors (un-rotated x y z)
+  static constexpr uint32_t el = 3 * FX_FRONT_CAP;                          // [CAP] their elevations
+  static constexpr uint32_t atan = 4 * FX_FRONT_CAP;                        // doubles
+  static constexpr uint32_t win = atan + a4(2 * (FX_ATAN_N + 1) * (FX_ATAN_DEG + 1));
+  static constexpr uint32_t cnt = win + 2 * FX_FRONT_RMAX;
+  static constexpr uint32_t r_cnt = cnt + 2 * FX_FRONT_NW;
+  static constexpr uint32_t r_off = r_cnt + FX_FRONT_RMAX;
+  static constexpr uint32_t cw = r_off + FX_FRONT_RMAX + 4;                 // [2][NW][RMAX]
+  static constexpr uint32_t end = cw + 2 * FX_FRONT_NW * FX_FRONT_RMAX;
+};
+static_assert((FrontAbOff::atan % 2) == 0, "k_front_ab alignment");
+__host__ __device__ inline size_t front_ab_lds_bytes() { return (size_t)FrontAbOff::end * 4; }
+#ifndef FX_FRONT_AB_OCC
+#define FX_FRONT_AB_OCC FX_PREP_OCC
+#endif
+
+extern "C" __global__ __launch_bounds__(FX_FRONT_T, FX_FRONT_AB_OCC) void k_front_ab(FxDevParams P, FxBuffers B, float near_margin, float el0, float inv_step,
+                                                                                 uint32_t clk_slot, uint32_t force_redo) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  using O = FrontAbOff;
+  constexpr uint32_t NT = FX_FRONT_T, NW = FX_FRONT_NW, CAP = FX_FRONT_CAP;
+  const uint32_t scan = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t R = (uint32_t)P.n_rings;
+  float *keep = reinterpret_cast<float *>(smem + O::keep), *s_el = reinterpret_cast<float *>(smem + O::el);
+  uint32_t *r_cnt = smem + O::r_cnt, *r_off = smem + O::r_off;
+  {  // the support-list counters of the batch are cleared here, a slice per scan (k_gather fills them)
+    const uint32_t per = (P.max_total_kp + gridDim.x - 1) / gridDim.x;
+    const uint32_t z0 = scan * per, z1 = min(z0 + per, P.max_total_kp);
+    for (uint32_t t = z0 + tid; t < z1; t += NT) B.s_cnt[t] = 0u;
+    if (tid == 0) B.ovf_cnt[scan] = 0u;  // entries in the scan's overflow region (k_gather)
+  }
+  const FxScanMeta M = B.meta[scan];
+  if (tid == 0) atomicMin(&B.clk[2 * clk_slot], (unsigned long long)wall_clock64());
+  auto stamp_end = [&]() {
+    if (tid == 0) atomicMax(&B.clk[2 * clk_slot + 1], (unsigned long long)wall_clock64());
+  };
+  auto no_keypoints = [&]() {  // ref: node.cpp:209-210, 263-264
+    if (tid == 0) {
+      B.n_cand[scan] = 0u;
+      B.n_kp[scan] = 0u;
+      B.n_kpc[scan] = 0u;
+      B.front_n[scan] = 0u;
+    }
+  };
+  if (M.n == 0) {  // empty scan: its pointer may be null — nothing is loaded
+    if (tid == 0) {
+      B.n_filt[scan] = 0u;
+      B.flags[scan] = 0u;
+    }
+    no_keypoints();
+    for (uint32_t r = tid; r < R; r += NT) B.ring_cnt[(size_t)scan * R + r] = 0u;
+    if (scan == 0 && tid < FX_N_COUNTERS) B.counters[tid] = 0u;
+    return;
+  }
+  // ---------------------------------------------------------------- A: the streaming pass
+  const PrepLds PL{smem + O::cnt, keep, r_cnt, reinterpret_cast<double *>(smem + O::atan), reinterpret_cast<float2 *>(smem + O::win), s_el, CAP};
+  uint32_t nf = prep_stream<true>(P, B, M, scan, near_margin, el0, inv_step, PL);
+  if (nf == FX_NONE) nf = prep_stream<false>(P, B, M, scan, near_margin, el0, inv_step, PL);  // (more survivors than the buffer keeps: once more, recycling it)
+  for (uint32_t r = tid; r < R; r += NT) B.ring_cnt[(size_t)scan * R + r] = r_cnt[r];  // (k_front_redo's ring split starts from these)
+  if (tid == 0) {
+    B.n_filt[scan] = nf;
+    B.flags[scan] = 0u;
+  }
+  if (scan == 0 && tid < FX_N_COUNTERS) B.counters[tid] = 0u;  // work-list counters of the batch (not the one the front kernels add to)
+  uint32_t n = 0, ring_max = 0;
+  for (uint32_t r = 0; r < R; ++r) {
+    const uint32_t c = r_cnt[r];
+    n += c;
+    ring_max = max(ring_max, c);
+  }
+  if (n > CAP || nf > CAP || ring_max > P.max_ring_points || force_redo) {  // (force_redo: the test build's hook)
+    if (tid == 0) {
+      B.redo[atomicAdd(&B.counters[FX_CNT_REDO], 1u)] = scan;
+      B.front_n[scan] = FX_NONE;
+    }
+    stamp_end();
+    return;
+  }
+  if (n == 0) {
+    no_keypoints();
+    stamp_end();
+    return;
+  }
+  // ---------------------------------------------------------------- B: ring split (ref: node.cpp:195-202), to B.ring_pts
+  // k_front's stable counting sort — every wavefront ranks a contiguous slice of the survivors per ring by packed prefix
+  // sums, the wavefronts' counts make each slice's base per ring — with the places in HBM instead of LDS.  (In two passes
+  // over the slice — count, then rank and store, nothing per point kept in registers between them — it was slower:
+  // k_front_ab alone 0.134 -> 0.146 ms, profiles/r06_experiments.md §1.)
+  {
+    const float2 *s_win = PL.win;
+    uint32_t *cw = smem + O::cw, *cbase = cw + NW * FX_FRONT_RMAX;  // [NW][R] points of the wavefront's slice per ring; its first place per ring
+    if (tid < 64) {
+      const uint32_t c = tid < R ? r_cnt[tid] : 0u;
+      uint32_t inc = c;
+      inc = wave_incl_scan(inc);
+      if (tid <= R) r_off[tid] = inc - c;  // (r_off[R] = n)
+    }
+    constexpr uint32_t kSub = (CAP + 64 * NW - 1) / (64 * NW);   // 64-point pieces of a wavefront's slice at most
+    const uint32_t S = ((nf + 64u * NW - 1u) / (64u * NW)) * 64u;  // slice length
+    uint32_t ring_a[kSub], place_b[kSub];  // ring_a: ring | 0x100: also in ring + 1 | place in the ring << 16; FX_NONE: in no ring
+    uint32_t run_cnt = 0;  // lane r: points of ring r in this wavefront's slice so far
+#pragma unroll
+    for (uint32_t u = 0; u < kSub; ++u) {
+      ring_a[u] = FX_NONE, place_b[u] = 0;
+      if (u * 64u >= S) continue;  // (workgroup-uniform)
+      const uint32_t i = wave * S + u * 64u + lane;
+      const float el = i < nf ? s_el[i] : NAN;
+      uint32_t mask = 0;
+      int r_first = 0;
+      if (isfinite(el)) mask = ring_membership(el, s_win, P.n_rings, el0, inv_step, r_first);
+      // (windows of neighbouring rings share their edge only: at most two memberships, in consecutive rings)
+      const int ra = mask ? r_first + (__ffs((int)mask) - 1) : -1;
+      const bool two = (mask & (mask - 1u)) != 0u;
+      if (mask) ring_a[u] = (uint32_t)ra | (two ? 0x100u : 0u);
+      const uint32_t rb = (uint32_t)ra + 1u;
+      const uint32_t one_a = mask ? 1u << (8u * ((uint32_t)ra & 3u)) : 0u, one_b = two ? 1u << (8u * (rb & 3u)) : 0u;
+      const uint32_t ka = (uint32_t)ra >> 2, kb = rb >> 2;
+      uint32_t mine_a = 0, mine_b = 0, tot = 0;  // the words of this lane's rings; lane r: the word of ring r's totals
+#pragma nounroll
+      for (uint32_t k = 0; 4u * k < R; ++k) {  // (a word of four rings a trip)
+        uint32_t x = (ka == k ? one_a : 0u) + (kb == k ? one_b : 0u);
+        x = wave_incl_scan(x);
+        if (ka == k) mine_a = x;
+        if (kb == k) mine_b = x;
+        const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+        if ((lane >> 2) == k) tot = t;
+      }
+      const uint32_t before_a = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)ra & 63u) << 2), (int)run_cnt);
+      if (mask) ring_a[u] |= (before_a + ((mine_a >> (8u * ((uint32_t)ra & 3u))) & 0xffu) - 1u) << 16;
+      if (__ballot(two)) {  // (wave-uniform; a point exactly on a window's edge: rare)
+        const uint32_t before_b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((rb & 63u) << 2), (int)run_cnt);
+        if (two) place_b[u] = before_b + ((mine_b >> (8u * (rb & 3u))) & 0xffu) - 1u;
+      }
+      if (lane < R) run_cnt += (tot >> (8u * (lane & 3u))) & 0xffu;
+    }
+    if (lane < R) cw[wave * R + lane] = run_cnt;
+    __syncthreads();  // (every count is in)
+    for (uint32_t t = tid; t < NW * R; t += NT) {
+      const uint32_t w = t / R, r = t - w * R;
+      uint32_t before = r_off[r];
+      for (uint32_t x = 0; x < w; ++x) before += cw[x * R + r];
+      cbase[t] = before;
+    }
+    if (tid < R) B.ring_off[(size_t)scan * R + tid] = r_off[tid];
+    if (tid == 0) B.front_n[scan] = n;
+    __syncthreads();
+    float4 *dst = B.ring_pts + (size_t)scan * P.ring_slot_cap;
+#pragma unroll
+    for (uint32_t u = 0; u < kSub; ++u) {
+      if (ring_a[u] == FX_NONE) continue;
+      const uint32_t i = wave * S + u * 64u + lane;
+      // rotated as the sweep rotated it for ~cloud (pcl::transformPointCloud's order, ref: node.cpp:161-166): the same record
+      const float x = keep[3 * i], y = keep[3 * i + 1], z = keep[3 * i + 2];
+      const float4 rec = make_float4(((M.R[0] * x + M.R[1] * y) + M.R[2] * z) + 0.0f, ((M.R[3] * x + M.R[4] * y) + M.R[5] * z) + 0.0f,
+                                     ((M.R[6] * x + M.R[7] * y) + M.R[8] * z) + 0.0f, s_el[i]);
+      const uint32_t ra = ring_a[u] & 0xffu;
+      dst[cbase[wave * R + ra] + (ring_a[u] >> 16)] = rec;
+      if (ring_a[u] & 0x100u) dst[cbase[wave * R + ra + 1u] + place_b[u]] = rec;
+    }
+  }
+  stamp_end();
+}
+
+extern "C" __global__ __launch_bounds__(FX_FRONT_T, FX_PREP_OCC) void k_front_cd(FxDevParams P, FxBuffers B, uint32_t clk_slot, uint32_t merge_cap) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  using O = FrontOff;
+  constexpr uint32_t NT = FX_FRONT_T, CAP = FX_FRONT_CAP;
+  const uint32_t scan = blockIdx.x, tid = threadIdx.x;
+  const uint32_t R = (uint32_t)P.n_rings;
+  const uint32_t n = B.front_n[scan];
+  if (n == 0u || n == FX_NONE) return;  // (k_front_ab wrote the empty results / handed the scan to k_front_redo)
+  float *px = reinterpret_cast<float *>(smem + O::px), *py = reinterpret_cast<float *>(smem + O::py), *pz = reinterpret_cast<float *>(smem + O::pz);
+  uint32_t *r_off = smem + O::r_off, *r_cnt = smem + O::r_cnt;
+  if (tid < R) {
+    r_off[tid] = B.ring_off[(size_t)scan * R + tid];
+    r_cnt[tid] = B.ring_cnt[(size_t)scan * R + tid];
+  }
+  if (tid == R) r_off[R] = n;
+  const float4 *src = B.ring_pts + (size_t)scan * P.ring_slot_cap;
+  constexpr uint32_t kSub = (CAP + NT - 1) / NT;
+  float4 v[kSub];
+#pragma unroll
+  for (uint32_t u = 0; u < kSub; ++u) v[u] = src[min(u * NT + tid, n - 1u)];
+#pragma unroll
+  for (uint32_t u = 0; u < kSub; ++u) {
+    const uint32_t i = u * NT + tid;
+    if (i < n) px[i] = v[u].x, py[i] = v[u].y, pz[i] = v[u].z;
+  }
+  __syncthreads();
+  front_cluster_merge<true>(P, B, scan, smem, n, clk_slot, merge_cap);
 }
 
 // The scans k_front could not take (k_front_redo, a workgroup of k_front's shape each — 512 threads, the same LDS image — so
@@ -6016,8 +6280,19 @@ uint32_t fxk_slow(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint3
   hipLaunchKernelGGL(k_slow, dim3(g), dim3(FX_SLOW_T), lds, s, P, B, huge_ccap, g == 1u ? 1u : 0u, batch, clk_next);
   return g == 1u ? 1u : 0u;
 }
+void fxk_front_ab(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float near_margin, float el0, float inv_step,
+                  uint32_t clk_slot, uint32_t force_redo) {
+  hipLaunchKernelGGL(k_front_ab, dim3(batch), dim3(FX_FRONT_T), front_ab_lds_bytes(), s, P, B, near_margin, el0, inv_step, clk_slot, force_redo);
+}
+void fxk_front_cd(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t clk_slot, uint32_t merge_cap) {
+  hipLaunchKernelGGL(k_front_cd, dim3(batch), dim3(FX_FRONT_T), front_lds_bytes(), s, P, B, clk_slot, merge_cap);
+}
 hipError_t fxk_configure_front(void) {
   hipError_t e = hipFuncSetAttribute((const void *)k_front, hipFuncAttributeMaxDynamicSharedMemorySize, (int)front_lds_bytes());
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void *)k_front_ab, hipFuncAttributeMaxDynamicSharedMemorySize, (int)front_ab_lds_bytes());
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void *)k_front_cd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)front_lds_bytes());
   if (e != hipSuccess) return e;
   return hipFuncSetAttribute((const void *)k_front_redo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)front_lds_bytes());
 }
