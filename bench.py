@@ -4,7 +4,7 @@
 A "step" is one pass of the whole hot path (rotate+filter -> per-ring clustering -> merge ->
 3DSC descriptors, ref: src/feature_extraction_node.cpp:83-115) over one batch of synthetic
 scans that are already resident in HBM, plus — at N > 1 — the one RCCL collective of the
-path (all-gather of fixed-stride keypoint records).  Scans are frame-sharded: every rank
+path (all-gather — or, --gather root, gather — of each rank's compact keypoint block).  Scans are frame-sharded: every rank
 owns `--batch` scans (weak scaling); there is no other data-path exchange.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
@@ -195,6 +195,8 @@ def main():
     ap.add_argument("--no-descriptors", action="store_true", help="diagnostic: estimate_descriptors = 0 (the detector alone; not the headline metric)")
     ap.add_argument("--no-extras", action="store_true", help="skip other_configs and the host-to-host measurement")
     ap.add_argument("--check", type=int, default=16, help="scans of rank 0 checked against the oracle after timing")
+    ap.add_argument("--gather", default="all", choices=["all", "root"],
+                    help="the path's one collective: every rank gets the keypoint table (ncclAllGather) or rank 0 only (ncclGather)")
     ap.add_argument("--repeats", type=int, default=0, help="timed regions of --steps steps (0: as many as fill --target-seconds); the median is reported")
     ap.add_argument("--target-seconds", type=float, default=1.0)
     args = ap.parse_args()
@@ -252,7 +254,11 @@ def main():
     ctx = ctxs[0]
     for c in ctxs:
         c.set_batches_in_flight(K)  # (launch-policy hint: the grid-stride kernels share the chip with the other batches' kernels)
-    REC_KP = int(ctx.limits.max_keypoints)  # record stride = the context's keypoint capacity: a gathered record is never truncated
+    # What crosses GPUs: ONE compact keypoint block per rank and batch (fx_pack_keypoint_block: offsets + flags + the keypoints
+    # packed in scan order), 64 keypoints a scan of capacity — 1.06 MB a rank and step where the fixed-stride records of 0.6
+    # (stride = the context's capacity, 256) were 4.21 MB; a batch with more keypoints is cut and FLAGGED (asserted below).
+    BLOCK_KP = sharding.block_keypoints_per_scan(B)
+    BLOCK_ROWS = sharding.block_rows(B, BLOCK_KP)
     # the contexts' own HIP streams, wrapped for torch (streams from torch's pool can share a hardware queue: two such
     # contexts then do not overlap at all; FX_BENCH_TORCH_STREAMS=1 brings them back)
     if os.environ.get("FX_BENCH_TORCH_STREAMS") == "1":
@@ -272,8 +278,9 @@ def main():
     del scans_b
     # keypoint records, one buffer per context: the gather of a batch (RCCL, its own stream) overlaps the
     # kernels of the batches behind it; a buffer is reused only after its collective has completed
-    recs = [torch.zeros((B, 1 + REC_KP, 4), dtype=torch.float32, device=dev) for _ in range(K)]
-    gathered = [torch.zeros((world * B, 1 + REC_KP, 4), dtype=torch.float32, device=dev) for _ in range(K)] if use_dist else None
+    recs = [torch.zeros((BLOCK_ROWS, 4), dtype=torch.float32, device=dev) for _ in range(K)]
+    to_root = args.gather == "root"
+    gathered = [torch.zeros((world * BLOCK_ROWS, 4), dtype=torch.float32, device=dev) for _ in range(K)] if use_dist and (rank == 0 or not to_root) else None
     # the collective goes straight on the context's stream through RCCL's C API (sharding.RcclGather);
     # FX_BENCH_TORCH_GATHER=1 takes torch.distributed's all_gather_into_tensor instead (sharding.all_gather_records, the
     # function the gloo test runs)
@@ -295,12 +302,22 @@ def main():
 
     def run_slot(j, which):
         ctxs[j].process_raw(descs_b if which else descs, B, capi.FX_IN_DEVICE)
-        ctxs[j].pack_keypoint_records(recs[j].data_ptr(), REC_KP)
-        if rccl is not None:  # the path's one collective, an ordinary kernel of this context's stream
+        ctxs[j].pack_keypoint_block(recs[j].data_ptr(), B, BLOCK_KP)
+        if rccl is not None and to_root:  # the path's one collective, an ordinary kernel of this context's stream
+            rccl.gather(recs[j], gathered[j] if gathered is not None else None, streams[j].cuda_stream, root=0, comm=j % rccl_comms)
+        elif rccl is not None:
             rccl.all_gather(recs[j], gathered[j], streams[j].cuda_stream, comm=j % rccl_comms)
-        elif use_dist and one_device:  # (test mode: gloo has no device all-gather — through host memory, synchronously)
+        elif use_dist and one_device:  # (test mode: gloo has no device collective — through host memory, synchronously)
             streams[j].synchronize()
-            gathered[j].copy_(sharding.all_gather_records(recs[j].cpu(), world))
+            if to_root:
+                t = sharding.gather_records_to_root(recs[j].cpu(), world, root=0)
+                if t is not None:
+                    gathered[j].copy_(t)
+            else:
+                gathered[j].copy_(sharding.all_gather_records(recs[j].cpu(), world))
+        elif use_dist and to_root:
+            streams[j].synchronize()
+            sharding.gather_records_to_root(recs[j], world, root=0, out=gathered[j].view(-1) if gathered is not None else None)
         elif use_dist:
             return sharding.all_gather_records(recs[j], world, out=gathered[j], async_op=True)[1]
         return None
@@ -412,10 +429,11 @@ def main():
     if use_dist and rank == 0:
         # the gathered table holds every rank's records in stream order: check this rank's block
         last = loop.last_slot
-        g = gathered[last][rank * B:(rank + 1) * B]
-        assert torch.equal(g, recs[last]), "gathered keypoint records differ from the local ones"
-        print(f"[bench] all-gather of keypoint records over {'RCCL (ncclAllGather on the context stream)' if rccl is not None else dist.get_backend()}: table {tuple(gathered[last].shape)}, "
-              f"this rank's block equals its local records", file=sys.stderr)
+        g = gathered[last][rank * BLOCK_ROWS:(rank + 1) * BLOCK_ROWS]
+        assert torch.equal(g, recs[last]), "gathered keypoint block differs from the local one"
+        how = (("ncclGather to rank 0" if to_root else "ncclAllGather") + " on the context stream (RCCL)") if rccl is not None else dist.get_backend()
+        print(f"[bench] {'gather' if to_root else 'all-gather'} of compact keypoint blocks over {how}: table {tuple(gathered[last].shape)} "
+              f"({BLOCK_ROWS * 16 / 1e6:.2f} MB a rank), this rank's block equals its local records", file=sys.stderr)
 
     result_line = None
     if rank == 0:
@@ -443,7 +461,10 @@ def main():
         own_bytes = own_r + own_w
         achieved = own_bytes / (dom_alone_ms * 1e-3) / 1e9  # (one batch on the chip: the reading a kernel trace reproduces)
         ms_per_step = elapsed / args.steps * 1e3
-        traffic = traffic_total = None
+        # HBM traffic is NOT measured in this run (PMC counters need rocprofv3 passes of their own): the figures are read
+        # from profiles/traffic.json, written by tools/summarize_profile.py from the round's rocprofv3 --pmc passes over this
+        # same command; `traffic_source` says which run that was.
+        traffic = traffic_total = traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
@@ -451,14 +472,16 @@ def main():
                 # stage -> kernels launched inside it (PMC rows are per kernel)
                 traffic = tj.get(dom_kernel) or sum(tj.get(k, 0.0) for k in capi.STAGE_KERNELS.get(dom, (dom,))) or None
                 traffic_total = sum(x for k, x in tj.items() if k.startswith("k_"))
+                traffic_source = "profiles/traffic.json, not measured in this run: " + str(tj.get("_source", "source not recorded"))
             except Exception:
-                traffic = traffic_total = None
+                traffic = traffic_total = traffic_source = None
         flag_msg = None
-        if use_dist:  # the gathered records carry every scan's flags: a truncated record (more keypoints than the stride) shows here
+        if use_dist:  # every rank's block header carries the OR of its scans' flags: a block that was cut (more keypoints than it holds) shows here
             last = loop.last_slot
-            hdr = gathered[last].view(torch.int32)[:, 0, :2].cpu().numpy()
-            flag_msg = int(np.bitwise_or.reduce(hdr[:, 1])) if len(hdr) else 0
-            assert flag_msg == 0, f"gathered keypoint records carry flags 0x{flag_msg:x} (0x4: more keypoints than the record stride)"
+            hdr = gathered[last].view(torch.int32).view(world, BLOCK_ROWS, 4)[:, 0, :].cpu().numpy()
+            flag_msg = int(np.bitwise_or.reduce(hdr[:, 2])) if len(hdr) else 0
+            assert flag_msg == 0, f"gathered keypoint blocks carry flags 0x{flag_msg:x} (0x4: more keypoints than the block holds)"
+            assert all(int(h[0]) == B for h in hdr), "a gathered block does not hold the rank's whole batch"
         out = {
             "metric": "VLP-16 scans/sec (16x1800 pts), detector+descriptor", "value": world * B * args.steps / elapsed,
             "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -469,7 +492,7 @@ def main():
             "config": {"workload": f"batch of {B} synthetic VLP-16 scans (16x1800 pts, 64 uniform poles) per GPU, "
                                    f"device-resident, preset '{args.preset}', roll/pitch 0.02/-0.015",
                        "scans_per_gpu": B, "points_per_scan": N, "preset": args.preset,
-                       "parallelism": f"frame-sharded x{world}" + (", all-gather of keypoint records (RCCL)" if world > 1 else "")
+                       "parallelism": f"frame-sharded x{world}" + ((", gather to rank 0" if to_root else ", all-gather") + f" of compact keypoint blocks ({BLOCK_ROWS * 16 / 1e6:.2f} MB a rank, RCCL)" if world > 1 else "")
                                       + (" — TEST MODE: all ranks on one device over gloo, not a measurement" if one_device else ""),
                        "keypoints_per_scan": k_all / (world * B), "flags_or": flags_or, "batches_in_flight": K,
                        "gathered_record_flags_or": flag_msg},
@@ -478,8 +501,20 @@ def main():
             # (profiles/*_c1_kernel_stats.csv).  frac_exec = the same bytes / the kernel's execution span (device clock, first
             # workgroup's start to last workgroup's end) INSIDE the timed region, the other batches in flight sharing the chip:
             # what rocprofv3 reports for the headline run (profiles/*_kernel_stats.csv).
-            "roofline": {"bound": "hbm", "kernel": dom_kernel, "stage": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "roofline": {"bound": "hbm", "kernel": dom_kernel,
+                         # (the profiling slot the kernel's events live in: slots are named after the separate kernels — slot
+                         #  "k_prep" is stage 0, which k_front occupies when the fused kernel runs)
+                         "event_slot": dom, "event_slot_index": capi.STAGE_NAMES.index(dom),
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS,
+                         # Which regime `frac` / `achieved` / `kernel_ms` describe: since round 5 the kernel's duration
+                         # with ONE batch on the chip — what a kernel trace of `--contexts 1` reproduces — NOT the regime of the
+                         # headline value (K batches in flight): that reading is `frac_in_timed_region` (= frac_exec) below.
+                         # Rounds 1-4 quoted the in-flight HIP-event span here; compare across rounds by the explicit keys.
+                         "frac_regime": "one batch on the chip (definition v2, rounds 5-6); the timed region's own figure: frac_in_timed_region",
+                         "frac_one_at_a_time": achieved / HBM_PEAK_GBS, "kernel_ms_one_at_a_time": dom_alone_ms,
+                         "frac_in_timed_region": (own_bytes / (dom_exec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if dom_exec_ms else None,
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "definition": "achieved = this kernel's own algorithmic bytes per launch (alg_bytes_read + alg_bytes_written, "
                                        "fx_get_stage_bytes) / kernel_ms, its duration with one batch on the chip; frac_exec: the same "
                                        "over its execution span with the other batches in flight; path_frac = the whole path's "

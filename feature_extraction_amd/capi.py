@@ -27,10 +27,10 @@ STAGE_NAMES = ("k_prep", "k_bucket", "k_rings_runs", "k_rings_large", "k_merge",
 # stages that are one kernel launch (eligible as the roofline line's dominant kernel: their HIP-event span is that kernel)
 SINGLE_LAUNCH_STAGES = ("k_prep", "k_bucket", "k_rings_runs", "k_gather", "k_desc_group", "k_desc_mid")
 # kernels launched inside each timed stage (rocprofv3 / PMC rows are per kernel name)
-STAGE_KERNELS = {"k_prep": ("k_prep", "k_front"),  # (k_front: stages 0-4 of scans that fit its LDS tables, in one launch)
+STAGE_KERNELS = {"k_prep": ("k_prep", "k_front", "k_front_ab"),  # (k_front: stages 0-4 of scans that fit its LDS tables, in one launch)
                  "k_bucket": ("k_bucket", "k_bucket_many"),  # (k_bucket_many: sensors of more than 24 rings)
                  "k_rings_large": ("k_rings_runs2", "k_rings_large"),  # (k_rings_runs2: sensors of more than 16 rings)
-                 "k_merge": ("k_merge_small", "k_merge_big", "k_merge_huge", "k_front_redo", "k_slow", "k_offsets"),
+                 "k_merge": ("k_merge_small", "k_merge_big", "k_merge_huge", "k_front_redo", "k_slow"),
                  "k_desc_mid": ("k_desc_mid",),
                  "k_gather": ("k_gather", "k_rng_ord"),  # (k_rng_ord only when several workgroups share a scan: small batches)
                  "k_desc_rare": ("k_dense_sort", "k_dense_density", "k_dense_finish_s", "k_dense_finish_l")}
@@ -100,10 +100,10 @@ class FxSynthCfg(C.Structure):
 
 
 # every symbol include/fx.h declares (tests/test_capi_symbols.py checks the list against the header)
-FX_HEADER_VERSION = (0 << 16) | 6  # the include/fx.h these ctypes structures mirror
+FX_HEADER_VERSION = (0 << 16) | 7  # the include/fx.h these ctypes structures mirror
 EXPORTS = ("fx_version", "fx_check_abi", "fx_status_str", "fx_last_error", "fx_params_default", "fx_params_launch",
            "fx_limits_default", "fx_limits_sparse", "fx_create", "fx_destroy", "fx_set_stream", "fx_get_stream", "fx_set_graph_batch", "fx_set_batches_in_flight", "fx_set_profiling", "fx_set_profiling_stages", "fx_get_timings",
-           "fx_get_stage_bytes", "fx_get_limits", "fx_process_batch", "fx_synchronize", "fx_pack_features", "fx_pack_keypoint_records",
+           "fx_get_stage_bytes", "fx_get_limits", "fx_process_batch", "fx_synchronize", "fx_pack_features", "fx_pack_keypoint_records", "fx_keypoint_block_bytes", "fx_pack_keypoint_block",
            "fx_rotation_from_roll_pitch", "fx_sc3d_tables", "fx_sc3d_xaxis", "fx_synth_cfg_vlp16",
            "fx_synth_scan", "fx_unpack_pointcloud2", "fx_pack_pointxyzi")
 # the header's FX_TEST_HOOKS section: exported by lib/libfx_hip_test.so only
@@ -197,6 +197,9 @@ def load():
     lib.fx_synchronize.argtypes = [C.c_void_p]
     lib.fx_pack_features.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     lib.fx_pack_keypoint_records.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    lib.fx_keypoint_block_bytes.argtypes = [C.c_uint32, C.c_uint32]
+    lib.fx_keypoint_block_bytes.restype = C.c_size_t
+    lib.fx_pack_keypoint_block.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
     lib.fx_rotation_from_roll_pitch.argtypes = [C.c_double, C.c_double, _F32P]
     lib.fx_rotation_from_roll_pitch.restype = None
     lib.fx_sc3d_tables.argtypes = [C.c_double, _F32P, _F32P, _F32P, _F32P]
@@ -353,6 +356,10 @@ class Context:
 
     def pack_keypoint_records(self, dst_device_ptr, rec_keypoints):
         check(self.lib.fx_pack_keypoint_records(self.handle, C.c_void_p(dst_device_ptr), rec_keypoints))
+
+    def pack_keypoint_block(self, dst_device_ptr, max_scans, max_total_keypoints):
+        """The last batch's keypoints as one compact block (fx_pack_keypoint_block; layout: sharding.unpack_block)."""
+        check(self.lib.fx_pack_keypoint_block(self.handle, C.c_void_p(dst_device_ptr), int(max_scans), int(max_total_keypoints)))
 
     def synchronize(self):
         check(self.lib.fx_synchronize(self.handle))

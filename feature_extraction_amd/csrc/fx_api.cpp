@@ -47,7 +47,6 @@ void fxk_rings_runs(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uin
 void fxk_merge_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap);
 void fxk_merge_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t grid, uint32_t last);
 void fxk_merge_huge(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t ccap, uint32_t grid);
-void fxk_offsets(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t clk_next);
 uint32_t fxk_front_max_rings(void);
 uint32_t fxk_front_merge_cap(void);
 void fxk_front(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float near_margin, float el0, float inv_step,
@@ -58,7 +57,7 @@ void fxk_front_cd(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint3
 void fxk_front_redo(hipStream_t s, const FxDevParams &P, const FxBuffers &B, float el0, float inv_step, uint32_t huge_ccap, uint32_t force_slow,
                     uint32_t grid);
 size_t fxk_slow_words(uint32_t max_ring_points, uint32_t max_candidates, uint32_t huge_ccap);
-uint32_t fxk_slow(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t huge_ccap, uint32_t grid, uint32_t batch, uint32_t clk_next);
+void fxk_slow(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t huge_ccap, uint32_t grid, uint32_t batch, uint32_t clk_next);
 hipError_t fxk_configure_front(void);
 uint32_t fxk_gather_slices(uint32_t batch);
 void fxk_gather(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float box_margin);
@@ -67,6 +66,9 @@ void fxk_desc_mid(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint3
                   uint32_t n_dslow);
 void fxk_pack_kp_records(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, void *dst,
                          uint32_t rec_kp);
+size_t fxk_kp_block_bytes(uint32_t max_scans, uint32_t max_total);
+void fxk_pack_kp_block(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, void *dst, uint32_t max_scans, uint32_t max_total,
+                       uint32_t grid);
 void fxk_rng_ord(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch);
 #ifdef FX_TEST_HOOKS
 void fxk_test_sort_replay(hipStream_t s, const uint32_t *sizes, uint32_t n_seq, uint32_t n, uint32_t *perm);
@@ -324,8 +326,7 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof, bo
       for (int i = 2; i <= 4; ++i) FX_HIP(mark(i));
       if (!(c->skip_mask & 1u))
       fxk_front_redo(s, P, B, el0, inv_step, c->merge_huge_ccap, c->front_force >= 2u ? 1u : 0u, tier_grid(hint[6], 2 * big_grid, batch, 1, 1));
-      if (!fxk_slow(s, P, B, c->merge_huge_ccap, tier_grid(hint[7], big_grid, batch, 1, 1), batch, clk_next))  // (one workgroup: it does the offsets too)
-        fxk_offsets(s, P, B, batch, clk_next);
+      fxk_slow(s, P, B, c->merge_huge_ccap, tier_grid(hint[7], big_grid, batch), batch, clk_next);  // (its last workgroup does the batch's keypoint offsets too)
       FX_HIP(mark(5));
     } else {
     // one workgroup a scan when the batch fills the chip with that, several (a counting pass first) when it does not and the
@@ -365,8 +366,7 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof, bo
     fxk_merge_big(s, P, B, c->merge_big_cap, tier_grid(hint[2], big_grid, batch), c->merge_big_cap >= L.max_candidates);
     if (c->merge_big_cap < L.max_candidates)
       fxk_merge_huge(s, P, B, c->merge_huge_cap, c->merge_huge_ccap, tier_grid(hint[3], big_grid, batch));
-    if (!fxk_slow(s, P, B, c->merge_huge_ccap, tier_grid(hint[7], big_grid, batch), batch, clk_next))  // (rings / merges beyond the LDS tiers: see the front path)
-      fxk_offsets(s, P, B, batch, clk_next);
+    fxk_slow(s, P, B, c->merge_huge_ccap, tier_grid(hint[7], big_grid, batch), batch, clk_next);  // (rings / merges beyond the LDS tiers, and the batch's keypoint offsets: see the front path)
     FX_HIP(mark(5));
     }
     if (P.estimate_descriptors) {
@@ -1322,6 +1322,19 @@ fx_status fx_pack_keypoint_records(fx_ctx *c, void *dst_device, uint32_t rec_key
   if (!c || !dst_device || !rec_keypoints) return fail(FX_ERR_INVALID_ARG, "null argument");
   FX_HIP(hipSetDevice(c->device));
   if (c->last_batch) fxk_pack_kp_records(c->stream, c->dp, c->buf, c->last_batch, dst_device, rec_keypoints);
+  FX_HIP(hipGetLastError());
+  return FX_OK;
+}
+
+size_t fx_keypoint_block_bytes(uint32_t max_scans, uint32_t max_total_keypoints) { return fxk_kp_block_bytes(max_scans, max_total_keypoints); }
+
+fx_status fx_pack_keypoint_block(fx_ctx *c, void *dst_device, uint32_t max_scans, uint32_t max_total_keypoints) {
+  if (!c || !dst_device || !max_scans) return fail(FX_ERR_INVALID_ARG, "null argument");
+  FX_HIP(hipSetDevice(c->device));
+  // a workgroup a scan up to four a CU (the block's zero tail is dealt by stride; an empty batch — kp_offset[0] is 0 — gives
+  // the empty block)
+  const uint32_t grid = std::max(1u, std::min(c->last_batch, 4u * (uint32_t)c->n_cu));
+  fxk_pack_kp_block(c->stream, c->dp, c->buf, c->last_batch, dst_device, max_scans, max_total_keypoints, grid);
   FX_HIP(hipGetLastError());
   return FX_OK;
 }

@@ -59,6 +59,7 @@ struct FxScTables {
 #define FX_CLK_SLOTS 64
 #define FX_N_COUNTERS 48  // counters k_prep / k_front clear for the batch
 #define FX_CNT_REDO 48    // counters[48]: scans k_front hands to k_front_redo, [49]: scans handed to the slow tier, k_slow (cleared by k_offsets, after their readers)
+#define FX_CNT_SLOW_TICKET 50  // counters[50]: workgroups of k_slow's launch that are done (the last one computes the batch's keypoint offsets and puts it back to 0)
 #define FX_N_COUNTER_WORDS 56
 #define FX_CNT_RUNS2_TICKET 40  // counters[40 + c]: next ring of XCD class c's list for k_rings_runs2
 #define FX_ATAN_N 64      // table step of k_prep's arctangent: 1 / 64 over [0, 1]

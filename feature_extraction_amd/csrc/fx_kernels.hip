@@ -6,7 +6,7 @@
 //   k_bucket     estimateKeypoints ring loop :195-207 (the 16 PassThrough filters as one stable split)
 //   k_rings_*    getCylinderSegments :261-327 (one wavefront per ring; workgroup tiers for big rings)
 //   k_merge_*    secondary merge :209-257 (+ ring-order assembly of keypoints_full / keypoint_cloud)
-//   k_offsets    batch-wide keypoint offsets
+//   k_slow       what exceeds every LDS-sized tier, on scratch in HBM; its last workgroup: the batch-wide keypoint offsets
 //   k_gather, k_desc_*   estimateDescriptors :329-355 == pcl::ShapeContext3DEstimation
 // Every stage has a fast tier sized for the common case and larger tiers fed through device-side
 // work lists, so no input is ever truncated silently (flags) and the common case stays small in LDS.
@@ -958,6 +958,34 @@ __device__ __forceinline__ uint32_t ring_membership(float el, const float2 *win,
   return mask;
 }
 
+// The streaming pass's rotate-and-test, ONE statement for every kernel that needs it (prep_stream, and k_prep_count, whose
+// counts the sliced pass's bases are: the two must agree bit for bit — ADVICE r5).  T = float, or fx_f2 for two points an
+// instruction (packed fp32 is IEEE per component: the same bits).
+// pcl::transformPointCloud, dense branch: ((m0 x + m1 y) + m2 z) + t, t = 0 (the + 0 only turns -0 into +0, which no range
+// test sees; the sweep, whose values are stored, adds it).
+template <typename T>
+__device__ __forceinline__ void prep_rotate(const float *R, T x, T y, T z, T &rx, T &ry, T &rz) {
+  rx = (R[0] * x + R[1] * y) + R[2] * z;
+  ry = (R[3] * x + R[4] * y) + R[5] * z;
+  rz = (R[6] * x + R[7] * y) + R[8] * z;
+}
+// Range tests with both ends clamped to the finite floats: a NaN or an infinite coordinate fails them (PassThrough drops
+// non-finite points first, ref: SURVEY.md A.2), a finite one compares as in PCL's !(v < min || v > max); an infinite or
+// NaN limit (no limit on that side; a NaN limit compares false in PCL too) becomes +-FLT_MAX.
+struct PrepBox {
+  float x0, x1, y0, y1, z0, z1;
+  __device__ __forceinline__ PrepBox(const FxDevParams &P, float margin)
+      : x0(fmaxf(P.x_min - margin, -FLT_MAX)), x1(fminf(P.x_max + margin, FLT_MAX)), y0(fmaxf(P.y_min - margin, -FLT_MAX)),
+        y1(fminf(P.y_max + margin, FLT_MAX)), z0(fmaxf(P.z_min - margin, -FLT_MAX)), z1(fminf(P.z_max + margin, FLT_MAX)) {}
+  // (the filter box itself: no arithmetic on the limits — P.x_min - 0.0f would turn a -0 limit... into the same -0: exact)
+  __device__ __forceinline__ explicit PrepBox(const FxDevParams &P)
+      : x0(fmaxf(P.x_min, -FLT_MAX)), x1(fminf(P.x_max, FLT_MAX)), y0(fmaxf(P.y_min, -FLT_MAX)), y1(fminf(P.y_max, FLT_MAX)),
+        z0(fmaxf(P.z_min, -FLT_MAX)), z1(fminf(P.z_max, FLT_MAX)) {}
+  __device__ __forceinline__ bool has(float rx, float ry, float rz) const {
+    return rx >= x0 && rx <= x1 && ry >= y0 && ry <= y1 && rz >= z0 && rz <= z1;
+  }
+};
+
 #ifndef FX_PREP_OCC
 #define FX_PREP_OCC 4  // waves per SIMD the register budget is held to: 4 = two workgroups per CU (129 registers would mean one)
 #endif
@@ -1085,31 +1113,10 @@ __device__ __forceinline__ uint32_t prep_stream(const FxDevParams &P, const FxBu
     FX_STAMP(28);
     FX_SS(5);
   };
-  // Range tests with both ends clamped to the finite floats: a NaN or an infinite coordinate fails them (PassThrough drops
-  // non-finite points first, ref: SURVEY.md A.2), a finite one compares as in PCL's !(v < min || v > max); an infinite or
-  // NaN limit (no limit on that side; a NaN limit compares false in PCL too) becomes +-FLT_MAX.
   // (Measured and not taken, profiles/r06_experiments.md §1: the twelve limits and the rotation made SCALAR by hand — the device
-  //  has no scalar float arithmetic, so what the compiler computes or loads per lane stays in vector registers, 21 of them —
-  //  -DFX_SCALAR_LIM / -DFX_SCALAR_R: k_prep 84 -> 72 registers, k_front 127 -> 109, and the headline 1 % lower either way.)
-  auto sgpr = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
-#ifdef FX_SCALAR_LIM
-  auto lo_lim = [&](float v) { return sgpr(fmaxf(v, -FLT_MAX)); };
-  auto hi_lim = [&](float v) { return sgpr(fminf(v, FLT_MAX)); };
-#else
-  auto lo_lim = [&](float v) { return fmaxf(v, -FLT_MAX); };
-  auto hi_lim = [&](float v) { return fminf(v, FLT_MAX); };
-#endif
-#ifdef FX_SCALAR_R
-  const float R0 = sgpr(M.R[0]), R1 = sgpr(M.R[1]), R2 = sgpr(M.R[2]), R3 = sgpr(M.R[3]), R4 = sgpr(M.R[4]), R5 = sgpr(M.R[5]), R6 = sgpr(M.R[6]),
-              R7 = sgpr(M.R[7]), R8 = sgpr(M.R[8]);
-#else
-  const float R0 = M.R[0], R1 = M.R[1], R2 = M.R[2], R3 = M.R[3], R4 = M.R[4], R5 = M.R[5], R6 = M.R[6], R7 = M.R[7], R8 = M.R[8];
-#endif
-  (void)sgpr;
-  const float nx0 = lo_lim(P.x_min - near_margin), nx1 = hi_lim(P.x_max + near_margin), ny0 = lo_lim(P.y_min - near_margin),
-              ny1 = hi_lim(P.y_max + near_margin), nz0 = lo_lim(P.z_min - near_margin), nz1 = hi_lim(P.z_max + near_margin);
-  const float fx0 = lo_lim(P.x_min), fx1 = hi_lim(P.x_max), fy0 = lo_lim(P.y_min), fy1 = hi_lim(P.y_max), fz0 = lo_lim(P.z_min),
-              fz1 = hi_lim(P.z_max);
+  //  has no scalar float arithmetic, so what the compiler computes or loads per lane stays in vector registers, 21 of them:
+  //  k_prep 84 -> 72 registers, k_front 127 -> 109, and the headline 1 % lower either way.)
+  const PrepBox near_box(P, near_margin), box(P);
   // (Measured, profiles/r05_experiments.md 12: a second tile of loads in flight, tile buffers that take turns without the register
   //  copies below, 16-byte loads and touching the tile after the next a period early all left the kernel's time where it was —
   //  the pass waits for its own instruction stream between the loads, not for the loads.  Round 4's "issuing the loads costs
@@ -1138,16 +1145,15 @@ __device__ __forceinline__ uint32_t prep_stream(const FxDevParams &P, const FxBu
 #pragma unroll
     for (int u = 0; u < FX_PREP_U; u += 2) {
       const fx_f2 X = {v[u].x, v[u + 1].x}, Y = {v[u].y, v[u + 1].y}, Z = {v[u].z, v[u + 1].z};
-      const fx_f2 a = (R0 * X + R1 * Y) + R2 * Z;
-      const fx_f2 b = (R3 * X + R4 * Y) + R5 * Z;
-      const fx_f2 c = (R6 * X + R7 * Y) + R8 * Z;
+      fx_f2 a, b, c;
+      prep_rotate<fx_f2>(M.R, X, Y, Z, a, b, c);
       rxs[u] = a.x, rxs[u + 1] = a.y, rys[u] = b.x, rys[u + 1] = b.y, rzs[u] = c.x, rzs[u + 1] = c.y;
     }
 #pragma unroll
     for (int u = 0; u < FX_PREP_U; ++u) {
       const float rx = rxs[u], ry = rys[u], rz = rzs[u];
-      const bool near = rx >= nx0 && rx <= nx1 && ry >= ny0 && ry <= ny1 && rz >= nz0 && rz <= nz1;
-      const bool k = rx >= fx0 && rx <= fx1 && ry >= fy0 && ry <= fy1 && rz >= fz0 && rz <= fz1;
+      const bool near = near_box.has(rx, ry, rz);
+      const bool k = box.has(rx, ry, rz);
       keep[u] = k;
       mask[u] = __ballot(k);
       wave_cnt += (uint32_t)__popcll(mask[u]);
@@ -1279,9 +1285,7 @@ extern "C" __global__ __launch_bounds__(FX_PREP_T) void k_prep_count(FxDevParams
     const uint32_t per = prep_slice_tiles(M.n, S) * FX_PREP_TILE;
     const uint32_t lo = slice * per, hi = min(M.n, lo + per);
     const gfloat *gpts = (const gfloat *)M.pts;
-    auto lo_lim = [](float v) { return fmaxf(v, -FLT_MAX); };
-    auto hi_lim = [](float v) { return fminf(v, FLT_MAX); };
-    const float fx0 = lo_lim(P.x_min), fx1 = hi_lim(P.x_max), fy0 = lo_lim(P.y_min), fy1 = hi_lim(P.y_max), fz0 = lo_lim(P.z_min), fz1 = hi_lim(P.z_max);
+    const PrepBox box(P);
     for (uint32_t i0 = lo; i0 < hi; i0 += 4u * FX_PREP_T) {  // (four loads in flight a lane)
       float x[4], y[4], z[4];
 #pragma unroll
@@ -1292,11 +1296,10 @@ extern "C" __global__ __launch_bounds__(FX_PREP_T) void k_prep_count(FxDevParams
         x[u] = i < hi ? w.x : NAN, y[u] = w.y, z[u] = w.z;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {  // prep_stream's predicate: the same arithmetic, the same clamped limits
-        const float rx = (M.R[0] * x[u] + M.R[1] * y[u]) + M.R[2] * z[u];
-        const float ry = (M.R[3] * x[u] + M.R[4] * y[u]) + M.R[5] * z[u];
-        const float rz = (M.R[6] * x[u] + M.R[7] * y[u]) + M.R[8] * z[u];
-        cnt += (rx >= fx0 && rx <= fx1 && ry >= fy0 && ry <= fy1 && rz >= fz0 && rz <= fz1) ? 1u : 0u;
+      for (int u = 0; u < 4; ++u) {  // prep_stream's predicate: the SAME functions (prep_rotate, PrepBox::has)
+        float rx, ry, rz;
+        prep_rotate<float>(M.R, x[u], y[u], z[u], rx, ry, rz);
+        cnt += box.has(rx, ry, rz) ? 1u : 0u;
       }
     }
   }
@@ -1308,6 +1311,7 @@ extern "C" __global__ __launch_bounds__(FX_PREP_T) void k_prep_count(FxDevParams
     uint32_t t = 0;
     for (int w = 0; w < FX_PREP_T / 64; ++w) t += s_tot[w];
     B.prep_cnt[(size_t)scan * S + slice] = t;
+    if (slice == 0) B.flags[scan] = 0u;  // (the batch's first launch: k_prep_sliced's slices only OR into it)
   }
 }
 extern "C" __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep_sliced(FxDevParams P, FxBuffers B, float near_margin, float el0, float inv_step,
@@ -1339,8 +1343,11 @@ extern "C" __global__ __launch_bounds__(FX_PREP_T, FX_PREP_OCC) void k_prep_slic
   const uint32_t end = prep_stream<false>(P, B, M, scan, near_margin, el0, inv_step, L, slice * per, slice * per + per, base0);
   for (uint32_t r = tid; r < R; r += FX_PREP_T) prc[r] = s_ring[r];
   if (tid == 0) {
-    if (slice == 0) B.flags[scan] = 0u;
+    // (the scan's flag word was cleared by k_prep_count, the launch before: a slice that fails the self-check below ORs into it)
     if (slice == S - 1u) B.n_filt[scan] = end;
+    // self-check: this pass's survivors of the slice against the counting pass's (the other slices' bases were built from
+    // those counts: a disagreement means overlapping or missing stretches of ~cloud)
+    if (end - base0 != B.prep_cnt[(size_t)scan * S + slice]) atomicOr(&B.flags[scan], FX_FLAG_INTERNAL);
   }
   if (tid == 0) atomicMax(&B.clk[2 * clk_slot + 1], (unsigned long long)wall_clock64());
 }
@@ -3796,10 +3803,12 @@ extern "C" __global__ __launch_bounds__(FX_FRONT_T) void k_front_redo(FxDevParam
 __host__ __device__ constexpr size_t slow_ring_words(uint32_t cap) { return (size_t)(FX_RING_WORDS_PER_POINT + FX_RING_WORDS_PER_CLUSTER) * cap; }
 __host__ __device__ constexpr size_t slow_merge_words(uint32_t cap, uint32_t ccap) { return 4 * (size_t)cap + cap + merge_aux_words(cap) + 3 * (size_t)ccap; }
 __device__ __forceinline__ void offsets_body(const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t clk_next, uint32_t *s_w);
-// (offsets: launched as ONE workgroup — the last 64 batches handed it nothing — it also does k_offsets' work, the batch-wide
-//  keypoint offsets, and that launch is left out: one launch less in every batch's chain of dependent launches)
-extern "C" __global__ __launch_bounds__(FX_SLOW_T) void k_slow(FxDevParams P, FxBuffers B, uint32_t huge_ccap, uint32_t offsets, uint32_t batch,
-                                                             uint32_t clk_next) {
+// The batch's keypoint offsets (offsets_body: k_offsets' work until round 5, a launch of its own) are computed by whichever
+// workgroup of this launch finishes LAST — a ticket: every workgroup makes its writes visible device-wide, draws a number,
+// and the one that draws gridDim.x - 1 knows all the others are done.  So the grid need not be one workgroup for the launch
+// to stand in for k_offsets (with one workgroup a batch that suddenly hands on many scans went through it one
+// after the other), and every batch has one launch less in its chain.
+extern "C" __global__ __launch_bounds__(FX_SLOW_T) void k_slow(FxDevParams P, FxBuffers B, uint32_t huge_ccap, uint32_t batch, uint32_t clk_next) {
   static_assert(FX_SLOW_T == FX_WG, "k_slow stands in for k_offsets");
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const uint32_t n_slow = B.counters[FX_CNT_REDO + 1];
@@ -3819,8 +3828,21 @@ extern "C" __global__ __launch_bounds__(FX_SLOW_T) void k_slow(FxDevParams P, Fx
     merge_body<FX_SLOW_T, false, false, true>(P, B, scan, P.max_candidates, huge_ccap, smem, true, nullptr, gs);
     wg_global_sync();
   }
-  if (offsets) {  // (the only workgroup of the launch: everything the offsets need has been written, by earlier launches or above)
-    wg_global_sync();
+  // ---- the last workgroup of the launch does the offsets
+  __syncthreads();  // (every wavefront's stores above are issued; smem is free)
+  if (threadIdx.x == 0) {
+    uint32_t last = 1u;
+    if (gridDim.x > 1u) {
+      __threadfence();  // (release at device scope: what this workgroup's scans got — n_kp, flags — before its ticket)
+      last = atomicAdd(&B.counters[FX_CNT_SLOW_TICKET], 1u) == gridDim.x - 1u ? 1u : 0u;
+      if (last) B.counters[FX_CNT_SLOW_TICKET] = 0u;  // (for the next batch: launches of a context are ordered)
+    }
+    smem[0] = last;
+  }
+  __syncthreads();
+  if (smem[0]) {  // (workgroup-uniform)
+    __syncthreads();  // (smem[0] is read by all before offsets_body reuses the words)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the other workgroups' results, whatever this CU's L1 holds
     offsets_body(P, B, batch, clk_next, smem);
   }
 }
@@ -3860,11 +3882,6 @@ __device__ __forceinline__ void offsets_body(const FxDevParams &P, const FxBuffe
     B.kp_offset[batch] = run;
     B.seq[0] += 1ull;  // batch tag of the dense tier's density cache (device side: a replayed HIP graph advances it too)
   }
-}
-
-extern "C" __global__ __launch_bounds__(FX_WG) void k_offsets(FxDevParams P, FxBuffers B, uint32_t batch, uint32_t clk_next) {
-  __shared__ uint32_t s_w[FX_NWAVE];
-  offsets_body(P, B, batch, clk_next, s_w);
 }
 
 // ====================================================================== stage 5: descriptors
@@ -6106,6 +6123,52 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_pack_kp_records(FxDevParam
   for (uint32_t k = threadIdx.x; k < rec_kp; k += FX_WG) rec[1 + k] = k < K ? kp[k] : make_float4(0, 0, 0, 0);
 }
 
+// The same keypoints as ONE compact block per batch — what crosses GPUs: a batch of VLP-16 scans has 54
+// keypoints a scan where the fixed-stride records above reserve max_keypoints (256): 4.2 MB a rank and step where 0.9 are
+// keypoints.  Block = float4 rows: row 0 {scans, keypoints stored, OR of the flags, max_total} (u32); then kp_offset[max_scans + 1]
+// (u32, four a row: scan b's keypoints are rows [kp_offset[b], kp_offset[b + 1]) of the keypoint area; entries beyond the
+// batch repeat the total); then flags[max_scans] (u32, four a row); then max_total keypoint rows (x, y, z, elevation), packed in
+// scan order, zero beyond the total.  A batch with more keypoints than max_total is cut there: the scans that lose keypoints
+// carry FX_FLAG_KP_OVERFLOW.  The size is fixed by (max_scans, max_total): every rank hands the collective the same count.
+__host__ __device__ inline uint32_t kp_block_off_rows(uint32_t max_scans) { return (max_scans + 1u + 3u) / 4u; }
+__host__ __device__ inline uint32_t kp_block_flag_rows(uint32_t max_scans) { return (max_scans + 3u) / 4u; }
+extern "C" __global__ __launch_bounds__(FX_WG) void k_pack_kp_block(FxDevParams P, FxBuffers B, uint32_t batch, uint32_t *dst, uint32_t max_scans,
+                                                                     uint32_t max_total) {
+  __shared__ uint32_t s_or[FX_NWAVE];
+  uint32_t *off = dst + 4, *flg = off + 4u * kp_block_off_rows(max_scans);
+  float4 *kp = reinterpret_cast<float4 *>(flg + 4u * kp_block_flag_rows(max_scans));
+  const uint32_t tid = threadIdx.x, nb = min(batch, max_scans);
+  const uint32_t total = min(B.kp_offset[nb], max_total);
+  if (blockIdx.x == 0) {  // the header rows
+    uint32_t acc = 0;
+    for (uint32_t i = tid; i < 4u * kp_block_off_rows(max_scans); i += FX_WG) off[i] = min(B.kp_offset[min(i, nb)], max_total);
+    for (uint32_t i = tid; i < 4u * kp_block_flag_rows(max_scans); i += FX_WG) {
+      uint32_t f = 0;
+      if (i < nb) {  // (cut: the scan keeps fewer keypoints in the block than it has)
+        const uint32_t o0 = B.kp_offset[i], o1 = B.kp_offset[i + 1u];
+        f = B.flags[i] | (min(o1, max_total) - min(o0, max_total) < o1 - o0 ? FX_FLAG_KP_OVERFLOW : 0u);
+      }
+      flg[i] = f;
+      acc |= f;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc |= (uint32_t)__shfl_xor((int)acc, d, 64);
+    if ((tid & 63u) == 0u) s_or[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t o = batch > max_scans ? FX_FLAG_KP_OVERFLOW : 0u;  // (a batch beyond the block's scan capacity: cut, and said so)
+      for (uint32_t w = 0; w < FX_NWAVE; ++w) o |= s_or[w];
+      dst[0] = nb, dst[1] = total, dst[2] = o, dst[3] = max_total;
+    }
+  }
+  for (uint32_t scan = blockIdx.x; scan < nb; scan += gridDim.x) {
+    const uint32_t o0 = min(B.kp_offset[scan], max_total), o1 = min(B.kp_offset[scan + 1u], max_total);
+    const float4 *src = B.keypoints + (size_t)scan * P.max_keypoints;
+    for (uint32_t k = tid; k < o1 - o0; k += FX_WG) kp[o0 + k] = src[k];
+  }
+  for (uint32_t k = total + blockIdx.x * FX_WG + tid; k < max_total; k += gridDim.x * FX_WG) kp[k] = make_float4(0, 0, 0, 0);
+}
+
 // ====================================================================== PointCloud2 wire formats
 // Ingress: pcl::fromPCLPointCloud2 (ref: node.cpp:79-81) picks the float32 fields x, y, z by name
 // out of point_step-byte records (velodyne driver clouds carry extra fields such as `ring`, and
@@ -6255,9 +6318,6 @@ void fxk_merge_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint
 void fxk_merge_huge(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t ccap, uint32_t grid) {
   hipLaunchKernelGGL(k_merge_huge, dim3(grid), dim3(FX_MBIG_T), fxk_merge_huge_lds_bytes(cap, ccap, P.n_rings), s, P, B, cap, ccap);
 }
-void fxk_offsets(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t clk_next) {
-  hipLaunchKernelGGL(k_offsets, dim3(1), dim3(FX_WG), 0, s, P, B, batch, clk_next);
-}
 // the fused front kernel takes sensors of up to FX_FRONT_RMAX rings (scans that do not fit its tables go on to k_front_redo)
 uint32_t fxk_front_max_rings(void) { return FX_FRONT_RMAX; }
 uint32_t fxk_front_merge_cap(void) { return FX_FRONT_MERGE; }
@@ -6273,12 +6333,11 @@ void fxk_front_redo(hipStream_t s, const FxDevParams &P, const FxBuffers &B, flo
 size_t fxk_slow_words(uint32_t max_ring_points, uint32_t max_candidates, uint32_t huge_ccap) {
   return (std::max(slow_ring_words(max_ring_points), slow_merge_words(max_candidates, huge_ccap)) + 3) & ~(size_t)3;
 }
-// returns 1 when the launch also did k_offsets' work (a single workgroup): the caller then leaves that launch out
-uint32_t fxk_slow(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t huge_ccap, uint32_t grid, uint32_t batch, uint32_t clk_next) {
+// (also computes the batch's keypoint offsets: its last workgroup, see k_slow)
+void fxk_slow(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t huge_ccap, uint32_t grid, uint32_t batch, uint32_t clk_next) {
   const size_t lds = std::max((size_t)SegCfg<FX_SLOW_T>::kWords, (size_t)FX_MERGE_HEAD + ((2 * ((size_t)P.n_rings + 1) + 3) & ~(size_t)3)) * 4;
   const uint32_t g = std::max(1u, std::min(grid, P.gs_slots));
-  hipLaunchKernelGGL(k_slow, dim3(g), dim3(FX_SLOW_T), lds, s, P, B, huge_ccap, g == 1u ? 1u : 0u, batch, clk_next);
-  return g == 1u ? 1u : 0u;
+  hipLaunchKernelGGL(k_slow, dim3(g), dim3(FX_SLOW_T), lds, s, P, B, huge_ccap, batch, clk_next);
 }
 void fxk_front_ab(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float near_margin, float el0, float inv_step,
                   uint32_t clk_slot, uint32_t force_redo) {
@@ -6393,6 +6452,13 @@ void fxk_rng_ord(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32
 void fxk_pack_kp_records(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, void *dst,
                          uint32_t rec_kp) {
   hipLaunchKernelGGL(k_pack_kp_records, dim3(batch), dim3(FX_WG), 0, s, P, B, batch, (float4 *)dst, rec_kp);
+}
+size_t fxk_kp_block_bytes(uint32_t max_scans, uint32_t max_total) {
+  return ((size_t)1 + kp_block_off_rows(max_scans) + kp_block_flag_rows(max_scans) + max_total) * 16;
+}
+void fxk_pack_kp_block(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, void *dst, uint32_t max_scans, uint32_t max_total,
+                       uint32_t grid) {
+  hipLaunchKernelGGL(k_pack_kp_block, dim3(grid), dim3(FX_WG), 0, s, P, B, batch, (uint32_t *)dst, max_scans, max_total);
 }
 void fxk_unpack_pc2(hipStream_t s, const void *src, uint32_t n, uint32_t point_step, uint32_t ox, uint32_t oy, uint32_t oz,
                     uint32_t oi, uint32_t big_endian, void *dst, uint32_t grid) {

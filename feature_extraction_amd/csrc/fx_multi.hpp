@@ -7,9 +7,10 @@
 // scans of several sensors / a recorded stream to chew through.
 //   * scan b of a batch of B goes to rank floor(b G / B) (contiguous blocks, fx_shard.hpp): output order is trivial;
 //   * every rank runs the unchanged single-GPU pipeline (fx_process_batch) on its block;
-//   * fx_pack_keypoint_records writes the block's fixed-stride records (stride = the context's keypoint capacity, so a
-//     record is never truncated), ncclAllGather assembles the table on every GPU (latency bound, not xGMI-bandwidth
-//     bound); descriptors stay on the producing GPU.
+//   * fx_pack_keypoint_block writes the block's keypoints as ONE compact block (offsets + flags + the keypoints packed in scan
+//     order, 64 a scan of capacity by default: 1.05 MB a rank for 1024 scans where max-stride records were 4.2 MB; what does
+//     not fit is flagged), ncclAllGather assembles the table on every GPU — or, Options::gather_root, ncclGather on one: a
+//     publisher needs one copy —; descriptors stay on the producing GPU.
 // Threads: ONE persistent worker per device, fed through a queue — no thread is created per batch.  Every device has
 // `in_flight` contexts, each on its own stream: submit() returns at once with a ticket, batch t runs on context
 // t % in_flight, and nothing in the worker waits for the GPU except the reuse of a context (the stage kernels of one
@@ -39,7 +40,8 @@ namespace fx {
 
 struct MultiGpuOptions {
   uint32_t in_flight = 2;  // contexts (batches in flight) per device (2: 1.59 million scans/s on one MI355X, 1: 1.24, 3: 1.48 — the shared communicator orders the slots)
-  uint32_t rec_kp = 0;     // keypoints per gathered record; 0 = the contexts' limits.max_keypoints
+  uint32_t block_keypoints = 0;  // keypoint rows of a rank's gathered block; 0 = 64 a scan of the rank's share (VLP-16 scenes have 54; a batch with more is cut and flagged FX_FLAG_KP_OVERFLOW)
+  int gather_root = -1;    // >= 0: the table is gathered on that rank only (ncclGather; the other ranks' tables stay untouched); -1: on every rank (ncclAllGather)
   fx_limits limits{};      // non-zero fields override fx_limits_default(scans per rank, max_points)
   // SELF-TEST: the ranks' collective is replaced by a gather through host memory (every rank downloads its block, all ranks
   // meet, every rank uploads the whole table) and no RCCL communicator is made — RCCL refuses a communicator with the same
@@ -52,7 +54,7 @@ struct MultiGpuOptions {
 struct MultiGpuBatch {
   uint32_t batch = 0;
   std::vector<fx_batch_view> views;    // per rank: that rank's block
-  std::vector<const float *> tables;   // per rank: the gathered table on that device (world * scans_per_rank records)
+  std::vector<const float *> tables;   // per rank: the gathered table on that device (world blocks of block_floats() floats; with gather_root: valid on that rank only)
   std::string error;                   // empty = ok
 };
 class MultiGpu;
@@ -88,11 +90,13 @@ class MultiGpu {
 
   // devices: HIP device ids, one rank each; max_batch: scans of one batch over all devices together
   MultiGpu(const fx_params &params, const std::vector<int> &devices, uint32_t max_batch, uint32_t max_points, const Options &opt = Options())
-      : devices_(devices), max_batch_(max_batch), in_flight_(opt.in_flight ? opt.in_flight : 1u), host_gather_(opt.host_gather) {
+      : devices_(devices), max_batch_(max_batch), in_flight_(opt.in_flight ? opt.in_flight : 1u), host_gather_(opt.host_gather), gather_root_(opt.gather_root) {
     const uint32_t G = (uint32_t)devices.size();
     if (!G) throw std::invalid_argument("fx::MultiGpu: no devices");
     if (FX_CHECK_ABI() != FX_OK) throw std::runtime_error(std::string("fx_check_abi: ") + fx_last_error());  // (this translation unit's fx.h against the library's)
     per_rank_ = (max_batch + G - 1) / G;
+    if (gather_root_ >= (int)G) throw std::invalid_argument("fx::MultiGpu: gather_root is not a rank");
+    block_kp_ = opt.block_keypoints ? opt.block_keypoints : 64u * per_rank_;
     for (uint32_t r = 0; r < G; ++r) ranks_.emplace_back(new Rank());
     comms_.assign(G, nullptr);
     try {
@@ -114,14 +118,11 @@ class MultiGpu {
           for (size_t i = 2; i < sizeof(fx_limits) / 4; ++i)  // (max_batch / max_points are the constructor's)
             if (ov[i]) dst[i] = ov[i];
           if (fx_create(&params, &lim, devices_[r], &S.ctx) != FX_OK) throw std::runtime_error(std::string("fx_create: ") + fx_last_error());
-          fx_limits got;
-          fx_get_limits(S.ctx, &got);
-          rec_kp_ = opt.rec_kp ? opt.rec_kp : got.max_keypoints;
           fx_set_batches_in_flight(S.ctx, in_flight_);  // (launch-policy hint: the slots of a device share its chip)
           hip(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking), "hipStreamCreate");
           fx_set_stream(S.ctx, S.stream);
           hip(hipEventCreateWithFlags(&S.done, hipEventDisableTiming), "hipEventCreate");
-          const size_t rec_bytes = (size_t)per_rank_ * record_floats(rec_kp_) * sizeof(float);
+          const size_t rec_bytes = block_floats() * sizeof(float);
           hip(hipMalloc((void **)&S.rec, rec_bytes), "hipMalloc records");
           hip(hipMalloc((void **)&S.table, rec_bytes * G), "hipMalloc table");
           hip(hipMemset(S.rec, 0, rec_bytes), "hipMemset");
@@ -140,7 +141,9 @@ class MultiGpu {
   uint32_t world() const { return (uint32_t)devices_.size(); }
   uint32_t scans_per_rank() const { return per_rank_; }
   uint32_t in_flight() const { return in_flight_; }
-  uint32_t record_keypoints() const { return rec_kp_; }
+  uint32_t block_keypoints() const { return block_kp_; }                                // keypoint rows of a rank's block
+  size_t block_floats() const { return fx::block_floats(per_rank_, block_kp_); }         // floats of a rank's block: the collective's count
+  int gather_root() const { return gather_root_; }
 
   // Enqueues the hot path on `batch` scans (host or device pointers per `flags`, as fx_process_batch takes them; block r
   // of the batch must be readable by device r) and the gather of the keypoint records.  Returns at once; `scans` and
@@ -156,7 +159,7 @@ class MultiGpu {
     job->out.views.resize(world());
     job->out.tables.resize(world());
     job->local_error.resize(world());
-    if (host_gather_) job->host_table.assign((size_t)per_rank_ * world() * record_floats(rec_kp_), 0.0f);
+    if (host_gather_) job->host_table.assign(block_floats() * world(), 0.0f);
     for (auto &rp : ranks_) {
       Rank &R = *rp;
       {
@@ -176,11 +179,18 @@ class MultiGpu {
     const Batch &b = t.wait(table_host);
     if (views) *views = b.views;
   }
-  // record of stream position `scan` of a batch of `batch` scans inside a gathered table
-  KeypointRecordView record(const std::vector<float> &table, uint64_t scan, uint64_t batch) const {
+  // the keypoints of stream position `scan` of a batch of `batch` scans inside a gathered table: its owner's block and its
+  // place in it
+  struct ScanKeypoints {
+    uint32_t n, flags;
+    const float *kp;  // n x (x, y, z, elevation)
+  };
+  KeypointBlockView block(const std::vector<float> &table, uint32_t rank) const { return {table.data() + (size_t)rank * block_floats(), per_rank_}; }
+  ScanKeypoints keypoints(const std::vector<float> &table, uint64_t scan, uint64_t batch) const {
     const uint32_t r = owner_of(scan, batch, world());
-    const uint64_t local = scan - shard_range(batch, world(), r).first;
-    return record_of(table.data(), (uint64_t)r * per_rank_ + local, rec_kp_);
+    const uint32_t local = (uint32_t)(scan - shard_range(batch, world(), r).first);
+    const KeypointBlockView v = block(table, r);
+    return {v.n_keypoints(local), v.flags(local), v.keypoint(local, 0)};
   }
 
  private:
@@ -240,8 +250,9 @@ class MultiGpu {
   std::vector<int> devices_;
   std::vector<std::unique_ptr<Rank>> ranks_;  // (a Rank holds a mutex: it never moves)
   std::vector<ncclComm_t> comms_;
-  uint32_t rec_kp_ = kRecKeypoints, max_batch_, per_rank_ = 0, in_flight_;
+  uint32_t block_kp_ = 0, max_batch_, per_rank_ = 0, in_flight_;
   bool host_gather_ = false;
+  int gather_root_ = -1;
   uint64_t next_ticket_ = 0;
 };
 
@@ -258,9 +269,10 @@ inline const MultiGpu::Batch &MultiGpu::Ticket::wait(std::vector<float> *table_h
     }
     if (table_host) {
       const MultiGpu &o = *job_->owner;
-      table_host->resize((size_t)o.per_rank_ * o.world() * record_floats(o.rec_kp_));
-      hip(hipSetDevice(o.devices_[0]), "hipSetDevice");
-      hip(hipMemcpy(table_host->data(), job_->out.tables[0], table_host->size() * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy table");
+      const uint32_t from = o.gather_root_ >= 0 ? (uint32_t)o.gather_root_ : 0u;  // (a rank that holds the table)
+      table_host->resize(o.block_floats() * o.world());
+      hip(hipSetDevice(o.devices_[from]), "hipSetDevice");
+      hip(hipMemcpy(table_host->data(), job_->out.tables[from], table_host->size() * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy table");
     }
     return job_->out;
   }
@@ -286,10 +298,9 @@ inline void MultiGpu::work(uint32_t r) {
       const uint32_t n = (uint32_t)(span.second - span.first);
       if (fx_process_batch(S.ctx, job->scans + span.first, n, job->flags, &job->out.views[r]) != FX_OK)
         throw std::runtime_error(std::string("fx_process_batch: ") + fx_last_error());
-      // the whole block is rewritten every batch: ranks with fewer scans than scans_per_rank leave zero records behind
-      hip(hipMemsetAsync(S.rec, 0, (size_t)per_rank_ * record_floats(rec_kp_) * sizeof(float), S.stream), "hipMemsetAsync");
-      if (n && fx_pack_keypoint_records(S.ctx, S.rec, rec_kp_) != FX_OK)
-        throw std::runtime_error(std::string("fx_pack_keypoint_records: ") + fx_last_error());
+      // (the whole block is rewritten every batch — header, offsets, flags, keypoints, the zero tail — whatever the rank's share)
+      if (fx_pack_keypoint_block(S.ctx, S.rec, per_rank_, block_kp_) != FX_OK)
+        throw std::runtime_error(std::string("fx_pack_keypoint_block: ") + fx_last_error());
     } catch (const std::exception &e) {
       job->local_error[r] = std::string("rank ") + std::to_string(r) + ": " + e.what();
     }
@@ -309,7 +320,7 @@ inline void MultiGpu::work(uint32_t r) {
     std::string late;
     if (all_ok && host_gather_) {
       // (self-test: the all-gather through host memory — every rank has passed the error barrier, so every rank gets here)
-      const size_t block = (size_t)per_rank_ * record_floats(rec_kp_);
+      const size_t block = block_floats();
       hipError_t ge = hipMemcpyAsync(job->host_table.data() + (size_t)r * block, S.rec, block * sizeof(float), hipMemcpyDeviceToHost, S.stream);
       if (ge == hipSuccess) ge = hipStreamSynchronize(S.stream);
       {
@@ -323,8 +334,9 @@ inline void MultiGpu::work(uint32_t r) {
       if (ge != hipSuccess) late = std::string("rank ") + std::to_string(r) + ": host gather: " + hipGetErrorString(ge);
     } else if (all_ok) {
       // the path's one collective, an ordinary kernel of the slot's stream
-      const ncclResult_t ce = ncclAllGather(S.rec, S.table, (size_t)per_rank_ * record_floats(rec_kp_), ncclFloat, comms_[r], S.stream);
-      if (ce != ncclSuccess) late = std::string("rank ") + std::to_string(r) + ": ncclAllGather: " + ncclGetErrorString(ce);
+      const ncclResult_t ce = gather_root_ >= 0 ? ncclGather(S.rec, S.table, block_floats(), ncclFloat, gather_root_, comms_[r], S.stream)
+                                                : ncclAllGather(S.rec, S.table, block_floats(), ncclFloat, comms_[r], S.stream);
+      if (ce != ncclSuccess) late = std::string("rank ") + std::to_string(r) + ": RCCL gather: " + ncclGetErrorString(ce);
     }
     const hipError_t he = hipEventRecord(S.done, S.stream);
     if (he != hipSuccess && late.empty()) late = std::string("rank ") + std::to_string(r) + ": hipEventRecord: " + hipGetErrorString(he);

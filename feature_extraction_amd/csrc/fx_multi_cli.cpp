@@ -2,7 +2,8 @@
 // visible GPUs (or --devices N of them), gathers the keypoint records over RCCL, checks the gathered table against the
 // per-rank results and prints scans/s with the inputs resident in device memory (--host-input: handed over as host
 // buffers).  On a 1-GPU box it runs with one rank: RCCL initialises and the collective runs.
-//   fx_multi_cli [--devices N] [--batch B] [--steps K] [--inflight F] [--default] [--host-input] [--selftest G] [--bad-scan I]
+//   fx_multi_cli [--devices N] [--batch B] [--steps K] [--inflight F] [--default] [--host-input] [--selftest G] [--bad-scan I] [--root R]
+// --root R: the table is gathered on rank R only (ncclGather) instead of on every rank (ncclAllGather).
 // --selftest G: G ranks on device 0 with the collective replaced by a gather through host memory (fx::MultiGpuOptions::
 // host_gather: RCCL refuses the same device twice) — worker threads, tickets, the error barrier, slots in flight and
 // uneven blocks with G > 1 on a one-GPU box.  --bad-scan I: scan I of one submitted batch claims more points than the
@@ -28,7 +29,7 @@ int main(int argc, char **argv) {
     int want = n_dev;
     uint32_t batch = 256, steps = 20, in_flight = 4;
     bool launch = true, host_input = false;
-    int selftest = 0, bad_scan = -1;
+    int selftest = 0, bad_scan = -1, root = -1;
     for (int i = 1; i < argc; ++i) {
       if (!std::strcmp(argv[i], "--devices") && i + 1 < argc) want = std::atoi(argv[++i]);
       else if (!std::strcmp(argv[i], "--batch") && i + 1 < argc) batch = (uint32_t)std::atoi(argv[++i]);
@@ -38,6 +39,7 @@ int main(int argc, char **argv) {
       else if (!std::strcmp(argv[i], "--host-input")) host_input = true;
       else if (!std::strcmp(argv[i], "--selftest") && i + 1 < argc) selftest = std::atoi(argv[++i]);
       else if (!std::strcmp(argv[i], "--bad-scan") && i + 1 < argc) bad_scan = std::atoi(argv[++i]);
+      else if (!std::strcmp(argv[i], "--root") && i + 1 < argc) root = std::atoi(argv[++i]);
     }
     if (want < 1 || want > n_dev) want = n_dev;
     std::vector<int> devices;
@@ -59,10 +61,12 @@ int main(int argc, char **argv) {
     opt.in_flight = in_flight;
     opt.sparse_limits = true;  // (the stream is synthetic VLP-16 scans)
     opt.host_gather = selftest > 0;
+    opt.gather_root = root;
     fx::MultiGpu multi(p, devices, batch, N, opt);
-    const uint32_t G = multi.world(), rec_kp = multi.record_keypoints();
+    const uint32_t G = multi.world();
     std::printf("fx_multi_cli: %d device(s) visible, %u rank(s), %u scans per batch (%u per rank), %u batches in flight per device, "
-                "records of %u keypoints, %s\n", n_dev, G, batch, multi.scans_per_rank(), multi.in_flight(), rec_kp,
+                "compact keypoint blocks of %u keypoints (%.2f MB a rank), %s, %s\n", n_dev, G, batch, multi.scans_per_rank(), multi.in_flight(),
+                multi.block_keypoints(), multi.block_floats() * 4.0 / 1e6, root >= 0 ? "gathered on one rank" : "gathered on every rank",
                 selftest > 0 ? "SELF-TEST: all ranks on device 0, gather through host memory" : "RCCL communicators up");
     // ---- a checked batch (host input, results back on the host): the gathered table against every rank's own results
     std::vector<float> table;
@@ -73,11 +77,11 @@ int main(int argc, char **argv) {
       const uint32_t r = fx::owner_of(b, batch, G);
       const uint32_t local = (uint32_t)(b - fx::shard_range(batch, G, r).first);
       const fx_batch_view &v = views[r];
-      const fx::KeypointRecordView rec = multi.record(table, b, batch);
+      const fx::MultiGpu::ScanKeypoints rec = multi.keypoints(table, b, batch);
       const uint32_t K = v.h_n_keypoints[local];
-      if (rec.n_keypoints() != K || rec.flags() != v.h_flags[local])
+      if (rec.n != K || rec.flags != v.h_flags[local])
         throw std::runtime_error("gathered keypoint count / flags differ from the producing rank's");
-      if (std::memcmp(rec.keypoint(0), v.h_keypoints + (size_t)local * v.max_keypoints * 4, (size_t)K * 16) != 0)
+      if (std::memcmp(rec.kp, v.h_keypoints + (size_t)local * v.max_keypoints * 4, (size_t)K * 16) != 0)
         throw std::runtime_error("gathered keypoints differ from the producing rank's");
       kp_total += K;
     }
@@ -86,7 +90,7 @@ int main(int argc, char **argv) {
       std::vector<float> t0;
       const fx::MultiGpu::Batch &res = t.wait(&t0);
       std::vector<float> other(t0.size());
-      for (uint32_t r = 1; r < G; ++r) {
+      for (uint32_t r = 1; r < G && root < 0; ++r) {  // (gathered on one rank: only that one holds it)
         if (hipSetDevice(devices[r]) != hipSuccess ||
             hipMemcpy(other.data(), res.tables[r], other.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
           throw std::runtime_error("hipMemcpy of a rank's table failed");

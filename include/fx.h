@@ -22,7 +22,7 @@ extern "C" {
 #endif
 
 #define FX_VERSION_MAJOR 0
-#define FX_VERSION_MINOR 6
+#define FX_VERSION_MINOR 7
 
 /* pcl::ShapeContext1980: 12 azimuth x 11 elevation x 15 radius bins + rf[9]
  * (ref: include/feature_extraction/feature_extraction_node.h:35-53,75). */
@@ -51,6 +51,8 @@ typedef enum fx_status {
                                          * overflow region holds max_points entries): the keypoint's descriptor is NaN */
 #define FX_FLAG_TOTAL_KP_OVERFLOW 0x10u /* batch-wide keypoint pool exhausted */
 #define FX_FLAG_KPC_OVERFLOW 0x20u      /* keypoint_cloud exceeded its pool */
+#define FX_FLAG_INTERNAL 0x40u          /* a self-check of the library failed for this scan (the sliced streaming pass's two
+                                           counts of a slice's survivors disagree): its results are not to be trusted — a bug */
 
 /* The 14 ROS private parameters of the reference node (ref: node.cpp:9-34,
  * members node.h:115-127) + the constants the reference hard-codes for the
@@ -283,6 +285,24 @@ fx_status fx_pack_pointxyzi(fx_ctx *ctx, uint32_t which, uint32_t scan, void *ds
  * followed by rec_keypoints (x, y, z, elevation) entries, zero padded.  dst_device must hold
  * batch * (1 + rec_keypoints) * 16 bytes. */
 fx_status fx_pack_keypoint_records(fx_ctx *ctx, void *dst_device, uint32_t rec_keypoints);
+
+/* The same keypoints as ONE compact block for the cross-GPU gather (0.7): a batch's keypoints packed
+ * in scan order behind their offsets, instead of max-stride records (54 keypoints a VLP-16 scan
+ * against a stride of 256: a quarter of the bytes on xGMI and in every receiver's HBM).  The block is
+ * fx_keypoint_block_bytes(max_scans, max_total_keypoints) bytes whatever the batch holds — every rank
+ * hands the collective the same count — as rows of 16 bytes:
+ *   row 0                       {scans, keypoints stored, OR of all flags, max_total_keypoints} (u32)
+ *   then ceil((max_scans+1)/4)  kp_offset[max_scans + 1] (u32): scan b's keypoints are rows
+ *                               [kp_offset[b], kp_offset[b+1]) of the keypoint area; entries beyond
+ *                               the batch repeat the total
+ *   then ceil(max_scans/4)      flags[max_scans] (u32; 0 beyond the batch)
+ *   then max_total_keypoints    (x, y, z, elevation) rows, zero beyond the total
+ * A batch with more keypoints than max_total_keypoints is cut there; the scans that lose keypoints
+ * (and row 0) carry FX_FLAG_KP_OVERFLOW.  Replaces what the reference would publish per scan on
+ * ~keypoints (ref: node.cpp:133-135) for the scans of a whole batch.  Enqueued on the context's
+ * stream behind the last fx_process_batch. */
+size_t fx_keypoint_block_bytes(uint32_t max_scans, uint32_t max_total_keypoints);
+fx_status fx_pack_keypoint_block(fx_ctx *ctx, void *dst_device, uint32_t max_scans, uint32_t max_total_keypoints);
 
 /* Rotation matrix of rotateCloud (ref: node.cpp:161-164): R = Ry(pitch)*Rx(roll)
  * through Eigen's AngleAxisf -> Quaternionf -> toRotationMatrix, all float. Host only. */

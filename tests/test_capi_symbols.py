@@ -54,7 +54,7 @@ def test_struct_sizes_match_header(fxlib):
 
 
 def test_version_and_status_strings(fxlib):
-    assert fxlib.fx_version() == (0 << 16) | 6 == capi.FX_HEADER_VERSION  # FX_VERSION_MAJOR << 16 | FX_VERSION_MINOR (include/fx.h)
+    assert fxlib.fx_version() == (0 << 16) | 7 == capi.FX_HEADER_VERSION  # FX_VERSION_MAJOR << 16 | FX_VERSION_MINOR (include/fx.h)
     for code in range(6):
         assert fxlib.fx_status_str(code)
     assert b"no CPU fallback" in fxlib.fx_status_str(capi.FX_ERR_NO_DEVICE)

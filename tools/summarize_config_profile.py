@@ -46,7 +46,7 @@ def counter(pattern, cname):
 if glob.glob(os.path.join(src, "fetch/**/*_counter_collection.csv"), recursive=True):
     fetch, dur, calls = counter("fetch/**/*_counter_collection.csv", "FETCH_SIZE")
     write, _, _ = counter("write/**/*_counter_collection.csv", "WRITE_SIZE")
-    nb = calls.get("k_prep") or calls.get("k_prep_sliced") or calls["k_offsets"]  # launches per batch: one (k_prep_sliced: small batches of big scans)
+    nb = calls.get("k_prep") or calls.get("k_prep_sliced") or calls["k_slow"]  # launches per batch: one (k_prep_sliced: small batches of big scans)
     rows = []
     for k in sorted(fetch, key=lambda k: -dur[k]):
         if not k.startswith("k_"):
