@@ -68,6 +68,18 @@ def build_trig_literal(force=False, verbose=False):
     return LIB_TRIG
 
 
+LIB_SKIPEPS = os.path.join(HERE, "lib", "libfx_hip_skipeps.so")
+
+
+def build_skip_epsilon(force=False, verbose=False):
+    """Measurement build (-DFX_SKIP_EPSILON): 3DSC skips a neighbour at d^2 < FLT_EPSILON (SURVEY.md A.8-6's reading) instead of
+    < numeric_limits<float>::min() — the one reading of PCL the oracle's policy switches show to be live.
+    tests/test_gpu_skip_policy.py holds it against the oracle's FXO_POLICY_SKIP_EPSILON."""
+    if force or stale(LIB_SKIPEPS):
+        _link(LIB_SKIPEPS, ["-DFX_SKIP_EPSILON"], verbose)
+    return LIB_SKIPEPS
+
+
 def build_variant(name, defines, force=False, verbose=False):
     """A measurement build lib/libfx_hip_<name>.so with extra -D flags (tools/bench_lib.py, tools/*_stamps.py): diagnostic, never
     the product."""
@@ -170,6 +182,7 @@ def build(force=False, verbose=False):
         _link(LIB, [], verbose)
     build_test_hooks(force, verbose)
     build_trig_literal(force, verbose)
+    build_skip_epsilon(force, verbose)
     build_cli(force, verbose)
     build_batcher(force, verbose)
     try:  # the multi-GPU driver needs RCCL's development files: without them the library and everything else still build

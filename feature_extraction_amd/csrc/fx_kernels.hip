@@ -4011,7 +4011,14 @@ __device__ __forceinline__ uint32_t sc3d_bin(const float4 kp, float bx, float by
 // 3DSC skips a neighbour whose squared distance "equals" zero: pcl::utils::equal(nn_dists[ne], 0.0f) with its
 // default tolerance std::numeric_limits<float>::min() (pcl/common/utils.h), i.e. |d2 - 0| < FLT_MIN — the point
 // the keypoint sits on (or one a subnormal d2 away), nothing farther.
+// (-DFX_SKIP_EPSILON: the other reading of PCL's skip rule — SURVEY.md A.8-6's `< FLT_EPSILON` instead of pcl::utils::equal's
+//  default tolerance — as ONE constant, so that whichever a PCL run confirms, the device and the oracle's switch
+//  FXO_POLICY_SKIP_EPSILON are already proven to flip together: lib/libfx_hip_skipeps.so, tests/test_gpu_skip_policy.py)
+#ifdef FX_SKIP_EPSILON
+__device__ __forceinline__ bool sc3d_is_origin(float d2) { return fabsf(d2 - 0.0f) < FLT_EPSILON; }
+#else
 __device__ __forceinline__ bool sc3d_is_origin(float d2) { return fabsf(d2 - 0.0f) < FLT_MIN; }
+#endif
 __device__ __forceinline__ unsigned long long sc3d_key(uint32_t bin, float d2, uint32_t idx) {
   return ((unsigned long long)bin << 52) | ((unsigned long long)__float_as_uint(d2) << 20) | (unsigned long long)idx;
 }

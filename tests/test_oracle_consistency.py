@@ -96,6 +96,44 @@ def test_ring_clusters_match_scipy_components(oracle, preset):
     assert checked >= 30
 
 
+@pytest.mark.parametrize("name", ["hdl64_64x2048_launch_seed10", "dense_128x2048_R2m_launch_seed10"])
+def test_ring_clusters_of_the_many_ring_fixtures_match_scipy_components(oracle, name):
+    """The same cross-check on the 64- and 128-ring fixtures (until round 5 VLP-16 scenes only): dense rings of
+    up to a thousand points, window edges at non-integer elevations (centre -+ step / 2 narrowed to float as PassThrough does,
+    ref: node.cpp:200-201)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    p, _lim, pts, roll, pitch = util.golden_case(g, name)
+    tol = float(np.float32(p.cluster_tolerance))
+    r = oracle.run(p, pts, roll=roll, pitch=pitch, want_labels=True)
+    f = r["filtered"].astype(np.float64)
+    el = r["filtered"][:, 3]
+    checked = members = 0
+    for ring in range(p.n_rings):
+        lab = r["ring_labels"][ring]
+        idx = np.where(lab >= 0)[0]
+        centre = p.el0_deg + ring * p.el_step_deg
+        lo, hi = np.float32(centre - p.el_step_deg / 2.0), np.float32(centre + p.el_step_deg / 2.0)
+        assert np.array_equal(idx, np.where((el >= lo) & (el <= hi))[0]), ring
+        if len(idx) < 2:
+            continue
+        P = f[idx, :3]
+        tree = cKDTree(P)
+        pairs = tree.query_pairs(tol, output_type="ndarray")
+        d = np.linalg.norm(P[pairs[:, 0]] - P[pairs[:, 1]], axis=1) if len(pairs) else np.zeros(0)
+        near = tree.query_pairs(tol * (1 + 1e-5), output_type="ndarray")
+        if len(near) != len(pairs) or (len(d) and d.max() > tol * (1 - 1e-5)):
+            continue  # (a pair sitting on the threshold: fp32 d2 < r2 against fp64 d <= r)
+        gr = coo_matrix((np.ones(len(pairs)), (pairs[:, 0], pairs[:, 1])), shape=(len(idx), len(idx)))
+        ncomp, comp = connected_components(gr, directed=False)
+        first = np.full(ncomp, np.iinfo(np.int64).max)
+        np.minimum.at(first, comp, idx)
+        assert np.array_equal(lab[idx], first[comp]), ring
+        checked += 1
+        members += len(idx)
+    assert checked >= p.n_rings // 3 and members > 5000, (checked, members)
+
+
 def test_keypoints_are_centroids_of_their_members(oracle):
     p = capi.params("launch")
     pts = util.vlp16_scan(41)

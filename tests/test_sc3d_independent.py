@@ -13,7 +13,9 @@ from tests import util
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = [("vlp16_default_seed1000", "default"), ("vlp16_launch_seed1000", "launch"),
-         ("vlp16_launch_seed1001_unleveled", "launch")]
+         ("vlp16_launch_seed1001_unleveled", "launch"),
+         # (the many-ring fixtures too — rows of thousands of neighbours, R = 2 m in the 128-ring one)
+         ("hdl64_64x2048_launch_seed10", "launch"), ("dense_128x2048_R2m_launch_seed10", "launch")]
 
 
 def test_mt19937_known_answers():
@@ -32,10 +34,7 @@ def test_bin_volumes_fill_the_support_sphere():
 @pytest.mark.parametrize("name,preset", CASES)
 def test_oracle_descriptors_match_the_independent_statement(oracle, name, preset):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
-    seed, roll, pitch = z["meta"]
-    pts = np.zeros((len(z["points_xyz"]), 4), np.float32)
-    pts[:, :3] = z["points_xyz"]
-    p = capi.params(preset)
+    p, _lim, pts, roll, pitch = util.golden_case(z, name)  # (the 64- / 128-ring fixtures store the generator's configuration)
     ora = oracle.run(p, pts, roll=float(roll), pitch=float(pitch), want_rotated=True)
     K = ora["n_keypoints"]
     assert K == len(z["keypoints"]) and K > 0
