@@ -140,6 +140,8 @@ def run_other_config(name, cfg, capi, torch, dev, threads, roll, pitch, steps=6,
     torch.cuda.synchronize(dev)
 
     def timed(cs, n_steps):
+        for c in cs:  # (launch-policy hint: how many of the caller's batches share the chip — grids and launch shapes, never results)
+            c.set_batches_in_flight(len(cs))
         for j in range(2 * len(cs)):
             cs[j % len(cs)].process_raw(descs_b if (j // len(cs)) % 2 else descs, B, capi.FX_IN_DEVICE)
         for c in cs:

@@ -47,6 +47,9 @@ void fxk_rings_runs(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uin
 void fxk_merge_small(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap);
 void fxk_merge_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t grid, uint32_t last);
 void fxk_merge_huge(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t ccap, uint32_t grid);
+size_t fxk_merge_hp_words(uint32_t cap);
+uint32_t fxk_merge_slices_max(void);
+void fxk_merge_huge_split(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t ccap, uint32_t grid, uint32_t slices);
 uint32_t fxk_front_max_rings(void);
 uint32_t fxk_front_merge_cap(void);
 void fxk_front(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float near_margin, float el0, float inv_step,
@@ -190,6 +193,7 @@ struct fx_ctx {
   // workgroups in k_desc_mid's launch (dense_slow_loop) that compute whatever does turn up, slower — the same results either way.
   uint32_t dense_fast_left = 0;            // batches that still get the four kernels after the last one that needed them
   static constexpr uint32_t dense_linger = 64;
+  int merge_slices = -1;                   // test hook (FX_MERGE_SLICES): workgroups a scan in the large merge tier's pair loop (1: the one launch)
   int prep_slices = -1;                    // test hook (FX_PREP_SLICES): workgroups a scan in the separate kernels' streaming pass and ring split
   int dense_force = -1;                    // test hook (FX_DENSE_SLOW): 1 always k_desc_mid's workgroups, 0 always the four kernels
   uint32_t skip_mask = 0;      // experiment hook (FX_SKIP_EMPTY, test build): bit 0 no k_front_redo, bit 1 no dense tier — only for workloads that need neither
@@ -364,8 +368,22 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof, bo
     FX_HIP(mark(4));
     fxk_merge_small(s, P, B, batch, merge_small);
     fxk_merge_big(s, P, B, c->merge_big_cap, tier_grid(hint[2], big_grid, batch), c->merge_big_cap >= L.max_candidates);
-    if (c->merge_big_cap < L.max_candidates)
-      fxk_merge_huge(s, P, B, c->merge_huge_cap, c->merge_huge_ccap, tier_grid(hint[3], big_grid, batch));
+    if (c->merge_big_cap < L.max_candidates) {
+      // one workgroup a scan in one launch — or, when the batches before had so few scans for this tier that those leave most
+      // of the chip idle (64 scans of config 5 on 256 CUs), three launches with several workgroups a scan in the pair loop,
+      // which is 97 % of the tier (merge_body's PHASE).  The hint decides speed, never a result.
+      const uint32_t g = tier_grid(hint[3], big_grid, batch);
+      uint32_t slices = 1;
+      if (c->merge_slices >= 0)
+        slices = (uint32_t)c->merge_slices;  // (test hook)
+      else if (!capture && hint[3] != 0xffffffffu && hint[3] > 0 && 2u * hint[3] * c->batches_in_flight <= big_grid)
+        slices = big_grid / (hint[3] * c->batches_in_flight);  // (the caller's other batches fill the chip as well: config 5 with four in flight 8.6e4 scans/s in one launch, 8.0e4 in three)
+      slices = std::min(slices, fxk_merge_slices_max());
+      if (slices > 1 && B.merge_hp)
+        fxk_merge_huge_split(s, P, B, c->merge_huge_cap, c->merge_huge_ccap, g, slices);
+      else
+        fxk_merge_huge(s, P, B, c->merge_huge_cap, c->merge_huge_ccap, g);
+    }
     fxk_slow(s, P, B, c->merge_huge_ccap, tier_grid(hint[7], big_grid, batch), batch, clk_next);  // (rings / merges beyond the LDS tiers, and the batch's keypoint offsets: see the front path)
     FX_HIP(mark(5));
     }
@@ -694,6 +712,9 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   // (the large merge tier's bin-ordered copy: k_merge_huge, and k_front_redo — whose LDS image holds fewer candidates as points
   //  than k_merge_big's — whenever a scan has more candidates than that)
   FX_A(dev_alloc(c, &b.merge_sorted, (size_t)B * L.max_candidates));
+  // (the large merge tier as three launches: a region per scan, when the tier exists and the regions stay within 256 MB)
+  if (c->merge_big_cap < L.max_candidates && (size_t)B * fxk_merge_hp_words(c->merge_huge_cap) * 4 <= ((size_t)256 << 20))
+    FX_A(dev_alloc(c, &b.merge_hp, (size_t)B * fxk_merge_hp_words(c->merge_huge_cap)));
   FX_A(dev_alloc(c, &b.list_desc, L.max_total_keypoints));
   FX_A(dev_alloc(c, &b.s_pts, (size_t)L.max_total_keypoints * P.list_cap));
   FX_A(dev_alloc(c, &b.s_cnt, L.max_total_keypoints));
@@ -802,6 +823,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   if (const char *e = test_hook("FX_SKIP_EMPTY")) c->skip_mask = (uint32_t)std::max(0, atoi(e));
   if (const char *e = test_hook("FX_DENSE_SLOW")) c->dense_force = atoi(e) != 0 ? 1 : 0;
   if (const char *e = test_hook("FX_PREP_SLICES")) c->prep_slices = std::max(1, atoi(e));
+  if (const char *e = test_hook("FX_MERGE_SLICES")) c->merge_slices = std::max(1, atoi(e));
   if (c->front_ok) {
     hipError_t ce = fxk_configure_front();
     if (ce != hipSuccess) return bail(fail(FX_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(ce)));

@@ -125,6 +125,7 @@ struct FxBuffers {
   uint32_t *ring_pending; // [B][(n_rings + 31) / 32]  bit r: ring r of the scan waits for k_slow (which clears it)
   uint32_t *gs_pool;      // [gs_slots][gs_words]  k_slow's scratch: the LDS tiers' per-point / per-cluster arrays, in HBM
   uint32_t *gsd_pool;     // [gsd_slots][gsd_words]  dense_slow_loop's scratch: a support set of up to max_points points
+  uint32_t *merge_hp;     // [B][merge_hp_words]  the large merge tier as three launches (batches of few scans): a scan's slices' roots, its bin table, its state (null: not allocated — the one launch)
   float4 *merge_sorted;   // [B][max_candidates] (x, y, pseudo z, id) in bin order: k_merge_huge's pair tests (allocated only when that tier exists)
   uint32_t *list_desc;    // [max_total_kp]  rows whose list is too long for one wavefront (257 .. dense_min support points)
   uint32_t *wave_desc;    // [max_total_kp]  rows with 65..256 support points (one wavefront each)

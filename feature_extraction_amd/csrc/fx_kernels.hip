@@ -2350,10 +2350,26 @@ struct FrontCands {
 // has been written by the caller.
 // GS (with LDS_PTS false): parents, bin table, ids, cluster tables and the bin-ordered copy live in the scratch region `gs` of
 // HBM instead of LDS (k_slow: any candidate count the limits allow); the head and the ring bases stay in LDS.
-template <int NT, bool LDS_PTS, bool FRONT = false, bool GS = false>
+// PHASE (the large tier, coordinates in HBM, for batches of FEW scans: 64 scans of config 5 are 64 workgroups on 256 CUs, and
+// 97 % of k_merge_huge is the pair loop — dependent loads a bin, sixteen wavefronts a scan to hide them with): the body as THREE
+// launches.  1: candidates in, cell sort, the bin table to the scan's region `hp`; 2: the pair loop alone, by SEVERAL
+// workgroups a scan — slice s takes the bins by ticket from a counter in `hp` and unites what it finds in a union-find of
+// its OWN in LDS (a union-find in HBM shared by the slices would pay an L2 or memory round trip per hop of every find), then
+// writes every candidate's root in its forest to `hp`; 3: one workgroup a scan unites the slices' forests — the edges
+// (candidate, its root in slice s) of all slices have the components of all pairs — and does everything after the pair loop
+// as before.  0: all of it in one launch (one workgroup a scan).  Which of the two runs is the host's choice by the batch's
+// size: the same edges, the same components, the same result (roots are their components' smallest members either way).
+// hp: [FX_MERGE_SLICES][cap] roots by slice, [merge_bins(cap) + 4] bin table, [0] status (candidates; FX_NONE: not this
+// tier's / nothing to do), [1] ticket, [2] slices of the pair launch.
+#define FX_MERGE_SLICES 8u
+__host__ __device__ constexpr size_t merge_hp_words(uint32_t cap) { return ((size_t)FX_MERGE_SLICES * cap + merge_bins(cap) + 4 + 4 + 3) & ~(size_t)3; }
+template <int NT, bool LDS_PTS, bool FRONT = false, bool GS = false, int PHASE = 0>
 __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers &B, uint32_t scan, uint32_t cap, uint32_t ccap,
-                                           uint32_t *smem, bool last_tier, const FrontCands *FC = nullptr, uint32_t *gs = nullptr) {
+                                           uint32_t *smem, bool last_tier, const FrontCands *FC = nullptr, uint32_t *gs = nullptr,
+                                           uint32_t *hp = nullptr, uint32_t slice = 0u) {
   static_assert(!GS || (!LDS_PTS && !FRONT), "the scratch tier keeps the coordinates in HBM");
+  static_assert(PHASE == 0 || (!GS && !LDS_PTS && !FRONT), "the phases are the large tier's");
+  uint32_t *const hp_bin = hp + (size_t)FX_MERGE_SLICES * cap, *const hp_state = hp_bin + merge_bins(cap) + 4;
   unsigned long long *const stamp_base = B.stamps ? B.stamps + 32 : nullptr;
   FX_STAMP_INIT(stamp_base);
   const uint32_t tid = threadIdx.x;
@@ -2398,17 +2414,25 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
     }
     if (tid == 0) rbase[R] = C;
   }
-  if (C > P.max_candidates) {
+  if (PHASE >= 2 && hp_state[0] == FX_NONE) return true;  // (phase 1 settled the scan: overflow flagged, or handed to the slow tier)
+  if (PHASE == 2 && C == 0) return true;
+  if (PHASE <= 1 && C > P.max_candidates) {
     if (tid == 0) {
       atomicOr(&B.flags[scan], FX_FLAG_CAND_OVERFLOW);
       B.n_cand[scan] = 0;
       B.n_kp[scan] = 0;
       B.n_kpc[scan] = 0;
+      if (PHASE == 1) hp_state[0] = FX_NONE;
     }
     return true;
   }
-  if (C > cap && !last_tier) return false;  // (cap == max_candidates in the last tier)
-  for (uint32_t t = tid; t <= NB; t += NT) bin[t] = 0;
+  if (PHASE <= 1 && C > cap && !last_tier) {  // (cap == max_candidates in the last tier)
+    if (PHASE == 1 && tid == 0) hp_state[0] = FX_NONE;
+    return false;
+  }
+  if (PHASE <= 1) {
+    for (uint32_t t = tid; t <= NB; t += NT) bin[t] = 0;
+  }
   wg_sync<GS>();
 
   float4 *cand = B.cand + (size_t)scan * P.max_candidates;
@@ -2434,7 +2458,7 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
     return cand[i];
   };
   // all candidates in parallel (each finds its ring in the prefix table)
-  for (uint32_t t = tid; t < (FRONT ? FC->n_c : C); t += NT) {
+  for (uint32_t t = tid; PHASE <= 1 && t < (FRONT ? FC->n_c : C); t += NT) {
     uint32_t idx = t, size;
     float4 v;
     if (FRONT) {
@@ -2455,15 +2479,19 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
     }
     cand[idx] = v;
     cand_size[idx] = size;
-    parent[idx] = idx;
+    if (PHASE == 0) parent[idx] = idx;
     atomicAdd(&bin[bin_of(cell_x(v.x), cell_y(v.y))], 1u);
   }
   wg_sync<GS>();
   if (!LDS_PTS) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // `cand` is re-read below by other waves of this workgroup (see wg_global_sync)
   FX_STAMP(1);
   uint32_t n_c = 0;
+  if (PHASE == 1 && C == 0) {  // (nothing to sort or pair: phase 3 writes the empty results)
+    if (tid == 0) hp_state[0] = 0u;
+    return true;
+  }
   if (C > 0) {  // ref: node.cpp:209-210
-    if (tid < 64) {  // counts -> exclusive starts, in place, by one wavefront
+    if (PHASE <= 1 && tid < 64) {  // counts -> exclusive starts, in place, by one wavefront
       const uint32_t per = NB / 64;
       uint32_t sum = 0;
       for (uint32_t u = 0; u < per; ++u) sum += bin[tid * per + u];
@@ -2480,7 +2508,7 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
     // (coordinates left in HBM: a copy of the merge points in bin order, id in .w, so that the pair tests below read a bin's
     //  entries from consecutive addresses instead of one dependent L2 load per id — 86 % of k_merge_huge was that loop)
     float4 *msort = LDS_PTS ? nullptr : (GS ? gs_sorted : B.merge_sorted + (size_t)scan * P.max_candidates);
-    for (uint32_t idx = tid; idx < C; idx += NT) {  // each id to its bin: a start becomes the bin's end
+    for (uint32_t idx = tid; PHASE <= 1 && idx < C; idx += NT) {  // each id to its bin: a start becomes the bin's end
       const float4 v = merge_pt(idx);
       const uint32_t pos = atomicAdd(&bin[bin_of(cell_x(v.x), cell_y(v.y))], 1u);
       sorted[pos] = (uint16_t)idx;
@@ -2488,13 +2516,23 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
     }
     if (tid == 0) s_w[152] = 0u;  // (the pair loop's bin ticket)
     wg_sync<GS>();
+    if (PHASE == 1) {  // the bin table (ends) for the pair launch's workgroups; the scan's state: its candidates, ticket 0
+      for (uint32_t t = tid; t <= NB; t += NT) hp_bin[t] = bin[t];
+      if (tid == 0) hp_state[0] = C, hp_state[1] = 0u;  // (hp_state[2], the slices, is the pair launch's own)
+      return true;
+    }
+    if (PHASE == 2) {  // this slice's own forest; the bin table
+      for (uint32_t i = tid; i < C; i += NT) parent[i] = i;
+      for (uint32_t t = tid; t <= NB; t += NT) bin[t] = hp_bin[t];
+      wg_sync<GS>();
+    }
     if (!LDS_PTS) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (msort is read below by other waves of this workgroup)
     FX_STAMP(2);
     // ---- pcl::EuclideanClusterExtraction on (x, y, pseudo z) (ref: node.cpp:222-229)
     // (one work item per (candidate, neighbouring bin): a wavefront's trip count is then the longest single bin of its
     //  lanes, not the sum over nine bins of the longest; two entries per trip, loaded before either is used; the
     //  distance test comes before any union-find lookup — one LDS round trip against several dependent ones)
-    if (!LDS_PTS) {
+    if (!LDS_PTS && PHASE != 3) {
       // Coordinates in HBM (k_merge_huge): bin by bin.  A wavefront takes a bin T, its entries 64 at a time one per lane
       // (the TARGETS: one coalesced load), and walks the entries of the nine bins around it (the SOURCES: up to 64 of
       // their concatenation per coalesced load, handed round by readlane).  Every lane then tests its target against the
@@ -2555,7 +2593,7 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
       (void)wave;
       while (true) {  // bins by ticket, a few at a time: a pole's bin costs a hundred times an empty one, and behind the loop is a barrier
         uint32_t T0 = 0;
-        if (lane == 0) T0 = atomicAdd(&s_w[152], FX_MERGE_BIN_TICKET);
+        if (lane == 0) T0 = atomicAdd(PHASE == 2 ? &hp_state[1] : &s_w[152], FX_MERGE_BIN_TICKET);
         T0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)T0);
         if (T0 >= NB) break;  // (NB is a multiple of the ticket)
         for (uint32_t T = T0; T < T0 + FX_MERGE_BIN_TICKET; ++T) pair_bin(T);
@@ -2584,6 +2622,27 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
           }
       }
     }
+    if (PHASE == 2) {  // every candidate's root in this slice's forest (the launch's end is the barrier between the slices)
+      wg_sync<GS>();
+      uint32_t *mine = hp + (size_t)slice * cap;
+      for (uint32_t i = tid; i < C; i += NT) mine[i] = uf_find_ro<GS>(parent, i);
+      return true;
+    }
+    if (PHASE == 3) {  // the slices' forests united: (candidate, its root in slice s) are edges enough
+      for (uint32_t i = tid; i < C; i += NT) parent[i] = i;
+      wg_sync<GS>();
+      const uint32_t S = hp_state[2];
+      for (uint32_t sl = 0; sl < S; ++sl) {
+        const uint32_t *theirs = hp + (size_t)sl * cap;
+        for (uint32_t i = tid; i < C; i += NT) {
+          const uint32_t r = theirs[i];
+          if (r != i && uf_load<GS>(parent, i) != uf_load<GS>(parent, r)) uf_union<GS>(parent, i, r);
+        }
+      }
+    }
+#if defined(FX_MERGE_STOP) && FX_MERGE_STOP == 1
+    if (PHASE == 3) return true;
+#endif
     wg_sync<GS>();
     FX_STAMP(3);
     for (uint32_t i = tid; i < C; i += NT) parent[i] = uf_find_ro<GS>(parent, i);
@@ -2591,6 +2650,9 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
     wg_sync<GS>();
     for (uint32_t i = tid; i < C; i += NT) atomicAdd(&csize[parent[i]], 1u);
     wg_sync<GS>();
+#if defined(FX_MERGE_STOP) && FX_MERGE_STOP == 2
+    if (PHASE == 3) return true;
+#endif
     FX_STAMP(4);
     n_c = cc_order<NT, GS>(C, parent, csize, P.ndc, P.secondary_max, croot, crec, tmp, ccap, s_w, stamp_base);
     if (n_c > ccap) {  // (large tier only: ccap >= max_keypoints there, so the scan overflows its keypoints anyway)
@@ -2602,6 +2664,9 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
 #endif
   }
 
+#if defined(FX_MERGE_STOP) && FX_MERGE_STOP == 3
+    if (PHASE == 3) return true;
+#endif
   // ---- clusters -> keypoints (ref: node.cpp:238-257)
   uint32_t K = 0;
   if (C > 0) {
@@ -2649,22 +2714,40 @@ __device__ __forceinline__ bool merge_body(const FxDevParams &P, const FxBuffers
     }
     wg_sync<GS>();
     if (!LDS_PTS) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#if defined(FX_MERGE_STOP) && FX_MERGE_STOP == 4
+    if (PHASE == 3) return true;
+#endif
     float4 *kp = B.keypoints + (size_t)scan * P.max_keypoints;
     uint32_t *kps = B.kp_size + (size_t)scan * P.max_keypoints;
     for (uint32_t s = tid; s < K; s += NT) {
       const uint32_t rec = crec[s];
       const uint32_t sz = rec >> 16, root = rec & 0xffffu, m0 = mbase[s];
       double sumx = 0.0, sumy = 0.0, sumz = 0.0;
-      for (uint32_t m = 0; m < sz; ++m) {
-        const float4 q = true_pt(ord[m0 + m]);
-        sumx += (double)q.x;
-        sumy += (double)q.y;
-        sumz += (double)q.z;
+      // (eight members a trip, their ids and then their points loaded before any is added: with the coordinates in HBM a member
+      //  is two DEPENDENT loads — its id, its point —, and a pole that 128 rings saw was 256 round trips one after the other
+      //  in the one lane that owns the keypoint: most of what k_merge_huge does after its pair loop; the sums stay in member order)
+      for (uint32_t m = 0; m < sz; m += 8u) {
+        uint32_t id[8];
+        float4 q[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; ++u) id[u] = ord[m0 + min(m + u, sz - 1u)];
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; ++u) q[u] = true_pt(id[u]);
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; ++u)
+          if (m + u < sz) {
+            sumx += (double)q[u].x;
+            sumy += (double)q[u].y;
+            sumz += (double)q[u].z;
+          }
       }
       kp[s] = make_float4((float)(sumx / (double)sz), (float)(sumy / (double)sz), (float)(sumz / (double)sz), true_pt(root).w);
       kps[s] = sz;
       B.kp_nbrs[(size_t)scan * P.max_keypoints + s] = 0u;  // (k_gather flags the keypoints that have a neighbour; the descriptor kernels count)
     }
+#if defined(FX_MERGE_STOP) && FX_MERGE_STOP == 5
+    if (PHASE == 3) return true;
+#endif
     wg_sync<GS>();
     FX_STAMP(8);
     for (uint32_t i = tid; i < C; i += NT) {
@@ -2768,6 +2851,39 @@ extern "C" __global__ __launch_bounds__(FX_MBIG_T) void k_merge_huge(FxDevParams
   for (uint32_t w = blockIdx.x; w < n_big; w += gridDim.x) {
     // (cap: what this tier's LDS holds; a scan with more candidates, up to limits.max_candidates, takes the slow tier)
     if (!merge_body<FX_MBIG_T, false>(P, B, B.huge_merge[w], cap, ccap, smem, cap >= P.max_candidates) && threadIdx.x == 0) slow_push(B, B.huge_merge[w]);
+    __syncthreads();
+  }
+}
+
+// the large tier as three launches (merge_body's PHASE): batches of few scans, several workgroups a scan in the pair loop
+extern "C" __global__ __launch_bounds__(FX_MBIG_T) void k_merge_huge_a(FxDevParams P, FxBuffers B, uint32_t cap, uint32_t ccap) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const uint32_t n_big = B.counters[9];
+  for (uint32_t w = blockIdx.x; w < n_big; w += gridDim.x) {
+    const uint32_t scan = B.huge_merge[w];
+    if (!merge_body<FX_MBIG_T, false, false, false, 1>(P, B, scan, cap, ccap, smem, cap >= P.max_candidates, nullptr, nullptr,
+                                                       B.merge_hp + (size_t)scan * merge_hp_words(cap)) && threadIdx.x == 0)
+      slow_push(B, scan);  // (more candidates than this tier's LDS holds: the slow tier; the scan's state says so to the launches behind)
+    __syncthreads();
+  }
+}
+extern "C" __global__ __launch_bounds__(FX_MBIG_T) void k_merge_huge_b(FxDevParams P, FxBuffers B, uint32_t cap, uint32_t ccap) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const uint32_t n_big = B.counters[9];
+  for (uint32_t w = blockIdx.y; w < n_big; w += gridDim.y) {
+    const uint32_t scan = B.huge_merge[w];
+    uint32_t *hp = B.merge_hp + (size_t)scan * merge_hp_words(cap);
+    if (blockIdx.x == 0 && threadIdx.x == 0) hp[(size_t)FX_MERGE_SLICES * cap + merge_bins(cap) + 4 + 2] = gridDim.x;  // (the slices phase 3 unites)
+    merge_body<FX_MBIG_T, false, false, false, 2>(P, B, scan, cap, ccap, smem, true, nullptr, nullptr, hp, blockIdx.x);
+    __syncthreads();
+  }
+}
+extern "C" __global__ __launch_bounds__(FX_MBIG_T) void k_merge_huge_c(FxDevParams P, FxBuffers B, uint32_t cap, uint32_t ccap) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const uint32_t n_big = B.counters[9];
+  for (uint32_t w = blockIdx.x; w < n_big; w += gridDim.x) {
+    const uint32_t scan = B.huge_merge[w];
+    merge_body<FX_MBIG_T, false, false, false, 3>(P, B, scan, cap, ccap, smem, true, nullptr, nullptr, B.merge_hp + (size_t)scan * merge_hp_words(cap));
     __syncthreads();
   }
 }
@@ -6264,6 +6380,12 @@ hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t merge_huge, s
   hipError_t e;
   e = hipFuncSetAttribute((const void *)k_merge_huge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)merge_huge);
   if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void *)k_merge_huge_a, hipFuncAttributeMaxDynamicSharedMemorySize, (int)merge_huge);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void *)k_merge_huge_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)merge_huge);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void *)k_merge_huge_c, hipFuncAttributeMaxDynamicSharedMemorySize, (int)merge_huge);
+  if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void *)k_gather, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gather);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void *)k_gather_wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gather);
@@ -6324,6 +6446,15 @@ void fxk_merge_big(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint
 }
 void fxk_merge_huge(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t ccap, uint32_t grid) {
   hipLaunchKernelGGL(k_merge_huge, dim3(grid), dim3(FX_MBIG_T), fxk_merge_huge_lds_bytes(cap, ccap, P.n_rings), s, P, B, cap, ccap);
+}
+// the same as three launches, `slices` workgroups a scan in the pair loop (needs FxBuffers::merge_hp)
+size_t fxk_merge_hp_words(uint32_t cap) { return merge_hp_words(cap); }
+uint32_t fxk_merge_slices_max(void) { return FX_MERGE_SLICES; }
+void fxk_merge_huge_split(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t cap, uint32_t ccap, uint32_t grid, uint32_t slices) {
+  const size_t lds = fxk_merge_huge_lds_bytes(cap, ccap, P.n_rings);
+  hipLaunchKernelGGL(k_merge_huge_a, dim3(grid), dim3(FX_MBIG_T), lds, s, P, B, cap, ccap);
+  hipLaunchKernelGGL(k_merge_huge_b, dim3(std::min(slices, (uint32_t)FX_MERGE_SLICES), grid), dim3(FX_MBIG_T), lds, s, P, B, cap, ccap);
+  hipLaunchKernelGGL(k_merge_huge_c, dim3(grid), dim3(FX_MBIG_T), lds, s, P, B, cap, ccap);
 }
 // the fused front kernel takes sensors of up to FX_FRONT_RMAX rings (scans that do not fit its tables go on to k_front_redo)
 uint32_t fxk_front_max_rings(void) { return FX_FRONT_RMAX; }

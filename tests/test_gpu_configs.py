@@ -86,11 +86,14 @@ def test_128_rings_by_4096_azimuths(fxlib, oracle):
     ctx.close()
 
 
-def test_large_merge_tier_on_vlp16_scans(fx_hooks, oracle):
+@pytest.mark.parametrize("slices", [1, 3, 8])
+def test_large_merge_tier_on_vlp16_scans(fx_hooks, oracle, slices):
     """The large merge tier (cell-sorted ids + union-find in LDS, coordinates in HBM) on ordinary scans: the test
     hooks take the separate kernels (k_front has its own merge) and lower the LDS tier's capacity so that every scan with
-    more than 16 candidates takes it."""
-    fx_hooks(FX_FRONT=0, FX_MERGE_BIG_CAP=16)
+    more than 16 candidates takes it — as ONE launch (slices 1: one workgroup a scan) and as the three launches batches of
+    few scans take (k_merge_huge_a / _b / _c: 3 or 8 workgroups a scan in the pair loop, each with a union-find of its own,
+    the forests united afterwards): the same components, the same keypoints."""
+    fx_hooks(FX_FRONT=0, FX_MERGE_BIG_CAP=16, FX_MERGE_SLICES=slices)
     scans = [util.vlp16_scan(1000 + b) for b in range(6)] + [np.zeros((0, 4), np.float32)]
     for preset in ("launch", "default"):
         p = capi.params(preset)
