@@ -63,7 +63,8 @@ size_t fxk_slow_words(uint32_t max_ring_points, uint32_t max_candidates, uint32_
 void fxk_slow(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t huge_ccap, uint32_t grid, uint32_t batch, uint32_t clk_next);
 hipError_t fxk_configure_front(void);
 uint32_t fxk_gather_slices(uint32_t batch);
-void fxk_gather(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float box_margin);
+uint32_t fxk_gather(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float box_margin, uint32_t counted);
+uint32_t fxk_gather_counted_max(void);
 void fxk_desc_group(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid);
 void fxk_desc_mid(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t cap, uint32_t n_wg, uint32_t n_wave,
                   uint32_t n_dslow);
@@ -193,6 +194,7 @@ struct fx_ctx {
   // workgroups in k_desc_mid's launch (dense_slow_loop) that compute whatever does turn up, slower — the same results either way.
   uint32_t dense_fast_left = 0;            // batches that still get the four kernels after the last one that needed them
   static constexpr uint32_t dense_linger = 64;
+  int gather_slices = -1;                  // test hook (FX_GATHER_COUNTED): workgroups a scan in the support gather's counted slices (1: one workgroup a scan)
   int merge_slices = -1;                   // test hook (FX_MERGE_SLICES): workgroups a scan in the large merge tier's pair loop (1: the one launch)
   int prep_slices = -1;                    // test hook (FX_PREP_SLICES): workgroups a scan in the separate kernels' streaming pass and ring split
   int dense_force = -1;                    // test hook (FX_DENSE_SLOW): 1 always k_desc_mid's workgroups, 0 always the four kernels
@@ -388,8 +390,17 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof, bo
     FX_HIP(mark(5));
     }
     if (P.estimate_descriptors) {
-      fxk_gather(s, P, B, batch, c->box_margin);
-      if (fxk_gather_slices(batch) > 1) fxk_rng_ord(s, P, B, batch);  // (one workgroup per scan settles the RNG ordinals itself)
+      // one workgroup a scan — or, for batches of few big scans with the chip to themselves (64 scans of 262 144 points: 64
+      // workgroups on 256 CUs), several a scan in two launches: a counting pass, then the scatter with every slice's list
+      // positions known (from four a scan on: the near sectors are read and tested twice)
+      uint32_t counted = 1;
+      if (c->gather_slices >= 0)
+        counted = (uint32_t)c->gather_slices;  // (test hook)
+      else if (!capture && 10u * batch * c->batches_in_flight <= 3u * big_grid && L.max_points >= 65536u)
+        // (256-thread workgroups, three a CU: all resident at once.  From ten a scan on: config 5 — 64 scans — 0.255 ms with one
+        //  wide workgroup a scan, 0.405 / 0.246 / 0.197 / 0.273 with 4 / 8 / 12 / 16 counted slices, profiles/r06_experiments.md §4)
+        counted = 3u * big_grid / (batch * c->batches_in_flight);
+      if (fxk_gather(s, P, B, batch, c->box_margin, counted) > 1) fxk_rng_ord(s, P, B, batch);  // (one workgroup per scan settles the RNG ordinals itself)
       FX_HIP(mark(6));
       fxk_desc_group(s, P, B, batch, desc_grid);
       FX_HIP(mark(7));
@@ -718,6 +729,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   FX_A(dev_alloc(c, &b.list_desc, L.max_total_keypoints));
   FX_A(dev_alloc(c, &b.s_pts, (size_t)L.max_total_keypoints * P.list_cap));
   FX_A(dev_alloc(c, &b.s_cnt, L.max_total_keypoints));
+  FX_A(dev_alloc(c, &b.gather_cnt, (size_t)B * fxk_gather_counted_max() * L.max_keypoints));
   FX_A(dev_alloc(c, &b.row_map, L.max_total_keypoints));
   FX_A(dev_alloc(c, &b.row_kp, L.max_total_keypoints));
   FX_A(dev_alloc(c, &b.row_xa, L.max_total_keypoints));
@@ -824,6 +836,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   if (const char *e = test_hook("FX_DENSE_SLOW")) c->dense_force = atoi(e) != 0 ? 1 : 0;
   if (const char *e = test_hook("FX_PREP_SLICES")) c->prep_slices = std::max(1, atoi(e));
   if (const char *e = test_hook("FX_MERGE_SLICES")) c->merge_slices = std::max(1, atoi(e));
+  if (const char *e = test_hook("FX_GATHER_COUNTED")) c->gather_slices = std::max(1, atoi(e));
   if (c->front_ok) {
     hipError_t ce = fxk_configure_front();
     if (ce != hipSuccess) return bail(fail(FX_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(ce)));

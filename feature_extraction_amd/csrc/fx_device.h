@@ -147,6 +147,7 @@ struct FxBuffers {
   float4 *ovf_pts;        // [B][ovf_cap]  list entries beyond list_cap, unordered (k_gather)
   uint32_t *ovf_kp;       // [B][ovf_cap]  keypoint ordinal of each
   uint32_t *ovf_cnt;      // [B]
+  uint32_t *gather_cnt;   // [B][16][max_keypoints]  k_gather_count -> k_gather_scatter: a slice's entries per keypoint (several workgroups a scan: batches of few big scans)
   // per-keypoint support lists written by k_gather
   float4 *s_pts;          // [max_total_kp][list_cap]  (x, y, z rotated, point index as bits)
   uint32_t *s_cnt;        // [max_total_kp]

@@ -4174,8 +4174,17 @@ __host__ __device__ inline uint32_t gather_words(uint32_t mk, uint32_t nt) {
   return w;
 }
 // PASSES: contexts whose max_keypoints exceeds FX_GATHER_KCAP (the instance without the pass loop keeps its registers)
-template <int NT, bool PASSES>
+// MODE (batches of few big scans: 64 scans of config 5 are 64 workgroups on 256 CUs): several workgroups a scan WITHOUT the
+// staged appends and their global atomics (which serialise on a dense scan's hot keypoints: 5 x slower, see drain below) — two
+// launches over the same slices.  1: the counting pass — every hit adds one to its keypoint's LDS counter, nothing is stored;
+// the slice's counts go to B.gather_cnt.  2: the scatter pass — a keypoint's first list position for this slice is the sum
+// of the earlier slices' counts, so its hits go straight to their slots as with one workgroup a scan; the overflow region's
+// positions (entries beyond list_cap) follow from the same counts.  The near sectors are read and tested twice, by several
+// times as many workgroups.  0: as before (one workgroup a scan, or the streaming mode's staged appends).
+template <int NT, bool PASSES, int MODE = 0>
 __device__ __forceinline__ void gather_body(const FxDevParams &P, const FxBuffers &B, float box_margin, uint32_t *smem) {
+  static_assert(MODE == 0 || !PASSES, "the counted slices hold a scan's keypoints in one pass");
+  static_assert(MODE == 0 || FX_GATHER_DIRECT, "the scatter pass writes its hits straight to their slots");
   constexpr uint32_t FX_GATHER_NW = NT / 64;
   // keypoints the LDS tables hold at a time: a scan with more (a forest under the launch preset) is gathered in passes —
   // the scan's near sectors are streamed once per FX_GATHER_KCAP keypoints
@@ -4192,7 +4201,8 @@ __device__ __forceinline__ void gather_body(const FxDevParams &P, const FxBuffer
   uint32_t *s_knbr = s_kpos + MK;                                // [MK] 1: some point lies within the search radius (one workgroup per scan)
   uint32_t *s_kovf = s_knbr + MK;                                // [MK] overflow-region slot of the keypoint's staged ordinal 0 (entries beyond list_cap)
   uint32_t *s_smeta = s_kcnt + ((5 * MK + 3) & ~3u);             // [STAGE] keypoint << 16 | staged ordinal
-  const bool solo = gridDim.x == 1;
+  const bool solo = gridDim.x == 1 && MODE == 0;
+  const bool own = solo || MODE == 2;  // list positions are this workgroup's own LDS counters
   float4 *s_spt = reinterpret_cast<float4 *>(s_smeta + FX_GATHER_STAGE);
   uint32_t *s_cur = reinterpret_cast<uint32_t *>(s_spt);        // [CELLS] fill cursors while the lists are built (4 STAGE >= CELLS words)
   const uint32_t scan = blockIdx.y, slice = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -4212,7 +4222,7 @@ __device__ __forceinline__ void gather_body(const FxDevParams &P, const FxBuffer
   const uint32_t K = PASSES ? min(MK, K_all - kb) : K_all, row0 = row_first + kb;
   __syncthreads();  // (the previous pass is done with the tables)
   // row -> (scan, keypoint) map for the per-keypoint kernels (one load instead of a binary search)
-  if (slice == 0)
+  if (slice == 0 && MODE != 1)
     for (uint32_t k = tid; k < K; k += NT) B.row_map[row0 + k] = make_uint2(scan, kb + k);
   // keypoints of the scan -> LDS; their bounding box (ordered-uint atomics) for a cheap reject
   if (tid < 6) s_w[tid] = (tid & 1) ? f2ord(-INFINITY) : f2ord(INFINITY);
@@ -4225,7 +4235,7 @@ __device__ __forceinline__ void gather_body(const FxDevParams &P, const FxBuffer
     s_kcnt[k] = 0;
     s_kpos[k] = 0;
     s_knbr[k] = 0;
-    if (slice == 0) B.row_kp[row0 + k] = kp;
+    if (slice == 0 && MODE != 1) B.row_kp[row0 + k] = kp;
     atomicMin(&s_w[0], f2ord(kp.x));
     atomicMax(&s_w[1], f2ord(kp.x));
     atomicMin(&s_w[2], f2ord(kp.y));
@@ -4283,19 +4293,43 @@ __device__ __forceinline__ void gather_body(const FxDevParams &P, const FxBuffer
   }
   __syncthreads();
 
+  if (MODE == 2) {  // this slice's first position in every list, and in the scan's overflow region, from the counting pass
+    const uint32_t S = gridDim.x;
+    const uint32_t *cnt = B.gather_cnt + (size_t)scan * S * P.max_keypoints;
+    uint32_t ovf_before = 0, ovf_all = 0;
+    for (uint32_t k = tid; k < K; k += NT) {
+      uint32_t run = 0, mine = 0;
+      for (uint32_t sl = 0; sl < S; ++sl) {
+        const uint32_t c = cnt[(size_t)sl * P.max_keypoints + k];
+        const uint32_t o = run + c > P.list_cap ? run + c - max(run, P.list_cap) : 0u;  // this slice's entries beyond the list
+        if (sl == slice) mine = run;
+        if (sl < slice) ovf_before += o;
+        ovf_all += o;
+        run += c;
+      }
+      s_kpos[k] = mine;
+      if (slice == 0) B.s_cnt[row0 + k] = run;  // (the TRUE support size, as with one workgroup a scan)
+    }
+    if (ovf_before) atomicAdd(&s_w[9], ovf_before);
+    if (slice == 0 && ovf_all) atomicAdd(&B.ovf_cnt[scan], ovf_all);  // (cleared by the front kernels)
+    __syncthreads();
+  }
   constexpr uint32_t kTile = NT * 4;  // 1024 points: wave w owns [256 w, 256 w + 256), 64 consecutive points per load
   const uint32_t n = M.n;
   uint32_t chunk = (n + gridDim.x - 1) / gridDim.x;
   chunk = (chunk + kTile - 1) / kTile * kTile;
-  const uint32_t lo = slice * chunk;
-  const uint32_t hi = lo + chunk < n ? lo + chunk : n;
+  // (the counted slices take the scan's tiles in turn — tile t is slice t mod S's —: a pole's hits lie in a few consecutive
+  //  tiles, and contiguous ranges gave them all to one slice)
+  const uint32_t tstep = MODE != 0 ? gridDim.x * kTile : kTile;
+  const uint32_t lo = MODE != 0 ? slice * kTile : slice * chunk;
+  const uint32_t hi = MODE != 0 ? n : (lo + chunk < n ? lo + chunk : n);
   const uint32_t *near_bits = B.near_bits + (size_t)scan * P.near_words;
   // called by the whole workgroup, after a barrier: reserve list positions, write the staged hits out
   // Entries beyond a list's list_cap slots go to the scan's overflow region (B.ovf_pts / B.ovf_kp, ovf_cap entries a
   // scan, unordered): the dense tier (k_dense_sort) collects a row's entries from there, so no support set is truncated.
   float4 *ovf_pts = B.ovf_pts + (size_t)scan * P.ovf_cap;
   uint32_t *ovf_kp = B.ovf_kp + (size_t)scan * P.ovf_cap;
-  auto ovf_reserve = [&](uint32_t n) -> uint32_t { return solo ? atomicAdd(&s_w[9], n) : atomicAdd(&B.ovf_cnt[scan], n); };
+  auto ovf_reserve = [&](uint32_t n) -> uint32_t { return own ? atomicAdd(&s_w[9], n) : atomicAdd(&B.ovf_cnt[scan], n); };
   auto flush = [&](uint32_t staged) {
     staged = min(staged, (uint32_t)FX_GATHER_STAGE);
     for (uint32_t k = tid; k < K; k += NT) {
@@ -4346,11 +4380,15 @@ __device__ __forceinline__ void gather_body(const FxDevParams &P, const FxBuffer
         const float d2 = dist2(kp.x, kp.y, kp.z, pq.x, pq.y, pq.z);
         if (d2 < P.r2_support) {
           // 3DSC draws its x-axis only for keypoints that have a neighbour (d2 < R^2: the descriptor kernels' count)
-          if (d2 < P.r2_search) {
+          if (d2 < P.r2_search && MODE != 2) {
             if (solo && !passes)
               s_knbr[k] = 1u;
             else
               B.kp_nbrs[(size_t)scan * P.max_keypoints + kb + k] = 1u;  // (cleared by the merge stage; k_rng_ord reads it)
+          }
+          if (MODE == 1) {  // the counting pass: one more entry for this keypoint from this slice
+            atomicAdd(&s_kpos[k], 1u);
+            continue;
           }
           // One workgroup per scan: the list position is the workgroup's own LDS counter, so the hit goes straight to
           // its slot (no staging, no flush, no workgroup barrier in the tile loop).  Several workgroups per scan
@@ -4358,12 +4396,12 @@ __device__ __forceinline__ void gather_body(const FxDevParams &P, const FxBuffer
           // fine for a handful of sparse scans, hopeless for dense ones (hundreds of flushes: BASELINE config 3 with four
           // workgroups per scan 5.4 ms against 0.66 with one; a global atomic per hit: 7.3 ms, the hot keypoints' counters
           // serialise), which is why dense scans get one WIDE workgroup instead (k_gather_wide).
-          const uint32_t slot = (FX_GATHER_DIRECT && solo) ? FX_GATHER_STAGE : atomicAdd(&s_w[8], 1u);
+          const uint32_t slot = (FX_GATHER_DIRECT && own) ? FX_GATHER_STAGE : atomicAdd(&s_w[8], 1u);
           if (slot < FX_GATHER_STAGE) {
             s_spt[slot] = pq;
             s_smeta[slot] = (k << 16) | atomicAdd(&s_kcnt[k], 1u);
           } else {  // (also: stage full — a burst of hits within one tile)
-            const uint32_t pos = solo ? atomicAdd(&s_kpos[k], 1u) : atomicAdd(&B.s_cnt[row0 + k], 1u);
+            const uint32_t pos = own ? atomicAdd(&s_kpos[k], 1u) : atomicAdd(&B.s_cnt[row0 + k], 1u);
             if (pos < P.list_cap) {
               B.s_pts[(size_t)(row0 + k) * P.list_cap + pos] = pq;
             } else {
@@ -4388,7 +4426,7 @@ __device__ __forceinline__ void gather_body(const FxDevParams &P, const FxBuffer
   uint32_t nb_first = lo;  // the tile lane 0 holds
   auto nb_fill = [&](uint32_t i_first) {
     nb_first = i_first;
-    const uint32_t i = i_first + lane * kTile;
+    const uint32_t i = i_first + lane * tstep;
     nb_words = make_uint2(0u, 0u);
     if (i < hi) {
       const uint32_t w = (i + wave * 256u) / 128u;  // (sector order: this wavefront's 256 points are 64 sectors = two words; w is even)
@@ -4398,7 +4436,7 @@ __device__ __forceinline__ void gather_body(const FxDevParams &P, const FxBuffer
   nb_fill(lo);
   auto near_sectors = [&](uint32_t i0) -> unsigned long long {
     if (i0 >= hi) return 0ull;
-    uint32_t t = (i0 - nb_first) / kTile;  // (workgroup-uniform)
+    uint32_t t = (i0 - nb_first) / tstep;  // (workgroup-uniform)
     if (t >= 64u) nb_fill(i0), t = 0u;
     const uint32_t ts = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
     return (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)nb_words.x, (int)ts) |
@@ -4415,10 +4453,10 @@ __device__ __forceinline__ void gather_body(const FxDevParams &P, const FxBuffer
   float4 v[4], nv[4];
   unsigned long long nib = near_sectors(lo), nnib = 0;
   load_tile(lo, nib, v);
-  for (uint32_t i0 = lo; i0 < hi; i0 += kTile) {
-    nnib = near_sectors(i0 + kTile);
-    load_tile(i0 + kTile, nnib, nv);  // the next tile's loads are in flight while this one is tested
-    if (i0 != lo && !(FX_GATHER_DIRECT && solo)) {  // flush when the next tile might not fit any more (workgroup-uniform decision)
+  for (uint32_t i0 = lo; i0 < hi; i0 += tstep) {
+    nnib = near_sectors(i0 + tstep);
+    load_tile(i0 + tstep, nnib, nv);  // the next tile's loads are in flight while this one is tested
+    if (MODE == 0 && i0 != lo && !(FX_GATHER_DIRECT && solo)) {  // flush when the next tile might not fit any more (workgroup-uniform decision)
       __syncthreads();
       const uint32_t staged = s_w[8];
       __syncthreads();
@@ -4454,7 +4492,11 @@ __device__ __forceinline__ void gather_body(const FxDevParams &P, const FxBuffer
   }
   drain();
   __syncthreads();
-  flush(s_w[8]);
+  if (MODE == 0) flush(s_w[8]);
+  if (MODE == 1) {  // this slice's entries per keypoint
+    uint32_t *cnt = B.gather_cnt + ((size_t)scan * gridDim.x + slice) * P.max_keypoints;
+    for (uint32_t k = tid; k < K; k += NT) cnt[k] = s_kpos[k];
+  }
   if (solo) {
     for (uint32_t k = tid; k < K; k += NT) B.s_cnt[row0 + k] = s_kpos[k];
     // RNG ordinals: keypoint k takes the x-axis number (keypoints before it that have a neighbour)
@@ -4495,6 +4537,15 @@ extern "C" __global__ __launch_bounds__(FX_GATHER_WIDE_T) void k_gather_wide(FxD
   gather_body<FX_GATHER_WIDE_T, false>(P, B, box_margin, smem);
 }
 // contexts of more than FX_GATHER_KCAP keypoints a scan: the wide workgroup, whatever the batch (its tables take most of a CU's LDS)
+// batches of few big scans: the counted slices (gather_body's MODE), two launches
+extern "C" __global__ __launch_bounds__(FX_GATHER_T) void k_gather_count(FxDevParams P, FxBuffers B, float box_margin) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  gather_body<FX_GATHER_T, false, 1>(P, B, box_margin, smem);
+}
+extern "C" __global__ __launch_bounds__(FX_GATHER_T) void k_gather_scatter(FxDevParams P, FxBuffers B, float box_margin) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  gather_body<FX_GATHER_T, false, 2>(P, B, box_margin, smem);
+}
 extern "C" __global__ __launch_bounds__(FX_GATHER_WIDE_T) void k_gather_passes(FxDevParams P, FxBuffers B, float box_margin) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   gather_body<FX_GATHER_WIDE_T, true>(P, B, box_margin, smem);
@@ -6390,6 +6441,10 @@ hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t merge_huge, s
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void *)k_gather_wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gather);
   if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void *)k_gather_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gather);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void *)k_gather_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gather);
+  if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void *)k_gather_passes, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gather);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void *)k_rings_large, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_big);
@@ -6502,14 +6557,27 @@ hipError_t fxk_configure_front(void) {
 // the batch alone fills the GPU, 1024 (k_gather_wide) when it does not; only a handful of scans (streaming) is split
 // over several workgroups per scan.
 uint32_t fxk_gather_slices(uint32_t batch) { return batch >= 64u ? FX_GATHER_SLICES : (batch >= 16u ? 4u : 16u); }
-void fxk_gather(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float box_margin) {
+#define FX_GATHER_COUNTED_MAX 16u
+uint32_t fxk_gather_counted_max(void) { return FX_GATHER_COUNTED_MAX; }
+// counted: > 1 = that many workgroups a scan in two launches (a counting pass, then the scatter with every slice's list
+// positions known: gather_body's MODE) — batches of few big scans; needs FxBuffers::gather_cnt.  Returns the workgroups a scan
+// the lists were written by (> 1: the RNG ordinals are k_rng_ord's).
+uint32_t fxk_gather(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float box_margin, uint32_t counted) {
   const uint32_t slices = fxk_gather_slices(batch);
-  if (P.max_keypoints > FX_GATHER_KCAP)
+  const size_t lds = (size_t)gather_words(std::min(P.max_keypoints, (uint32_t)FX_GATHER_KCAP), FX_GATHER_T) * 4;
+  if (P.max_keypoints > FX_GATHER_KCAP) {
     hipLaunchKernelGGL(k_gather_passes, dim3(slices, batch), dim3(FX_GATHER_WIDE_T), (size_t)gather_words(FX_GATHER_KCAP, FX_GATHER_WIDE_T) * 4, s, P, B, box_margin);
-  else if (slices == 1 && batch < 1024u)
+  } else if (counted > 1u && B.gather_cnt) {
+    counted = std::min(counted, (uint32_t)FX_GATHER_COUNTED_MAX);
+    hipLaunchKernelGGL(k_gather_count, dim3(counted, batch), dim3(FX_GATHER_T), lds, s, P, B, box_margin);
+    hipLaunchKernelGGL(k_gather_scatter, dim3(counted, batch), dim3(FX_GATHER_T), lds, s, P, B, box_margin);
+    return counted;
+  } else if (slices == 1 && batch < 1024u) {
     hipLaunchKernelGGL(k_gather_wide, dim3(1, batch), dim3(FX_GATHER_WIDE_T), (size_t)gather_words(std::min(P.max_keypoints, (uint32_t)FX_GATHER_KCAP), FX_GATHER_WIDE_T) * 4, s, P, B, box_margin);
-  else
-    hipLaunchKernelGGL(k_gather, dim3(slices, batch), dim3(FX_GATHER_T), (size_t)gather_words(std::min(P.max_keypoints, (uint32_t)FX_GATHER_KCAP), FX_GATHER_T) * 4, s, P, B, box_margin);
+  } else {
+    hipLaunchKernelGGL(k_gather, dim3(slices, batch), dim3(FX_GATHER_T), lds, s, P, B, box_margin);
+  }
+  return slices;
 }
 void fxk_desc_group(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t grid) {
   hipLaunchKernelGGL(k_desc_group, dim3(grid), dim3(FX_WG), (size_t)(FX_NWAVE * FX_GROUPS * FX_GROUP_WORDS + FX_TABLE_WORDS) * 4, s, P, B, batch);
