@@ -56,7 +56,7 @@ void fxk_front(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t
                uint32_t clk_slot, uint32_t merge_cap, uint32_t force_redo);
 void fxk_front_ab(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float near_margin, float el0, float inv_step,
                   uint32_t clk_slot, uint32_t force_redo);
-void fxk_front_cd(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t clk_slot, uint32_t merge_cap);
+void fxk_front_cd(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t clk_slot, uint32_t merge_cap, uint32_t lean);
 void fxk_front_redo(hipStream_t s, const FxDevParams &P, const FxBuffers &B, float el0, float inv_step, uint32_t huge_ccap, uint32_t force_slow,
                     uint32_t grid);
 size_t fxk_slow_words(uint32_t max_ring_points, uint32_t max_candidates, uint32_t huge_ccap);
@@ -182,7 +182,7 @@ struct fx_ctx {
   // clustering + merge).  Built, parity-green, and NOT the default: alone the two take what the one takes
   // (0.134 + 0.156 against 0.286 ms), with four batches in flight the headline is 3 % lower (profiles/r06_experiments.md §1).
   // The test build's FX_FRONT_SPLIT=1 runs it (tests/test_gpu_front_split.py, the fuzz's front-split path).
-  int front_split = 0;         // 1: the two launches; 0: the one fused launch
+  int front_split = 0;         // 1: the two launches; 2: the same with k_front_cd's lean image (the points left in HBM); 0: the one fused launch
   // A batch that failed after its kernels were enqueued leaves state the next batch would build on: descriptor rows are
   // cleared by un-writing what the last batch recorded for them (desc_nbins / desc_bins), the work-list counters are
   // cleared by the batch's first kernel, the tier hints size the next grids.  The next batch then starts from scratch:
@@ -324,7 +324,7 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof, bo
       if (split) {  // (stage 0: k_front_ab, stage 1: k_front_cd)
         fxk_front_ab(s, P, B, batch, c->box_margin, el0, inv_step, clk_slot, c->front_force >= 1u ? 1u : 0u);
         FX_HIP(mark(1));
-        fxk_front_cd(s, P, B, batch, clk_slot, mcap);
+        fxk_front_cd(s, P, B, batch, clk_slot, mcap, c->front_split >= 2 ? 1u : 0u);
       } else {
         fxk_front(s, P, B, batch, c->box_margin, el0, inv_step, clk_slot, mcap, c->front_force >= 1u ? 1u : 0u);
         FX_HIP(mark(1));
@@ -830,7 +830,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   if (const char *e = test_hook("FX_FRONT")) c->front_ok = c->front_ok && atoi(e) != 0;  // 0 = the separate kernels (measurements; tests of those kernels)
   // 1: k_front hands every scan to k_front_redo; 2: and that one every ring and merge to the slow tier, k_slow (tests of those two)
   if (const char *e = test_hook("FX_FRONT_FORCE")) c->front_force = (uint32_t)std::max(0, atoi(e));
-  if (const char *e = test_hook("FX_FRONT_SPLIT")) c->front_split = atoi(e) != 0 ? 1 : 0;
+  if (const char *e = test_hook("FX_FRONT_SPLIT")) c->front_split = std::max(0, std::min(2, atoi(e)));  // (2: k_front_cd with the lean image)
   if (const char *e = test_hook("FX_FAIL_AFTER_ENQUEUE")) c->fail_after = (uint32_t)std::max(0, atoi(e));
   if (const char *e = test_hook("FX_SKIP_EMPTY")) c->skip_mask = (uint32_t)std::max(0, atoi(e));
   if (const char *e = test_hook("FX_DENSE_SLOW")) c->dense_force = atoi(e) != 0 ? 1 : 0;

@@ -2959,6 +2959,42 @@ static_assert(FX_FRONT_RUNS <= 1024 && FX_FRONT_CAP <= 4096 && FX_FRONT_BLOCKS <
                   FX_FRONT_CAP >= FX_PREP_KEEP, "k_front packings");
 static_assert((FrontOff::smask % 2) == 0 && (FrontOff::rsm % 2) == 0 && (FrontOff::seg_box % 4) == 0 && (FrontOff::rbox % 4) == 0, "k_front alignment");
 __host__ __device__ inline size_t front_lds_bytes() { return (size_t)FrontOff::end * 4; }
+// The same tables WITHOUT the points (k_front_cdl, round 6): phases C and D read the ring-major records from B.ring_pts —
+// every phase but the rare general edge search reads them as a stream — and the image is the tables alone, with the merge's
+// image (which borrows the points in FrontOff) laid over the tables that are dead by then: 37 KB instead of 79, four workgroups
+// a CU's LDS instead of two.  Same names, same overlays (pairs / queues over croot..ctmp, the replay's scratch over seg_box).
+struct FrontLeanOff {
+  static constexpr uint32_t px = 0, py = 0, pz = 0, sidx = 0;              // (no points: never dereferenced in the lean instance)
+  static constexpr uint32_t merge = 0;                                     // merge_body's image: [0, merge_end) — over what follows up to croot
+  static constexpr uint32_t seg_box = 0;                                   // [SEGS][4]
+  static constexpr uint32_t smask = seg_box + 4 * FX_FRONT_SEGS;           // [BLOCKS] uint64
+  static constexpr uint32_t gmask = smask + 2 * FX_FRONT_BLOCKS;
+  static constexpr uint32_t run_base = gmask + 2 * FX_FRONT_BLOCKS;
+  static constexpr uint32_t seg_base = run_base + FX_FRONT_BLOCKS;
+  static constexpr uint32_t seg_start = seg_base + FX_FRONT_BLOCKS;        // uint16 [SEGS + 1]
+  static constexpr uint32_t rseg = a4(seg_start + (FX_FRONT_SEGS + 2) / 2); // uint16 [RUNS + 1]
+  static constexpr uint32_t rparent = a4(rseg + (FX_FRONT_RUNS + 2) / 2);
+  static constexpr uint32_t rsize = rparent + FX_FRONT_RUNS;
+  static constexpr uint32_t roff = rsize + FX_FRONT_RUNS;                  // uint16 [RUNS]
+  static constexpr uint32_t merge_end = a4((uint32_t)merge_words(FX_FRONT_MERGE, FX_FRONT_MERGE, FX_FRONT_RMAX, true));
+  static constexpr uint32_t croot_min = a4(roff + FX_FRONT_RUNS / 2);
+  static constexpr uint32_t croot = (croot_min + FX_FRONT_RUNS / 2 + 4 > merge_end ? croot_min : merge_end - (FX_FRONT_RUNS / 2 + 4));  // uint16 [RUNS + 8]: the last of the tables the merge's image lies over
+  static constexpr uint32_t crec = croot + FX_FRONT_RUNS / 2 + 4;          // ---- live through the merge from here on
+  static constexpr uint32_t ctmp = crec + FX_FRONT_RUNS + 4;
+  static constexpr uint32_t rbox = a4(ctmp + FX_FRONT_RUNS + 4);           // [RUNS][4] run boxes, cluster boxes, centroids
+  static constexpr uint32_t s_w = rbox + 4 * FX_FRONT_RUNS;
+  static constexpr uint32_t r_off = s_w + 64;
+  static constexpr uint32_t r_cnt = r_off + FX_FRONT_RMAX + 4;
+  static constexpr uint32_t r_run0 = r_cnt + FX_FRONT_RMAX;
+  static constexpr uint32_t r_cb = r_run0 + FX_FRONT_RMAX + 4;
+  static constexpr uint32_t end = r_cb + FX_FRONT_RMAX + 4;
+  static constexpr uint32_t rsm = croot, pairs = croot, queues = pairs + FX_FRONT_PAIRS, q_end = queues + FX_FRONT_NW * FX_FRONT_QUEUE;
+};
+static_assert(FrontLeanOff::crec >= FrontLeanOff::merge_end, "k_front_cdl: the merge's image ends before the tables it needs");
+static_assert(FrontLeanOff::q_end <= FrontLeanOff::rbox, "k_front_cdl overlays");
+static_assert((FrontLeanOff::smask % 2) == 0 && (FrontLeanOff::rsm % 2) == 0 && (FrontLeanOff::seg_box % 4) == 0 && (FrontLeanOff::rbox % 4) == 0, "k_front_cdl alignment");
+static_assert(FrontLeanOff::end * 4 <= 40 * 1024, "four workgroups of k_front_cdl a CU");
+__host__ __device__ inline size_t front_lean_lds_bytes() { return (size_t)FrontLeanOff::end * 4; }
 
 __device__ __forceinline__ unsigned long long le_mask64(uint32_t lane) { return lane == 63u ? ~0ull : ((2ull << lane) - 1ull); }
 
@@ -2967,11 +3003,13 @@ __device__ __forceinline__ unsigned long long le_mask64(uint32_t lane) { return 
 // k_front (the scan never left the workgroup; RM = false: a member's record is ~cloud's, through the survivor index sidx) and
 // k_front_cd (RM = true: the ring-major records k_front_ab wrote to B.ring_pts, entry i = record i).  Ends the workgroup's
 // work for the scan: results written, or the scan handed to k_front_redo.
-template <bool RM>
+template <bool RM, class O = FrontOff, uint32_t NT_ = FX_FRONT_T>
 __device__ __forceinline__ void front_cluster_merge(const FxDevParams &P, const FxBuffers &B, uint32_t scan, uint32_t *smem, uint32_t n,
                                                     uint32_t clk_slot, uint32_t merge_cap) {
-  using O = FrontOff;
-  constexpr uint32_t NT = FX_FRONT_T, NW = FX_FRONT_NW, RUNS = FX_FRONT_RUNS, SEGS = FX_FRONT_SEGS;
+  constexpr bool LEAN = std::is_same<O, FrontLeanOff>::value;  // the points stay in B.ring_pts (k_front_cdl)
+  static_assert(!LEAN || RM, "the lean image reads ring-major records");
+  constexpr uint32_t NT = NT_, NW = NT_ / 64, RUNS = FX_FRONT_RUNS, SEGS = FX_FRONT_SEGS;
+  static_assert(NW <= FX_FRONT_NW, "the image's per-wavefront areas are sized for FX_FRONT_NW");
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t R = (uint32_t)P.n_rings;
   float *px = reinterpret_cast<float *>(smem + O::px), *py = reinterpret_cast<float *>(smem + O::py), *pz = reinterpret_cast<float *>(smem + O::pz);
@@ -3002,6 +3040,8 @@ __device__ __forceinline__ void front_cluster_merge(const FxDevParams &P, const 
   // a ring-major entry's record (rotated x y z, elevation)
   const float4 *src = RM ? B.ring_pts + (size_t)scan * P.ring_slot_cap : B.filt + (size_t)scan * P.max_points;
   auto member = [&](uint32_t i) -> float4 { return RM ? src[i] : src[sidx[i]]; };
+  // a ring-major entry's point: LDS, or — the lean image — its record in HBM (one 16-byte load)
+  auto ld = [&](uint32_t i) -> float4 { return LEAN ? src[i] : make_float4(px[i], py[i], pz[i], 0.0f); };
   (void)no_keypoints;
   (void)r_cnt;
   (void)NW;
@@ -3026,7 +3066,10 @@ __device__ __forceinline__ void front_cluster_merge(const FxDevParams &P, const 
       bool start = false;
       if (in) {
         start = (rsm[k] >> lane) & 1ull;
-        if (!start) start = !(dist2(px[i], py[i], pz[i], px[i - 1], py[i - 1], pz[i - 1]) < r2);  // (entry 0 starts a ring)
+        if (!start) {
+          const float4 a = ld(i), b = ld(i - 1u);
+          start = !(dist2(a.x, a.y, a.z, b.x, b.y, b.z) < r2);  // (entry 0 starts a ring)
+        }
       }
       const unsigned long long m = __ballot(start), g = __ballot(in && (start || (i & 15u) == 0u));
       if (lane == 0 && b0 + wave * 64u < n) smask[k] = m, gmask[k] = g;
@@ -3054,7 +3097,8 @@ __device__ __forceinline__ void front_cluster_merge(const FxDevParams &P, const 
       const uint32_t r = run_base[i >> 6] + (uint32_t)__popcll(sm & le) - 1u, sg = seg_base[i >> 6] + (uint32_t)__popcll(gm & le) - 1u;
       if ((gm >> lane) & 1ull) seg_start[sg] = (uint16_t)i;
       if ((sm >> lane) & 1ull) rseg[r] = (uint16_t)sg;
-      const uint32_t ox = f2ord(px[i]), oy = f2ord(py[i]);
+      const float4 pi = ld(i);
+      const uint32_t ox = f2ord(pi.x), oy = f2ord(pi.y);
       atomicMin(&seg_box[4 * sg + 0], ox);
       atomicMax(&seg_box[4 * sg + 1], ox);
       atomicMin(&seg_box[4 * sg + 2], oy);
@@ -3172,7 +3216,8 @@ __device__ __forceinline__ void front_cluster_merge(const FxDevParams &P, const 
         const uint32_t item = wq[t];
         const uint32_t i = item & 0xfffu, b = (item >> 12) & 0x3ffu, a = item >> 22;
         if (uf_find(rparent, a) == uf_find(rparent, b)) continue;  // already one component
-        const float qx = px[i], qy = py[i], qz = pz[i];
+        const float4 pq = ld(i);
+        const float qx = pq.x, qy = pq.y, qz = pq.z;
         bool linked = false;
         for (uint32_t sg = rseg[b]; sg < rseg[b + 1] && !linked; ++sg) {
           const float4 sb = sbox4[sg];
@@ -3185,7 +3230,8 @@ __device__ __forceinline__ void front_cluster_merge(const FxDevParams &P, const 
 #pragma unroll
             for (uint32_t u = 0; u < 4; ++u) {
               const uint32_t ju = min(j + u, j1 - 1u);
-              jx[u] = px[ju], jy[u] = py[ju], jz[u] = pz[ju];
+              const float4 pj = ld(ju);
+              jx[u] = pj.x, jy[u] = pj.y, jz[u] = pj.z;
             }
 #pragma unroll
             for (uint32_t u = 0; u < 4; ++u) linked |= dist2(qx, qy, qz, jx[u], jy[u], jz[u]) < r2;
@@ -3203,7 +3249,8 @@ __device__ __forceinline__ void front_cluster_merge(const FxDevParams &P, const 
     for (uint32_t t = tid; t < n_rp; t += NT) {
       const uint32_t pr = pairs[t], a = pr >> 16, b = pr & 0xffffu;
       const uint32_t ia = run_first(a + 1u) - 1u, ib = run_first(b);
-      if (dist2(px[ib], py[ib], pz[ib], px[ia], py[ia], pz[ia]) < r2) {
+      const float4 pb = ld(ib), pa = ld(ia);
+      if (dist2(pb.x, pb.y, pb.z, pa.x, pa.y, pa.z) < r2) {
         uf_union(rparent, b, a);
         pairs[t] = FX_NONE;
       }
@@ -3218,7 +3265,8 @@ __device__ __forceinline__ void front_cluster_merge(const FxDevParams &P, const 
         const uint32_t i = i0 + lane;
         bool ok = false;
         if (i < i_end) {
-          const float qx = px[i], qy = py[i];
+          const float4 pq = ld(i);
+          const float qx = pq.x, qy = pq.y;
           const float dx = fmaxf(fmaxf(bb.x - qx, qx - bb.y), 0.0f);
           const float dy = fmaxf(fmaxf(bb.z - qy, qy - bb.w), 0.0f);
           ok = !(dx * dx + dy * dy > r2_pad);
@@ -3361,7 +3409,8 @@ __device__ __forceinline__ void front_cluster_merge(const FxDevParams &P, const 
 #pragma unroll
         for (uint32_t u = 0; u < 4; ++u) {
           const uint32_t iu = min(i + u, i1 - 1u);
-          x[u] = px[iu], y[u] = py[iu], z[u] = pz[iu];
+          const float4 pu = ld(iu);
+          x[u] = pu.x, y[u] = pu.y, z[u] = pu.z;
         }
 #pragma unroll
         for (uint32_t u = 0; u < 4; ++u) {
@@ -3426,8 +3475,9 @@ __device__ __forceinline__ void front_cluster_merge(const FxDevParams &P, const 
   return;
 #endif
   // ---------------------------------------------------------------- D: secondary merge (ref: node.cpp:209-257)
+  if (LEAN) __syncthreads();  // (the merge's image lies over the run tables the keypoint_cloud loop above still reads: in FrontOff it lies over the points)
   const FrontCands FC{crec, ctmp, rbox4, n_c, C};
-  merge_body<NT, true, true>(P, B, scan, merge_cap, merge_cap, smem, true, &FC);
+  merge_body<NT, true, true>(P, B, scan, merge_cap, merge_cap, LEAN ? smem + FrontLeanOff::merge : smem, true, &FC);
   FX_STAMP(15);
   stamp_end();
 }
@@ -3841,6 +3891,29 @@ extern "C" __global__ __launch_bounds__(FX_FRONT_T, FX_PREP_OCC) void k_front_cd
   }
   __syncthreads();
   front_cluster_merge<true>(P, B, scan, smem, n, clk_slot, merge_cap);
+}
+
+// k_front_cd with the lean image (FrontLeanOff): the points stay in B.ring_pts.
+// (256 threads: held to 80 registers for three 512-thread workgroups a CU the kernel misses its occupancy target — the scalar
+//  registers it spills take vector ones —; four wavefronts a workgroup at its natural 86 make four workgroups a CU)
+#ifndef FX_FRONT_CDL_T
+#define FX_FRONT_CDL_T 256
+#endif
+extern "C" __global__ __launch_bounds__(FX_FRONT_CDL_T) void k_front_cdl(FxDevParams P, FxBuffers B, uint32_t clk_slot, uint32_t merge_cap) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  using O = FrontLeanOff;
+  const uint32_t scan = blockIdx.x, tid = threadIdx.x;
+  const uint32_t R = (uint32_t)P.n_rings;
+  const uint32_t n = B.front_n[scan];
+  if (n == 0u || n == FX_NONE) return;  // (k_front_ab wrote the empty results / handed the scan to k_front_redo)
+  uint32_t *r_off = smem + O::r_off, *r_cnt = smem + O::r_cnt;
+  if (tid < R) {
+    r_off[tid] = B.ring_off[(size_t)scan * R + tid];
+    r_cnt[tid] = B.ring_cnt[(size_t)scan * R + tid];
+  }
+  if (tid == R) r_off[R] = n;
+  __syncthreads();
+  front_cluster_merge<true, FrontLeanOff, FX_FRONT_CDL_T>(P, B, scan, smem, n, clk_slot, merge_cap);
 }
 
 // The scans k_front could not take (k_front_redo, a workgroup of k_front's shape each — 512 threads, the same LDS image — so
@@ -6536,8 +6609,11 @@ void fxk_front_ab(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint3
                   uint32_t clk_slot, uint32_t force_redo) {
   hipLaunchKernelGGL(k_front_ab, dim3(batch), dim3(FX_FRONT_T), front_ab_lds_bytes(), s, P, B, near_margin, el0, inv_step, clk_slot, force_redo);
 }
-void fxk_front_cd(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t clk_slot, uint32_t merge_cap) {
-  hipLaunchKernelGGL(k_front_cd, dim3(batch), dim3(FX_FRONT_T), front_lds_bytes(), s, P, B, clk_slot, merge_cap);
+void fxk_front_cd(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t clk_slot, uint32_t merge_cap, uint32_t lean) {
+  if (lean)
+    hipLaunchKernelGGL(k_front_cdl, dim3(batch), dim3(FX_FRONT_CDL_T), front_lean_lds_bytes(), s, P, B, clk_slot, merge_cap);
+  else
+    hipLaunchKernelGGL(k_front_cd, dim3(batch), dim3(FX_FRONT_T), front_lds_bytes(), s, P, B, clk_slot, merge_cap);
 }
 hipError_t fxk_configure_front(void) {
   hipError_t e = hipFuncSetAttribute((const void *)k_front, hipFuncAttributeMaxDynamicSharedMemorySize, (int)front_lds_bytes());

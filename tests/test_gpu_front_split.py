@@ -1,8 +1,10 @@
 """The fused front path as TWO launches (k_front_ab: streaming pass + ring split, the ring-major records through HBM;
 k_front_cd: per-ring clustering + secondary merge; ref: node.cpp:147-259) — VERDICT r5 #1's split.  Built and measured in
 round 6 (profiles/r06_experiments.md §1: alone the two take what the one takes, with batches in flight the one wins by 3 %),
-so the product launches the one fused kernel; the test build's hook FX_FRONT_SPLIT=1 sends batches through the two launches:
-the same table limits, the same hand-over to k_front_redo / k_slow, bit-identical results."""
+so the product launches the one fused kernel; the test build's hook FX_FRONT_SPLIT=1 sends batches through the two launches,
+FX_FRONT_SPLIT=2 through the variant whose second launch keeps only its TABLES in LDS (k_front_cdl: the ring-major points read
+from HBM, 37 KB instead of 79, four 256-thread workgroups a CU — alone 0.134 ms against 0.156, in flight level with the fused
+kernel: profiles/r06_experiments.md §5): the same table limits, the same hand-over to k_front_redo / k_slow, bit-identical results."""
 import numpy as np
 import pytest
 
@@ -14,7 +16,14 @@ from tests.test_gpu_ring_run_tier import (interleaved_arc, isolated_points, long
 pytestmark = pytest.mark.gpu
 
 
-def test_a_64_scan_batch_through_the_two_launches_equals_the_fused_kernel(fxlib, fx_hooks, oracle):
+@pytest.fixture(params=[1, 2], ids=["cd", "cd-lean"])
+def split(request):
+    """FX_FRONT_SPLIT: 1 = k_front_ab + k_front_cd (the ring-major points loaded into k_front's image), 2 = k_front_ab +
+    k_front_cdl (the lean image: tables only, the points read from B.ring_pts; 256 threads, four workgroups a CU)."""
+    return request.param
+
+
+def test_a_64_scan_batch_through_the_two_launches_equals_the_fused_kernel(fxlib, fx_hooks, oracle, split):
     """64 bench scans (with an empty and a ragged one): the two launches against the oracle, and bit-identical to the product's
     one fused launch."""
     scans = [util.vlp16_scan(3000 + b) for b in range(64)]
@@ -24,21 +33,21 @@ def test_a_64_scan_batch_through_the_two_launches_equals_the_fused_kernel(fxlib,
     lim = capi.limits(64, 28800)
     keys = ("filtered", "candidates", "cand_size", "kpc", "kpc_cand", "cand_keypoint", "keypoints", "kp_size", "kp_neighbors", "descriptors")
     res = {}
-    for split in (0, 1):
-        fx_hooks(FX_FRONT_SPLIT=split)
+    for mode in (0, split):
+        fx_hooks(FX_FRONT_SPLIT=mode)
         ctx = capi.Context(p, lim)
-        res[split] = ctx.process_host(scans, roll=0.02, pitch=-0.015)
+        res[min(mode, 1)] = ctx.process_host(scans, roll=0.02, pitch=-0.015)
         assert _hints(ctx) == (0, 0)
         ctx.close()
     for b in (0, 5, 9, 33, 63):
-        util.compare_scan(res[1][b], oracle.run(p, scans[b], roll=0.02, pitch=-0.015), tag=f"64-scan batch, two launches, scan {b}")
+        util.compare_scan(res[1][b], oracle.run(p, scans[b], roll=0.02, pitch=-0.015), tag=f"64-scan batch, two launches ({split}), scan {b}")
     for b in range(64):
         for key in keys:
             util.assert_bit_equal(res[0][b][key], res[1][b][key], f"fused vs two launches, scan {b} {key}")
 
 
-def test_ring_shapes_and_bench_scans(fx_hooks, oracle):
-    fx_hooks(FX_FRONT_SPLIT=1)
+def test_ring_shapes_and_bench_scans(fx_hooks, oracle, split):
+    fx_hooks(FX_FRONT_SPLIT=split)
     scans = [long_ring_with_late_poles(), two_arcs_in_blocks(3), interleaved_arc(12, 60), isolated_points(14, 100), isolated_points(9, 129),
              interleaved_arc(6, 100),
              np.concatenate([long_ring_with_late_poles(), two_arcs_in_blocks(9), interleaved_arc(6, 36), isolated_points(10, 128)]),
@@ -51,10 +60,10 @@ def test_ring_shapes_and_bench_scans(fx_hooks, oracle):
         assert hints == (0, 0) and sum(g["n_keypoints"] for g in got) > 0
 
 
-def test_table_limits_hand_over_to_the_kernels_behind(fx_hooks, oracle):
+def test_table_limits_hand_over_to_the_kernels_behind(fx_hooks, oracle, split):
     """k_front_cd's run table / near-pair list at their limits; more ring entries than either launch holds (k_front_ab hands the
     scan on itself)."""
-    fx_hooks(FX_FRONT_SPLIT=1)
+    fx_hooks(FX_FRONT_SPLIT=split)
 
     def runs(total):
         per, rest = divmod(total, 4)
@@ -74,18 +83,18 @@ def test_table_limits_hand_over_to_the_kernels_behind(fx_hooks, oracle):
 
 
 @pytest.mark.parametrize("force", [1, 2])
-def test_every_scan_through_the_kernels_behind(fx_hooks, oracle, force):
-    fx_hooks(FX_FRONT_SPLIT=1, FX_FRONT_FORCE=force)
+def test_every_scan_through_the_kernels_behind(fx_hooks, oracle, force, split):
+    fx_hooks(FX_FRONT_SPLIT=split, FX_FRONT_FORCE=force)
     scans = [util.vlp16_scan(1000 + b) for b in range(6)] + [np.zeros((0, 4), np.float32), long_ring_with_late_poles(), interleaved_arc(6, 100)]
     got, hints = _run(oracle, scans, f"split forced {force}", roll=0.02, pitch=-0.015)
     assert [g["flags"] for g in got] == [0] * len(scans)
     assert hints == (len(scans) - 1, len(scans) - 1 if force == 2 else 0)
 
 
-def test_interleaving_and_the_slow_tier(fx_hooks, oracle):
+def test_interleaving_and_the_slow_tier(fx_hooks, oracle, split):
     """Per-scan results are a function of the scan alone through the two launches too; a ring beyond the LDS tiers is exact on
     its first presentation."""
-    fx_hooks(FX_FRONT_SPLIT=1)
+    fx_hooks(FX_FRONT_SPLIT=split)
     p = capi.params("launch")
     big = np.concatenate([shells_ring(), long_ring_with_late_poles()])
     pool = {"small0": util.vlp16_scan(1000), "big": big, "runs": np.concatenate([isolated_points(7 + r, 129) for r in range(4)]),
@@ -110,8 +119,8 @@ def test_interleaving_and_the_slow_tier(fx_hooks, oracle):
     ctx.close()
 
 
-def test_window_boundary_points_and_a_32_ring_sensor(fx_hooks, oracle):
-    fx_hooks(FX_FRONT_SPLIT=1)
+def test_window_boundary_points_and_a_32_ring_sensor(fx_hooks, oracle, split):
+    fx_hooks(FX_FRONT_SPLIT=split)
     rng = np.random.default_rng(3)
     pts = []
     for ring in range(16):
