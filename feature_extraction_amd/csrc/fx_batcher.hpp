@@ -57,12 +57,20 @@ class StreamBatcher {
   // more keypoints than the default's average of 64 a scan must not flag FX_FLAG_TOTAL_KP_OVERFLOW), the library's
   // default (64 a scan) beyond: max_batch 1024 is then 65 536 rows = 1.6 GB, not 6 GB.
   // limits: non-zero fields (other than max_batch / max_points) override the preset's.
+  // full_pools: NB the preset is fx_limits_SPARSE (since 0.6: streaming sensors are VLP-16 class — small dense-tier pools and
+  // overflow regions, 4.5 GB a 1024-scan context instead of 7): a stream of DENSE scans (64 / 128 rings, rows of thousands of
+  // support points) exhausts them, and the rows they cannot hold come back as NaN descriptors with FX_FLAG_NBR_OVERFLOW where
+  // the reference computes them (ref: node.cpp:343-353).  full_pools = true starts from fx_limits_default instead
+  // (ADVICE r5).
   StreamBatcher(const fx_params &params, uint32_t max_batch, uint32_t max_points, int device, Callback cb, uint32_t pool_keypoints = 0,
-                const fx_limits *limits = nullptr)
+                const fx_limits *limits = nullptr, bool full_pools = false)
       : cb_(std::move(cb)), max_batch_(max_batch), max_points_(max_points) {
     if (FX_CHECK_ABI() != FX_OK) throw std::runtime_error(std::string("fx_check_abi: ") + fx_last_error());  // (this translation unit's fx.h against the library's)
     fx_limits lim;
-    fx_limits_sparse(&lim, max_batch, max_points);  // (streaming sensors are VLP-16 class: no dense-tier pools — INTEGRATION.md §6)
+    if (full_pools)
+      fx_limits_default(&lim, max_batch, max_points);
+    else
+      fx_limits_sparse(&lim, max_batch, max_points);
     if (pool_keypoints)
       lim.max_total_keypoints = pool_keypoints;
     else if (max_batch <= 64u)
