@@ -56,7 +56,8 @@ void fxk_front(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t
                uint32_t clk_slot, uint32_t merge_cap, uint32_t force_redo);
 void fxk_front_ab(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, float near_margin, float el0, float inv_step,
                   uint32_t clk_slot, uint32_t force_redo);
-void fxk_front_cd(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t clk_slot, uint32_t merge_cap, uint32_t lean);
+void fxk_front_cd(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t clk_slot, uint32_t merge_cap, uint32_t lean,
+                  uint32_t self_n, uint32_t force_redo);
 void fxk_front_redo(hipStream_t s, const FxDevParams &P, const FxBuffers &B, float el0, float inv_step, uint32_t huge_ccap, uint32_t force_slow,
                     uint32_t grid);
 size_t fxk_slow_words(uint32_t max_ring_points, uint32_t max_candidates, uint32_t huge_ccap);
@@ -182,6 +183,8 @@ struct fx_ctx {
   // clustering + merge).  Built, parity-green, and NOT the default: alone the two take what the one takes
   // (0.134 + 0.156 against 0.286 ms), with four batches in flight the headline is 3 % lower (profiles/r06_experiments.md §1).
   // The test build's FX_FRONT_SPLIT=1 runs it (tests/test_gpu_front_split.py, the fuzz's front-split path).
+  int front_stream = -1;       // test hook (FX_FRONT_STREAM): 1 always the sliced streaming pass + k_front_cd, 0 never; -1: batches of up to front_stream_max_batch scans
+  static constexpr uint32_t front_stream_max_batch = 8;
   int front_split = 0;         // 1: the two launches; 2: the same with k_front_cd's lean image (the points left in HBM); 0: the one fused launch
   // A batch that failed after its kernels were enqueued leaves state the next batch would build on: descriptor rows are
   // cleared by un-writing what the last batch recorded for them (desc_nbins / desc_bins), the work-list counters are
@@ -321,10 +324,20 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof, bo
       // with EVERY batch: the hints size grids, they never decide whether a scan gets what it needs.
       const uint32_t mcap = std::min(fxk_front_merge_cap(), L.max_candidates);
       const bool split = c->front_split != 0;
-      if (split) {  // (stage 0: k_front_ab, stage 1: k_front_cd)
+      // A handful of scans per call (the reference's own mode: one scan per callback, ref: node.cpp:72, :386): k_front's streaming
+      // pass would be ONE workgroup a scan on a chip of 256 CUs — 0.036 of a scan's 0.093 ms in k_front.  So the streaming pass
+      // and the ring split go out SLICED, sixteen workgroups a scan (the counting pass, k_prep_sliced, k_bucket_sliced: the
+      // separate kernels' own, whose ring-major records are what k_front_ab writes), and k_front_cd clusters and merges in one.
+      const bool stream = c->front_stream >= 0 ? c->front_stream != 0 : batch <= fx_ctx::front_stream_max_batch;
+      if (stream && !split) {  // (stage 0: the streaming pass, stage 1: ring split + k_front_cd)
+        fxk_prep_sliced(s, P, B, batch, fxk_prep_slices_max(), c->box_margin, el0, inv_step, clk_slot);
+        FX_HIP(mark(1));
+        fxk_bucket_sliced(s, P, B, batch, fxk_prep_slices_max(), el0, inv_step, clk_next);
+        fxk_front_cd(s, P, B, batch, clk_slot, mcap, 0u, 1u, c->front_force >= 1u ? 1u : 0u);
+      } else if (split) {  // (stage 0: k_front_ab, stage 1: k_front_cd)
         fxk_front_ab(s, P, B, batch, c->box_margin, el0, inv_step, clk_slot, c->front_force >= 1u ? 1u : 0u);
         FX_HIP(mark(1));
-        fxk_front_cd(s, P, B, batch, clk_slot, mcap, c->front_split >= 2 ? 1u : 0u);
+        fxk_front_cd(s, P, B, batch, clk_slot, mcap, c->front_split >= 2 ? 1u : 0u, 0u, 0u);
       } else {
         fxk_front(s, P, B, batch, c->box_margin, el0, inv_step, clk_slot, mcap, c->front_force >= 1u ? 1u : 0u);
         FX_HIP(mark(1));
@@ -830,6 +843,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   if (const char *e = test_hook("FX_FRONT")) c->front_ok = c->front_ok && atoi(e) != 0;  // 0 = the separate kernels (measurements; tests of those kernels)
   // 1: k_front hands every scan to k_front_redo; 2: and that one every ring and merge to the slow tier, k_slow (tests of those two)
   if (const char *e = test_hook("FX_FRONT_FORCE")) c->front_force = (uint32_t)std::max(0, atoi(e));
+  if (const char *e = test_hook("FX_FRONT_STREAM")) c->front_stream = atoi(e) != 0 ? 1 : 0;
   if (const char *e = test_hook("FX_FRONT_SPLIT")) c->front_split = std::max(0, std::min(2, atoi(e)));  // (2: k_front_cd with the lean image)
   if (const char *e = test_hook("FX_FAIL_AFTER_ENQUEUE")) c->fail_after = (uint32_t)std::max(0, atoi(e));
   if (const char *e = test_hook("FX_SKIP_EMPTY")) c->skip_mask = (uint32_t)std::max(0, atoi(e));

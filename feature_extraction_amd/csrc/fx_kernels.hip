@@ -3864,14 +3864,48 @@ extern "C" __global__ __launch_bounds__(FX_FRONT_T, FX_FRONT_AB_OCC) void k_fron
   stamp_end();
 }
 
-extern "C" __global__ __launch_bounds__(FX_FRONT_T, FX_PREP_OCC) void k_front_cd(FxDevParams P, FxBuffers B, uint32_t clk_slot, uint32_t merge_cap) {
+// (self_n: behind the SLICED streaming pass and ring split instead of k_front_ab — k_prep_count / k_prep_sliced / k_bucket_sliced,
+//  several workgroups a scan: what a scan per call takes, where k_front's streaming pass is one workgroup on one
+//  CU.  The kernel then does k_front_ab's bookkeeping itself: the scan's entries from the ring counts, the hand-over to
+//  k_front_redo, the empty results, the support-list counters' slice.)
+extern "C" __global__ __launch_bounds__(FX_FRONT_T, FX_PREP_OCC) void k_front_cd(FxDevParams P, FxBuffers B, uint32_t clk_slot, uint32_t merge_cap,
+                                                                              uint32_t self_n, uint32_t force_redo) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   using O = FrontOff;
   constexpr uint32_t NT = FX_FRONT_T, CAP = FX_FRONT_CAP;
   const uint32_t scan = blockIdx.x, tid = threadIdx.x;
   const uint32_t R = (uint32_t)P.n_rings;
-  const uint32_t n = B.front_n[scan];
-  if (n == 0u || n == FX_NONE) return;  // (k_front_ab wrote the empty results / handed the scan to k_front_redo)
+  uint32_t n;
+  if (self_n) {
+    {  // the support-list counters of the batch are cleared here, a slice per scan (k_gather fills them)
+      const uint32_t per = (P.max_total_kp + gridDim.x - 1) / gridDim.x;
+      const uint32_t z0 = scan * per, z1 = min(z0 + per, P.max_total_kp);
+      for (uint32_t t = z0 + tid; t < z1; t += NT) B.s_cnt[t] = 0u;
+      if (tid == 0) B.ovf_cnt[scan] = 0u;
+    }
+    if (B.meta[scan].n == 0u) {  // an empty scan (ref: node.cpp:209-210, 263-264): never handed on, as in k_front
+      if (tid == 0) B.n_cand[scan] = 0u, B.n_kp[scan] = 0u, B.n_kpc[scan] = 0u;
+      return;
+    }
+    uint32_t ring_max = 0;
+    n = 0;
+    for (uint32_t r = 0; r < R; ++r) {  // (uniform loads)
+      const uint32_t c = B.ring_cnt[(size_t)scan * R + r];
+      n += c;
+      ring_max = max(ring_max, c);
+    }
+    if (n > CAP || B.n_filt[scan] > CAP || ring_max > P.max_ring_points || force_redo) {  // (k_front's conditions)
+      if (tid == 0) B.redo[atomicAdd(&B.counters[FX_CNT_REDO], 1u)] = scan;
+      return;
+    }
+    if (n == 0u) {  // ref: node.cpp:209-210, 263-264
+      if (tid == 0) B.n_cand[scan] = 0u, B.n_kp[scan] = 0u, B.n_kpc[scan] = 0u;
+      return;
+    }
+  } else {
+    n = B.front_n[scan];
+    if (n == 0u || n == FX_NONE) return;  // (k_front_ab wrote the empty results / handed the scan to k_front_redo)
+  }
   float *px = reinterpret_cast<float *>(smem + O::px), *py = reinterpret_cast<float *>(smem + O::py), *pz = reinterpret_cast<float *>(smem + O::pz);
   uint32_t *r_off = smem + O::r_off, *r_cnt = smem + O::r_cnt;
   if (tid < R) {
@@ -6609,11 +6643,12 @@ void fxk_front_ab(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint3
                   uint32_t clk_slot, uint32_t force_redo) {
   hipLaunchKernelGGL(k_front_ab, dim3(batch), dim3(FX_FRONT_T), front_ab_lds_bytes(), s, P, B, near_margin, el0, inv_step, clk_slot, force_redo);
 }
-void fxk_front_cd(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t clk_slot, uint32_t merge_cap, uint32_t lean) {
-  if (lean)
+void fxk_front_cd(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t batch, uint32_t clk_slot, uint32_t merge_cap, uint32_t lean,
+                  uint32_t self_n, uint32_t force_redo) {
+  if (lean && !self_n)
     hipLaunchKernelGGL(k_front_cdl, dim3(batch), dim3(FX_FRONT_CDL_T), front_lean_lds_bytes(), s, P, B, clk_slot, merge_cap);
   else
-    hipLaunchKernelGGL(k_front_cd, dim3(batch), dim3(FX_FRONT_T), front_lds_bytes(), s, P, B, clk_slot, merge_cap);
+    hipLaunchKernelGGL(k_front_cd, dim3(batch), dim3(FX_FRONT_T), front_lds_bytes(), s, P, B, clk_slot, merge_cap, self_n, force_redo);
 }
 hipError_t fxk_configure_front(void) {
   hipError_t e = hipFuncSetAttribute((const void *)k_front, hipFuncAttributeMaxDynamicSharedMemorySize, (int)front_lds_bytes());

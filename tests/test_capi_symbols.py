@@ -77,7 +77,7 @@ def test_product_library_has_no_environment_hooks(fxlib):
     from feature_extraction_amd import build
     product = open(build.LIB, "rb").read()
     test = open(build.build_test_hooks(), "rb").read()
-    for name in (b"FX_MERGE_BIG_CAP", b"FX_FRONT_FORCE", b"FX_FRONT_SPLIT", b"FX_MERGE_SLICES", b"FX_GATHER_COUNTED", b"FX_TIER_MIN_GRID", b"FX_DENSE_LDS_KEYS", b"FX_DENSE_WON_POINTS", b"FX_GRAPH_MAX_BATCH", b"FX_DEBUG_SYNC",
+    for name in (b"FX_MERGE_BIG_CAP", b"FX_FRONT_FORCE", b"FX_FRONT_SPLIT", b"FX_FRONT_STREAM", b"FX_MERGE_SLICES", b"FX_GATHER_COUNTED", b"FX_TIER_MIN_GRID", b"FX_DENSE_LDS_KEYS", b"FX_DENSE_WON_POINTS", b"FX_GRAPH_MAX_BATCH", b"FX_DEBUG_SYNC",
                  b"FX_FAIL_AFTER_ENQUEUE"):
         assert name not in product, name
         assert name in test, name

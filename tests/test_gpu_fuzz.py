@@ -40,17 +40,18 @@ def _case(seed):
     return np.ascontiguousarray(s), p, roll, pitch, dict(scene=scene, over=over, kind=kind)
 
 
-@pytest.mark.parametrize("path", ["front", "front-split", "front-split-lean", "separate", "separate-large-merge", "separate-large-merge-sliced", "front-redo", "front-tail"])
+@pytest.mark.parametrize("path", ["front", "front-fused", "front-split", "front-split-lean", "separate", "separate-large-merge", "separate-large-merge-sliced", "front-redo", "front-tail"])
 @pytest.mark.parametrize("block", range(8))
 def test_random_scenes_parameters_and_perturbations(fx_hooks, oracle, block, path):
-    """Every case through the fused front kernel (the default), through its two-launch forms (k_front_ab + k_front_cd / k_front_cdl:
+    """Every case through the front path a scan per call takes by default (the sliced streaming pass and ring split + k_front_cd:
+    batches of up to eight scans), through the fused front kernel (k_front: what larger batches take), through its two-launch forms (k_front_ab + k_front_cd / k_front_cdl:
     measured in round 6, not the default), through the separate kernels, through those with the LDS merge
     tier's capacity lowered (scans with more than 16 candidates take the large merge tier: as one launch, and as its three
     launches with five workgroups a scan in the pair loop), and through the two kernels behind
     k_front (k_front_redo: the general bodies in k_front's shape; k_slow: the same on scratch in HBM)."""
     if path in ("front-redo", "front-tail", "separate-large-merge-sliced", "front-split") and block >= 4:
         pytest.skip("half of the blocks are enough for the rarely used kernels")
-    fx_hooks(**{"front": {}, "front-split": dict(FX_FRONT_SPLIT=1), "front-split-lean": dict(FX_FRONT_SPLIT=2), "separate": dict(FX_FRONT=0), "separate-large-merge": dict(FX_FRONT=0, FX_MERGE_BIG_CAP=16, FX_MERGE_SLICES=1),
+    fx_hooks(**{"front": {}, "front-fused": dict(FX_FRONT_STREAM=0), "front-split": dict(FX_FRONT_SPLIT=1), "front-split-lean": dict(FX_FRONT_SPLIT=2), "separate": dict(FX_FRONT=0), "separate-large-merge": dict(FX_FRONT=0, FX_MERGE_BIG_CAP=16, FX_MERGE_SLICES=1),
                 "separate-large-merge-sliced": dict(FX_FRONT=0, FX_MERGE_BIG_CAP=16, FX_MERGE_SLICES=5), "front-redo": dict(FX_FRONT_FORCE=1), "front-tail": dict(FX_FRONT_FORCE=2)}[path])
     total_k = 0
     for seed in range(block * 10, block * 10 + 10):

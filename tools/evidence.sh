@@ -3,7 +3,7 @@
 # usage: tools/evidence.sh TAG        -> gpurun_out/evidence_TAG/* and gpurun_out/prof_TAG*/ (summarised afterwards with
 #        tools/summarize_profile.py TAG, TAG_c1 and tools/summarize_config_profile.py TAG 3|5)
 set -u
-TAG=${1:-r05c}
+TAG=${1:-r06a}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 E=$R/gpurun_out/evidence_$TAG
 mkdir -p "$E"
@@ -16,6 +16,7 @@ feature_extraction_amd/bin/fx_multi_cli --batch 1024 --steps 40 --inflight 1 > "
 feature_extraction_amd/bin/fx_multi_cli --batch 1024 --steps 40 --inflight 2 >> "$E/fx_multi_1gpu.log" 2>&1
 feature_extraction_amd/bin/fx_multi_cli --batch 1024 --steps 40 --inflight 4 >> "$E/fx_multi_1gpu.log" 2>&1
 feature_extraction_amd/bin/fx_multi_cli --batch 1024 --steps 20 --inflight 4 --host-input >> "$E/fx_multi_1gpu.log" 2>&1
+feature_extraction_amd/bin/fx_multi_cli --batch 1024 --steps 40 --inflight 4 --root 0 >> "$E/fx_multi_1gpu.log" 2>&1
 feature_extraction_amd/bin/fx_batcher_cli --sensors 4 --hz 10 --seconds 3 --out /tmp/batcher_a.bin > "$E/batcher.log" 2>&1
 feature_extraction_amd/bin/fx_batcher_cli --sensors 8 --burst 32 --out /tmp/batcher_b.bin >> "$E/batcher.log" 2>&1
 : > "$E/streaming_latency.jsonl"
@@ -25,8 +26,8 @@ bash tools/profile.sh $TAG > "$E/profile.log" 2>&1
 bash tools/profile.sh ${TAG}_c1 --contexts 1 > "$E/profile_c1.log" 2>&1
 FX_PROFILE_PMC=1 bash tools/profile_config.sh $TAG 3 > "$E/profile_cfg3.log" 2>&1
 FX_PROFILE_PMC=1 bash tools/profile_config.sh $TAG 5 > "$E/profile_cfg5.log" 2>&1
-# parity beyond the suite, on this binary: the VLP-16 fuzz through five front paths, the dense fuzz, determinism
-timeout 1500 python3 tools/fuzz_more.py 0 1500 > "$E/fuzz_more.log" 2>&1
+# parity beyond the suite, on this binary: the VLP-16 fuzz through every front path (eight since round 6), the dense fuzz, determinism
+timeout 2700 python3 tools/fuzz_more.py 0 1000 > "$E/fuzz_more.log" 2>&1
 timeout 900 python3 tools/fuzz_dense.py 0 300 > "$E/fuzz_dense.log" 2>&1
 feature_extraction_amd/bin/fx_multi_cli --selftest 8 --batch 61 --steps 6 --inflight 3 --bad-scan 60 > "$E/fx_multi_selftest8.log" 2>&1
 ls "$E"

@@ -9,10 +9,10 @@ from feature_extraction_amd import capi
 from oracle import oracle_py as O
 from tests import util
 from tests.test_gpu_fuzz import _case
-PATHS = {"front": None, "front-split": dict(FX_FRONT_SPLIT="1"), "front-split-lean": dict(FX_FRONT_SPLIT="2"), "separate": dict(FX_FRONT="0"), "separate-large-merge": dict(FX_FRONT="0", FX_MERGE_BIG_CAP="16", FX_MERGE_SLICES="1"),
+PATHS = {"front": None, "front-fused": dict(FX_FRONT_STREAM="0"), "front-split": dict(FX_FRONT_SPLIT="1"), "front-split-lean": dict(FX_FRONT_SPLIT="2"), "separate": dict(FX_FRONT="0"), "separate-large-merge": dict(FX_FRONT="0", FX_MERGE_BIG_CAP="16", FX_MERGE_SLICES="1"),
          "separate-large-merge-sliced": dict(FX_FRONT="0", FX_MERGE_BIG_CAP="16", FX_MERGE_SLICES="5"),
          "front-redo": dict(FX_FRONT_FORCE="1"), "front-tail": dict(FX_FRONT_FORCE="2")}
-HOOKS = ("FX_FRONT", "FX_MERGE_BIG_CAP", "FX_FRONT_FORCE", "FX_FRONT_SPLIT", "FX_MERGE_SLICES")
+HOOKS = ("FX_FRONT", "FX_MERGE_BIG_CAP", "FX_FRONT_FORCE", "FX_FRONT_SPLIT", "FX_MERGE_SLICES", "FX_FRONT_STREAM")
 t0 = time.time(); bad = 0; total_k = 0; n_over = 0
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 paths = sys.argv[3].split(",") if len(sys.argv) > 3 else list(PATHS)
