@@ -64,3 +64,27 @@ def test_the_product_library_slices_big_scans_in_small_batches(fxlib, oracle):
         util.compare_scan(got[b], oracle.run(p, hd[b], roll=0.02, pitch=-0.015), tag=f"hdl64 sliced {b}")
         for key in ("filtered", "candidates", "kpc", "keypoints", "descriptors"):
             util.assert_bit_equal(got[b][key], one[b][key], f"sliced == one workgroup a scan: scan {b} {key}")
+
+
+@pytest.mark.parametrize("batch", [1, 3, 8, 9])
+def test_a_scan_per_call_takes_the_sliced_pass_with_the_clustering_kernel_behind_it(fxlib, fx_hooks, oracle, batch):
+    """VERDICT r5 #5 (ref: node.cpp:72, :386 — the reference handles one scan per callback): batches of up to eight VLP-16 scans
+    take k_prep_count + k_prep_sliced + k_bucket_sliced (sixteen workgroups a scan) with k_front_cd behind them instead of
+    k_front; from nine on the fused kernel.  The product's own choice against the oracle, and bit-identical to the other path
+    forced by the test build's hook — ragged, empty, NaN, window-boundary and reversed scans included, twice per context."""
+    scans = (_scans() * 2)[:batch]
+    p = capi.params("launch")
+    lim = capi.limits(batch, 28800, max_keypoints=512, max_total_keypoints=4096)
+    ctx = capi.Context(p, lim)
+    got = [ctx.process_host(scans if rep == 0 else scans[::-1], roll=0.02, pitch=-0.015) for rep in range(2)]
+    ctx.close()
+    for b, s in enumerate(scans):
+        util.compare_scan(got[0][b], oracle.run(p, s, roll=0.02, pitch=-0.015), tag=f"batch of {batch}, scan {b}")
+    fx_hooks(FX_FRONT_STREAM=0 if batch <= 8 else 1)  # the other path
+    ctx = capi.Context(p, lim)
+    other = ctx.process_host(scans, roll=0.02, pitch=-0.015)
+    ctx.close()
+    for b in range(batch):
+        for key in ("filtered", "candidates", "cand_size", "kpc", "kpc_cand", "cand_keypoint", "keypoints", "kp_size", "kp_neighbors", "descriptors"):
+            util.assert_bit_equal(got[0][b][key], other[b][key], f"batch of {batch}: sliced + k_front_cd against k_front, scan {b} {key}")
+            util.assert_bit_equal(got[1][batch - 1 - b][key], other[b][key], f"batch of {batch}: second batch of the context, scan {b} {key}")
