@@ -343,8 +343,13 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof, bo
         FX_HIP(mark(1));
       }
       for (int i = 2; i <= 4; ++i) FX_HIP(mark(i));
+      // (the grid k_front_redo gets when the last 64 batches handed it nothing: ONE workgroup when the caller keeps four
+      //  batches in flight — an empty launch of k_front-shaped workgroups waits for whole free CUs in the other batches' way:
+      //  four of them cost the headline 0.6 %, eight 1.1 % —, four otherwise: a stream with the chip to itself pays nothing for
+      //  them, and a batch that suddenly hands on many scans is not dealt through a single workgroup — ADVICE r5)
+      const uint32_t redo_floor = c->batches_in_flight >= 4u ? 1u : 4u;
       if (!(c->skip_mask & 1u))
-      fxk_front_redo(s, P, B, el0, inv_step, c->merge_huge_ccap, c->front_force >= 2u ? 1u : 0u, tier_grid(hint[6], 2 * big_grid, batch, 1, 1));
+      fxk_front_redo(s, P, B, el0, inv_step, c->merge_huge_ccap, c->front_force >= 2u ? 1u : 0u, tier_grid(hint[6], 2 * big_grid, batch, 1, redo_floor));
       fxk_slow(s, P, B, c->merge_huge_ccap, tier_grid(hint[7], big_grid, batch), batch, clk_next);  // (its last workgroup does the batch's keypoint offsets too)
       FX_HIP(mark(5));
     } else {
