@@ -4037,7 +4037,9 @@ extern "C" __global__ __launch_bounds__(FX_SLOW_T) void k_slow(FxDevParams P, Fx
   const uint32_t n_slow = B.counters[FX_CNT_REDO + 1];
   const uint32_t R = (uint32_t)P.n_rings, PW = (R + 31u) / 32u;
   uint32_t *gs = B.gs_pool + (size_t)blockIdx.x * P.gs_words;
+  bool did = false;  // (workgroup-uniform) this workgroup wrote results
   for (uint32_t w = blockIdx.x; w < n_slow; w += gridDim.x) {
+    did = true;
     const uint32_t scan = B.slow[w];
     uint32_t *pend = B.ring_pending + (size_t)scan * PW;
     for (uint32_t ring = 0; ring < R; ++ring) {
@@ -4052,7 +4054,8 @@ extern "C" __global__ __launch_bounds__(FX_SLOW_T) void k_slow(FxDevParams P, Fx
     wg_global_sync();
   }
   // ---- the last workgroup of the launch does the offsets
-  __syncthreads();  // (every wavefront's stores above are issued; smem is free)
+  if (did && gridDim.x > 1u) __threadfence();  // (EVERY wavefront that stored results waits for its own stores and writes them back before the ticket is drawn)
+  __syncthreads();  // (smem is free)
   if (threadIdx.x == 0) {
     uint32_t last = 1u;
     if (gridDim.x > 1u) {
