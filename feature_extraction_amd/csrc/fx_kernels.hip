@@ -5966,6 +5966,10 @@ extern "C" __global__ __launch_bounds__(FX_DDENS_T) void k_dense_density(FxDevPa
         }
       }
       __syncthreads();
+#if defined(FX_DDENS_STOP) && FX_DDENS_STOP == 1  // (measurement build: windows loaded, nothing walked)
+      __syncthreads();
+      continue;
+#endif
       // ---- passes: every lane lists up to FX_DDENS_RUNS units of its quad, the workgroup sorts them, its wavefronts walk them
       // (the rows come in the order of the concatenation, so a lane's cursor r0 only moves forward: rows that end before the
       //  window are behind it, the row loop stops at the first row that starts after the window)
@@ -6021,6 +6025,10 @@ extern "C" __global__ __launch_bounds__(FX_DDENS_T) void k_dense_density(FxDevPa
         for (int k = 0; k < FX_DDENS_RUNS; ++k)
           if ((uint32_t)k < n_run) s_unit[atomicAdd(&s_hist[ddens_bin((run[k] >> 19) + 1u)], 1u)] = run[k];
         __syncthreads();
+#if defined(FX_DDENS_STOP) && FX_DDENS_STOP == 2  // (measurement build: units listed and sorted, nothing walked)
+        __syncthreads();
+        continue;
+#endif
         while (true) {  // slots of 64 units, longest first, to whichever wavefront is free
           uint32_t j = 0;
           if (lane == 0) j = atomicAdd(&s_w[1], 64u);
