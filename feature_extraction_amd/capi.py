@@ -33,7 +33,7 @@ STAGE_KERNELS = {"k_prep": ("k_prep", "k_front", "k_front_ab"),  # (k_front: sta
                  "k_merge": ("k_merge_small", "k_merge_big", "k_merge_huge", "k_front_redo", "k_slow"),
                  "k_desc_mid": ("k_desc_mid",),
                  "k_gather": ("k_gather", "k_rng_ord"),  # (k_rng_ord only when several workgroups share a scan: small batches)
-                 "k_desc_rare": ("k_dense_sort", "k_dense_density", "k_dense_finish_s", "k_dense_finish_l")}
+                 "k_desc_rare": ("k_dense_sort", "k_dense_density", "k_dense_finish")}
 
 
 class FxParams(C.Structure):

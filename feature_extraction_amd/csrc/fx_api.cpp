@@ -28,7 +28,7 @@ size_t fxk_desc_lds_bytes(uint32_t cap);
 size_t fxk_gather_lds_bytes(uint32_t max_keypoints);
 uint32_t fxk_dense_cells(void);
 uint32_t fxk_group_cap(void);
-uint32_t fxk_dfin_kl(void);
+uint32_t fxk_dfin_k(void);
 void fxk_dense(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t n_cu, uint32_t rows, uint32_t items);
 size_t fxk_dense_slow_words(uint32_t max_points);
 size_t fxk_merge_huge_lds_bytes(uint32_t cap, uint32_t ccap, uint32_t n_rings);
@@ -635,7 +635,7 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
     P.max_dense_rows = (uint32_t)(rows < L.max_total_keypoints ? rows : L.max_total_keypoints);
   }
   P.dense_qcap = P.dense_cap > 0x7ff00000u ? 0xfff00000u : 2u * P.dense_cap;  // (cells' queries padded to four: typically 1.2 entries per query)
-  P.dense_lds_keys = fxk_dfin_kl();
+  P.dense_lds_keys = fxk_dfin_k();
   if (const char *e = test_hook("FX_DENSE_LDS_KEYS")) {  // test hook: push rows on to the global-memory key sort (can only lower the cap)
     const int v = atoi(e);
     if (v >= 1 && (uint32_t)v < P.dense_lds_keys) P.dense_lds_keys = (uint32_t)v;

@@ -39,7 +39,7 @@ struct FxDevParams {
   uint32_t dense_cap;       // entries of the sorted pool (and of the key pool) per batch
   uint32_t max_dense_rows;  // rows of the dense-row list / cell tables
   uint32_t dense_qcap;      // entries of the query pool (every cell's queries padded to four: up to 4 per support point)
-  uint32_t dense_lds_keys;  // binned neighbours k_dense_finish_l sorts in LDS (16384; tests lower it to reach the key pool)
+  uint32_t dense_lds_keys;  // binned neighbours k_dense_finish sorts in LDS (14336; tests lower it to reach the key pool)
   uint32_t dense_won_points;  // support points of a row whose query marks k_dense_sort keeps as a bit map in LDS (65536; tests lower it)
   // slow tier (k_slow): scratch regions in HBM for what exceeds every LDS-sized tier
   uint32_t gs_slots;  // regions (= the largest grid k_slow is launched with)

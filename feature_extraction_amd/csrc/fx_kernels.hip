@@ -5486,10 +5486,15 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_mid(FxDevParams P, Fx
 #endif
 #define FX_DSORT_WONW 2048     // words of k_dense_sort's winners bit map
 #define FX_DQ_WON 0x80000000u  // sorted region, index word: the row computes this point's density (set by k_dense_sort)
-#define FX_DFIN_KS 4096    // binned neighbours the small finishing kernel sorts in LDS
-#define FX_DFIN_KL 14336   // ... the large one (keys + order + bin table: 152 KB of LDS)
-#define FX_DFIN_TS 256
-#define FX_DFIN_TL 1024
+#ifndef FX_DFIN_K
+#define FX_DFIN_K 14336    // binned neighbours the finishing kernel sorts in LDS (keys + order + bin table: 152 KB)
+#endif
+#ifndef FX_DFIN_T
+#define FX_DFIN_T 1024
+#endif
+#ifndef FX_DFIN_OCC
+#define FX_DFIN_OCC 1
+#endif
 // size classes of the tier's rows and the batch counters that count them (k_desc_group fills the class lists)
 __device__ __forceinline__ uint32_t dense_class(uint32_t nS) { return nS > 8192u ? 0u : (nS > 4096u ? 1u : (nS > 2048u ? 2u : 3u)); }
 __device__ __forceinline__ uint32_t dense_class_counter(uint32_t cls) { return cls == 0u ? 2u : (cls == 1u ? 3u : (cls == 2u ? 7u : 10u)); }
@@ -5774,7 +5779,7 @@ extern "C" __global__ __launch_bounds__(FX_DSORT_T) void k_dense_sort(FxDevParam
       B.dense_nq[slot] = n_q;
       B.dense_qoff[slot] = qoff;
       B.dense_nm[slot] = s_w[10];
-      if (s_w[10] > min(P.dense_lds_keys, (uint32_t)FX_DFIN_KL)) {  // keys beyond the finishing kernel's LDS array: a region of the key pool
+      if (s_w[10] > min(P.dense_lds_keys, (uint32_t)FX_DFIN_K)) {  // keys beyond the finishing kernel's LDS array: a region of the key pool
         uint32_t p2 = 1;
         while (p2 < s_w[10]) p2 <<= 1;
         const uint32_t koff = atomicAdd(&B.counters[12], p2);
@@ -6323,8 +6328,12 @@ __device__ __forceinline__ void dense_finish_row(const FxDevParams &P, const FxB
     FX_COUNT(56, nS);
   }
 }
-// rows of up to KS binned neighbours: 256-thread workgroups, several per CU; larger: one 1024-thread workgroup per CU
-template <int KMAX, int NT, bool LARGE>
+// Every row of the tier by ONE kernel shape, the largest first (1024 threads, the LDS of a CU).  Until round 6 rows of up to 4096
+// binned neighbours had a kernel of their own (256 threads, three workgroups a CU) launched before this one: a row is a chain of a
+// dozen barrier-separated steps whose length hardly depends on the row — a quarter of the lanes made it longer, and the second
+// launch waited for the first: one launch is 3 % (config 3, 2528 rows) to 10 % (10 240 small rows) shorter a batch
+// (profiles/r06_experiments.md §11).
+template <int KMAX, int NT>
 __device__ __forceinline__ void dense_finish_loop(const FxDevParams &P, const FxBuffers &B) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   if (B.counters[6] == 0u) return;  // no dense rows in this batch
@@ -6333,13 +6342,10 @@ __device__ __forceinline__ void dense_finish_loop(const FxDevParams &P, const Fx
   uint32_t *s_slot = tl + FX_TABLE_WORDS + 8;
   const unsigned long long seq = B.seq[0];
   while (true) {
-    const uint32_t slot = dense_next(P, B, LARGE ? 0u : 5u, s_slot);
+    const uint32_t slot = dense_next(P, B, 0u, s_slot);
     if (slot == FX_NONE) break;
     const uint32_t nM = B.dense_nm[slot];
     if (nM == FX_NONE) continue;  // failed row (flagged)
-    // (P.dense_lds_keys: tests lower it to reach the global-memory sort)
-    const bool large = nM > (uint32_t)FX_DFIN_KS || nM > P.dense_lds_keys;
-    if (large != LARGE) continue;
     const uint32_t row = B.dense_rows[slot];
     const uint2 rm = B.row_map[row];
     if (B.kp_nbrs[(size_t)rm.x * P.max_keypoints + rm.y] == 0u) {  // no point within R: NaN descriptor, no RNG draw (A.8-3)
@@ -6347,14 +6353,11 @@ __device__ __forceinline__ void dense_finish_loop(const FxDevParams &P, const Fx
       continue;
     }
     if (nM == 0) continue;  // (only the keypoint's own point: the cleared row is the descriptor)
-    dense_finish_row<KMAX, NT>(P, B, slot, smem, T, seq);
+    dense_finish_row<KMAX, NT>(P, B, slot, smem, T, seq);  // (more keys than KMAX or P.dense_lds_keys — tests lower it —: sorted in the key pool)
   }
 }
-extern "C" __global__ __launch_bounds__(FX_DFIN_TS) void k_dense_finish_s(FxDevParams P, FxBuffers B) {
-  dense_finish_loop<FX_DFIN_KS, FX_DFIN_TS, false>(P, B);
-}
-extern "C" __global__ __launch_bounds__(FX_DFIN_TL) void k_dense_finish_l(FxDevParams P, FxBuffers B) {
-  dense_finish_loop<FX_DFIN_KL, FX_DFIN_TL, true>(P, B);
+extern "C" __global__ __launch_bounds__(FX_DFIN_T, FX_DFIN_OCC) void k_dense_finish(FxDevParams P, FxBuffers B) {
+  dense_finish_loop<FX_DFIN_K, FX_DFIN_T>(P, B);
 }
 
 // RNG ordinals when several workgroups of k_gather shared a scan (small batches): 3DSC draws its three numbers only for
@@ -6535,14 +6538,14 @@ void fxk_rings_large(hipStream_t s, const FxDevParams &P, const FxBuffers &B, ui
 size_t fxk_merge_lds_bytes(uint32_t cap, uint32_t n_rings) { return merge_words(cap, cap, n_rings, true) * 4; }
 size_t fxk_merge_huge_lds_bytes(uint32_t cap, uint32_t ccap, uint32_t n_rings) { return merge_words(cap, ccap, n_rings, false) * 4; }
 size_t fxk_gather_lds_bytes(uint32_t max_keypoints) { return (size_t)gather_words(std::min(max_keypoints, (uint32_t)FX_GATHER_KCAP), FX_GATHER_WIDE_T) * 4; }
-size_t fxk_dense_finish_lds_bytes(int large) {
-  const size_t k = large ? FX_DFIN_KL : FX_DFIN_KS;
+size_t fxk_dense_finish_lds_bytes(void) {
+  const size_t k = FX_DFIN_K;
   return (2 * k + k / 2 + 1984 + FX_TABLE_WORDS + 16) * 4;
 }
 uint32_t fxk_dense_cells(void) { return FX_DCELLS; }
 // build parameters of this translation unit the host sizes buffers by (a build with other values must not outrun them)
 uint32_t fxk_group_cap(void) { return FX_GROUP_CAP; }  // bins k_desc_group records per row (FxBuffers::desc_bins)
-uint32_t fxk_dfin_kl(void) { return FX_DFIN_KL; }      // binned neighbours k_dense_finish_l sorts in LDS
+uint32_t fxk_dfin_k(void) { return FX_DFIN_K; }        // binned neighbours k_dense_finish sorts in LDS
 size_t fxk_desc_lds_bytes(uint32_t cap) { return (size_t)(16 + FX_DESC_WORDS_PER_POINT * cap + FX_DESC_BINS) * 4; }
 
 hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t merge_huge, size_t desc_big, size_t gather) {
@@ -6571,7 +6574,7 @@ hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t merge_huge, s
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void *)k_desc_mid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)desc_big);
   if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void *)k_dense_finish_l, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fxk_dense_finish_lds_bytes(1));
+  e = hipFuncSetAttribute((const void *)k_dense_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fxk_dense_finish_lds_bytes());
   return e;
 }
 
@@ -6717,8 +6720,7 @@ void fxk_dense(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t
   auto grid = [](uint32_t want, uint32_t full) { return want < full ? (want ? want : 1u) : full; };
   hipLaunchKernelGGL(k_dense_sort, dim3(grid(rows, n_cu * (1024 / FX_DSORT_T))), dim3(FX_DSORT_T), 0, s, P, B);
   hipLaunchKernelGGL(k_dense_density, dim3(grid(items, n_cu * 3)), dim3(FX_DDENS_T), 0, s, P, B);
-  hipLaunchKernelGGL(k_dense_finish_s, dim3(grid(rows, n_cu * 3)), dim3(FX_DFIN_TS), fxk_dense_finish_lds_bytes(0), s, P, B);
-  hipLaunchKernelGGL(k_dense_finish_l, dim3(grid(rows, n_cu)), dim3(FX_DFIN_TL), fxk_dense_finish_lds_bytes(1), s, P, B);
+  hipLaunchKernelGGL(k_dense_finish, dim3(grid(rows, n_cu)), dim3(FX_DFIN_T), fxk_dense_finish_lds_bytes(), s, P, B);
 }
 #ifdef FX_TEST_HOOKS
 extern "C" __global__ __launch_bounds__(FX_WG) void k_test_elevation(const float *xyz, uint32_t n, const double *tab, float *fast, uint8_t *ok,

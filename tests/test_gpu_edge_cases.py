@@ -224,7 +224,7 @@ def test_overflowed_lists_take_the_dense_tier(fxlib, oracle):
 
 
 def test_dense_tier_key_sort_in_global_memory(fx_hooks, oracle):
-    """k_dense_finish_l sorts up to 16384 keys in LDS; rows beyond that sort in their region of the key pool. Reached
+    """k_dense_finish sorts up to 14336 keys in LDS; rows beyond that sort in their region of the key pool. Reached
     here by lowering the LDS capacity (FX_DENSE_LDS_KEYS is read at fx_create; it can only lower it)."""
     s = util.vlp16_scan(1000)
     fx_hooks(FX_DENSE_LDS_KEYS=20)

@@ -41,7 +41,7 @@ t, d, q, wv, lanes = v[44], v[45], v[46], v[47], v[48]
 if q:
     print(f"k_dense_density: {q:.0f} queries in {lanes:.0f} quads ({q / lanes:.2f} per quad); targets walked per quad {t / lanes:.0f}, "
           f"trips per wavefront and 64 quads (unit slots: the longest unit of each) {wv / (lanes / 64):.0f}; true density per query {d / q:.0f}")
-# k_dense_finish_s / _l (LDS path): columns 49..57 of a -DFX_STAMPS -DFX_STAMPS_FINISH build (FX_STAMPS_LIB names it)
+# k_dense_finish (LDS path): columns 49..57 of a -DFX_STAMPS -DFX_STAMPS_FINISH build (FX_STAMPS_LIB names it)
 if v[57] and "finish" in os.environ.get("FX_STAMPS_LIB", ""):
     n = v[54]
     print(f"k_dense_finish: {n:.0f} rows (stamped workgroups only), binned neighbours {v[55] / n:.0f}, support {v[56] / n:.0f}; cycles per row: "

@@ -14,7 +14,10 @@ from oracle import oracle_py as O
 from tests import util
 from tests.test_gpu_fuzz_dense import dense_case
 
-capi.load()
+if os.environ.get("FX_USE_TEST_LIB"):  # the test build, so that the FX_* hooks of the environment apply (e.g. FX_DENSE_ONE_FINISH=1)
+    capi.test_hooks().__enter__()
+else:
+    capi.load()
 O.load()
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 t0 = time.time()
