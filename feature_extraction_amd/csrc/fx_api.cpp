@@ -360,8 +360,11 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof, bo
       slices = (uint32_t)c->prep_slices;  // (test hook)
     } else if (4u * batch <= 2u * big_grid && L.max_points >= 65536u) {
       // (from four workgroups a scan on: with two — 256 scans of 131 072 points — the second read of the scan costs more
-      //  than the wider grid gains: k_prep 0.15 -> 0.23 ms; with eight — 64 scans of 262 144 points — 0.23 -> 0.125 ms)
-      slices = (2u * big_grid + batch - 1u) / batch;
+      //  than the wider grid gains: k_prep 0.15 -> 0.23 ms; with eight — 64 scans of 262 144 points — 0.23 -> 0.125 ms.
+      //  Three workgroups a CU in all: what k_bucket_sliced's scalar registers (106: six wavefronts a SIMD) let be resident at once — 64 scans: the ring split
+      //  0.092 / 0.065 / 0.109 ms with 8 / 12 / 16 a scan; 128 scans: 0.16 / 0.109 / 0.206 with 4 / 6 / 8,
+      //  profiles/r06_experiments.md §12)
+      slices = 3u * big_grid / batch;
     }
     slices = std::max(1u, std::min(slices, fxk_prep_slices_max()));
     if (slices > 1) {

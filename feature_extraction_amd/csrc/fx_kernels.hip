@@ -5484,6 +5484,9 @@ extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_mid(FxDevParams P, Fx
 #ifndef FX_DSORT_T
 #define FX_DSORT_T 512
 #endif
+#ifndef FX_DSORT_PER_CU
+#define FX_DSORT_PER_CU (1024 / FX_DSORT_T)  // workgroups a CU of the full grid
+#endif
 #define FX_DSORT_WONW 2048     // words of k_dense_sort's winners bit map
 #define FX_DQ_WON 0x80000000u  // sorted region, index word: the row computes this point's density (set by k_dense_sort)
 #ifndef FX_DFIN_K
@@ -6718,7 +6721,7 @@ size_t fxk_dense_slow_words(uint32_t max_points) { return ((size_t)FX_DESC_WORDS
 // (rows and items are taken by ticket: any grid is correct; the full ones are what is resident at once)
 void fxk_dense(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t n_cu, uint32_t rows, uint32_t items) {
   auto grid = [](uint32_t want, uint32_t full) { return want < full ? (want ? want : 1u) : full; };
-  hipLaunchKernelGGL(k_dense_sort, dim3(grid(rows, n_cu * (1024 / FX_DSORT_T))), dim3(FX_DSORT_T), 0, s, P, B);
+  hipLaunchKernelGGL(k_dense_sort, dim3(grid(rows, n_cu * FX_DSORT_PER_CU)), dim3(FX_DSORT_T), 0, s, P, B);
   hipLaunchKernelGGL(k_dense_density, dim3(grid(items, n_cu * 3)), dim3(FX_DDENS_T), 0, s, P, B);
   hipLaunchKernelGGL(k_dense_finish, dim3(grid(rows, n_cu)), dim3(FX_DFIN_T), fxk_dense_finish_lds_bytes(), s, P, B);
 }
