@@ -29,7 +29,7 @@ size_t fxk_gather_lds_bytes(uint32_t max_keypoints);
 uint32_t fxk_dense_cells(void);
 uint32_t fxk_group_cap(void);
 uint32_t fxk_dfin_k(void);
-void fxk_dense(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t n_cu, uint32_t rows, uint32_t items);
+void fxk_dense(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t n_cu, uint32_t rows, uint32_t items, uint32_t skip);
 size_t fxk_dense_slow_words(uint32_t max_points);
 size_t fxk_merge_huge_lds_bytes(uint32_t cap, uint32_t ccap, uint32_t n_rings);
 hipError_t fxk_configure(size_t ring_big, size_t merge_big, size_t merge_huge, size_t desc_big, size_t gather);
@@ -201,7 +201,7 @@ struct fx_ctx {
   int merge_slices = -1;                   // test hook (FX_MERGE_SLICES): workgroups a scan in the large merge tier's pair loop (1: the one launch)
   int prep_slices = -1;                    // test hook (FX_PREP_SLICES): workgroups a scan in the separate kernels' streaming pass and ring split
   int dense_force = -1;                    // test hook (FX_DENSE_SLOW): 1 always k_desc_mid's workgroups, 0 always the four kernels
-  uint32_t skip_mask = 0;      // experiment hook (FX_SKIP_EMPTY, test build): bit 0 no k_front_redo, bit 1 no dense tier — only for workloads that need neither
+  uint32_t skip_mask = 0;      // experiment hook (FX_SKIP_EMPTY, test build): bit 0 no k_front_redo, bit 1 no dense tier — only for workloads that need neither; bits 2 / 3: no k_dense_finish / k_dense_density (measurement: results wrong)
   static constexpr uint32_t front_retry = 64;
 };
 
@@ -442,7 +442,7 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof, bo
         const uint32_t rows = tier_grid(hint[4], 3 * big_grid, max_rows);
         // density items: 1024 queries each, at most one a row more than the support points fill
         const uint32_t items = hint[5] == 0xffffffffu ? 3 * big_grid : tier_grid(hint[4] + hint[5] / 1024u, 3 * big_grid, 0xffffffffu);
-        fxk_dense(s, P, B, big_grid, rows, items);
+        fxk_dense(s, P, B, big_grid, rows, items, (c->skip_mask >> 2) & 3u);
       }
     } else {
       for (int i = 6; i <= 8; ++i) FX_HIP(mark(i));

@@ -6719,11 +6719,12 @@ void fxk_desc_mid(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint3
 }
 size_t fxk_dense_slow_words(uint32_t max_points) { return ((size_t)FX_DESC_WORDS_PER_POINT * max_points + 3) & ~(size_t)3; }
 // (rows and items are taken by ticket: any grid is correct; the full ones are what is resident at once)
-void fxk_dense(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t n_cu, uint32_t rows, uint32_t items) {
+void fxk_dense(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t n_cu, uint32_t rows, uint32_t items, uint32_t skip) {
   auto grid = [](uint32_t want, uint32_t full) { return want < full ? (want ? want : 1u) : full; };
   hipLaunchKernelGGL(k_dense_sort, dim3(grid(rows, n_cu * FX_DSORT_PER_CU)), dim3(FX_DSORT_T), 0, s, P, B);
-  hipLaunchKernelGGL(k_dense_density, dim3(grid(items, n_cu * 3)), dim3(FX_DDENS_T), 0, s, P, B);
-  hipLaunchKernelGGL(k_dense_finish, dim3(grid(rows, n_cu)), dim3(FX_DFIN_T), fxk_dense_finish_lds_bytes(), s, P, B);
+  // (skip: measurement only — a test build's FX_SKIP_EMPTY bits 2 / 3: the tier's share of a step with batches in flight)
+  if (!(skip & 2u)) hipLaunchKernelGGL(k_dense_density, dim3(grid(items, n_cu * 3)), dim3(FX_DDENS_T), 0, s, P, B);
+  if (!(skip & 1u)) hipLaunchKernelGGL(k_dense_finish, dim3(grid(rows, n_cu)), dim3(FX_DFIN_T), fxk_dense_finish_lds_bytes(), s, P, B);
 }
 #ifdef FX_TEST_HOOKS
 extern "C" __global__ __launch_bounds__(FX_WG) void k_test_elevation(const float *xyz, uint32_t n, const double *tab, float *fast, uint8_t *ok,

@@ -3,7 +3,7 @@
 # usage: tools/evidence.sh TAG        -> gpurun_out/evidence_TAG/* and gpurun_out/prof_TAG*/ (summarised afterwards with
 #        tools/summarize_profile.py TAG, TAG_c1 and tools/summarize_config_profile.py TAG 3|5)
 set -u
-TAG=${1:-r06c}
+TAG=${1:-r06d}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 E=$R/gpurun_out/evidence_$TAG
 mkdir -p "$E"
