@@ -193,14 +193,14 @@ struct fx_ctx {
   bool state_suspect = false;
   uint32_t fail_after = 0;     // test hook (FX_FAIL_AFTER_ENQUEUE = n: the n-th batch returns an error after its kernels were enqueued)
   uint32_t front_pause = 0;    // batches left on the separate kernels
-  // The dense descriptor tier: its four kernels when a recent batch had rows for it (or nothing is known), else a handful of
+  // The dense descriptor tier: its own kernels (k_dense_sort, k_dense_density, k_dense_finish) when a recent batch had rows for it (or nothing is known), else a handful of
   // workgroups in k_desc_mid's launch (dense_slow_loop) that compute whatever does turn up, slower — the same results either way.
-  uint32_t dense_fast_left = 0;            // batches that still get the four kernels after the last one that needed them
+  uint32_t dense_fast_left = 0;            // batches that still get the tier's kernels after the last one that needed them
   static constexpr uint32_t dense_linger = 64;
   int gather_slices = -1;                  // test hook (FX_GATHER_COUNTED): workgroups a scan in the support gather's counted slices (1: one workgroup a scan)
   int merge_slices = -1;                   // test hook (FX_MERGE_SLICES): workgroups a scan in the large merge tier's pair loop (1: the one launch)
   int prep_slices = -1;                    // test hook (FX_PREP_SLICES): workgroups a scan in the separate kernels' streaming pass and ring split
-  int dense_force = -1;                    // test hook (FX_DENSE_SLOW): 1 always k_desc_mid's workgroups, 0 always the four kernels
+  int dense_force = -1;                    // test hook (FX_DENSE_SLOW): 1 always k_desc_mid's workgroups, 0 always the tier's own kernels
   uint32_t skip_mask = 0;      // experiment hook (FX_SKIP_EMPTY, test build): bit 0 no k_front_redo, bit 1 no dense tier — only for workloads that need neither; bits 2 / 3: no k_dense_finish / k_dense_density (measurement: results wrong)
   static constexpr uint32_t front_retry = 64;
 };
@@ -425,7 +425,7 @@ fx_status enqueue_stages(fx_ctx *c, hipStream_t s, uint32_t batch, bool prof, bo
       FX_HIP(mark(6));
       fxk_desc_group(s, P, B, batch, desc_grid);
       FX_HIP(mark(7));
-      // The dense tier (larger support sets and overflowed lists; nothing on sparse scans): its four kernels, or a handful of
+      // The dense tier (larger support sets and overflowed lists; nothing on sparse scans): its own three kernels, or a handful of
       // workgroups of k_desc_mid's launch — the previous batches decide speed, never results.
       // (beside k_desc_mid on a second stream of the context: measured and dropped, profiles/r04_front_experiments.md)
       bool fast = capture || hint[4] != 0u;  // (0xffffffff: nothing known yet)

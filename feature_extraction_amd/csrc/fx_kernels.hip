@@ -5416,8 +5416,8 @@ __device__ __forceinline__ void desc_wg_loop(const FxDevParams &P, const FxBuffe
 // The fp32 pass runs 256-thread workgroups, four keypoints per CU at a time (most phases of a keypoint are
 // latency chains that leave lanes idle, so concurrency beats width).
 #define FX_DESC_WG_FAST_T 256
-// The dense tier's rows WITHOUT its four launches: a batch whose predecessors had no dense row (every VLP-16-class batch) gets
-// a handful of workgroups of k_desc_mid's launch instead — 256 threads and 8 KB of LDS place anywhere, where the four kernels'
+// The dense tier's rows WITHOUT its launches (four in round 5, three since k_dense_finish takes every row): a batch whose predecessors had no dense row (every VLP-16-class batch) gets
+// a handful of workgroups of k_desc_mid's launch instead — 256 threads and 8 KB of LDS place anywhere, where the tier's own kernels'
 // workgroups each wait for a large LDS slot behind the other batches' kernels (+3.7 % on the headline with them gone,
 // profiles/r05_experiments.md).  A row that does turn up is computed here by the list tier's body on scratch in HBM, its
 // support set re-gathered from the scan: slower, the same result (each row counts its neighbours' densities itself: what the
@@ -5439,7 +5439,7 @@ __device__ __forceinline__ void dense_slow_loop(const FxDevParams &P, const FxBu
 // workgroup at a time), the others take wave rows (65..192, one keypoint per wavefront).  Neither tier fills the chip
 // alone (1600 and 900 of the 8192 wave slots on the VLP-16 bench) and neither depends on the other: one after the
 // other they cost 0.135 + 0.075 ms, together about the longer of the two.  The last n_dslow workgroups (when the dense
-// tier's four kernels are not launched) take the dense tier's rows: k_desc_group, which lists them, has completed.
+// tier's own kernels are not launched) take the dense tier's rows: k_desc_group, which lists them, has completed.
 static_assert(FX_DSLOW_T == FX_WG && FX_DESC_WG_FAST_T == FX_WG, "k_desc_mid's three kinds of workgroups");
 extern "C" __global__ __launch_bounds__(FX_WG) void k_desc_mid(FxDevParams P, FxBuffers B, uint32_t batch, uint32_t cap,
                                                                 uint32_t n_wg, uint32_t n_dslow) {

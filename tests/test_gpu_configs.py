@@ -58,7 +58,7 @@ def test_dense_128_ring_scan_radius_2m(fxlib, oracle, preset):
 
 def test_dense_128_ring_scan_through_the_one_small_dense_launch(fx_hooks, oracle):
     """The same scan with every dense row — support sets of up to ~10 000 points — computed by dense_slow_loop (k_desc_mid's last workgroups) instead of the
-    dense tier's four kernels (what a batch gets whose predecessors had no dense row): the same result."""
+    dense tier's own kernels (what a batch gets whose predecessors had no dense row): the same result."""
     fx_hooks(FX_DENSE_SLOW=1)
     s = capi.synth_scan(capi.synth_cfg(50, n_poles=256, **DENSE))
     p = _dense_params("launch")

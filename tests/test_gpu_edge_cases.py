@@ -245,7 +245,7 @@ def test_dense_tier_query_marks_in_the_sorted_region(fx_hooks, oracle):
 @pytest.mark.parametrize("dense_slow", [0, 1])
 def test_dense_tier_pool_exhaustion_is_flagged(fx_hooks, oracle, dense_slow):
     """A sorted pool too small for the batch's dense rows: FX_FLAG_NBR_OVERFLOW on the scan, NaN descriptors for the rows
-    that did not fit, every other row still exact — whether the tier's four kernels run or the one small launch that stands
+    that did not fit, every other row still exact — whether the tier's own kernels run or the one small launch that stands
     in for them (the pool accounting is k_desc_group's, before either)."""
     fx_hooks(FX_DENSE_SLOW=dense_slow)
     s = util.vlp16_scan(1000, n_poles=8, x_lo=3.0, x_hi=8.0, y_lo=-4.0, y_hi=4.0)

@@ -60,7 +60,7 @@ def test_dense_many_ring_scans(fxlib, oracle, block):
 @pytest.mark.parametrize("block", range(2))
 def test_dense_rows_through_the_one_small_launch(fx_hooks, oracle, block):
     """The dense tier's rows computed by dense_slow_loop, k_desc_mid's last workgroups (the list tier's body on scratch in HBM, what a batch gets whose
-    predecessors had no dense row) instead of the tier's four kernels: forced by the test build's hook, the same scans, the
+    predecessors had no dense row) instead of the tier's own kernels: forced by the test build's hook, the same scans, the
     same results — the choice between the two is the host's memory of earlier batches and may only ever decide speed."""
     fx_hooks(FX_DENSE_SLOW=1)
     checked, dense_rows = 0, 0
