@@ -145,6 +145,8 @@ struct fx_ctx {
   float *d_stage = nullptr;
   uint32_t stage_stride = 0;  // record stride the staging buffer is sized for
   // pinned host mirrors (lazy)
+  uint32_t *h_hdr = nullptr;  // the per-scan words' block (hdr_stride words an array, the device block's layout): one copy a batch
+  size_t hdr_stride = 0;
   uint32_t *h_n_kp = nullptr, *h_kp_offset = nullptr, *h_flags = nullptr, *h_n_filt = nullptr, *h_n_kpc = nullptr,
            *h_n_cand = nullptr, *h_cand_size = nullptr, *h_kpc_cand = nullptr, *h_kp_size = nullptr,
            *h_kp_nbrs = nullptr;
@@ -678,7 +680,16 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   FX_A(dev_alloc(c, &d_xa, L.max_keypoints));
   b.xaxis = d_xa;
   FX_A(dev_alloc(c, &b.filt, B * L.max_points));
-  FX_A(dev_alloc(c, &b.n_filt, B));
+  {
+    // the five words a scan the host reads back after every batch — counts, the keypoint offsets, flags — in ONE block, so
+    // that FX_OUT_HOST is one copy instead of five
+    c->hdr_stride = (B + 1 + 3) & ~(size_t)3;
+    uint32_t *hdr = nullptr;
+    FX_A(dev_alloc(c, &hdr, 5 * c->hdr_stride));
+    if (hipMemset(hdr, 0, 5 * c->hdr_stride * sizeof(uint32_t)) != hipSuccess) return bail(fail(FX_ERR_HIP, "hipMemset"));
+    b.n_kp = hdr, b.kp_offset = hdr + c->hdr_stride, b.flags = hdr + 2 * c->hdr_stride, b.n_filt = hdr + 3 * c->hdr_stride,
+    b.n_kpc = hdr + 4 * c->hdr_stride;
+  }
   FX_A(dev_alloc(c, &b.near_bits, B * P.near_words));
   FX_A(dev_alloc(c, &b.prep_cnt, B * fxk_prep_slices_max()));
   FX_A(dev_alloc(c, &b.prep_ring_cnt, B * fxk_prep_slices_max() * R));
@@ -698,11 +709,8 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   FX_A(dev_alloc(c, &b.keypoints, B * L.max_keypoints));
   FX_A(dev_alloc(c, &b.kp_size, B * L.max_keypoints));
   FX_A(dev_alloc(c, &b.kp_nbrs, B * L.max_keypoints));
-  FX_A(dev_alloc(c, &b.n_kp, B));
-  FX_A(dev_alloc(c, &b.kp_offset, B + 1));
   FX_A(dev_alloc(c, &b.kpc, B * L.max_kpc_points));
   FX_A(dev_alloc(c, &b.kpc_cand, B * L.max_kpc_points));
-  FX_A(dev_alloc(c, &b.n_kpc, B));
   FX_A(dev_alloc(c, &b.desc, (size_t)L.max_total_keypoints * FX_DESC_FLOATS + 4));
   FX_A(dev_alloc(c, &b.desc_nbins, (size_t)L.max_total_keypoints));
   FX_A(dev_alloc(c, &b.desc_bins, (size_t)L.max_total_keypoints * fxk_group_cap()));
@@ -710,7 +718,6 @@ fx_status fx_create(const fx_params *params, const fx_limits *limits, int device
   if (hipMemset(b.desc, 0, ((size_t)L.max_total_keypoints * FX_DESC_FLOATS + 4) * sizeof(float)) != hipSuccess ||
       hipMemset(b.desc_nbins, 0, (size_t)L.max_total_keypoints * sizeof(uint32_t)) != hipSuccess)
     return bail(fail(FX_ERR_HIP, "hipMemset"));
-  FX_A(dev_alloc(c, &b.flags, B));
   FX_A(dev_alloc(c, &b.huge_rings, (size_t)8 * P.ring_list_cap));
   FX_A(dev_alloc(c, &b.huge_rings2, (size_t)8 * P.ring_list_cap));
   FX_A(dev_alloc(c, &b.big_merge, B));
@@ -1181,19 +1188,14 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
     return FX_OK;
   }
   const size_t Bm = L.max_batch;
-  FX_TRY(host_alloc(c, &c->h_n_kp, Bm));
-  FX_TRY(host_alloc(c, &c->h_kp_offset, Bm + 1));
-  FX_TRY(host_alloc(c, &c->h_flags, Bm));
-  FX_TRY(host_alloc(c, &c->h_n_filt, Bm));
-  FX_TRY(host_alloc(c, &c->h_n_kpc, Bm));
+  const size_t S = c->hdr_stride;
+  FX_TRY(host_alloc(c, &c->h_hdr, 5 * S));
+  c->h_n_kp = c->h_hdr, c->h_kp_offset = c->h_hdr + S, c->h_flags = c->h_hdr + 2 * S, c->h_n_filt = c->h_hdr + 3 * S, c->h_n_kpc = c->h_hdr + 4 * S;
   FX_TRY(host_alloc(c, &c->h_keypoints, Bm * L.max_keypoints * 4));
   FX_TRY(host_alloc(c, &c->h_desc, (size_t)L.max_total_keypoints * FX_DESC_FLOATS));
   if (batch) {
-    FX_HIP(hipMemcpyAsync(c->h_n_kp, B.n_kp, batch * 4, hipMemcpyDeviceToHost, s));
-    FX_HIP(hipMemcpyAsync(c->h_kp_offset, B.kp_offset, (batch + 1) * 4, hipMemcpyDeviceToHost, s));
-    FX_HIP(hipMemcpyAsync(c->h_flags, B.flags, batch * 4, hipMemcpyDeviceToHost, s));
-    FX_HIP(hipMemcpyAsync(c->h_n_filt, B.n_filt, batch * 4, hipMemcpyDeviceToHost, s));
-    FX_HIP(hipMemcpyAsync(c->h_n_kpc, B.n_kpc, batch * 4, hipMemcpyDeviceToHost, s));
+    // (n_kp | kp_offset | flags | n_filt | n_kpc, S words each: everything up to the last array's last scan of this batch)
+    FX_HIP(hipMemcpyAsync(c->h_hdr, B.n_kp, (4 * S + batch) * 4, hipMemcpyDeviceToHost, s));
     FX_HIP(hipMemcpyAsync(c->h_keypoints, B.keypoints, (size_t)batch * L.max_keypoints * 16, hipMemcpyDeviceToHost, s));
   } else {
     c->h_kp_offset[0] = 0;
@@ -1202,6 +1204,8 @@ fx_status fx_process_batch(fx_ctx *c, const fx_scan_desc *scans, uint32_t batch,
   uint32_t total = batch ? c->h_kp_offset[batch] : 0;
   if (total > L.max_total_keypoints) total = L.max_total_keypoints;
   out->total_keypoints = total;
+  // (about as many rows as the last call had, copied BEFORE the wait, and the per-scan words in one block instead of five
+  //  copies: measured for a scan per call, 0.244 ms either way — the copies are not what the call waits for; the one block stayed)
   if (total && P.estimate_descriptors)
     FX_HIP(hipMemcpyAsync(c->h_desc, B.desc, (size_t)total * FX_DESC_FLOATS * 4, hipMemcpyDeviceToHost, s));
   if (flags & FX_OUT_CLOUDS) {

@@ -5828,6 +5828,9 @@ extern "C" __global__ __launch_bounds__(FX_DSORT_T) void k_dense_sort(FxDevParam
 #ifndef FX_DDENS_RUNS
 #define FX_DDENS_RUNS 8              // units a lane lists per pass
 #endif
+#ifndef FX_DDENS_PER_CU
+#define FX_DDENS_PER_CU 3             // workgroups a CU of the full grid (52 KB of LDS each)
+#endif
 #define FX_DDENS_BINS 96             // length classes of the units (exponent, three mantissa bits)
 static_assert(FX_DDENS_C <= 2048 && FX_DDENS_T == 256, "k_dense_density packs a unit as quad (8 bits) | first (11) | length - 1 (11)");
 static_assert(FX_DDENS_BINS <= FX_DDENS_T, "one bin a thread in the prefix");
@@ -6723,7 +6726,7 @@ void fxk_dense(hipStream_t s, const FxDevParams &P, const FxBuffers &B, uint32_t
   auto grid = [](uint32_t want, uint32_t full) { return want < full ? (want ? want : 1u) : full; };
   hipLaunchKernelGGL(k_dense_sort, dim3(grid(rows, n_cu * FX_DSORT_PER_CU)), dim3(FX_DSORT_T), 0, s, P, B);
   // (skip: measurement only — a test build's FX_SKIP_EMPTY bits 2 / 3: the tier's share of a step with batches in flight)
-  if (!(skip & 2u)) hipLaunchKernelGGL(k_dense_density, dim3(grid(items, n_cu * 3)), dim3(FX_DDENS_T), 0, s, P, B);
+  if (!(skip & 2u)) hipLaunchKernelGGL(k_dense_density, dim3(grid(items, n_cu * FX_DDENS_PER_CU)), dim3(FX_DDENS_T), 0, s, P, B);
   if (!(skip & 1u)) hipLaunchKernelGGL(k_dense_finish, dim3(grid(rows, n_cu)), dim3(FX_DFIN_T), fxk_dense_finish_lds_bytes(), s, P, B);
 }
 #ifdef FX_TEST_HOOKS

@@ -31,6 +31,26 @@ def test_empty_and_ragged_batch(fxlib, oracle):
     assert got[0]["n_keypoints"] == 0 and len(got[0]["filtered"]) == 0 and got[4]["n_keypoints"] > 0
 
 
+def test_host_results_of_a_stream_of_calls_with_changing_keypoint_counts(fxlib, oracle):
+    """FX_OUT_HOST: the per-scan words (counts, offsets, flags) come back in one copy of one block, the descriptor rows in a copy
+    sized by the batch's own total.  One context, a scan a call: sparse, crowded, empty, sparse again, then a batch of three —
+    every call's results equal the oracle's, whatever the call before left in the host buffers."""
+    p = capi.params("launch")
+    sparse, crowded = util.vlp16_scan(1000, n_poles=6), util.vlp16_scan(7, n_poles=400)
+    ora = {id(s): oracle.run(p, s, roll=0.02, pitch=-0.015) for s in (sparse, crowded)}
+    assert ora[id(crowded)]["n_keypoints"] > 4 * max(1, ora[id(sparse)]["n_keypoints"])
+    ctx = capi.Context(p, capi.limits(3, 28800, max_keypoints=512, max_total_keypoints=1536, max_kpc_points=8192, max_candidates=3500))
+    empty = np.zeros((0, 4), np.float32)
+    for step, scans in enumerate(([sparse], [crowded], [empty], [sparse], [crowded, sparse, crowded], [sparse])):
+        got = ctx.process_host(scans, roll=0.02, pitch=-0.015)
+        for b, sc in enumerate(scans):
+            if len(sc):
+                util.compare_scan(got[b], ora[id(sc)], tag=f"call {step} scan {b}")
+            else:
+                assert got[b]["n_keypoints"] == 0 and got[b]["flags"] == 0
+    ctx.close()
+
+
 def test_empty_batch_call(fxlib):
     ctx = capi.Context(capi.params("default"), capi.limits(4, 1024))
     v = ctx.process_raw(ctx.make_descs([], []), 0, capi.FX_OUT_HOST)

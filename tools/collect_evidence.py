@@ -17,7 +17,8 @@ for cmd in (["tools/summarize_profile.py", tag + "_c1"], ["tools/summarize_profi
     r = subprocess.run([sys.executable] + cmd, cwd=ROOT, capture_output=True, text=True)
     print(" ".join(cmd), "->", r.returncode, (r.stdout + r.stderr)[-600:])
 for name in ("bench_default_run.json", "force_dist.json", "bench_one_at_a_time.json", "fx_multi_1gpu.log", "batcher.log", "streaming_latency.jsonl",
-             "kernel_info.txt", "fuzz_more.log", "fuzz_dense.log", "fx_multi_selftest8.log"):
+             "kernel_info.txt", "fuzz_more.log", "fuzz_dense.log", "fx_multi_selftest8.log",
+             "fuzz_more_1000_5000.log", "fuzz_dense_300_1800.log", "determinism.log", "gpu_tests.log", "smoke.log"):  # (the last five: FX_EVIDENCE_LONG=1)
     src = os.path.join(ev, name)
     if os.path.exists(src) and os.path.getsize(src):
         if name.endswith(".log"):  # (without the runtime's noise)

@@ -30,4 +30,12 @@ FX_PROFILE_PMC=1 bash tools/profile_config.sh $TAG 5 > "$E/profile_cfg5.log" 2>&
 timeout 2700 python3 tools/fuzz_more.py 0 1000 > "$E/fuzz_more.log" 2>&1
 timeout 900 python3 tools/fuzz_dense.py 0 300 > "$E/fuzz_dense.log" 2>&1
 feature_extraction_amd/bin/fx_multi_cli --selftest 8 --batch 61 --steps 6 --inflight 3 --bad-scan 60 > "$E/fx_multi_selftest8.log" 2>&1
+# FX_EVIDENCE_LONG=1: 4000 more fuzz seeds x 9 paths, 1500 more dense seeds, 30 repetitions of a 64-scan batch, the GPU suite, smoke()
+if [ "${FX_EVIDENCE_LONG:-0}" = "1" ]; then
+  timeout 1500 python3 tools/fuzz_more.py 1000 5000 > "$E/fuzz_more_1000_5000.log" 2>&1
+  timeout 300 python3 tools/fuzz_dense.py 300 1800 > "$E/fuzz_dense_300_1800.log" 2>&1
+  timeout 300 python3 tools/stress_determinism.py > "$E/determinism.log" 2>&1
+  timeout 1800 python3 -m pytest tests -m gpu -q > "$E/gpu_tests.log" 2>&1
+  python3 -c "import __graft_entry__ as g; g.smoke()" > "$E/smoke.log" 2>&1
+fi
 ls "$E"
