@@ -16,11 +16,19 @@ HOOKS = ("FX_FRONT", "FX_MERGE_BIG_CAP", "FX_FRONT_FORCE", "FX_FRONT_SPLIT", "FX
 t0 = time.time(); bad = 0; total_k = 0; n_over = 0
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 paths = sys.argv[3].split(",") if len(sys.argv) > 3 else list(PATHS)
-lim = dict(max_candidates=3500, max_kpc_points=57600, max_keypoints=1024, max_total_keypoints=1024, max_ring_candidates=512)
+lim = dict(max_candidates=3500, max_kpc_points=57600, max_keypoints=1024, max_total_keypoints=1024,
+           max_ring_candidates=int(os.environ.get("FX_FUZZ_RING_CANDIDATES", "512")))
 for seed in range(lo, hi):
     s, p, roll, pitch, what = _case(seed)
     ora = O.run(p, s, roll=roll, pitch=pitch)
     over = ora["n_keypoints"] > lim["max_keypoints"] or len(ora["candidates"]) > lim["max_candidates"]  # (the scene exceeds THIS tool's limits: every path must say so)
+    # ... and the per-ring limit (seed 33442: cluster_min_count 1, four rings of ~600 candidates — flagged on every path, which
+    # this tool then reported as nine mismatches).  A candidate's intensity is its ring's elevation: the ring it came from, to
+    # within a window boundary — so a count within eight of the limit accepts either outcome.
+    c = ora["candidates"]
+    ring_max = int(np.bincount(np.clip(np.round((c[:, 3] - p.el0_deg) / p.el_step_deg).astype(int), 0, p.n_rings - 1)).max()) if len(c) else 0
+    over = over or ring_max > lim["max_ring_candidates"] + 8
+    maybe_over = not over and ring_max + 8 >= lim["max_ring_candidates"]
     for path in paths:
         for h in HOOKS:
             os.environ.pop(h, None)
@@ -33,6 +41,9 @@ for seed in range(lo, hi):
                 ctx = capi.Context(p, capi.limits(1, 28800, **lim))
         got = ctx.process_host([s], roll=roll, pitch=pitch)[0]
         ctx.close()
+        if maybe_over and (got["flags"] & capi.FX_FLAG_CAND_OVERFLOW):
+            n_over += 1
+            continue
         if over:
             n_over += 1
             if not (got["flags"] & (capi.FX_FLAG_KP_OVERFLOW | capi.FX_FLAG_CAND_OVERFLOW)):
